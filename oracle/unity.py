@@ -1,0 +1,471 @@
+"""ORACLE (test infrastructure, never shipped or benchmarked as the product).
+
+CPU fp32 restatement, in plain PyTorch ops, of the UnitY2 speech-to-unit path
+that ``Translator.predict(..., "S2ST")`` runs in the reference
+(src/seamless_communication/inference/translator.py:216-428 ->
+inference/generator.py:228-364).  It consumes a state dict in the reference's
+fairseq2 key schema so a real converted checkpoint
+loads unchanged.
+
+The arithmetic of most modules lives in fairseq2 0.2.* (pinned by the
+reference's setup.py:25, NOT vendored under /root/reference and not
+installable here), so those parts restate fairseq2's published algorithm and
+are anchored on the reference's call sites and on the in-tree C++ restatement
+(ggml/examples/unity/fairseq2.cpp).  PARITY PIN STATUS per block is listed in
+DESIGN.md: fbank is pinned against the compiled kaldi-native-fbank, the
+vocoder / unit tokenizer / NAR frontend logic against the reference's own
+Python files (tests/golden/make_reference_goldens.py); Shaw attention, the
+Conformer convolution module and the beam-search length rule are "parity
+unpinned" (no reference test or executable reference exists offline).
+
+Citations `file:line` are relative to
+/root/reference/src/seamless_communication unless they start with ggml/.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+LN_EPS = 1e-5
+
+
+# --------------------------------------------------------------------------- #
+# fairseq2 building blocks
+# --------------------------------------------------------------------------- #
+def sinusoidal_table(num_pos: int, dim: int, legacy_pad_idx: Optional[int] = 1) -> Tensor:
+    """fairseq2 SinusoidalPositionEncoder ``freqs`` buffer (appendix A-5):
+    [sin | cos] halves, factors exp(-i*ln(1e4)/(half-1)), first row is
+    position ``legacy_pad_idx + 1``.  Corroborated by ggml/ggml_convert.py:370-402."""
+    start = 0 if legacy_pad_idx is None else 1 + legacy_pad_idx
+    half = dim // 2
+    idx = torch.arange(start, start + num_pos, dtype=torch.float32)
+    fct = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000.0) / (half - 1)))
+    ang = torch.outer(idx, fct)
+    out = torch.zeros(num_pos, dim, dtype=torch.float32)
+    out[:, :half] = torch.sin(ang)
+    out[:, half : 2 * half] = torch.cos(ang)
+    return out
+
+
+def padding_mask(lens: Tensor, max_len: int) -> Tensor:
+    """True for valid positions, (N, max_len)."""
+    return torch.arange(max_len)[None, :] < lens[:, None]
+
+
+class Params:
+    def __init__(self, sd: Dict[str, Tensor]) -> None:
+        self.sd = {k: v.detach().to(torch.float32) for k, v in sd.items()}
+
+    def __getitem__(self, k: str) -> Tensor:
+        return self.sd[k]
+
+    def linear(self, x: Tensor, prefix: str) -> Tensor:
+        return F.linear(x, self.sd[prefix + ".weight"], self.sd.get(prefix + ".bias"))
+
+    def layer_norm(self, x: Tensor, prefix: str) -> Tensor:
+        w = self.sd[prefix + ".weight"]
+        return F.layer_norm(x, (w.shape[0],), w, self.sd[prefix + ".bias"], LN_EPS)
+
+
+def mha(
+    P: Params,
+    prefix: str,
+    x_q: Tensor,
+    x_kv: Tensor,
+    num_heads: int,
+    key_lens: Optional[Tensor] = None,
+    causal: bool = False,
+    shaw: Optional[Tuple[int, int]] = None,
+) -> Tensor:
+    """fairseq2 StandardMultiheadAttention + default SDPA (appendix A-8);
+    ``shaw=(left,right)`` adds ShawRelativePositionSDPA (appendix A-1,
+    models/conformer_shaw/builder.py:127-146)."""
+    N, S, M = x_q.shape
+    Skv = x_kv.shape[1]
+    H = num_heads
+    D = M // H
+    q = P.linear(x_q, prefix + ".q_proj").view(N, S, H, D).transpose(1, 2)
+    k = P.linear(x_kv, prefix + ".k_proj").view(N, Skv, H, D).transpose(1, 2)
+    v = P.linear(x_kv, prefix + ".v_proj").view(N, Skv, H, D).transpose(1, 2)
+    w = torch.matmul(q, k.transpose(-1, -2)) * (D ** -0.5)
+    if shaw is not None:
+        left, right = shaw
+        rel = P[prefix + ".sdpa.rel_k_embed.weight"]  # (left+1+right, D)
+        idx = torch.arange(Skv)[None, :] - torch.arange(Skv)[:, None]  # [i, j] = j - i
+        idx = idx.clamp(-left, right) + left
+        rel_keys = rel[idx][-S:]  # (S, Skv, D)
+        rel_w = torch.einsum("nhsm,stm->nhst", q, rel_keys) * (D ** -0.5)
+        w = w + rel_w
+    if causal:
+        cm = torch.ones(S, Skv, dtype=torch.bool).tril(diagonal=Skv - S)
+        w = w.masked_fill(~cm, float("-inf"))
+    if key_lens is not None:
+        km = padding_mask(key_lens, Skv)  # (N, Skv)
+        w = w.masked_fill(~km[:, None, None, :], float("-inf"))
+    a = torch.softmax(w, dim=-1)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(N, S, M)
+    return P.linear(o, prefix + ".output_proj")
+
+
+def ffn(P: Params, prefix: str, x: Tensor, act: str) -> Tensor:
+    h = P.linear(x, prefix + ".inner_proj")
+    h = F.silu(h) if act == "silu" else F.relu(h)
+    return P.linear(h, prefix + ".output_proj")
+
+
+# --------------------------------------------------------------------------- #
+# Speech encoder  (a3..a7 of SURVEY.md section 8)
+# --------------------------------------------------------------------------- #
+def speech_frontend(P: Params, cfg, fbank: Tensor, lens: Tensor) -> Tuple[Tensor, Tensor]:
+    """Wav2Vec2Frontend on fbank input (appendix A-4; ggml/examples/unity/
+    fairseq2.cpp:597-600,765-767): stack ``fbank_stride`` frames dropping the
+    odd tail, LayerNorm, Linear; no positional encoder for shaw_relative."""
+    N, T, C = fbank.shape
+    s = cfg.fbank_stride
+    T2 = T // s
+    x = fbank[:, : T2 * s].reshape(N, T2, C * s)
+    lens2 = torch.div(lens, s, rounding_mode="floor")
+    x = P.layer_norm(x, "speech_encoder_frontend.post_extract_layer_norm")
+    x = P.linear(x, "speech_encoder_frontend.model_dim_proj")
+    return x, lens2
+
+
+def conformer_conv(P: Params, cfg, prefix: str, x: Tensor, lens: Tensor) -> Tensor:
+    """fairseq2 ConformerConvolution(causal_depthwise_conv=True,
+    norm_type="layer_norm") (appendix A-3; conformer_shaw/builder.py:148-156)."""
+    N, S, M = x.shape
+    x = x * padding_mask(lens, S)[:, :, None]
+    x = x.transpose(1, 2)
+    x = F.conv1d(x, P[prefix + ".pointwise_conv1.weight"])
+    x = F.glu(x, dim=1)
+    K = cfg.depthwise_conv_kernel_size
+    x = F.pad(x, (K - 1, 0))
+    x = F.conv1d(x, P[prefix + ".depthwise_conv.weight"], groups=M)
+    x = P.layer_norm(x.transpose(1, 2), prefix + ".layer_norm").transpose(1, 2)
+    x = F.silu(x)
+    x = F.conv1d(x, P[prefix + ".pointwise_conv2.weight"])
+    return x.transpose(1, 2)
+
+
+def conformer_block(P: Params, cfg, prefix: str, x: Tensor, lens: Tensor) -> Tensor:
+    """fairseq2 ConformerBlock (appendix A-2; order corroborated by
+    ggml/examples/unity/fairseq2.cpp:733-756)."""
+    x = x + 0.5 * ffn(P, prefix + ".ffn1", P.layer_norm(x, prefix + ".ffn1_layer_norm"), "silu")
+    h = P.layer_norm(x, prefix + ".self_attn_layer_norm")
+    x = x + mha(
+        P, prefix + ".self_attn", h, h, cfg.num_heads, key_lens=lens,
+        shaw=(cfg.shaw_max_left, cfg.shaw_max_right),
+    )
+    x = x + conformer_conv(P, cfg, prefix + ".conv", P.layer_norm(x, prefix + ".conv_layer_norm"), lens)
+    x = x + 0.5 * ffn(P, prefix + ".ffn2", P.layer_norm(x, prefix + ".ffn2_layer_norm"), "silu")
+    return P.layer_norm(x, prefix + ".layer_norm")
+
+
+def adaptor_layer(P: Params, cfg, prefix: str, x: Tensor, lens: Tensor) -> Tuple[Tensor, Tensor]:
+    """UnitYTransformerAdaptorLayer (models/unity/adaptor_block.py:237-314)."""
+    k, s = cfg.adaptor_kernel_size, cfg.adaptor_stride
+    res = P.layer_norm(x, prefix + ".residual_layer_norm").transpose(1, 2)
+    res = F.conv1d(res, P[prefix + ".residual_conv.weight"], P[prefix + ".residual_conv.bias"], stride=s, padding=k // 2)
+    res = F.glu(res, dim=1).transpose(1, 2)
+    h = P.layer_norm(x, prefix + ".self_attn_layer_norm").transpose(1, 2)
+    h = F.conv1d(h, P[prefix + ".self_attn_conv.weight"], P[prefix + ".self_attn_conv.bias"], stride=s, padding=k // 2)
+    h = F.glu(h, dim=1).transpose(1, 2)
+    # _compute_new_padding_mask (adaptor_block.py:426-438)
+    pad = k // 2
+    new_lens = torch.floor(((lens + 2 * pad - k) / s) + 1).to(torch.int64)
+    h = mha(P, prefix + ".self_attn", h, h, cfg.num_heads, key_lens=new_lens)
+    h = h + res
+    h = h + ffn(P, prefix + ".ffn", P.layer_norm(h, prefix + ".ffn_layer_norm"), "relu")
+    return h, new_lens
+
+
+def encode_speech(P: Params, cfg, fbank: Tensor, lens: Tensor) -> Tuple[Tensor, Tensor]:
+    """UnitYModel.encode_speech (models/unity/model.py:132-139) =
+    frontend + UnitYEncoderAdaptor.forward (adaptor_block.py:98-116)."""
+    x, lens = speech_frontend(P, cfg, fbank, lens)
+    for i in range(cfg.enc_layers):
+        x = conformer_block(P, cfg, f"speech_encoder.inner.layers.{i}", x, lens)
+    x = P.layer_norm(x, "speech_encoder.inner_layer_norm")
+    x = x + 0.5 * P.linear(F.relu(P.linear(x, "speech_encoder.proj1")), "speech_encoder.proj2")
+    x, lens = adaptor_layer(P, cfg, "speech_encoder.adaptor_layers.0", x, lens)
+    x = P.layer_norm(x, "speech_encoder.layer_norm")
+    return x, lens
+
+
+# --------------------------------------------------------------------------- #
+# Text decoder (a9..a11)
+# --------------------------------------------------------------------------- #
+def embed_text(P: Params, cfg, tokens: Tensor, start: int, pos_table: Tensor) -> Tensor:
+    """TransformerEmbeddingFrontend (appendix A-5; ggml/examples/unity/
+    fairseq2.cpp:917-953): embed * sqrt(M) + sinusoidal position (no LN)."""
+    e = F.embedding(tokens, P["text_decoder_frontend.embed.weight"]) * math.sqrt(cfg.model_dim)
+    return e + pos_table[start : start + tokens.shape[1]][None]
+
+
+def decoder_layer(
+    P: Params, cfg, prefix: str, x: Tensor, enc: Tensor, enc_lens: Optional[Tensor],
+    self_kv: Optional[Tensor] = None, self_lens: Optional[Tensor] = None,
+) -> Tensor:
+    """StandardTransformerDecoderLayer, pre-LN (appendix A-8;
+    ggml/examples/unity/fairseq2.cpp:979-1094).  ``self_kv``: the normed
+    inputs of all positions so far when decoding incrementally."""
+    h = P.layer_norm(x, prefix + ".self_attn_layer_norm")
+    if self_kv is None:
+        a = mha(P, prefix + ".self_attn", h, h, cfg.num_heads, key_lens=self_lens, causal=True)
+    else:
+        a = mha(P, prefix + ".self_attn", h, self_kv, cfg.num_heads, causal=True)
+    x = x + a
+    h = P.layer_norm(x, prefix + ".encoder_decoder_attn_layer_norm")
+    x = x + mha(P, prefix + ".encoder_decoder_attn", h, enc, cfg.num_heads, key_lens=enc_lens)
+    x = x + ffn(P, prefix + ".ffn", P.layer_norm(x, prefix + ".ffn_layer_norm"), "relu")
+    return x
+
+
+def decode_text(
+    P: Params, cfg, tokens: Tensor, tok_lens: Optional[Tensor], enc: Tensor, enc_lens: Optional[Tensor],
+    pos_table: Tensor,
+) -> Tensor:
+    """UnitYModel.decode without state bag (models/unity/model.py:154-180):
+    the teacher-forced pass of generator.py:294-299."""
+    x = embed_text(P, cfg, tokens, 0, pos_table)
+    for i in range(cfg.dec_layers):
+        x = decoder_layer(P, cfg, f"text_decoder.layers.{i}", x, enc, enc_lens, self_lens=tok_lens)
+    return P.layer_norm(x, "text_decoder.layer_norm")
+
+
+class IncrementalDecoder:
+    """Incremental decode with cached self-attention inputs — the arithmetic
+    of fairseq2's IncrementalStateBag path used by beam search
+    (models/unity/model.py:233-252; KV cache in ggml/examples/unity/
+    fairseq2.cpp:57-153).  Caching the normed layer inputs instead of K/V is
+    arithmetically the same projection applied to the same rows."""
+
+    def __init__(self, P: Params, cfg, enc: Tensor, enc_lens: Optional[Tensor], pos_table: Tensor) -> None:
+        self.P, self.cfg, self.enc, self.enc_lens, self.pos = P, cfg, enc, enc_lens, pos_table
+        self.cache: List[Optional[Tensor]] = [None] * cfg.dec_layers
+        self.step = 0
+
+    def __call__(self, tokens: Tensor) -> Tensor:
+        """tokens (N, S_new) -> decoder output (N, S_new, M)."""
+        P, cfg = self.P, self.cfg
+        x = embed_text(P, cfg, tokens, self.step, self.pos)
+        for i in range(cfg.dec_layers):
+            prefix = f"text_decoder.layers.{i}"
+            h = P.layer_norm(x, prefix + ".self_attn_layer_norm")
+            self.cache[i] = h if self.cache[i] is None else torch.cat([self.cache[i], h], dim=1)
+            x = decoder_layer(P, cfg, prefix, x, self.enc, self.enc_lens, self_kv=self.cache[i])
+        self.step += tokens.shape[1]
+        return P.layer_norm(x, "text_decoder.layer_norm")
+
+
+def max_seq_len_rule(soft_a: float, soft_b: int, hard_max: int, source_len: int) -> int:
+    """ggml/examples/unity/fairseq2.cpp:1097-1105 (`_determine_max_seq_len`),
+    the in-tree restatement of the rule documented in generator.py:66-73.
+    Length INCLUDES the prefix.  (appendix A-6: ambiguity vs fairseq2 0.2's
+    max_gen_len only matters when EOS is never emitted.)"""
+    if source_len <= 0 or soft_a <= 0:
+        return hard_max
+    return min(hard_max, int(soft_a * source_len) + soft_b)
+
+
+def greedy_generate(
+    P: Params, cfg, enc: Tensor, enc_lens: Tensor, prefix: Sequence[int],
+    soft_max_seq_len: Tuple[float, int] = (1, 200), hard_max_seq_len: int = 1024,
+    min_seq_len: int = 1, unk_penalty: float = 0.0, pos_table: Optional[Tensor] = None,
+    return_margins: bool = False,
+):
+    """Beam search with beam_size=1 == greedy arg-max with the step rules of
+    ggml/examples/unity/fairseq2.cpp:1269-1305,1463-1594 (echo_prompt=True:
+    hypotheses start with the prompt).  Runs each batch item independently
+    like the reference (no cross-item arithmetic)."""
+    N = enc.shape[0]
+    if pos_table is None:
+        pos_table = sinusoidal_table(cfg.text_max_seq_len, cfg.model_dim, 1)
+    W = P["final_proj.weight"]
+    out: List[List[int]] = []
+    margins: List[List[float]] = []
+    for b in range(N):
+        # The reference runs the whole batch with the batch-max source length.
+        max_len = max_seq_len_rule(soft_max_seq_len[0], soft_max_seq_len[1], hard_max_seq_len, enc.shape[1])
+        max_len = min(max_len, cfg.text_max_seq_len)
+        dec = IncrementalDecoder(P, cfg, enc[b : b + 1], enc_lens[b : b + 1], pos_table)
+        seq = list(prefix)
+        mg: List[float] = []
+        # bootstrap: feed prefix[:-1] (fairseq2.cpp `_bootstrap_seqs_and_scores`)
+        if len(prefix) > 1:
+            dec(torch.tensor([seq[:-1]], dtype=torch.int64))
+        for step_nr in range(len(prefix) - 1, max_len - 1):
+            h = dec(torch.tensor([[seq[-1]]], dtype=torch.int64))
+            logits = F.linear(h[0, -1], W)
+            lprobs = torch.log_softmax(logits, dim=-1)
+            if step_nr < min_seq_len:
+                lprobs[cfg.eos_idx] = -math.inf
+            if step_nr == max_len - 2:
+                lprobs[: cfg.eos_idx] = -math.inf
+                lprobs[cfg.eos_idx + 1 :] = -math.inf
+            lprobs[cfg.pad_idx] = -math.inf
+            if unk_penalty != 0:
+                lprobs[cfg.unk_idx] -= unk_penalty
+            top2 = torch.topk(lprobs, 2)
+            mg.append(float(top2.values[0] - top2.values[1]))
+            tok = int(top2.indices[0])
+            seq.append(tok)
+            if tok == cfg.eos_idx:
+                break
+        out.append(seq)
+        margins.append(mg)
+    return (out, margins) if return_margins else out
+
+
+# --------------------------------------------------------------------------- #
+# NAR T2U (a12..a17)
+# --------------------------------------------------------------------------- #
+SPACE = "▁"
+
+
+def text_to_char_seqs(text_seqs: Tensor, text_tok, char_tok, pad_idx: int, unk_idx: int, eos_idx: int):
+    """NARDecoderFrontend.text_to_char_seqs
+    (models/unity/nar_decoder_frontend.py:143-259 with TagManager :31-49),
+    loops kept as in the reference."""
+    text_seqs = text_seqs[:, 2:].clone()
+    text_seqs[text_seqs == eos_idx] = pad_idx
+    N, S = text_seqs.shape
+    subwords_batch = [[str(text_tok.index_to_token(int(text_seqs[b, i]))) for i in range(S)] for b in range(N)]
+    char_lens = torch.zeros_like(text_seqs)
+    subword_lens = (text_seqs != pad_idx).sum(1)
+    for b in range(N):
+        n = int(subword_lens[b])
+        idxs = text_seqs[b, :n]
+        sw = subwords_batch[b][:n]
+        nxt_sp = [(len(sw[i + 1]) > 1 and sw[i + 1][0] == SPACE) if i < n - 1 else False for i in range(n)]
+        punc = [len(sw[i]) == 1 and not sw[i].isalpha() and not sw[i].isnumeric() and sw[i] != SPACE for i in range(n)]
+        for i in range(n):
+            if int(idxs[i]) == pad_idx:
+                break
+            if int(idxs[i]) == unk_idx:
+                cl = 1
+            else:
+                cl = len(sw[i])
+                if punc[i] and nxt_sp[i]:
+                    cl += 1
+                elif i > 0 and punc[i - 1] and nxt_sp[i - 1]:
+                    cl -= 1
+            char_lens[b, i] = cl
+    zero = char_lens.new_zeros((N, 1))
+    char_lens = torch.cat([zero, char_lens, zero], dim=1)
+    max_len = int(char_lens.sum(1).max())
+    char_seqs = text_seqs.new_full((N, max_len), pad_idx)
+    char_seq_lens = text_seqs.new_zeros(N)
+    for b in range(N):
+        n = int(subword_lens[b])
+        total = 0
+        for i in range(n):
+            if int(text_seqs[b, i]) == unk_idx:
+                ids = [unk_idx]
+            else:
+                ids = [char_tok.token_to_index(ch) for ch in list(subwords_batch[b][i])]
+            char_seqs[b, total : total + len(ids)] = torch.tensor(ids, dtype=char_seqs.dtype)
+            total += len(ids)
+        char_seq_lens[b] = total
+    return char_seqs, char_seq_lens, char_lens
+
+
+def hard_upsample(seqs: Tensor, durations: Tensor) -> Tuple[Tensor, Tensor]:
+    """HardUpsampling.forward (models/unity/length_regulator.py:24-39)."""
+    lens = durations.sum(dim=1)
+    max_len = int(lens.max())
+    N, _, M = seqs.shape
+    out = seqs.new_zeros((N, max_len, M))
+    for b in range(N):
+        out[b, : lens[b]] = seqs[b].repeat_interleave(durations[b], dim=0)
+    return out, lens
+
+
+def variance_predictor(P: Params, prefix: str, x: Tensor, lens: Tensor) -> Tensor:
+    """VariancePredictor.forward (models/unity/length_regulator.py:172-218)."""
+    m = padding_mask(lens, x.shape[1])[:, :, None]
+    x = (x * m).transpose(1, 2)
+    x = F.relu(F.conv1d(x, P[prefix + ".conv1.0.weight"], P[prefix + ".conv1.0.bias"], padding="same"))
+    x = P.layer_norm(x.transpose(1, 2), prefix + ".ln1")
+    x = (x * m).transpose(1, 2)
+    x = F.relu(F.conv1d(x, P[prefix + ".conv2.0.weight"], P[prefix + ".conv2.0.bias"], padding="same"))
+    x = P.layer_norm(x.transpose(1, 2), prefix + ".ln2")
+    x = x * m
+    return P.linear(x, prefix + ".proj").squeeze(2)
+
+
+def nar_decoder_frontend(
+    P: Params, cfg, enc_out: Tensor, text_seqs: Tensor, text_tok, char_tok, duration_factor: float,
+    char_pos: Tensor, unit_pos: Tensor,
+):
+    """NARDecoderFrontend.forward (models/unity/nar_decoder_frontend.py:300-334)."""
+    f = "t2u_model.decoder_frontend"
+    char_seqs, char_seq_lens, char_lens = text_to_char_seqs(
+        text_seqs, text_tok, char_tok, cfg.pad_idx, cfg.unk_idx, cfg.eos_idx
+    )
+    # character_level_upsampling (:261-283)
+    seqs, _ = hard_upsample(enc_out, char_lens)
+    S_c = seqs.shape[1]
+    pos = P[f + ".pos_emb_alpha_char"] * ((seqs + char_pos[:S_c][None]) - seqs)
+    ce = F.embedding(char_seqs, P[f + ".embed_char.weight"]) * math.sqrt(cfg.model_dim)
+    pos = pos + ce
+    seqs = seqs + pos
+    # variance adaptor (length_regulator.py:275-321)
+    logd = variance_predictor(P, f + ".variance_adaptor.duration_predictor", seqs, char_seq_lens)
+    dur = torch.clamp(torch.round((torch.exp(logd) - 1) * duration_factor).long(), min=1)
+    dur = dur * padding_mask(char_seq_lens, S_c)
+    seqs, unit_lens = hard_upsample(seqs, dur)
+    # forward_unit_pos_embedding (:285-297)
+    S_u = seqs.shape[1]
+    seqs = seqs + P[f + ".pos_emb_alpha"] * ((seqs + unit_pos[:S_u][None]) - seqs)
+    return seqs, unit_lens, dur, char_seqs, char_seq_lens, char_lens
+
+
+def fft_layer(P: Params, cfg, prefix: str, x: Tensor, lens: Tensor) -> Tensor:
+    """FeedForwardTransformerLayer (models/unity/fft_decoder_layer.py:177-231,
+    Conv1dBlock :74-101), post-LN."""
+    x = P.layer_norm(x + mha(P, prefix + ".self_attn", x, x, cfg.num_heads, key_lens=lens), prefix + ".self_attn_layer_norm")
+    m = padding_mask(lens, x.shape[1])[:, :, None]
+    h = (x * m).transpose(1, 2)
+    h = F.conv1d(h, P[prefix + ".conv1d.conv1.weight"], P[prefix + ".conv1d.conv1.bias"], padding="same")
+    h = F.relu(h.transpose(1, 2) * m).transpose(1, 2)
+    h = F.conv1d(h, P[prefix + ".conv1d.conv2.weight"], P[prefix + ".conv1d.conv2.bias"], padding="same")
+    return P.layer_norm(h.transpose(1, 2) + x, prefix + ".conv1d_layer_norm")
+
+
+def t2u_nar(
+    P: Params, cfg, dec_out: Tensor, dec_lens: Tensor, text_seqs: Tensor, text_tok, char_tok,
+    duration_factor: float = 1.0,
+):
+    """UnitYNART2UModel.forward (models/unity/model.py:379-441) + arg-max,
+    padding and unit decoding of generator.py:338-353."""
+    x = dec_out
+    for i in range(cfg.t2u_enc_layers):
+        p = f"t2u_model.encoder.layers.{i}"
+        h = P.layer_norm(x, p + ".self_attn_layer_norm")
+        x = x + mha(P, p + ".self_attn", h, h, cfg.num_heads, key_lens=dec_lens)
+        x = x + ffn(P, p + ".ffn", P.layer_norm(x, p + ".ffn_layer_norm"), "relu")
+    x = P.layer_norm(x, "t2u_model.encoder.layer_norm")
+    char_pos = sinusoidal_table(cfg.char_max_seq_len, cfg.model_dim, cfg.unit_pad_idx)
+    unit_pos = sinusoidal_table(cfg.unit_max_seq_len, cfg.model_dim, cfg.unit_pad_idx)
+    seqs, unit_lens, dur, char_seqs, char_seq_lens, char_lens = nar_decoder_frontend(
+        P, cfg, x, text_seqs, text_tok, char_tok, duration_factor, char_pos, unit_pos
+    )
+    for i in range(cfg.t2u_dec_layers):
+        seqs = fft_layer(P, cfg, f"t2u_model.decoder.layers.{i}", seqs, unit_lens)
+    seqs = P.layer_norm(seqs, "t2u_model.decoder.layer_norm")
+    logits = F.linear(seqs, P["t2u_model.final_proj.weight"])
+    unit_seqs = logits.argmax(dim=2)
+    unit_seqs = torch.where(padding_mask(unit_lens, unit_seqs.shape[1]), unit_seqs, torch.full_like(unit_seqs, cfg.unit_pad_idx))
+    # UnitTokenDecoder NAR branch (models/unity/unit_tokenizer.py:232-243)
+    units = unit_seqs.clone()
+    units[units == cfg.unit_eos_idx] = cfg.unit_pad_idx
+    units[units == cfg.unit_pad_idx] = cfg.unit_pad_idx + 4
+    units = units - 4
+    aux = dict(durations=dur, char_seqs=char_seqs, char_seq_lens=char_seq_lens, char_lens=char_lens,
+               unit_lens=unit_lens, t2u_encoder_out=x, decoder_in=None, logits=logits)
+    return units, aux

@@ -1,0 +1,152 @@
+"""Architecture configuration of the S2ST hot path.
+
+Field values of :func:`seamless_m4t_v2_large` restate the reference configs
+(citations are relative to /root/reference/src/seamless_communication):
+
+* ``base_v2`` UnitY arch                 models/unity/builder.py:165-192
+* conformer_shaw 600m speech encoder     models/conformer_shaw/builder.py:54-68
+* ``base_nar`` T2U arch                  models/unity/t2u_builder.py:186-232
+* vocoder ``base`` arch                  models/vocoder/builder.py:42-64
+
+Only the S2ST path is described (speech in -> text -> units -> waveform); the
+text encoder that the reference builds for T2TT is not part of it.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, asdict
+from typing import List
+
+
+@dataclass
+class VocoderConfig:
+    """Code-HiFi-GAN generator (models/vocoder/builder.py:44-63)."""
+
+    upsample_rates: List[int] = field(default_factory=lambda: [5, 4, 4, 2, 2])
+    upsample_kernel_sizes: List[int] = field(default_factory=lambda: [11, 8, 8, 4, 4])
+    upsample_initial_channel: int = 512
+    resblock_kernel_sizes: List[int] = field(default_factory=lambda: [3, 7, 11])
+    resblock_dilation_sizes: List[List[int]] = field(
+        default_factory=lambda: [[1, 3, 5], [1, 3, 5], [1, 3, 5]]
+    )
+    num_embeddings: int = 10000
+    embedding_dim: int = 1280
+    lang_embedding_dim: int = 256
+    num_langs: int = 36
+    spkr_embedding_dim: int = 256
+    num_spkrs: int = 200
+
+    @property
+    def model_in_dim(self) -> int:
+        return self.embedding_dim + self.lang_embedding_dim + self.spkr_embedding_dim
+
+    @property
+    def hop(self) -> int:
+        h = 1
+        for r in self.upsample_rates:
+            h *= r
+        return h
+
+
+@dataclass
+class S2STConfig:
+    """Everything the HIP runtime needs to lay the model out in HBM."""
+
+    name: str = "seamlessM4T_v2_large"
+    model_dim: int = 1024
+    num_heads: int = 16  # head_dim must be 64 (kernels are specialised for it)
+
+    # speech encoder: W2v-BERT 2.0 Conformer with Shaw rel-pos attention
+    num_fbank_channels: int = 80
+    fbank_stride: int = 2
+    enc_layers: int = 24
+    enc_ffn_dim: int = 4096
+    depthwise_conv_kernel_size: int = 31
+    shaw_max_left: int = 64
+    shaw_max_right: int = 8
+    adaptor_kernel_size: int = 8
+    adaptor_stride: int = 8
+    adaptor_ffn_dim: int = 4096  # = w2v2 ffn_inner_dim (builder.py:508)
+    adaptor_proj_dim: int = 4096  # model_dim * 4 (adaptor_block.py:79-87)
+
+    # NLLB dense_1b text decoder
+    dec_layers: int = 24
+    dec_ffn_dim: int = 8192
+    text_vocab_size: int = 256102
+    text_max_seq_len: int = 4096
+    pad_idx: int = 0
+    unk_idx: int = 1
+    bos_idx: int = 2
+    eos_idx: int = 3
+
+    # UnitY2 NAR T2U
+    t2u_enc_layers: int = 6
+    t2u_dec_layers: int = 6
+    t2u_ffn_dim: int = 8192
+    t2u_conv_kernel: int = 7
+    t2u_conv_inner_dim: int = 1024
+    unit_vocab_size: int = 10082
+    unit_pad_idx: int = 1
+    unit_eos_idx: int = 2
+    unit_max_seq_len: int = 4096
+    char_vocab_size: int = 10943
+    char_max_seq_len: int = 4096
+    var_pred_hidden_dim: int = 256
+    var_pred_kernel_size: int = 3
+
+    vocoder: VocoderConfig = field(default_factory=VocoderConfig)
+
+    @property
+    def head_dim(self) -> int:
+        return self.model_dim // self.num_heads
+
+    @property
+    def shaw_num_pos(self) -> int:
+        return self.shaw_max_left + 1 + self.shaw_max_right
+
+    def to_dict(self) -> dict:
+        return asdict(self)
+
+
+def seamless_m4t_v2_large() -> S2STConfig:
+    return S2STConfig()
+
+
+def tiny_config() -> S2STConfig:
+    """A structurally identical, small model for parity tests and golden
+    fixtures (the oracle finishes it in well under a second on CPU)."""
+    return S2STConfig(
+        name="tiny_v2",
+        model_dim=128,
+        num_heads=2,
+        enc_layers=2,
+        enc_ffn_dim=256,
+        depthwise_conv_kernel_size=31,
+        adaptor_ffn_dim=256,
+        adaptor_proj_dim=512,
+        dec_layers=2,
+        dec_ffn_dim=256,
+        text_vocab_size=1200,
+        text_max_seq_len=256,
+        t2u_enc_layers=2,
+        t2u_dec_layers=2,
+        t2u_ffn_dim=256,
+        t2u_conv_kernel=7,
+        t2u_conv_inner_dim=128,
+        unit_vocab_size=340,
+        unit_max_seq_len=1024,
+        char_vocab_size=96,
+        char_max_seq_len=1024,
+        var_pred_hidden_dim=64,
+        var_pred_kernel_size=3,
+        vocoder=VocoderConfig(
+            upsample_rates=[5, 4, 4, 2, 2],
+            upsample_kernel_sizes=[11, 8, 8, 4, 4],
+            upsample_initial_channel=128,
+            num_embeddings=300,
+            embedding_dim=48,
+            lang_embedding_dim=8,
+            num_langs=36,
+            spkr_embedding_dim=8,
+            num_spkrs=200,
+        ),
+    )

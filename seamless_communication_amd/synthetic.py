@@ -1,0 +1,227 @@
+"""Seeded synthetic checkpoints with the reference's state-dict schema.
+
+No model-card weights are reachable offline, so benchmarks and parity tests
+run on random-init weights that use *exactly* the key names and shapes that
+``convert_unity_checkpoint`` / ``convert_vocoder_checkpoint`` produce
+(src/seamless_communication/models/unity/loader.py:27-155,179-389;
+models/vocoder/loader.py:20-36), stored in fp16 like the
+published checkpoints.  A real converted checkpoint can be dropped in instead.
+
+Every tensor is drawn from its own generator seeded by (seed, crc32(key)), so
+the values do not depend on generation order, device or which sub-models are
+requested.
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from typing import Dict, Optional
+
+import torch
+
+from .config import S2STConfig
+
+DEFAULT_SEED = 20240901  # BASELINE.md "weights from seed 20240901"
+
+
+class _Gen:
+    def __init__(self, seed: int, dtype: torch.dtype) -> None:
+        self.seed = seed
+        self.dtype = dtype
+        self.sd: Dict[str, torch.Tensor] = {}
+
+    def _g(self, key: str) -> torch.Generator:
+        g = torch.Generator(device="cpu")
+        g.manual_seed((self.seed * 1000003 + zlib.crc32(key.encode())) % (2**63 - 1))
+        return g
+
+    def uniform(self, key: str, shape, bound: float, center: float = 0.0) -> None:
+        t = torch.rand(*shape, generator=self._g(key), dtype=torch.float32)
+        t.mul_(2 * bound).add_(center - bound)
+        self.sd[key] = t.to(self.dtype)
+
+    def normal(self, key: str, shape, std: float) -> None:
+        t = torch.randn(*shape, generator=self._g(key), dtype=torch.float32)
+        t.mul_(std)
+        self.sd[key] = t.to(self.dtype)
+
+    # ---- module-shaped helpers ------------------------------------------- #
+    def linear(self, prefix: str, out_dim: int, in_dim: int, bias: bool = True, gain: float = 1.0) -> None:
+        bound = gain * math.sqrt(6.0 / (in_dim + out_dim))  # Xavier uniform
+        self.uniform(prefix + ".weight", (out_dim, in_dim), bound)
+        if bias:
+            self.uniform(prefix + ".bias", (out_dim,), 0.02)
+
+    def layer_norm(self, prefix: str, dim: int) -> None:
+        self.uniform(prefix + ".weight", (dim,), 0.1, center=1.0)
+        self.uniform(prefix + ".bias", (dim,), 0.05)
+
+    def conv1d(self, prefix: str, out_ch: int, in_ch_per_group: int, k: int, bias: bool = True) -> None:
+        bound = math.sqrt(3.0 / (in_ch_per_group * k))
+        self.uniform(prefix + ".weight", (out_ch, in_ch_per_group, k), bound)
+        if bias:
+            self.uniform(prefix + ".bias", (out_ch,), 0.02)
+
+    def mha(self, prefix: str, dim: int) -> None:
+        for p in ("q_proj", "k_proj", "v_proj", "output_proj"):
+            self.linear(f"{prefix}.{p}", dim, dim)
+
+    def ffn(self, prefix: str, dim: int, inner: int) -> None:
+        self.linear(prefix + ".inner_proj", inner, dim)
+        self.linear(prefix + ".output_proj", dim, inner)
+
+
+def make_unity_state_dict(
+    cfg: S2STConfig, seed: int = DEFAULT_SEED, dtype: torch.dtype = torch.float16,
+    with_t2u: bool = True,
+) -> Dict[str, torch.Tensor]:
+    """UnitY2 speech-encoder / text-decoder / NAR-T2U weights."""
+    g = _Gen(seed, dtype)
+    M = cfg.model_dim
+    feat = cfg.num_fbank_channels * cfg.fbank_stride
+
+    # speech encoder frontend (loader.py:207-208)
+    g.layer_norm("speech_encoder_frontend.post_extract_layer_norm", feat)
+    g.linear("speech_encoder_frontend.model_dim_proj", M, feat)
+
+    # conformer-shaw blocks (loader.py:209-231)
+    for i in range(cfg.enc_layers):
+        p = f"speech_encoder.inner.layers.{i}"
+        for f in ("ffn1", "ffn2"):
+            g.layer_norm(f"{p}.{f}_layer_norm", M)
+            g.ffn(f"{p}.{f}", M, cfg.enc_ffn_dim)
+        g.layer_norm(f"{p}.self_attn_layer_norm", M)
+        g.mha(f"{p}.self_attn", M)
+        g.normal(f"{p}.self_attn.sdpa.rel_k_embed.weight", (cfg.shaw_num_pos, cfg.head_dim), cfg.head_dim ** -0.5)
+        g.layer_norm(f"{p}.conv_layer_norm", M)
+        g.conv1d(f"{p}.conv.pointwise_conv1", 2 * M, M, 1, bias=False)
+        g.conv1d(f"{p}.conv.depthwise_conv", M, 1, cfg.depthwise_conv_kernel_size, bias=False)
+        g.layer_norm(f"{p}.conv.layer_norm", M)
+        g.conv1d(f"{p}.conv.pointwise_conv2", M, M, 1, bias=False)
+        g.layer_norm(f"{p}.layer_norm", M)
+
+    # adaptor (adaptor_block.py:61-96, 170-225)
+    g.layer_norm("speech_encoder.inner_layer_norm", M)
+    g.linear("speech_encoder.proj1", cfg.adaptor_proj_dim, M)
+    g.linear("speech_encoder.proj2", M, cfg.adaptor_proj_dim)
+    p = "speech_encoder.adaptor_layers.0"
+    g.layer_norm(f"{p}.residual_layer_norm", M)
+    g.conv1d(f"{p}.residual_conv", 2 * M, M, cfg.adaptor_kernel_size)
+    g.layer_norm(f"{p}.self_attn_layer_norm", M)
+    g.conv1d(f"{p}.self_attn_conv", 2 * M, M, cfg.adaptor_kernel_size)
+    g.mha(f"{p}.self_attn", M)
+    g.layer_norm(f"{p}.ffn_layer_norm", M)
+    g.ffn(f"{p}.ffn", M, cfg.adaptor_ffn_dim)
+    g.layer_norm("speech_encoder.layer_norm", M)
+
+    # text decoder (tied embedding, loader.py:130-133)
+    # std 0.5/sqrt(M): with the full 1/sqrt(M) a random-init decoder with tied
+    # input/output embeddings just echoes its input token with a huge margin.
+    g.normal("text_decoder_frontend.embed.weight", (cfg.text_vocab_size, M), 0.5 * M ** -0.5)
+    g.sd["text_decoder_frontend.embed.weight"][cfg.pad_idx].zero_()
+    g.sd["final_proj.weight"] = g.sd["text_decoder_frontend.embed.weight"]
+    for i in range(cfg.dec_layers):
+        p = f"text_decoder.layers.{i}"
+        g.layer_norm(f"{p}.self_attn_layer_norm", M)
+        g.mha(f"{p}.self_attn", M)
+        g.layer_norm(f"{p}.encoder_decoder_attn_layer_norm", M)
+        g.mha(f"{p}.encoder_decoder_attn", M)
+        g.layer_norm(f"{p}.ffn_layer_norm", M)
+        g.ffn(f"{p}.ffn", M, cfg.dec_ffn_dim)
+    g.layer_norm("text_decoder.layer_norm", M)
+
+    if not with_t2u:
+        return g.sd
+
+    # NAR T2U (t2u_builder.py:455-715)
+    for i in range(cfg.t2u_enc_layers):
+        p = f"t2u_model.encoder.layers.{i}"
+        g.layer_norm(f"{p}.self_attn_layer_norm", M)
+        g.mha(f"{p}.self_attn", M)
+        g.layer_norm(f"{p}.ffn_layer_norm", M)
+        g.ffn(f"{p}.ffn", M, cfg.t2u_ffn_dim)
+    g.layer_norm("t2u_model.encoder.layer_norm", M)
+
+    f = "t2u_model.decoder_frontend"
+    g.normal(f"{f}.embed.weight", (cfg.unit_vocab_size, M), M ** -0.5)
+    # Rows that are not speech units (control symbols 0..3 and the language /
+    # spare symbols above num_units+4) are zeroed so that the arg-max of the
+    # synthetic model is always a valid vocoder unit.
+    n_units = cfg.vocoder.num_embeddings
+    g.sd[f"{f}.embed.weight"][:4].zero_()
+    g.sd[f"{f}.embed.weight"][4 + n_units:].zero_()
+    g.sd["t2u_model.final_proj.weight"] = g.sd[f"{f}.embed.weight"]
+    g.normal(f"{f}.embed_char.weight", (cfg.char_vocab_size, M), M ** -0.5)
+    g.sd[f"{f}.pos_emb_alpha"] = torch.tensor([0.9], dtype=dtype)
+    g.sd[f"{f}.pos_emb_alpha_char"] = torch.tensor([1.1], dtype=dtype)
+    d = f"{f}.variance_adaptor.duration_predictor"
+    H, K = cfg.var_pred_hidden_dim, cfg.var_pred_kernel_size
+    g.conv1d(f"{d}.conv1.0", H, M, K)
+    g.layer_norm(f"{d}.ln1", H)
+    g.conv1d(f"{d}.conv2.0", H, H, K)
+    g.layer_norm(f"{d}.ln2", H)
+    # log(dur+1) ~ N(1.25, 0.3): durations of 2..4 units per character.
+    g.uniform(f"{d}.proj.weight", (1, H), 0.3 * math.sqrt(3.0 / H))
+    g.sd[f"{d}.proj.bias"] = torch.tensor([1.25], dtype=dtype)
+    for i in range(cfg.t2u_dec_layers):
+        p = f"t2u_model.decoder.layers.{i}"
+        g.mha(f"{p}.self_attn", M)
+        g.layer_norm(f"{p}.self_attn_layer_norm", M)
+        g.conv1d(f"{p}.conv1d.conv1", cfg.t2u_conv_inner_dim, M, cfg.t2u_conv_kernel)
+        g.conv1d(f"{p}.conv1d.conv2", M, cfg.t2u_conv_inner_dim, cfg.t2u_conv_kernel)
+        g.layer_norm(f"{p}.conv1d_layer_norm", M)
+    g.layer_norm("t2u_model.decoder.layer_norm", M)
+    return g.sd
+
+
+def make_vocoder_state_dict(
+    cfg: S2STConfig, seed: int = DEFAULT_SEED, dtype: torch.dtype = torch.float16
+) -> Dict[str, torch.Tensor]:
+    """Code-HiFi-GAN weights, weight-norm parametrised (``weight_g`` /
+    ``weight_v``) as in the published ``vocoder_v2.pt`` (hifigan.py:143-176)."""
+    v = cfg.vocoder
+    g = _Gen(seed + 1, dtype)
+    P = "code_generator"
+
+    def wn_conv(prefix: str, out_ch: int, in_ch: int, k: int, transposed: bool = False) -> None:
+        # Conv1d weight_v: (out,in,k), g per out-channel; ConvTranspose1d
+        # weight_v: (in,out,k), g per in-channel (torch weight_norm dim=0).
+        shape = (in_ch, out_ch, k) if transposed else (out_ch, in_ch, k)
+        fan_in = in_ch * k / (1 if not transposed else 1)
+        bound = math.sqrt(3.0 / fan_in)
+        g.uniform(prefix + ".weight_v", shape, bound)
+        vv = g.sd[prefix + ".weight_v"].float()
+        norm = vv.reshape(shape[0], -1).norm(dim=1).reshape(shape[0], 1, 1)
+        scale = torch.rand(shape[0], 1, 1, generator=g._g(prefix + ".gs")) * 0.4 + 0.8
+        g.sd[prefix + ".weight_g"] = (norm * scale).to(dtype)
+        g.uniform(prefix + ".bias", (out_ch,), 0.02)
+
+    g.normal(f"{P}.dict.weight", (v.num_embeddings, v.embedding_dim), 1.0)
+    g.normal(f"{P}.spkr.weight", (v.num_spkrs, v.spkr_embedding_dim), 1.0)
+    g.normal(f"{P}.lang.weight", (v.num_langs, v.lang_embedding_dim), 1.0)
+    wn_conv(f"{P}.conv_pre", v.upsample_initial_channel, v.model_in_dim, 7)
+    ch = v.upsample_initial_channel
+    for i, (u, k) in enumerate(zip(v.upsample_rates, v.upsample_kernel_sizes)):
+        wn_conv(f"{P}.ups.{i}", ch // 2, ch, k, transposed=True)
+        ch //= 2
+        for j, (rk, dil) in enumerate(zip(v.resblock_kernel_sizes, v.resblock_dilation_sizes)):
+            r = f"{P}.resblocks.{i * len(v.resblock_kernel_sizes) + j}"
+            for m in range(len(dil)):
+                wn_conv(f"{r}.convs1.{m}", ch, ch, rk)
+                wn_conv(f"{r}.convs2.{m}", ch, ch, rk)
+    wn_conv(f"{P}.conv_post", 1, ch, 7)
+    return g.sd
+
+
+def synthetic_waveform(index: int, seconds: float = 10.0, sample_rate: int = 16000) -> torch.Tensor:
+    """SURVEY.md section 8(d) synthetic audio: 0.1*N(0,1) noise + three tones
+    (220/440/1760 Hz, amplitude 0.2) under a 4 Hz envelope, in [-1, 1)."""
+    n = int(round(seconds * sample_rate))
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(1234 + index)
+    t = torch.arange(n, dtype=torch.float64) / sample_rate
+    x = 0.1 * torch.randn(n, generator=gen, dtype=torch.float64)
+    env = 0.5 * (1.0 + torch.sin(2 * math.pi * 4.0 * t))
+    for f in (220.0, 440.0, 1760.0):
+        x = x + 0.2 * env * torch.sin(2 * math.pi * f * t + 0.3 * index)
+    return x.clamp_(-1.0, 1.0 - 2**-15).to(torch.float32)

@@ -1,0 +1,294 @@
+"""Host-side tokenizers of the S2ST path (integer / string logic only).
+
+* :class:`UnitTokenizer` mirrors
+  src/seamless_communication/models/unity/unit_tokenizer.py:15-243.
+* :class:`NllbTextTokenizer` exposes what the hot path needs from fairseq2's
+  ``NllbTokenizer``: vocabulary info, ``index_to_token`` (used by
+  nar_decoder_frontend.py:130-141), the target-mode prefix ``[</s>, __lang__]``
+  and id -> text decoding.  It is backed either by a real SentencePiece model
+  (``tokenizer.model`` of cards/unity_nllb-100.yaml) or, when no model file is
+  reachable, by a deterministic synthetic vocabulary of the same layout.
+* :class:`CharTokenizer` is the character SPM used by the NAR T2U frontend
+  (``token_to_index`` only, nar_decoder_frontend.py:249-252).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+SPACE = "▁"  # nar_decoder_frontend.py:28
+
+
+@dataclass(frozen=True)
+class VocabularyInfo:
+    size: int
+    unk_idx: Optional[int]
+    bos_idx: Optional[int]
+    eos_idx: Optional[int]
+    pad_idx: Optional[int]
+
+
+# --------------------------------------------------------------------------- #
+# Units
+# --------------------------------------------------------------------------- #
+class UnitTokenizer:
+    """unit_tokenizer.py:15-117 (vocabulary arithmetic only)."""
+
+    def __init__(self, num_units: int, langs: Sequence[str], model_arch: str) -> None:
+        self.num_units = num_units
+        self.langs = list(langs)
+        self.lang_map = {lang: idx for idx, lang in enumerate(langs)}
+        # "_v2" architectures have a NAR decoder (unit_tokenizer.py:38).
+        if model_arch.split("_")[-1] == "v2":
+            self.is_nar_decoder = True
+            self.lang_symbol_repititions = 1
+        else:
+            self.is_nar_decoder = False
+            self.lang_symbol_repititions = 2
+        vocab_size = num_units + self.lang_symbol_repititions * (len(langs) + 1) + 4
+        self.vocab_info = VocabularyInfo(
+            size=vocab_size, bos_idx=0, pad_idx=1, eos_idx=2, unk_idx=3
+        )
+
+    def lang_to_index(self, lang: str) -> int:
+        try:
+            return (
+                self.num_units
+                + (self.lang_symbol_repititions - 1) * (len(self.langs) + 1)
+                + self.lang_map[lang]
+                + 4
+            )
+        except KeyError:
+            langs = ", ".join(self.langs)
+            raise ValueError(
+                f"`lang` must be one of the supported languages, but is '{lang}' instead. Supported languages: {langs}"
+            )
+
+    def index_to_lang(self, idx: int) -> str:
+        relative_idx = (
+            idx - self.num_units - (self.lang_symbol_repititions - 1) * (len(self.langs) + 1) - 4
+        )
+        if relative_idx < 0 or relative_idx >= len(self.langs):
+            raise ValueError(
+                f"`idx` must correspond to one of the supported language symbol indices (0 to {len(self.langs) - 1}), but is {idx} instead."
+            )
+        return self.langs[relative_idx]
+
+    def create_encoder(self, lang: str) -> "UnitTokenEncoder":
+        return UnitTokenEncoder(self, lang, self.is_nar_decoder)
+
+    def create_decoder(self) -> "UnitTokenDecoder":
+        return UnitTokenDecoder(self, self.is_nar_decoder)
+
+
+class UnitTokenEncoder:
+    """unit_tokenizer.py:120-206 on int64 numpy arrays of shape (N, S)."""
+
+    def __init__(self, tokenizer: UnitTokenizer, lang: str, is_nar_decoder: bool) -> None:
+        if lang not in tokenizer.lang_map:
+            langs = ", ".join(tokenizer.langs)
+            raise ValueError(
+                f"`lang` must be one of the supported languages, but is '{lang}' instead. Supported languages: {langs}"
+            )
+        self.tokenizer = tokenizer
+        self.is_nar_decoder = is_nar_decoder
+        self.eos_idx = tokenizer.vocab_info.eos_idx
+        self.unk_idx = tokenizer.vocab_info.unk_idx
+        self.lang_idx = tokenizer.lang_to_index(lang)
+        if not is_nar_decoder:
+            self.prefix_indices = np.array([self.eos_idx, self.lang_idx], dtype=np.int64)
+        else:
+            self.prefix_indices = None
+
+    def __call__(self, units: np.ndarray) -> np.ndarray:
+        units = np.asarray(units, dtype=np.int64)
+        n = units.shape[0]
+        if self.prefix_indices is not None:
+            out = np.concatenate([np.tile(self.prefix_indices, (n, 1)), units], axis=1)
+            seqs = out[:, 2:]
+        else:
+            out = units.copy()
+            seqs = out
+        seqs += 4
+        seqs[seqs >= self.tokenizer.num_units + 4] = self.unk_idx
+        return out
+
+
+class UnitTokenDecoder:
+    """unit_tokenizer.py:209-243."""
+
+    def __init__(self, tokenizer: UnitTokenizer, is_nar_decoder: bool) -> None:
+        self.eos_idx = tokenizer.vocab_info.eos_idx
+        self.pad_idx = tokenizer.vocab_info.pad_idx
+        self.is_nar_decoder = is_nar_decoder
+
+    def __call__(self, token_indices: np.ndarray) -> np.ndarray:
+        token_indices = np.asarray(token_indices, dtype=np.int64)
+        if token_indices.shape[1] == 0:
+            return token_indices
+        units = token_indices.copy()
+        if not self.is_nar_decoder:
+            units = units[:, 1:]
+        units[units == self.eos_idx] = self.pad_idx
+        units[units == self.pad_idx] = self.pad_idx + 4
+        if self.is_nar_decoder:
+            units -= 4
+        else:
+            units[:, 1:] -= 4
+        return units
+
+
+# --------------------------------------------------------------------------- #
+# Text
+# --------------------------------------------------------------------------- #
+_PUNCT = [",", ".", "!", "?", ";", ":", "-", "'", '"', "(", ")"]
+
+
+def _mix(i: int) -> int:
+    x = (i * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 29
+    x = (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 32
+    return x
+
+
+def synthetic_piece(i: int) -> str:
+    """Deterministic pseudo sentence piece for vocabulary slot ``i``."""
+    h = _mix(i)
+    kind = h % 100
+    if kind < 3:
+        return _PUNCT[(h >> 8) % len(_PUNCT)]
+    if kind < 4:
+        return SPACE
+    n = 1 + (h >> 8) % 6
+    s = "".join(chr(ord("a") + ((h >> (16 + 5 * k)) % 26)) for k in range(n))
+    if kind < 60:
+        s = SPACE + s
+    return s
+
+
+class NllbTextTokenizer:
+    """NLLB-layout text vocabulary.
+
+    Layout (fairseq2 NllbTokenizer: ``<pad>@0`` control symbol in front of the
+    SentencePiece model, language + data-source control symbols appended):
+    ``<pad>=0 <unk>=1 <s>=2 </s>=3``, pieces, ``__lang__`` x len(langs),
+    ``<MINED_DATA> <MMT_BT_DATA> <SMT_BT_DATA>``, padding pieces up to ``size``.
+    """
+
+    def __init__(
+        self,
+        size: int,
+        langs: Sequence[str],
+        default_lang: str = "eng",
+        spm_path: Optional[str] = None,
+    ) -> None:
+        self.langs = list(langs)
+        self.default_lang = default_lang
+        self.vocab_info = VocabularyInfo(size=size, unk_idx=1, bos_idx=2, eos_idx=3, pad_idx=0)
+        extra = [f"__{l}__" for l in self.langs] + ["<MINED_DATA>", "<MMT_BT_DATA>", "<SMT_BT_DATA>"]
+        self._spm = None
+        if spm_path is not None:
+            import sentencepiece as spm
+
+            self._spm = spm.SentencePieceProcessor(model_file=spm_path)
+            n_spm = self._spm.get_piece_size()
+            # SPM ids 0..2 are <unk>,<s>,</s>; fairseq2 inserts <pad> at 0.
+            pieces = ["<pad>"] + [self._spm.id_to_piece(i) for i in range(n_spm)]
+            self._first_lang = len(pieces)
+            pieces += extra
+        else:
+            n_pieces = size - len(extra) - 4
+            if n_pieces < 16:
+                raise ValueError("text vocabulary too small for the control symbols")
+            pieces = ["<pad>", "<unk>", "<s>", "</s>"] + [synthetic_piece(i) for i in range(4, 4 + n_pieces)]
+            self._first_lang = len(pieces)
+            pieces += extra
+        while len(pieces) < size:
+            pieces.append(f"<extra_{len(pieces)}>")
+        self._pieces: List[str] = pieces[:size]
+        self._index: Optional[Dict[str, int]] = None
+        self._lang_idx = {l: self._first_lang + i for i, l in enumerate(self.langs)}
+
+    # -- fairseq2 SentencePieceModel surface used by the reference ---------- #
+    def index_to_token(self, idx: int) -> str:
+        return self._pieces[idx]
+
+    def token_to_index(self, tok: str) -> int:
+        if self._index is None:
+            self._index = {}
+            for i, p in enumerate(self._pieces):
+                self._index.setdefault(p, i)
+        return self._index.get(tok, self.vocab_info.unk_idx)
+
+    def lang_token_idx(self, lang: str) -> int:
+        if lang not in self._lang_idx:
+            raise ValueError(
+                f"`lang` must be a supported language, but is '{lang}' instead."
+            )
+        return self._lang_idx[lang]
+
+    def target_prefix(self, lang: str) -> List[int]:
+        """NLLB "target" mode prefix: ``[</s>, __lang__]``."""
+        return [self.vocab_info.eos_idx, self.lang_token_idx(lang)]
+
+    def decode(self, ids: Sequence[int]) -> str:
+        """ids -> text; control symbols are skipped (SentencePiece decode)."""
+        first, last = self._first_lang, self._first_lang + len(self.langs) + 3
+        toks = []
+        for i in ids:
+            i = int(i)
+            if i in (0, 2, 3) or first <= i < last or i >= last:
+                continue
+            toks.append(" ⁇ " if i == 1 else self._pieces[i])
+        return "".join(toks).replace(SPACE, " ").strip()
+
+    # -- per-vocabulary tables for the NAR frontend (built once) ------------ #
+    def nar_tables(self, char_tokenizer: "CharTokenizer"):
+        """Vectorised form of the per-token string rules of
+        nar_decoder_frontend.py:158-259: for every vocabulary entry its length,
+        "starts with SPACE and longer than one char", "is punctuation", and the
+        char-id sequence (CSR)."""
+        if getattr(self, "_nar_tables", None) is None:
+            n = len(self._pieces)
+            tok_len = np.zeros(n, dtype=np.int64)
+            starts_sp = np.zeros(n, dtype=bool)
+            is_punc = np.zeros(n, dtype=bool)
+            offs = np.zeros(n + 1, dtype=np.int64)
+            ids: List[int] = []
+            for i, p in enumerate(self._pieces):
+                tok_len[i] = len(p)
+                starts_sp[i] = len(p) > 1 and p[0] == SPACE
+                is_punc[i] = (
+                    len(p) == 1 and not p.isalpha() and not p.isnumeric() and p != SPACE
+                )
+                ids.extend(char_tokenizer.token_to_index(ch) for ch in p)
+                offs[i + 1] = len(ids)
+            self._nar_tables = (tok_len, starts_sp, is_punc, offs, np.asarray(ids, dtype=np.int64))
+        return self._nar_tables
+
+
+class CharTokenizer:
+    """Character vocabulary (fairseq control order bos=0,pad=1,eos=2,unk=3;
+    t2u_builder.py:229 ``char_pad_idx=1``)."""
+
+    def __init__(self, size: int, spm_path: Optional[str] = None) -> None:
+        self.vocab_info = VocabularyInfo(size=size, bos_idx=0, pad_idx=1, eos_idx=2, unk_idx=3)
+        self._spm = None
+        if spm_path is not None:
+            import sentencepiece as spm
+
+            self._spm = spm.SentencePieceProcessor(model_file=spm_path)
+            self._map = None
+        else:
+            chars = [SPACE] + [chr(ord("a") + k) for k in range(26)] + _PUNCT
+            if 4 + len(chars) > size:
+                raise ValueError("char vocabulary too small")
+            self._map = {c: 4 + i for i, c in enumerate(chars)}
+
+    def token_to_index(self, ch: str) -> int:
+        if self._spm is not None:
+            return int(self._spm.piece_to_id(ch))
+        return self._map.get(ch, self.vocab_info.unk_idx)
