@@ -1,0 +1,195 @@
+/*
+ * seamless_hip.h — C ABI of libseamless_hip.so, the MI355X (gfx950) native
+ * implementation of the SeamlessM4T-v2 speech-to-speech hot path.
+ *
+ * This is the drop-in boundary for the arithmetic that the reference reaches
+ * through fairseq2/PyTorch operators from
+ *   src/seamless_communication/inference/translator.py:216-428 (Translator.predict)
+ *   src/seamless_communication/inference/generator.py:228-364  (UnitYGenerator.__call__)
+ * and is shaped after the reference's own native boundary
+ *   ggml/examples/unity/lib/unity_lib.h:45-61, ggml/examples/unity/fairseq2.h:86-334
+ * but C-clean: plain pointers and sizes, no C++ types, no exceptions across the
+ * boundary.  Every function returns 0 on success or a negative sc_status; the
+ * message of the last failure on the calling thread is sc_last_error().
+ *
+ * Pointer conventions
+ *   d_*   device pointers (HBM of the model's GPU), fp32 unless stated
+ *   h_*   host pointers (small integer arrays: lengths, token ids)
+ * A handle owns one HIP stream; it is not thread-safe; handles on different
+ * GPUs are independent (one process per GPU in the data-parallel driver).
+ */
+#ifndef SEAMLESS_HIP_H_
+#define SEAMLESS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_ABI_VERSION 1
+#define SC_MAX_UPSAMPLES 8
+#define SC_MAX_RESBLOCK_KERNELS 4
+#define SC_MAX_RESBLOCK_DILATIONS 4
+
+typedef enum sc_status {
+    SC_OK = 0,
+    SC_ERR_INVALID = -1,  /* bad argument / missing tensor / shape mismatch */
+    SC_ERR_HIP = -2,      /* a HIP runtime call failed                      */
+    SC_ERR_CAPACITY = -3, /* caller buffer too small                        */
+    SC_ERR_INTERNAL = -4
+} sc_status;
+
+typedef enum sc_dtype { SC_F16 = 0, SC_F32 = 1, SC_I32 = 2 } sc_dtype;
+
+/* One entry of the weight table handed to sc_load(): tensors carry the
+ * fairseq2 state-dict key names produced by the reference's
+ * convert_unity_checkpoint / convert_vocoder_checkpoint
+ * (models/unity/loader.py:27-155, models/vocoder/loader.py:20-36). */
+typedef struct sc_tensor_desc {
+    const char* name;
+    int32_t dtype; /* sc_dtype */
+    int32_t ndim;
+    int64_t shape[4];
+    const void* data; /* host pointer, or device pointer when on_device != 0 */
+    int32_t on_device;
+} sc_tensor_desc;
+
+/* Architecture description (reference: unity `base_v2` builder.py:165-192,
+ * conformer_shaw 600m builder.py:54-68, t2u `base_nar` t2u_builder.py:186-232,
+ * vocoder `base` vocoder/builder.py:42-64). */
+typedef struct sc_config {
+    int32_t abi_version;
+    int32_t model_dim, num_heads;
+    int32_t num_fbank_channels, fbank_stride;
+    int32_t enc_layers, enc_ffn_dim, depthwise_conv_kernel_size, shaw_max_left, shaw_max_right;
+    int32_t adaptor_kernel_size, adaptor_stride, adaptor_ffn_dim, adaptor_proj_dim;
+    int32_t dec_layers, dec_ffn_dim, text_vocab_size, text_max_seq_len;
+    int32_t pad_idx, unk_idx, bos_idx, eos_idx;
+    int32_t t2u_enc_layers, t2u_dec_layers, t2u_ffn_dim, t2u_conv_kernel, t2u_conv_inner_dim;
+    int32_t unit_vocab_size, unit_pad_idx, unit_eos_idx, unit_max_seq_len;
+    int32_t char_vocab_size, char_max_seq_len, var_pred_hidden_dim, var_pred_kernel_size;
+    /* vocoder */
+    int32_t voc_num_upsamples;
+    int32_t voc_upsample_rates[SC_MAX_UPSAMPLES];
+    int32_t voc_upsample_kernel_sizes[SC_MAX_UPSAMPLES];
+    int32_t voc_upsample_initial_channel;
+    int32_t voc_num_resblock_kernels;
+    int32_t voc_resblock_kernel_sizes[SC_MAX_RESBLOCK_KERNELS];
+    int32_t voc_num_resblock_dilations;
+    int32_t voc_resblock_dilation_sizes[SC_MAX_RESBLOCK_KERNELS][SC_MAX_RESBLOCK_DILATIONS];
+    int32_t voc_num_embeddings, voc_embedding_dim, voc_lang_embedding_dim, voc_num_langs;
+    int32_t voc_spkr_embedding_dim, voc_num_spkrs;
+    int32_t has_t2u, has_vocoder;
+} sc_config;
+
+/* Text generation options: the fields of SequenceGeneratorOptions
+ * (inference/generator.py:59-84) that the greedy path honours. */
+typedef struct sc_gen_opts {
+    int32_t beam_size;        /* must be 1 (greedy); >1 is rejected with SC_ERR_INVALID */
+    float soft_max_seq_len_a; /* max_len = min(hard, int(a*S_src) + b), prefix included */
+    int32_t soft_max_seq_len_b;
+    int32_t hard_max_seq_len;
+    int32_t min_seq_len;
+    float unk_penalty;
+    int32_t use_graph; /* replay the decoder step from a captured hipGraph */
+} sc_gen_opts;
+
+typedef struct sc_model sc_model;
+
+const char* sc_last_error(void);
+int sc_abi_version(void);
+
+/* Copies the weights into HBM (the library owns them), repacks conv weights,
+ * folds weight-norm, fuses QKV.  Replaces load_unity_model/load_vocoder_model +
+ * model.to(device) (inference/translator.py:113-154). */
+sc_model* sc_load(const sc_tensor_desc* tensors, size_t n_tensors, const sc_config* cfg, int device);
+void sc_free(sc_model* m);
+int sc_synchronize(sc_model* m);
+
+/* Per-vocabulary tables for NARDecoderFrontend's string rules
+ * (models/unity/nar_decoder_frontend.py:158-259), built once by the host from
+ * the text / char tokenizers: token length, "starts with SPACE and len>1",
+ * "is punctuation", CSR char ids. */
+int sc_set_nar_tables(sc_model* m, int32_t vocab, const int32_t* h_tok_len, const uint8_t* h_starts_space,
+                      const uint8_t* h_is_punct, const int64_t* h_char_offsets, const int32_t* h_char_ids);
+
+/* a1: WaveformToFbankConverter(num_mel_bins=80, waveform_scale=2**15, standardize)
+ * (translator.py:136-143) + Collater zero padding.  d_wav: [n][wav_stride] fp32
+ * in [-1,1).  d_out: [n][t_rows][80]; rows >= frames are zero. */
+int sc_fbank(sc_model* m, const float* d_wav, int32_t n, int64_t wav_stride, const int32_t* h_num_samples,
+             int32_t standardize, float* d_out, int32_t t_rows, int32_t* h_out_frames);
+
+/* a3-a7: UnitYModel.encode_speech (models/unity/model.py:132-139).
+ * d_fbank [n][t_frames][80] (t_frames even), d_enc_out [n][sc_encoder_out_len(t_frames)][model_dim]. */
+int32_t sc_encoder_out_len(const sc_model* m, int32_t t_frames);
+int sc_encode_speech(sc_model* m, const float* d_fbank, int32_t n, int32_t t_frames, const int32_t* h_frame_lens,
+                     float* d_enc_out, int32_t* h_out_lens);
+
+/* a8-a11: greedy text generation with KV cache (BeamSearchSeq2SeqGenerator with
+ * beam_size=1, echo_prompt=True; generator.py:147-156, :261-263).  h_out_ids
+ * [n][max_len] (pad filled), h_out_lens[n] include prompt and EOS.  If
+ * d_dec_hidden != NULL it receives the decoder output (after the final
+ * LayerNorm) of every fed position: [n][max_len-1][model_dim] — the tensor the
+ * reference recomputes with a second teacher-forced pass (generator.py:294-299). */
+int32_t sc_text_max_len(const sc_model* m, const sc_gen_opts* opts, int32_t s_enc);
+int sc_generate_text(sc_model* m, const float* d_enc, int32_t n, int32_t s_enc, const int32_t* h_enc_lens,
+                     const sc_gen_opts* opts, const int32_t* h_prefix, int32_t prefix_len, int32_t* h_out_ids,
+                     int32_t* h_out_lens, float* h_out_scores, float* d_dec_hidden);
+
+/* Teacher-forced decoder pass over given tokens (UnitYModel.decode without
+ * state bag, models/unity/model.py:154-180).  h_tokens [n][s_text];
+ * d_dec_hidden [n][s_text][model_dim]. */
+int sc_decode_text(sc_model* m, const float* d_enc, int32_t n, int32_t s_enc, const int32_t* h_enc_lens,
+                   const int32_t* h_tokens, int32_t s_text, float* d_dec_hidden);
+
+/* a12-a17: UnitYNART2UModel.forward + argmax + unit decoding
+ * (models/unity/model.py:379-441, generator.py:338-353).  h_text_seqs
+ * [n][s_text] is text_seqs[:, :-1] (pad filled), h_text_lens its PaddingMask.
+ * Results are kept in the handle: sizes via the out params, ids via
+ * sc_get_units / sc_get_durations. */
+int sc_t2u_nar(sc_model* m, const float* d_dec_hidden, int32_t n, int32_t s_text, const int32_t* h_text_lens,
+               const int32_t* h_text_seqs, float duration_factor, int32_t* h_unit_lens, int32_t* out_s_unit_max,
+               int32_t* out_s_char_max);
+int sc_get_units(sc_model* m, int32_t* h_units /* [n][s_unit_max], pad = unit_pad_idx */);
+int sc_get_durations(sc_model* m, int32_t* h_durations /* [n][s_char_max] */, int32_t* h_char_ids,
+                     int32_t* h_char_seq_lens);
+
+/* a19-a20: Vocoder.forward with dur_prediction=False (models/vocoder/vocoder.py:25-49,
+ * codehifigan.py:75-101, hifigan.py:180-196).  d_wav [n][s_units*hop]. */
+int32_t sc_vocoder_hop(const sc_model* m);
+int sc_vocode(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, const int32_t* h_lang_idx,
+              const int32_t* h_spkr_idx, float* d_wav);
+
+/* Per-kernel HIP-event timing on the handle's stream (bench.py roofline).  The report is text:
+ * one "name launches total_ms algorithmic_flops algorithmic_bytes" line per kernel family. */
+int sc_prof_enable(int on);
+int sc_prof_reset(void);
+int64_t sc_prof_report(char* buf, int64_t cap);
+
+/* Kernel-level entry points used by the parity tests (tests/test_ops_gpu.py).
+ * All pointers are device pointers; weights fp16, activations fp32. */
+int sc_op_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float* d_y, int32_t rows, int32_t C,
+                    int32_t act);
+int sc_op_linear(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y,
+                 int32_t M, int32_t N, int32_t K, int32_t act, float alpha, int32_t split, int32_t force_gemv);
+int sc_op_conv1d(const float* d_x, const void* d_w_f16_packed, const float* d_bias, const float* d_res, float* d_y,
+                 int32_t nb, int32_t t_in, int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t pad,
+                 int32_t dil, const int32_t* d_in_lens, int32_t in_act, int32_t act);
+int sc_op_pack_conv_weight(const void* d_w_f16, void* d_dst_f16, int32_t cout, int32_t cin, int32_t k);
+int sc_op_conv_transpose1d(const float* d_x, const void* d_v_f16, const void* d_g_f16, const float* d_bias,
+                           float* d_y, int32_t nb, int32_t t_in, int32_t cin, int32_t cout, int32_t k,
+                           int32_t stride, int32_t pad, int32_t in_act);
+int sc_op_attention(const float* d_q, const float* d_k, const float* d_v, float* d_out, int32_t nb, int32_t heads,
+                    int32_t sq, int32_t skv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                    const int32_t* d_kv_lens, int32_t causal, const float* d_rel_k, int32_t rel_left,
+                    int32_t rel_right);
+int sc_op_glu_dwconv(const float* d_x, const float* d_w, float* d_y, int32_t nb, int32_t T, int32_t C, int32_t k,
+                     const int32_t* d_lens);
+int sc_op_argmax(const float* d_logits, int32_t rows, int32_t V, int32_t* d_idx, float* d_lprob);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEAMLESS_HIP_H_ */

@@ -1,0 +1,329 @@
+// extern "C" surface of libseamless_hip.so (declared in include/seamless_hip.h).
+#include <cstring>
+
+#include "model.h"
+
+using namespace sc;
+
+struct sc_model {
+    Model m;
+};
+
+#define SC_API_BEGIN try {
+#define SC_API_END                                                       \
+    }                                                                    \
+    catch (const sc::Error& e) { return e.code; }                        \
+    catch (const std::exception& e) {                                    \
+        sc::set_error("unexpected C++ exception: %s", e.what());         \
+        return SC_ERR_INTERNAL;                                          \
+    }                                                                    \
+    return SC_OK;
+
+static hipStream_t g_op_stream = nullptr;  // ops use the default stream
+
+extern "C" {
+
+const char* sc_last_error(void) { return sc::get_error(); }
+int sc_abi_version(void) { return SC_ABI_VERSION; }
+
+sc_model* sc_load(const sc_tensor_desc* tensors, size_t n_tensors, const sc_config* cfg, int device) {
+    sc_model* h = nullptr;
+    try {
+        SC_CHECK(tensors && cfg, "sc_load: null argument");
+        SC_CHECK(cfg->abi_version == SC_ABI_VERSION, "sc_load: config ABI version %d != library %d", cfg->abi_version,
+                 SC_ABI_VERSION);
+        int ndev = 0;
+        SC_HIP(hipGetDeviceCount(&ndev));
+        SC_CHECK(device >= 0 && device < ndev, "sc_load: device %d not available (%d visible)", device, ndev);
+        SC_HIP(hipSetDevice(device));
+        h = new sc_model();
+        h->m.cfg = *cfg;
+        h->m.device = device;
+        SC_HIP(hipStreamCreateWithFlags(&h->m.stream, hipStreamNonBlocking));
+        load_model(h->m, tensors, n_tensors);
+        return h;
+    } catch (const sc::Error&) {
+    } catch (const std::exception& e) {
+        sc::set_error("sc_load: unexpected C++ exception: %s", e.what());
+    }
+    delete h;
+    return nullptr;
+}
+
+void sc_free(sc_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->m.device);
+    delete m;
+}
+
+int sc_synchronize(sc_model* m) {
+    SC_API_BEGIN
+    SC_CHECK(m, "null handle");
+    SC_HIP(hipSetDevice(m->m.device));
+    SC_HIP(hipStreamSynchronize(m->m.stream));
+    SC_API_END
+}
+
+int sc_set_nar_tables(sc_model* m, int32_t vocab, const int32_t* tok_len, const uint8_t* starts_space,
+                      const uint8_t* is_punct, const int64_t* offs, const int32_t* ids) {
+    SC_API_BEGIN
+    SC_CHECK(m && tok_len && starts_space && is_punct && offs && ids, "sc_set_nar_tables: null argument");
+    SC_CHECK(vocab == m->m.cfg.text_vocab_size, "sc_set_nar_tables: table has %d entries, text vocabulary has %d", vocab,
+             m->m.cfg.text_vocab_size);
+    Model& mm = m->m;
+    mm.tok_len.assign(tok_len, tok_len + vocab);
+    mm.starts_space.assign(starts_space, starts_space + vocab);
+    mm.is_punct.assign(is_punct, is_punct + vocab);
+    mm.char_offsets.assign(offs, offs + vocab + 1);
+    mm.char_ids.assign(ids, ids + offs[vocab]);
+    for (int64_t i = 0; i < offs[vocab]; ++i)
+        SC_CHECK(ids[i] >= 0 && ids[i] < mm.cfg.char_vocab_size, "sc_set_nar_tables: char id %d out of range", ids[i]);
+    SC_API_END
+}
+
+int sc_fbank(sc_model* m, const float* d_wav, int32_t n, int64_t wav_stride, const int32_t* h_num_samples,
+             int32_t standardize, float* d_out, int32_t t_rows, int32_t* h_out_frames) {
+    SC_API_BEGIN
+    SC_CHECK(m && d_wav && h_num_samples && d_out, "sc_fbank: null argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    run_fbank(m->m, d_wav, n, wav_stride, h_num_samples, standardize, d_out, t_rows, h_out_frames);
+    SC_API_END
+}
+
+int32_t sc_encoder_out_len(const sc_model* m, int32_t t_frames) { return m ? encoder_out_len(m->m, t_frames) : -1; }
+
+int sc_encode_speech(sc_model* m, const float* d_fbank, int32_t n, int32_t t_frames, const int32_t* h_frame_lens,
+                     float* d_enc_out, int32_t* h_out_lens) {
+    SC_API_BEGIN
+    SC_CHECK(m && d_fbank && h_frame_lens && d_enc_out, "sc_encode_speech: null argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    run_encode_speech(m->m, d_fbank, n, t_frames, h_frame_lens, d_enc_out, h_out_lens);
+    SC_API_END
+}
+
+int32_t sc_text_max_len(const sc_model* m, const sc_gen_opts* opts, int32_t s_enc) {
+    return (m && opts) ? text_max_len(m->m, *opts, s_enc) : -1;
+}
+
+int sc_generate_text(sc_model* m, const float* d_enc, int32_t n, int32_t s_enc, const int32_t* h_enc_lens,
+                     const sc_gen_opts* opts, const int32_t* h_prefix, int32_t prefix_len, int32_t* h_out_ids,
+                     int32_t* h_out_lens, float* h_out_scores, float* d_dec_hidden) {
+    SC_API_BEGIN
+    SC_CHECK(m && d_enc && h_enc_lens && opts && h_prefix && h_out_ids && h_out_lens, "sc_generate_text: null argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    run_generate_text(m->m, d_enc, n, s_enc, h_enc_lens, *opts, h_prefix, prefix_len, h_out_ids, h_out_lens, h_out_scores,
+                      d_dec_hidden, nullptr, 0);
+    SC_API_END
+}
+
+int sc_decode_text(sc_model* m, const float* d_enc, int32_t n, int32_t s_enc, const int32_t* h_enc_lens,
+                   const int32_t* h_tokens, int32_t s_text, float* d_dec_hidden) {
+    SC_API_BEGIN
+    SC_CHECK(m && d_enc && h_enc_lens && h_tokens && d_dec_hidden && s_text > 0, "sc_decode_text: bad argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    sc_gen_opts o{};
+    o.beam_size = 1;
+    o.min_seq_len = 1;
+    run_generate_text(m->m, d_enc, n, s_enc, h_enc_lens, o, nullptr, 0, nullptr, nullptr, nullptr, d_dec_hidden, h_tokens,
+                      s_text);
+    SC_API_END
+}
+
+int sc_t2u_nar(sc_model* m, const float* d_dec_hidden, int32_t n, int32_t s_text, const int32_t* h_text_lens,
+               const int32_t* h_text_seqs, float duration_factor, int32_t* h_unit_lens, int32_t* out_s_unit_max,
+               int32_t* out_s_char_max) {
+    SC_API_BEGIN
+    SC_CHECK(m && d_dec_hidden && h_text_lens && h_text_seqs, "sc_t2u_nar: null argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    run_t2u_nar(m->m, d_dec_hidden, n, s_text, h_text_lens, h_text_seqs, duration_factor, h_unit_lens, out_s_unit_max,
+                out_s_char_max);
+    SC_API_END
+}
+
+int sc_get_units(sc_model* m, int32_t* h_units) {
+    SC_API_BEGIN
+    SC_CHECK(m && h_units, "sc_get_units: null argument");
+    SC_CHECK(!m->m.last_units.empty(), "sc_get_units: no sc_t2u_nar result is available");
+    std::memcpy(h_units, m->m.last_units.data(), m->m.last_units.size() * 4);
+    SC_API_END
+}
+
+int sc_get_durations(sc_model* m, int32_t* h_durations, int32_t* h_char_ids, int32_t* h_char_seq_lens) {
+    SC_API_BEGIN
+    SC_CHECK(m, "sc_get_durations: null handle");
+    SC_CHECK(!m->m.last_durations.empty(), "sc_get_durations: no sc_t2u_nar result is available");
+    if (h_durations) std::memcpy(h_durations, m->m.last_durations.data(), m->m.last_durations.size() * 4);
+    if (h_char_ids) std::memcpy(h_char_ids, m->m.last_char_ids.data(), m->m.last_char_ids.size() * 4);
+    if (h_char_seq_lens) std::memcpy(h_char_seq_lens, m->m.last_char_seq_lens.data(), m->m.last_char_seq_lens.size() * 4);
+    SC_API_END
+}
+
+int32_t sc_vocoder_hop(const sc_model* m) {
+    if (!m) return -1;
+    int hop = 1;
+    for (int i = 0; i < m->m.cfg.voc_num_upsamples; ++i) hop *= m->m.cfg.voc_upsample_rates[i];
+    return hop;
+}
+
+int sc_vocode(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, const int32_t* h_lang_idx,
+              const int32_t* h_spkr_idx, float* d_wav) {
+    SC_API_BEGIN
+    SC_CHECK(m && h_units && h_lang_idx && h_spkr_idx && d_wav, "sc_vocode: null argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    run_vocode(m->m, h_units, n, s_units, h_lang_idx, h_spkr_idx, d_wav);
+    SC_API_END
+}
+
+int sc_prof_enable(int on) {
+    sc::prof::enable(on != 0);
+    return SC_OK;
+}
+int sc_prof_reset(void) {
+    sc::prof::reset();
+    return SC_OK;
+}
+int64_t sc_prof_report(char* buf, int64_t cap) { return (int64_t)sc::prof::report(buf, (size_t)(cap > 0 ? cap : 0)); }
+
+// --------------------------------------------------------------------------- //
+// kernel-level entry points for the parity tests (default stream, synchronous)
+// --------------------------------------------------------------------------- //
+int sc_op_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float* d_y, int32_t rows, int32_t C,
+                    int32_t act) {
+    SC_API_BEGIN
+    launch_layernorm(d_x, C, d_gamma, d_beta, d_y, C, rows, C, act, nullptr, 1, g_op_stream);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+int sc_op_linear(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y, int32_t M,
+                 int32_t N, int32_t K, int32_t act, float alpha, int32_t split, int32_t force_gemv) {
+    SC_API_BEGIN
+    if (force_gemv) {
+        launch_gemv(d_x, K, static_cast<const __half*>(d_w_f16), K, d_bias, d_res, N, d_y, N, M, N, K, act, alpha, g_op_stream);
+    } else {
+        GemmArgs a;
+        a.A = d_x;
+        a.lda = K;
+        a.W = static_cast<const __half*>(d_w_f16);
+        a.ldw = K;
+        a.bias = d_bias;
+        a.res = d_res;
+        a.ldr = N;
+        a.C = d_y;
+        a.ldc = N;
+        a.M = M;
+        a.N = N;
+        a.K = K;
+        a.rows_per_batch = M;
+        a.t_in = M;
+        a.t_out = M;
+        a.taps = 1;
+        a.cin = K;
+        a.act = act;
+        a.alpha = alpha;
+        a.split = split;
+        launch_gemm(a, g_op_stream);
+    }
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+int sc_op_pack_conv_weight(const void* d_w_f16, void* d_dst_f16, int32_t cout, int32_t cin, int32_t k) {
+    SC_API_BEGIN
+    const int kpad = (int)align_up((int64_t)cin * k, 32);
+    launch_pack_conv_weight(static_cast<const __half*>(d_w_f16), static_cast<__half*>(d_dst_f16), cout, cin, k, kpad,
+                            g_op_stream);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+int sc_op_conv1d(const float* d_x, const void* d_w_f16_packed, const float* d_bias, const float* d_res, float* d_y,
+                 int32_t nb, int32_t t_in, int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t pad, int32_t dil,
+                 const int32_t* d_in_lens, int32_t in_act, int32_t act) {
+    SC_API_BEGIN
+    Model tmp;  // only the stream (null = default) is used by conv1d()
+    Conv c;
+    c.w = static_cast<const __half*>(d_w_f16_packed);
+    c.b = d_bias;
+    c.cout = cout;
+    c.cin = cin;
+    c.k = k;
+    c.kpad = (int)align_up((int64_t)cin * k, 32);
+    conv1d(tmp, d_x, c, d_res, d_y, nb, t_in, stride, pad, dil, d_in_lens, in_act, act);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+int sc_op_conv_transpose1d(const float* d_x, const void* d_v_f16, const void* d_g_f16, const float* d_bias, float* d_y,
+                           int32_t nb, int32_t t_in, int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t pad,
+                           int32_t in_act) {
+    SC_API_BEGIN
+    SC_CHECK(pad == (k - stride) / 2 && k - 2 * pad == stride, "sc_op_conv_transpose1d: unsupported geometry");
+    Model tmp;
+    ConvT c;
+    c.cin = cin;
+    c.cout = cout;
+    c.k = k;
+    c.stride = stride;
+    c.pad = pad;
+    c.taps = cdiv(k, stride);
+    c.kpad = (int)align_up((int64_t)cin * c.taps, 32);
+    float* folded = nullptr;
+    __half* packed = nullptr;
+    SC_HIP(hipMalloc(&folded, (size_t)cin * cout * k * 4));
+    SC_HIP(hipMalloc(&packed, (size_t)stride * cout * c.kpad * 2));
+    launch_weight_norm_fold(static_cast<const __half*>(d_v_f16), static_cast<const __half*>(d_g_f16), folded, cin, cout * k,
+                            g_op_stream);
+    launch_pack_convT_weight(folded, packed, cin, cout, k, stride, c.kpad, g_op_stream);
+    c.w = packed;
+    c.b = d_bias;
+    conv_transpose1d(tmp, d_x, c, d_y, nb, t_in, in_act);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    (void)hipFree(folded);
+    (void)hipFree(packed);
+    SC_API_END
+}
+
+int sc_op_attention(const float* d_q, const float* d_k, const float* d_v, float* d_out, int32_t nb, int32_t heads,
+                    int32_t sq, int32_t skv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* d_kv_lens,
+                    int32_t causal, const float* d_rel_k, int32_t rel_left, int32_t rel_right) {
+    SC_API_BEGIN
+    AttnArgs a;
+    a.q = d_q;
+    a.k = d_k;
+    a.v = d_v;
+    a.out = d_out;
+    a.ldq = ldq;
+    a.ldk = ldk;
+    a.ldv = ldv;
+    a.ldo = ldo;
+    a.nb = nb;
+    a.heads = heads;
+    a.Sq = sq;
+    a.Skv = skv;
+    a.kv_lens = d_kv_lens;
+    a.causal = causal;
+    a.rel_k = d_rel_k;
+    a.rel_left = rel_left;
+    a.rel_right = rel_right;
+    launch_attention(a, g_op_stream);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+int sc_op_glu_dwconv(const float* d_x, const float* d_w, float* d_y, int32_t nb, int32_t T, int32_t C, int32_t k,
+                     const int32_t* d_lens) {
+    SC_API_BEGIN
+    launch_glu_dwconv(d_x, 2 * C, d_w, d_y, C, nb, T, C, k, d_lens, g_op_stream);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+int sc_op_argmax(const float* d_logits, int32_t rows, int32_t V, int32_t* d_idx, float* d_lprob) {
+    SC_API_BEGIN
+    launch_argmax_rows(d_logits, V, rows, V, nullptr, -1, -1, -1, -1, -1, 0.f, d_idx, d_lprob, g_op_stream);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+}  // extern "C"

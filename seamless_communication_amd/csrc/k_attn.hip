@@ -1,0 +1,334 @@
+// Attention kernels (head_dim = 64), fp32 math on the vector ALU.
+//
+// attn_kernel: flash-style tiled attention for a 64-query x 64-key tile per
+//   iteration, K/V tiles staged in LDS, online softmax with wave shuffles,
+//   optional key-length mask, causal mask and Shaw relative-position keys
+//   (logits[i][j] += q_i . R[clamp(j-i,-L,R)+L], the q.R table is computed
+//   once per query tile instead of materialising the (S,S,64) relative keys
+//   of the reference's einsum).
+// decode_attn_kernel: one query per (batch, head) against a KV cache, with the
+//   append of the new key/value row fused in.
+//
+// fp32 everywhere: attention is < 6 % of the encoder FLOPs and the parity
+// target is the fp32 CPU reference; see DESIGN.md for the MFMA follow-up.
+#include "kernels.h"
+
+namespace sc {
+
+static constexpr int HD = 64;   // head dim
+static constexpr int BQ = 64;   // queries per block
+static constexpr int BKV = 64;  // keys per iteration
+static constexpr int QS = 68;   // padded LDS row stride (floats) for Q / K / P tiles
+static constexpr int MAX_REL = 96;
+
+template <bool SHAW>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sQ = smem;                 // [BQ][QS]
+    float* sK = sQ + BQ * QS;         // [BKV][QS]   (also P tile)
+    float* sV = sK + BKV * QS;        // [BKV][HD]
+    float* sQR = sV + BKV * HD;       // [BQ][npos]  (SHAW only)
+
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int q0 = blockIdx.x * BQ;
+    const int h = blockIdx.y;
+    const int n = blockIdx.z;
+    const int kv_len = p.kv_lens ? min(p.kv_lens[n], p.Skv) : p.Skv;
+    const int shift = p.Skv - p.Sq;  // absolute position of query i is i + shift
+    const int npos = p.rel_left + 1 + p.rel_right;
+    const float scale = 0.125f;  // 64^-0.5
+
+    // ---- stage Q tile -------------------------------------------------------
+    for (int idx = tid; idx < BQ * (HD / 4); idx += 256) {
+        const int r = idx >> 4, c4 = idx & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q0 + r < p.Sq)
+            v = *reinterpret_cast<const float4*>(p.q + ((int64_t)n * p.Sq + q0 + r) * p.ldq + h * HD + c4 * 4);
+        *reinterpret_cast<float4*>(&sQ[r * QS + c4 * 4]) = v;
+    }
+    if (SHAW) {
+        // relative keys R[npos][64] staged (temporarily) over the K/V region
+        float* sR = sK;
+        for (int idx = tid; idx < npos * (HD / 4); idx += 256) {
+            const int r = idx >> 4, c4 = idx & 15;
+            *reinterpret_cast<float4*>(&sR[r * QS + c4 * 4]) =
+                *reinterpret_cast<const float4*>(p.rel_k + r * HD + c4 * 4);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < BQ * npos; idx += 256) {
+            const int r = idx / npos, e = idx - r * npos;
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; d += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(&sQ[r * QS + d]);
+                const float4 b = *reinterpret_cast<const float4*>(&sR[e * QS + d]);
+                acc = fmaf(a.x, b.x, acc);
+                acc = fmaf(a.y, b.y, acc);
+                acc = fmaf(a.z, b.z, acc);
+                acc = fmaf(a.w, b.w, acc);
+            }
+            sQR[r * npos + e] = acc;
+        }
+    }
+    __syncthreads();
+
+    float m_i[4], l_i[4], o[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        m_i[r] = -1e30f;
+        l_i[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[r][c] = 0.f;
+    }
+
+    // keys beyond this bound are masked for every query of the tile
+    int k_end = kv_len;
+    if (p.causal) k_end = min(k_end, q0 + BQ - 1 + shift + 1);
+
+    for (int k0 = 0; k0 < k_end; k0 += BKV) {
+        // ---- stage K and V tiles ----------------------------------------------
+        for (int idx = tid; idx < BKV * (HD / 4); idx += 256) {
+            const int r = idx >> 4, c4 = idx & 15;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (k0 + r < kv_len) {
+                const int64_t row = (int64_t)n * p.Skv + k0 + r;
+                kv = *reinterpret_cast<const float4*>(p.k + row * p.ldk + h * HD + c4 * 4);
+                vv = *reinterpret_cast<const float4*>(p.v + row * p.ldv + h * HD + c4 * 4);
+            }
+            *reinterpret_cast<float4*>(&sK[r * QS + c4 * 4]) = kv;
+            *reinterpret_cast<float4*>(&sV[r * HD + c4 * 4]) = vv;
+        }
+        __syncthreads();
+
+        // ---- S = Q K^T : thread owns rows ty+16r, cols tx+16c -------------------
+        float sc_[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sc_[r][c] = 0.f;
+#pragma unroll 4
+        for (int d = 0; d < HD; d += 4) {
+            float4 qa[4], kb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qa[r] = *reinterpret_cast<const float4*>(&sQ[(ty + 16 * r) * QS + d]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) kb[c] = *reinterpret_cast<const float4*>(&sK[(tx + 16 * c) * QS + d]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float a = sc_[r][c];
+                    a = fmaf(qa[r].x, kb[c].x, a);
+                    a = fmaf(qa[r].y, kb[c].y, a);
+                    a = fmaf(qa[r].z, kb[c].z, a);
+                    a = fmaf(qa[r].w, kb[c].w, a);
+                    sc_[r][c] = a;
+                }
+        }
+        // ---- bias, scale, masks, online softmax ---------------------------------
+        float alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + ty + 16 * r;
+            const int qabs = qi + shift;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int kj = k0 + tx + 16 * c;
+                float s = sc_[r][c];
+                if (SHAW) {
+                    int rel = kj - qabs;
+                    rel = max(-p.rel_left, min(p.rel_right, rel)) + p.rel_left;
+                    s += sQR[(ty + 16 * r) * npos + rel];
+                }
+                s *= scale;
+                const bool ok = (kj < kv_len) && (!p.causal || kj <= qabs);
+                s = ok ? s : -INFINITY;
+                sc_[r][c] = s;
+                mx = fmaxf(mx, s);
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+            const float m_new = fmaxf(m_i[r], mx);
+            alpha[r] = expf(m_i[r] - m_new);
+            float rs = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float pv = expf(sc_[r][c] - m_new);
+                sc_[r][c] = pv;
+                rs += pv;
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off);
+            l_i[r] = l_i[r] * alpha[r] + rs;
+            m_i[r] = m_new;
+        }
+        __syncthreads();  // everyone is done reading sK
+        float* sP = sK;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sP[(ty + 16 * r) * QS + tx + 16 * c] = sc_[r][c];
+        __syncthreads();
+        // ---- O = alpha*O + P V : thread owns rows ty+16r, dims tx+16c -----------
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[r][c] *= alpha[r];
+#pragma unroll 4
+        for (int j = 0; j < BKV; j += 4) {
+            float4 pa[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pa[r] = *reinterpret_cast<const float4*>(&sP[(ty + 16 * r) * QS + j]);
+            float vb[4][4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vb[jj][c] = sV[(j + jj) * HD + tx + 16 * c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float a = o[r][c];
+                    a = fmaf(pa[r].x, vb[0][c], a);
+                    a = fmaf(pa[r].y, vb[1][c], a);
+                    a = fmaf(pa[r].z, vb[2][c], a);
+                    a = fmaf(pa[r].w, vb[3][c], a);
+                    o[r][c] = a;
+                }
+        }
+        __syncthreads();  // before the next tile overwrites sK / sV
+    }
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + ty + 16 * r;
+        if (qi >= p.Sq) continue;
+        const float inv = l_i[r] > 0.f ? 1.0f / l_i[r] : 0.f;
+        float* orow = p.out + ((int64_t)n * p.Sq + qi) * p.ldo + h * HD;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) orow[tx + 16 * c] = o[r][c] * inv;
+    }
+}
+
+static bool g_attn_attr_set = false;
+
+void launch_attention(const AttnArgs& a, hipStream_t s) {
+    SC_CHECK(a.nb > 0 && a.heads > 0 && a.Sq > 0 && a.Skv > 0, "attention: empty problem");
+    SC_CHECK(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0, "attention: row strides must be multiples of 4");
+    const int npos = a.rel_left + 1 + a.rel_right;
+    SC_CHECK(!a.rel_k || npos <= MAX_REL, "attention: %d relative positions > %d", npos, MAX_REL);
+    if (!g_attn_attr_set) {
+        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        g_attn_attr_set = true;
+    }
+    dim3 grid(cdiv(a.Sq, BQ), a.heads, a.nb);
+    prof::Scope scope(a.rel_k ? "attention_shaw" : "attention", 4.0 * a.nb * a.heads * (double)a.Sq * a.Skv * HD,
+                      4.0 * a.nb * a.heads * HD * (2.0 * a.Sq + 2.0 * a.Skv), s);
+    size_t lds = (size_t)(BQ * QS + BKV * QS + BKV * HD) * sizeof(float);
+    if (a.rel_k) {
+        // the R staging area (npos rows of QS floats) must fit in the K+V region
+        SC_CHECK(npos * QS <= BKV * QS + BKV * HD, "attention: relative table too large");
+        lds += (size_t)BQ * npos * sizeof(float);
+        hipLaunchKernelGGL((attn_kernel<true>), grid, dim3(256), lds, s, a);
+    } else {
+        hipLaunchKernelGGL((attn_kernel<false>), grid, dim3(256), lds, s, a);
+    }
+    SC_LAUNCH_CHECK();
+}
+
+// --------------------------------------------------------------------------- //
+// Decoder-step attention: grid (heads, nb), 256 threads.
+// --------------------------------------------------------------------------- //
+static constexpr int MAX_CACHE = 4096;
+
+__global__ __launch_bounds__(256) void decode_attn_kernel(
+    const float* __restrict__ q, int64_t ldq, const float* __restrict__ k_new,
+    const float* __restrict__ v_new, int64_t ldkv, float* __restrict__ kcache,
+    float* __restrict__ vcache, int64_t cache_ld, int64_t cache_bs, int cap, float* __restrict__ out,
+    int64_t ldo, int heads, const int* __restrict__ d_pos, const int* __restrict__ kv_lens, int use_lens) {
+    __shared__ float s_q[HD];
+    __shared__ float s_sc[MAX_CACHE];
+    __shared__ float s_red[8];
+    __shared__ float s_part[4][HD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int pos = d_pos ? *d_pos : 0;
+    const int kv_len = use_lens ? min(kv_lens[b], cap) : pos + 1;
+    // key/value row j of (batch b, head h) lives at base + b*cache_bs + j*cache_ld + h*64
+    float* kc = kcache + (int64_t)b * cache_bs + h * HD;
+    float* vc = vcache + (int64_t)b * cache_bs + h * HD;
+    if (tid < HD) {
+        s_q[tid] = q[(int64_t)b * ldq + h * HD + tid];
+        if (k_new) {
+            kc[(int64_t)pos * cache_ld + tid] = k_new[(int64_t)b * ldkv + h * HD + tid];
+            vc[(int64_t)pos * cache_ld + tid] = v_new[(int64_t)b * ldkv + h * HD + tid];
+        }
+    }
+    __syncthreads();
+    // scores: 16 lanes per key row
+    const int sub = lane & 15, grp = lane >> 4;
+    const float4 q4 = *reinterpret_cast<const float4*>(&s_q[sub * 4]);
+    float lmax = -INFINITY;
+    for (int j0 = 0; j0 < kv_len; j0 += 16) {
+        const int j = j0 + wave * 4 + grp;
+        float d = 0.f;
+        if (j < kv_len) {
+            const float4 kv = *reinterpret_cast<const float4*>(kc + (int64_t)j * cache_ld + sub * 4);
+            d = fmaf(q4.x, kv.x, d);
+            d = fmaf(q4.y, kv.y, d);
+            d = fmaf(q4.z, kv.z, d);
+            d = fmaf(q4.w, kv.w, d);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) d += __shfl_xor(d, off);
+        if (j < kv_len) {
+            d *= 0.125f;
+            if (sub == 0) s_sc[j] = d;
+            lmax = fmaxf(lmax, d);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    if (lane == 0) s_red[wave] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float lsum = 0.f;
+    for (int j = tid; j < kv_len; j += 256) {
+        const float e = expf(s_sc[j] - mx);
+        s_sc[j] = e;
+        lsum += e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
+    if (lane == 0) s_red[4 + wave] = lsum;
+    __syncthreads();
+    const float denom = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    // PV: lane = dim, wave = key partition
+    float acc = 0.f;
+    for (int j = wave; j < kv_len; j += 4) acc = fmaf(s_sc[j], vc[(int64_t)j * cache_ld + lane], acc);
+    s_part[wave][lane] = acc;
+    __syncthreads();
+    if (tid < HD) {
+        const float v = (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
+        out[(int64_t)b * ldo + h * HD + tid] = v / denom;
+    }
+}
+
+void launch_decode_attention(const float* q, int64_t ldq, const float* k_new, const float* v_new,
+                             int64_t ldkv, float* kcache, float* vcache, int64_t cache_ld, int64_t cache_bs,
+                             int cap, float* out, int64_t ldo, int nb, int heads, const int* d_pos,
+                             const int* kv_lens, int use_lens, hipStream_t s) {
+    SC_CHECK(cap <= MAX_CACHE, "decode attention: cache capacity %d > %d", cap, MAX_CACHE);
+    SC_CHECK(nb > 0 && heads > 0, "decode attention: empty problem");
+    hipLaunchKernelGGL(decode_attn_kernel, dim3(heads, nb), dim3(256), 0, s, q, ldq, k_new, v_new, ldkv,
+                       kcache, vcache, cache_ld, cache_bs, cap, out, ldo, heads, d_pos, kv_lens, use_lens);
+    SC_LAUNCH_CHECK();
+}
+
+}  // namespace sc

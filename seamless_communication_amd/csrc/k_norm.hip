@@ -1,0 +1,204 @@
+// Row-wise normalisation and the Conformer convolution middle section.
+// All kernels are HBM-bound: one pass over the data with 16-byte loads, wave64
+// shuffle reductions, no LDS round trip.
+#include "kernels.h"
+
+namespace sc {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float act_f(float v, int act) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_SILU) return v / (1.f + expf(-v));
+    return v;
+}
+
+// One wave per row, row cached in registers (C <= 64*4*MAXV).
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        float* __restrict__ y, int64_t ldy, int rows,
+                                                        int C, int act, const int* __restrict__ lens,
+                                                        int t_per_batch) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = C >> 2;  // float4 per row
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
+    float4* yr = reinterpret_cast<float4*>(y + (int64_t)row * ldy);
+    if (lens) {
+        const int n = row / t_per_batch;
+        const int t = row - n * t_per_batch;
+        if (t >= lens[n]) {
+            for (int i = lane; i < nv; i += 64) yr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            return;
+        }
+    }
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        v[i] = idx < nv ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float var = wave_sum(q) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float4 g = g4[idx], b = b4[idx];
+            float4 o;
+            o.x = act_f((v[i].x - mean) * rstd * g.x + b.x, act);
+            o.y = act_f((v[i].y - mean) * rstd * g.y + b.y, act);
+            o.z = act_f((v[i].z - mean) * rstd * g.z + b.z, act);
+            o.w = act_f((v[i].w - mean) * rstd * g.w + b.w, act);
+            yr[idx] = o;
+        }
+    }
+}
+
+void launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
+                      int64_t ldy, int rows, int C, int act, const int* lens, int t_per_batch,
+                      hipStream_t s) {
+    SC_CHECK(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: C=%d ldx=%lld ldy=%lld must be multiples of 4", C,
+             (long long)ldx, (long long)ldy);
+    SC_CHECK(C <= 4096, "layernorm: C=%d > 4096 unsupported", C);
+    if (rows <= 0) return;
+    dim3 grid(cdiv(rows, 4));
+    if (C <= 256) {
+        hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch);
+    } else if (C <= 1024) {
+        hipLaunchKernelGGL((layernorm_kernel<4>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch);
+    } else {
+        hipLaunchKernelGGL((layernorm_kernel<16>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch);
+    }
+    SC_LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void glu_kernel(const float* __restrict__ x, int64_t ldx,
+                                                  float* __restrict__ y, int64_t ldy, int rows, int C) {
+    const int cv = C >> 2;
+    const int64_t total = (int64_t)rows * cv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cv);
+        const int c = (int)(i - (int64_t)r * cv);
+        const float4 a = *reinterpret_cast<const float4*>(x + (int64_t)r * ldx + c * 4);
+        const float4 g = *reinterpret_cast<const float4*>(x + (int64_t)r * ldx + C + c * 4);
+        float4 o;
+        o.x = a.x / (1.f + expf(-g.x));
+        o.y = a.y / (1.f + expf(-g.y));
+        o.z = a.z / (1.f + expf(-g.z));
+        o.w = a.w / (1.f + expf(-g.w));
+        *reinterpret_cast<float4*>(y + (int64_t)r * ldy + c * 4) = o;
+    }
+}
+
+void launch_glu(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int C, hipStream_t s) {
+    SC_CHECK(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "glu: alignment");
+    if (rows <= 0) return;
+    const int64_t total = (int64_t)rows * (C / 4);
+    const int blocks = (int)std::min<int64_t>(cdiv64(total, 256), 4096);
+    hipLaunchKernelGGL(glu_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, y, ldy, rows, C);
+    SC_LAUNCH_CHECK();
+}
+
+// GLU + causal depthwise conv (Conformer conv module, between the two
+// pointwise convs).  Thread = one channel; it walks TT + K - 1 input rows of
+// its channel through registers (GLU applied on load, rows outside [0,len)
+// read as zero = the module's padding-mask + causal left pad) and emits TT
+// outputs.  Consecutive threads own consecutive channels -> coalesced rows.
+template <int K, int TT>
+__global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ w,
+                                                         float* __restrict__ y, int64_t ldy, int T,
+                                                         int C, const int* __restrict__ lens) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.y * TT;
+    const int n = blockIdx.z;
+    if (c >= C) return;
+    const int len = lens ? min(lens[n], T) : T;
+    float wr[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) wr[j] = w[c * K + j];
+    float g[TT + K - 1];
+#pragma unroll
+    for (int i = 0; i < TT + K - 1; ++i) {
+        const int t = t0 - (K - 1) + i;
+        float v = 0.f;
+        if (t >= 0 && t < len) {
+            const float* xr = x + ((int64_t)n * T + t) * ldx;
+            const float a = xr[c];
+            const float b = xr[C + c];
+            v = a / (1.f + expf(-b));
+        }
+        g[i] = v;
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        const int t = t0 + tt;
+        if (t < T) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc = fmaf(wr[j], g[tt + j], acc);
+            y[((int64_t)n * T + t) * ldy + c] = acc;
+        }
+    }
+}
+
+// Generic kernel size fallback (one output per thread-iteration).
+__global__ __launch_bounds__(256) void glu_dwconv_generic_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                 const float* __restrict__ w,
+                                                                 float* __restrict__ y, int64_t ldy,
+                                                                 int T, int C, int K,
+                                                                 const int* __restrict__ lens) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    const int n = blockIdx.z;
+    if (c >= C) return;
+    const int len = lens ? min(lens[n], T) : T;
+    float acc = 0.f;
+    for (int j = 0; j < K; ++j) {
+        const int ts = t - (K - 1) + j;
+        if (ts >= 0 && ts < len) {
+            const float* xr = x + ((int64_t)n * T + ts) * ldx;
+            acc = fmaf(w[c * K + j], xr[c] / (1.f + expf(-xr[C + c])), acc);
+        }
+    }
+    y[((int64_t)n * T + t) * ldy + c] = acc;
+}
+
+void launch_glu_dwconv(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy, int nb, int T,
+                       int C, int ksize, const int* lens, hipStream_t s) {
+    if (nb <= 0 || T <= 0) return;
+    if (ksize == 31) {
+        constexpr int TT = 16;
+        dim3 grid(cdiv(C, 256), cdiv(T, TT), nb);
+        hipLaunchKernelGGL((glu_dwconv_kernel<31, TT>), grid, dim3(256), 0, s, x, ldx, w, y, ldy, T, C, lens);
+    } else {
+        dim3 grid(cdiv(C, 256), T, nb);
+        hipLaunchKernelGGL(glu_dwconv_generic_kernel, grid, dim3(256), 0, s, x, ldx, w, y, ldy, T, C, ksize, lens);
+    }
+    SC_LAUNCH_CHECK();
+}
+
+}  // namespace sc

@@ -1,0 +1,134 @@
+// Kernel launchers of libseamless_hip (gfx950 / CDNA4 only, wave64).
+//
+// Conventions
+//   * activations: fp32, row-major [rows, channels], rows = batch-major time
+//     (row = n * T + t), zero-padded to the batch maximum T;
+//   * GEMM weights: fp16 [N_out, K] with K contiguous (nn.Linear layout); Conv1d
+//     weights are repacked at load to [C_out, tap * C_in + c];
+//   * every dense product is "A(fp32) x W(fp16)": A is split on the fly into
+//     hi + lo fp16 halves and both halves go through
+//     v_mfma_f32_32x32x16_f16 with fp32 accumulation, which reproduces an
+//     fp32 x fp16 product to ~2^-22 relative (needed for bit-exact greedy ids
+//     against the fp32 CPU reference) at 2x the fp16 MFMA cost.
+#pragma once
+#include "common.h"
+#include "prof.h"
+
+namespace sc {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_TANH = 3 };
+enum InAct { IN_NONE = 0, IN_LRELU_01 = 1, IN_LRELU_001 = 2 };
+
+struct GemmArgs {
+    const float* A = nullptr;
+    int64_t lda = 0;  // floats between consecutive input rows
+    const __half* W = nullptr;
+    int64_t ldw = 0;             // halfs between weight rows (= padded K)
+    int64_t w_phase_stride = 0;  // halfs between per-phase weight blocks
+    const float* bias = nullptr;
+    const float* res = nullptr;  // residual, indexed like C
+    int64_t ldr = 0;
+    float* C = nullptr;
+    int64_t ldc = 0;
+    int M = 0;  // GEMM rows = batch * rows_per_batch
+    int N = 0;
+    int K = 0;  // padded to a multiple of 32; k >= taps*cin reads as zero
+    // implicit 1-D convolution addressing (plain GEMM: taps=1, cin=K, rows_per_batch=M)
+    int rows_per_batch = 0;
+    int t_in = 0;   // input rows per batch item
+    int t_out = 0;  // output rows per batch item
+    int taps = 1, cin = 0, dil = 0, stride = 1, pad = 0;  // src_t = q*stride + tap*dil - pad
+    int out_mul = 1, out_off = 0, out_off_phase_step = 0;  // dst_t = q*out_mul + out_off + phase*step
+    const int* in_lens = nullptr;  // per batch item: input rows >= len read as zero
+    int in_act = IN_NONE;
+    int act = ACT_NONE;
+    float alpha = 1.0f;  // C = alpha * act(acc + bias) + res
+    int phases = 1;
+    int split = 1;  // 1: hi+lo split (near-fp32), 0: single fp16 rounding of A
+    double algo_flops = 0;  // algorithmic FLOPs of this launch for the profiler (0: 2*M*N*taps*cin*phases)
+};
+
+void launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// out[m][n] = alpha*act(sum_k x[m][k]*W[n][k] + bias[n]) + res[m][n], exact fp32 FMA, M <= 8.
+void launch_gemv(const float* x, int64_t ldx, const __half* W, int64_t ldw, const float* bias,
+                 const float* res, int64_t ldr, float* out, int64_t ldo, int M, int N, int K,
+                 int act, float alpha, hipStream_t s);
+
+// y = act(LayerNorm(x) * gamma + beta); rows masked to zero when t >= lens[n] (optional).
+void launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
+                      int64_t ldy, int rows, int C, int act, const int* lens, int t_per_batch,
+                      hipStream_t s);
+
+// y[r][c] = x[r][c] * sigmoid(x[r][C + c])
+void launch_glu(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int C, hipStream_t s);
+
+// Conformer conv middle: g = GLU(x) (masked by lens), y = causal depthwise conv_k(g)
+void launch_glu_dwconv(const float* x, int64_t ldx, const float* w /*[C][k]*/, float* y, int64_t ldy,
+                       int nb, int T, int C, int ksize, const int* lens, hipStream_t s);
+
+struct AttnArgs {
+    const float* q = nullptr;  // [nb*Sq rows][ldq], head h at column h*64
+    const float* k = nullptr;
+    const float* v = nullptr;
+    float* out = nullptr;
+    int64_t ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+    int nb = 0, heads = 0, Sq = 0, Skv = 0;
+    const int* kv_lens = nullptr;  // per batch item valid keys (nullable)
+    int causal = 0;                // key j visible iff j <= i + (Skv - Sq)
+    const float* rel_k = nullptr;  // Shaw relative keys [left+1+right][64] (nullable)
+    int rel_left = 0, rel_right = 0;
+};
+void launch_attention(const AttnArgs& a, hipStream_t s);
+
+// Single-query attention over a KV cache (decoder step).  q: [nb][heads*64];
+// key/value row j of (b, h) lives at base + b*cache_bs + j*cache_ld + h*64.  If k_new != null the
+// new key/value rows are appended at position *d_pos first.  kv_len = use_lens ? lens[b] : *d_pos + 1.
+void launch_decode_attention(const float* q, int64_t ldq, const float* k_new, const float* v_new,
+                             int64_t ldkv, float* kcache, float* vcache, int64_t cache_ld, int64_t cache_bs,
+                             int cap, float* out, int64_t ldo, int nb, int heads, const int* d_pos,
+                             const int* kv_lens, int use_lens, hipStream_t s);
+
+// fbank front-end
+// consts = window[400] | melT[256][80] | twiddle cos[256] | twiddle sin[256]
+void launch_fbank(const float* wav, int64_t wav_stride, const int* num_samples, int nb, float* out,
+                  int t_rows /*rows per item in out*/, const float* consts, float scale, hipStream_t s);
+void launch_standardize(float* feat, int nb, int t_rows, const int* num_frames, int C, hipStream_t s);
+
+// misc elementwise / gather kernels (k_misc.hip)
+// out[row] = emb[tok[row]]*scale + pos_table[(d_pos ? *d_pos : 0) + (t_per_batch>0 ? row%t_per_batch : 0)]
+void launch_embed_tokens(const int* tokens, int rows, const __half* emb, int M, float scale,
+                         const float* pos_table, const int* d_pos, int t_per_batch, float* out,
+                         int64_t ldo, hipStream_t s);
+void launch_step_update(int* next_tok, int* hist, int hist_ld, int* finished, int* out_len,
+                        const float* lprob, float* score, int nb, const int* d_pos, int pad_idx,
+                        int eos_idx, int* n_unfinished, hipStream_t s);
+void launch_argmax_rows(const float* logits, int64_t ld, int rows, int V, const int* d_pos,
+                        int min_pos_for_eos, int force_eos_pos, int pad_idx, int eos_idx, int unk_idx,
+                        float unk_penalty, int* out_idx, float* out_lprob, hipStream_t s);
+void launch_cvt_f16_f32(const __half* src, float* dst, int64_t n, hipStream_t s);
+void launch_cvt_f32_f16(const float* src, __half* dst, int64_t n, hipStream_t s);
+void launch_pack_conv_weight(const __half* w /*[Co][Ci][k]*/, __half* dst /*[Co][Kpad]*/, int Co,
+                             int Ci, int k, int Kpad, hipStream_t s);
+void launch_pack_convT_weight(const float* w /*[Ci][Co][k] folded*/, __half* dst /*[s][Co][Kpad]*/,
+                              int Ci, int Co, int k, int stride, int Kpad, hipStream_t s);
+void launch_weight_norm_fold(const __half* v, const __half* g, float* out, int d0, int inner,
+                             hipStream_t s);
+void launch_gather_rows(const float* src, int64_t lds, const int* row_idx /*-1 => zero*/, float* dst,
+                        int64_t ldd, int rows, int C, hipStream_t s);
+void launch_char_embed_add(float* seqs /*in-place [rows][M]*/, int64_t ld, const int* char_ids,
+                           const __half* embed_char, const float* pos_table, int t_per_batch,
+                           float alpha, float scale, int rows, int M, hipStream_t s);
+void launch_pos_add(float* seqs, int64_t ld, const float* pos_table, int t_per_batch, float alpha,
+                    int rows, int M, hipStream_t s);
+void launch_durations(const float* h /*[rows][H]*/, int64_t ld, const float* w, const float* b,
+                      int rows, int H, int t_per_batch, const int* lens, float duration_factor,
+                      int min_dur, int* durations, hipStream_t s);
+void launch_vocoder_embed(const int* units, int nb, int T, const __half* dict, int E,
+                          const __half* lang, int Lg, const int* lang_idx, const __half* spkr, int Sp,
+                          const int* spkr_idx, float* out /*[nb*T][Lg+E+Sp]*/, hipStream_t s);
+void launch_avg3(const float* a, const float* b, const float* c, float* out, int64_t n, hipStream_t s);
+void launch_fill_i32(int* p, int v, int n, hipStream_t s);
+void launch_add_i32(int* p, int v, hipStream_t s);
+
+}  // namespace sc

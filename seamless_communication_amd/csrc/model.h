@@ -1,0 +1,208 @@
+// Host-side runtime of libseamless_hip: weights resident in HBM, a caching
+// device allocator for activations, and the per-stage launch sequences.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/seamless_hip.h"
+#include "kernels.h"
+
+namespace sc {
+
+// Size-bucketed caching allocator.  Every launch of a handle goes to ONE
+// stream, so a block can be handed out again as soon as the host released it:
+// stream order already serialises the old readers and the new writer.
+class DevicePool {
+   public:
+    ~DevicePool();
+    void* get(size_t bytes);
+    void put(void* p);
+    void release_all();
+
+   private:
+    std::multimap<size_t, void*> free_;
+    std::unordered_map<void*, size_t> size_;
+};
+
+template <typename T>
+class Buf {
+   public:
+    Buf() = default;
+    Buf(DevicePool* pool, size_t n) : pool_(pool), n_(n) { p_ = n ? static_cast<T*>(pool->get(n * sizeof(T))) : nullptr; }
+    Buf(const Buf&) = delete;
+    Buf& operator=(const Buf&) = delete;
+    Buf(Buf&& o) noexcept : pool_(o.pool_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; }
+    Buf& operator=(Buf&& o) noexcept {
+        if (this != &o) {
+            reset();
+            pool_ = o.pool_;
+            p_ = o.p_;
+            n_ = o.n_;
+            o.p_ = nullptr;
+        }
+        return *this;
+    }
+    ~Buf() { reset(); }
+    void reset() {
+        if (p_) pool_->put(p_);
+        p_ = nullptr;
+    }
+    T* get() const { return p_; }
+    operator T*() const { return p_; }
+    size_t size() const { return n_; }
+
+   private:
+    DevicePool* pool_ = nullptr;
+    T* p_ = nullptr;
+    size_t n_ = 0;
+};
+
+struct Linear {
+    const __half* w = nullptr;  // [out][ldw]
+    int64_t ldw = 0;
+    const float* b = nullptr;
+    int out = 0, in = 0, kpad = 0;
+};
+struct LNorm {
+    const float* g = nullptr;
+    const float* b = nullptr;
+    int dim = 0;
+};
+struct Conv {
+    const __half* w = nullptr;  // packed [cout][kpad]
+    const float* b = nullptr;
+    int cout = 0, cin = 0, k = 0, kpad = 0;
+};
+struct ConvT {
+    const __half* w = nullptr;  // [stride][cout][kpad]
+    const float* b = nullptr;
+    int cin = 0, cout = 0, k = 0, stride = 0, pad = 0, taps = 0, kpad = 0;
+};
+
+struct ConformerLayer {
+    LNorm ffn1_ln, attn_ln, conv_ln, conv_inner_ln, ffn2_ln, final_ln;
+    Linear ffn1_in, ffn1_out, ffn2_in, ffn2_out, qkv, attn_out, pw1, pw2;
+    const float* rel_k = nullptr;  // [npos][64] fp32
+    const float* dw = nullptr;     // [C][k] fp32
+};
+struct AdaptorLayer {
+    LNorm res_ln, attn_ln, ffn_ln;
+    Conv res_conv, attn_conv;
+    Linear qkv, attn_out, ffn_in, ffn_out;
+};
+struct DecoderLayer {
+    LNorm self_ln, cross_ln, ffn_ln;
+    Linear qkv, self_out, cross_q, cross_kv, cross_out, ffn_in, ffn_out;
+};
+struct EncoderLayer {  // standard pre-LN transformer encoder layer (T2U encoder)
+    LNorm attn_ln, ffn_ln;
+    Linear qkv, attn_out, ffn_in, ffn_out;
+};
+struct FFTLayer {  // NAR decoder layer (post-LN)
+    Linear qkv, attn_out;
+    LNorm attn_ln, conv_ln;
+    Conv conv1, conv2;
+};
+struct ResBlock {
+    std::vector<Conv> convs1, convs2;
+    std::vector<int> dil;
+};
+
+struct Model {
+    sc_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevicePool pool;
+    std::vector<void*> owned;  // weight allocations
+
+    // raw uploaded tensors by name
+    struct Raw {
+        void* p;
+        int dtype;
+        std::vector<int64_t> shape;
+        int64_t numel;
+    };
+    std::unordered_map<std::string, Raw> raw;
+
+    // speech encoder
+    float* fbank_consts = nullptr;
+    LNorm fe_ln;
+    Linear fe_proj;
+    std::vector<ConformerLayer> enc;
+    LNorm enc_inner_ln, enc_final_ln;
+    Linear enc_proj1, enc_proj2;
+    AdaptorLayer adaptor;
+    // text decoder
+    const __half* text_embed = nullptr;  // [V][M]
+    const float* text_pos = nullptr;     // [max_len][M]
+    std::vector<DecoderLayer> dec;
+    LNorm dec_final_ln;
+    // t2u
+    std::vector<EncoderLayer> t2u_enc;
+    LNorm t2u_enc_ln;
+    const __half* unit_embed = nullptr;
+    const __half* char_embed = nullptr;
+    const float* char_pos = nullptr;
+    const float* unit_pos = nullptr;
+    float pos_alpha = 1.f, pos_alpha_char = 1.f;
+    Conv dp_conv1, dp_conv2;
+    LNorm dp_ln1, dp_ln2;
+    const float* dp_proj_w = nullptr;
+    const float* dp_proj_b = nullptr;
+    std::vector<FFTLayer> t2u_dec;
+    LNorm t2u_dec_ln;
+    // NAR char tables (host)
+    std::vector<int32_t> tok_len;
+    std::vector<uint8_t> starts_space, is_punct;
+    std::vector<int64_t> char_offsets;
+    std::vector<int32_t> char_ids;
+    // vocoder
+    const __half* voc_dict = nullptr;
+    const __half* voc_lang = nullptr;
+    const __half* voc_spkr = nullptr;
+    Conv voc_pre, voc_post;
+    std::vector<ConvT> voc_ups;
+    std::vector<ResBlock> voc_res;
+
+    // results of the last sc_t2u_nar call
+    std::vector<int32_t> last_units, last_durations, last_char_ids, last_char_seq_lens;
+    int last_n = 0, last_su = 0, last_sc = 0;
+
+    // captured decoder step
+    hipGraph_t step_graph = nullptr;
+    hipGraphExec_t step_exec = nullptr;
+
+    ~Model();
+};
+
+// stage implementations (model_*.hip)
+void load_model(Model& m, const sc_tensor_desc* t, size_t n);
+void run_fbank(Model& m, const float* d_wav, int n, int64_t wav_stride, const int32_t* h_ns, int standardize,
+               float* d_out, int t_rows, int32_t* h_frames);
+int encoder_out_len(const Model& m, int t_frames);
+void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, const int32_t* h_lens, float* d_out,
+                       int32_t* h_out_lens);
+int text_max_len(const Model& m, const sc_gen_opts& o, int s_enc);
+void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens,
+                       const sc_gen_opts& o, const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids,
+                       int32_t* h_out_lens, float* h_scores, float* d_dec_hidden, const int32_t* h_forced_tokens,
+                       int forced_len);
+void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const int32_t* h_text_lens,
+                 const int32_t* h_text_seqs, float duration_factor, int32_t* h_unit_lens, int32_t* out_su,
+                 int32_t* out_sc);
+void run_vocode(Model& m, const int32_t* h_units, int n, int s_units, const int32_t* h_lang, const int32_t* h_spkr,
+                float* d_wav);
+
+// helpers shared by the stages
+void linear(Model& m, const float* x, int64_t ldx, const Linear& L, const float* res, int64_t ldr, float* y,
+            int64_t ldy, int rows, int act, float alpha);
+void layernorm(Model& m, const float* x, const LNorm& L, float* y, int rows, int act = ACT_NONE,
+               const int* lens = nullptr, int t_per_batch = 1);
+void conv1d(Model& m, const float* x, const Conv& c, const float* res, float* y, int nb, int t_in, int stride, int pad,
+            int dil, const int* d_in_lens, int in_act, int act);
+void conv_transpose1d(Model& m, const float* x, const ConvT& c, float* y, int nb, int t_in, int in_act);
+
+}  // namespace sc

@@ -1,0 +1,232 @@
+// NLLB text decoder: greedy autoregressive generation with a KV cache, the
+// per-step launch sequence optionally replayed from a captured hipGraph.
+//
+// Reference call sites (src/seamless_communication/...):
+//   inference/generator.py:147-156,261-263   BeamSearchSeq2SeqGenerator (beam 1 here)
+//   models/unity/model.py:233-260            UnitYX2TModel.decode / project
+//   inference/generator.py:281-299           teacher-forced second decoder pass
+// Step rules restated from ggml/examples/unity/fairseq2.cpp:1097-1126 (max length),
+// :1269-1305 (_tweak_lprobs), :1463-1594 (step loop).
+#include "model.h"
+
+namespace sc {
+
+int text_max_len(const Model& m, const sc_gen_opts& o, int s_enc) {
+    int max_len;
+    if (s_enc <= 0 || o.soft_max_seq_len_a <= 0) max_len = o.hard_max_seq_len;
+    else max_len = std::min(o.hard_max_seq_len, (int)(o.soft_max_seq_len_a * (float)s_enc) + o.soft_max_seq_len_b);
+    return std::min(max_len, m.cfg.text_max_seq_len);
+}
+
+namespace {
+
+struct StepCtx {
+    int nb = 0, cap = 0, s_enc = 0;
+    int* d_pos = nullptr;
+    int* d_tok = nullptr;
+    int* d_hist = nullptr;
+    int* d_finished = nullptr;
+    int* d_out_len = nullptr;
+    int* d_enc_lens = nullptr;
+    float* d_lprob = nullptr;
+    float* d_score = nullptr;
+    float *x = nullptr, *h = nullptr, *wide = nullptr, *att = nullptr, *hN = nullptr, *logits = nullptr;
+    std::vector<float*> kcache, vcache;  // per layer [nb][cap][M]
+    std::vector<float*> cross_kv;        // per layer [nb*s_enc][2M]
+    float* dec_hidden = nullptr;         // [nb][cap-1][M] or null
+    int min_seq_len = 1, force_eos_step = -1;
+    float unk_penalty = 0.f;
+};
+
+__global__ void store_hidden_kernel(const float* __restrict__ hN, float* __restrict__ dst, int M, int hid_rows,
+                                    const int* __restrict__ d_pos) {
+    const int b = blockIdx.x;
+    const int pos = *d_pos;
+    if (pos >= hid_rows) return;
+    const float4* s = reinterpret_cast<const float4*>(hN + (int64_t)b * M);
+    float4* d = reinterpret_cast<float4*>(dst + ((int64_t)b * hid_rows + pos) * M);
+    for (int c = threadIdx.x; c < M / 4; c += blockDim.x) d[c] = s[c];
+}
+
+// One decoder step for all batch rows: feeds d_tok at position *d_pos.
+void decoder_step(Model& m, StepCtx& c, bool project) {
+    const sc_config& cfg = m.cfg;
+    const int M = cfg.model_dim, nb = c.nb;
+    launch_embed_tokens(c.d_tok, nb, m.text_embed, M, sqrtf((float)M), m.text_pos, c.d_pos, 0, c.x, M, m.stream);
+    for (int li = 0; li < cfg.dec_layers; ++li) {
+        const DecoderLayer& l = m.dec[li];
+        layernorm(m, c.x, l.self_ln, c.h, nb);
+        linear(m, c.h, M, l.qkv, nullptr, 0, c.wide, 3 * M, nb, ACT_NONE, 1.f);
+        launch_decode_attention(c.wide, 3 * M, c.wide + M, c.wide + 2 * M, 3 * M, c.kcache[li], c.vcache[li], M,
+                                (int64_t)c.cap * M, c.cap, c.att, M, nb, cfg.num_heads, c.d_pos, nullptr, 0, m.stream);
+        linear(m, c.att, M, l.self_out, c.x, M, c.x, M, nb, ACT_NONE, 1.f);
+        layernorm(m, c.x, l.cross_ln, c.h, nb);
+        linear(m, c.h, M, l.cross_q, nullptr, 0, c.wide, M, nb, ACT_NONE, 1.f);
+        launch_decode_attention(c.wide, M, nullptr, nullptr, 0, c.cross_kv[li], c.cross_kv[li] + M, 2 * M,
+                                (int64_t)c.s_enc * 2 * M, c.s_enc, c.att, M, nb, cfg.num_heads, nullptr, c.d_enc_lens, 1,
+                                m.stream);
+        linear(m, c.att, M, l.cross_out, c.x, M, c.x, M, nb, ACT_NONE, 1.f);
+        layernorm(m, c.x, l.ffn_ln, c.h, nb);
+        linear(m, c.h, M, l.ffn_in, nullptr, 0, c.wide, cfg.dec_ffn_dim, nb, ACT_RELU, 1.f);
+        linear(m, c.wide, cfg.dec_ffn_dim, l.ffn_out, c.x, M, c.x, M, nb, ACT_NONE, 1.f);
+    }
+    layernorm(m, c.x, m.dec_final_ln, c.hN, nb);
+    if (c.dec_hidden) {
+        hipLaunchKernelGGL(store_hidden_kernel, dim3(nb), dim3(256), 0, m.stream, c.hN, c.dec_hidden, M, c.cap - 1, c.d_pos);
+        SC_LAUNCH_CHECK();
+    }
+    if (project) {
+        Linear proj;
+        proj.w = m.text_embed;
+        proj.ldw = M;
+        proj.kpad = M;
+        proj.in = M;
+        proj.out = cfg.text_vocab_size;
+        linear(m, c.hN, M, proj, nullptr, 0, c.logits, cfg.text_vocab_size, nb, ACT_NONE, 1.f);
+        launch_argmax_rows(c.logits, cfg.text_vocab_size, nb, cfg.text_vocab_size, c.d_pos, c.min_seq_len, c.force_eos_step,
+                           cfg.pad_idx, cfg.eos_idx, cfg.unk_idx, c.unk_penalty, c.d_tok, c.d_lprob, m.stream);
+        launch_step_update(c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len, c.d_lprob, c.d_score, nb, c.d_pos,
+                           cfg.pad_idx, cfg.eos_idx, nullptr, m.stream);
+    }
+    launch_add_i32(c.d_pos, 1, m.stream);
+}
+
+}  // namespace
+
+// forced_tokens != null: teacher-forced pass over the given tokens (no arg-max
+// feedback, hidden states only).  Otherwise greedy generation.
+void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens,
+                       const sc_gen_opts& o, const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids,
+                       int32_t* h_out_lens, float* h_scores, float* d_dec_hidden, const int32_t* h_forced_tokens,
+                       int forced_len) {
+    const sc_config& cfg = m.cfg;
+    const int M = cfg.model_dim;
+    SC_CHECK(n > 0 && s_enc > 0, "sc_generate_text: empty batch");
+    const bool forced = h_forced_tokens != nullptr;
+    int max_len;
+    if (forced) {
+        max_len = forced_len + 1;  // hidden buffer has max_len-1 = forced_len rows
+    } else {
+        SC_CHECK(o.beam_size == 1, "sc_generate_text: beam_size=%d is not supported by the greedy HIP path (use 1)", o.beam_size);
+        SC_CHECK(prefix_len >= 1, "sc_generate_text: the prompt must hold at least one token");
+        max_len = text_max_len(m, o, s_enc);
+        SC_CHECK(o.min_seq_len <= max_len, "sc_generate_text: min_seq_len %d > effective max length %d", o.min_seq_len, max_len);
+        SC_CHECK(prefix_len < max_len, "sc_generate_text: prompt length %d >= effective max length %d", prefix_len, max_len);
+    }
+    SC_CHECK(max_len <= 4096 && max_len <= cfg.text_max_seq_len + 1, "sc_generate_text: length %d exceeds the decoder limit", max_len);
+    SC_CHECK(s_enc <= 4096, "sc_generate_text: encoder length %d > 4096", s_enc);
+    for (int i = 0; i < n; ++i)
+        SC_CHECK(h_enc_lens[i] > 0 && h_enc_lens[i] <= s_enc, "sc_generate_text: enc_lens[%d]=%d out of range", i, h_enc_lens[i]);
+
+    StepCtx c;
+    c.nb = n;
+    c.cap = max_len;
+    c.s_enc = s_enc;
+    c.min_seq_len = o.min_seq_len;
+    c.force_eos_step = max_len - 2;
+    c.unk_penalty = o.unk_penalty;
+    c.dec_hidden = d_dec_hidden;
+
+    Buf<int> ints(&m.pool, (size_t)8 + 4 * n + (size_t)n * max_len);
+    c.d_pos = ints;
+    c.d_tok = ints.get() + 8;
+    c.d_finished = c.d_tok + n;
+    c.d_out_len = c.d_finished + n;
+    c.d_enc_lens = c.d_out_len + n;
+    c.d_hist = c.d_enc_lens + n;
+    Buf<float> fl(&m.pool, (size_t)2 * n);
+    c.d_lprob = fl;
+    c.d_score = fl.get() + n;
+    const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
+    Buf<float> x(&m.pool, (size_t)n * M), h(&m.pool, (size_t)n * M), wide(&m.pool, (size_t)n * wideN), att(&m.pool, (size_t)n * M),
+        hN(&m.pool, (size_t)n * M), logits(&m.pool, forced ? 4 : (size_t)n * cfg.text_vocab_size);
+    c.x = x;
+    c.h = h;
+    c.wide = wide;
+    c.att = att;
+    c.hN = hN;
+    c.logits = logits;
+    std::vector<Buf<float>> caches;
+    caches.reserve(3 * cfg.dec_layers);
+    for (int li = 0; li < cfg.dec_layers; ++li) {
+        caches.emplace_back(&m.pool, (size_t)n * max_len * M);
+        c.kcache.push_back(caches.back());
+        caches.emplace_back(&m.pool, (size_t)n * max_len * M);
+        c.vcache.push_back(caches.back());
+        caches.emplace_back(&m.pool, (size_t)n * s_enc * 2 * M);
+        c.cross_kv.push_back(caches.back());
+        // encoder-decoder K/V once per utterance (fairseq2 caches them in the state bag at step 0)
+        linear(m, d_enc, M, m.dec[li].cross_kv, nullptr, 0, c.cross_kv.back(), 2 * M, n * s_enc, ACT_NONE, 1.f);
+    }
+
+    // ---- initial state ------------------------------------------------------------
+    std::vector<int32_t> hist((size_t)n * max_len, cfg.pad_idx), init(8 + 4 * n, 0);
+    const int feed_len = forced ? forced_len : prefix_len;
+    for (int b = 0; b < n; ++b)
+        for (int t = 0; t < feed_len; ++t) hist[(size_t)b * max_len + t] = forced ? h_forced_tokens[(size_t)b * forced_len + t] : h_prefix[t];
+    for (int b = 0; b < n; ++b) {
+        init[8 + b] = hist[(size_t)b * max_len];  // token fed at position 0
+        init[8 + n + b] = 0;                      // finished
+        init[8 + 2 * n + b] = max_len;            // out_len default (forced EOS at the end)
+        init[8 + 3 * n + b] = h_enc_lens[b];
+    }
+    SC_HIP(hipMemcpyAsync(ints.get(), init.data(), init.size() * 4, hipMemcpyHostToDevice, m.stream));
+    SC_HIP(hipMemcpyAsync(c.d_hist, hist.data(), hist.size() * 4, hipMemcpyHostToDevice, m.stream));
+    SC_HIP(hipMemsetAsync(fl.get(), 0, (size_t)2 * n * 4, m.stream));
+    if (d_dec_hidden) SC_HIP(hipMemsetAsync(d_dec_hidden, 0, (size_t)n * (max_len - 1) * M * 4, m.stream));
+
+    // ---- feed the known tokens (prompt echo / teacher forcing) ---------------------
+    // positions 0 .. feed_len-2 are fed without projection; the next input is read from hist.
+    for (int t = 0; t + 1 < feed_len; ++t) {
+        decoder_step(m, c, /*project=*/false);
+        SC_HIP(hipMemcpy2DAsync(c.d_tok, 4, c.d_hist + t + 1, (size_t)max_len * 4, 4, n, hipMemcpyDeviceToDevice, m.stream));
+    }
+    if (forced) {
+        decoder_step(m, c, false);  // last forced position
+        SC_HIP(hipStreamSynchronize(m.stream));
+        return;
+    }
+
+    // ---- generation loop: step_nr = prefix_len-1 .. max_len-2 -----------------------
+    const int first = prefix_len - 1;
+    bool use_graph = o.use_graph != 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<int32_t> fin(n);
+    for (int step = first; step <= max_len - 2; ++step) {
+        if (use_graph) {
+            if (!exec) {
+                SC_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeGlobal));
+                decoder_step(m, c, true);
+                SC_HIP(hipStreamEndCapture(m.stream, &graph));
+                SC_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            }
+            SC_HIP(hipGraphLaunch(exec, m.stream));
+        } else {
+            decoder_step(m, c, true);
+        }
+        if (((step - first) & 3) == 3 && step < max_len - 2) {
+            SC_HIP(hipMemcpyAsync(fin.data(), c.d_finished, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
+            SC_HIP(hipStreamSynchronize(m.stream));
+            bool all = true;
+            for (int b = 0; b < n; ++b) all = all && fin[b];
+            if (all) break;
+        }
+    }
+    std::vector<int32_t> lens(n);
+    std::vector<float> scores(n);
+    SC_HIP(hipMemcpyAsync(hist.data(), c.d_hist, hist.size() * 4, hipMemcpyDeviceToHost, m.stream));
+    SC_HIP(hipMemcpyAsync(lens.data(), c.d_out_len, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
+    SC_HIP(hipMemcpyAsync(scores.data(), c.d_score, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
+    SC_HIP(hipStreamSynchronize(m.stream));
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    for (int b = 0; b < n; ++b) {
+        const int len = lens[b];
+        for (int t = 0; t < max_len; ++t) h_out_ids[(size_t)b * max_len + t] = t < len ? hist[(size_t)b * max_len + t] : cfg.pad_idx;
+        h_out_lens[b] = len;
+        if (h_scores) h_scores[b] = scores[b];
+    }
+}
+
+}  // namespace sc

@@ -1,0 +1,152 @@
+// Speech side of the hot path: fbank front-end and the W2v-BERT 2.0
+// Conformer-Shaw encoder with the UnitY length adaptor.
+//
+// Reference call sites (src/seamless_communication/...):
+//   inference/translator.py:136-143,293  WaveformToFbankConverter + Collater
+//   models/unity/model.py:132-139        UnitYModel.encode_speech
+//   models/unity/adaptor_block.py:98-125 UnitYEncoderAdaptor.forward
+//   models/unity/adaptor_block.py:237-314 UnitYTransformerAdaptorLayer
+//   models/conformer_shaw/builder.py:127-156 Shaw SDPA + causal depthwise conv
+#include "model.h"
+
+namespace sc {
+
+static void upload_i32(Model& m, int* d, const int32_t* h, int n) {
+    SC_HIP(hipMemcpyAsync(d, h, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+}
+
+void run_fbank(Model& m, const float* d_wav, int n, int64_t wav_stride, const int32_t* h_ns, int standardize,
+               float* d_out, int t_rows, int32_t* h_frames) {
+    SC_CHECK(n > 0 && t_rows > 0, "sc_fbank: empty batch");
+    std::vector<int32_t> frames(n);
+    for (int i = 0; i < n; ++i) {
+        SC_CHECK(h_ns[i] >= 0 && h_ns[i] <= wav_stride, "sc_fbank: num_samples[%d]=%d exceeds the row stride", i, h_ns[i]);
+        frames[i] = h_ns[i] < 400 ? 0 : 1 + (h_ns[i] - 400) / 160;
+        SC_CHECK(frames[i] <= t_rows, "sc_fbank: item %d has %d frames but the output has only %d rows", i, frames[i],
+                 t_rows);
+        if (h_frames) h_frames[i] = frames[i];
+    }
+    Buf<int> d_ns(&m.pool, n), d_fr(&m.pool, n);
+    upload_i32(m, d_ns, h_ns, n);
+    upload_i32(m, d_fr, frames.data(), n);
+    launch_fbank(d_wav, wav_stride, d_ns, n, d_out, t_rows, m.fbank_consts, 32768.0f, m.stream);
+    if (standardize) launch_standardize(d_out, n, t_rows, d_fr, m.cfg.num_fbank_channels, m.stream);
+    SC_HIP(hipStreamSynchronize(m.stream));  // host-side length vectors must outlive the copies
+}
+
+static int adaptor_len(const sc_config& c, int len) {
+    // _compute_new_padding_mask (adaptor_block.py:426-438): floor((len + 2*pad - k)/stride + 1)
+    const int pad = c.adaptor_kernel_size / 2;
+    const double v = (double)(len + 2 * pad - c.adaptor_kernel_size) / (double)c.adaptor_stride + 1.0;
+    return (int)std::floor(v);
+}
+
+int encoder_out_len(const Model& m, int t_frames) {
+    const sc_config& c = m.cfg;
+    const int S = t_frames / c.fbank_stride;
+    const int pad = c.adaptor_kernel_size / 2;
+    return (S + 2 * pad - c.adaptor_kernel_size) / c.adaptor_stride + 1;  // Conv1d output length
+}
+
+static void attention_self(Model& m, const float* qkv, int Mdim, float* out, int nb, int S, const int* d_lens,
+                           const float* rel_k) {
+    AttnArgs a;
+    a.q = qkv;
+    a.k = qkv + Mdim;
+    a.v = qkv + 2 * Mdim;
+    a.out = out;
+    a.ldq = a.ldk = a.ldv = 3 * Mdim;
+    a.ldo = Mdim;
+    a.nb = nb;
+    a.heads = m.cfg.num_heads;
+    a.Sq = S;
+    a.Skv = S;
+    a.kv_lens = d_lens;
+    a.rel_k = rel_k;
+    a.rel_left = rel_k ? m.cfg.shaw_max_left : 0;
+    a.rel_right = rel_k ? m.cfg.shaw_max_right : 0;
+    launch_attention(a, m.stream);
+}
+
+void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, const int32_t* h_lens, float* d_out,
+                       int32_t* h_out_lens) {
+    const sc_config& c = m.cfg;
+    const int M = c.model_dim;
+    SC_CHECK(n > 0 && t_frames > 0, "sc_encode_speech: empty batch");
+    SC_CHECK(t_frames % c.fbank_stride == 0, "sc_encode_speech: t_frames=%d must be a multiple of fbank_stride=%d (Collater pad_to_multiple)",
+             t_frames, c.fbank_stride);
+    const int S = t_frames / c.fbank_stride;
+    const int rows = n * S;
+    const int feat = c.num_fbank_channels * c.fbank_stride;
+    std::vector<int32_t> lens(n), alens(n);
+    for (int i = 0; i < n; ++i) {
+        SC_CHECK(h_lens[i] >= 0 && h_lens[i] <= t_frames, "sc_encode_speech: frame_lens[%d]=%d out of range", i, h_lens[i]);
+        lens[i] = h_lens[i] / c.fbank_stride;
+        alens[i] = adaptor_len(c, lens[i]);
+        if (h_out_lens) h_out_lens[i] = alens[i];
+    }
+    Buf<int> d_lens(&m.pool, n), d_alens(&m.pool, n);
+    upload_i32(m, d_lens, lens.data(), n);
+    upload_i32(m, d_alens, alens.data(), n);
+
+    const int F = std::max(std::max(c.enc_ffn_dim, c.adaptor_proj_dim), std::max(3 * M, c.adaptor_ffn_dim));
+    Buf<float> x(&m.pool, (size_t)rows * M), h(&m.pool, (size_t)rows * std::max(M, feat)), wide(&m.pool, (size_t)rows * F),
+        att(&m.pool, (size_t)rows * M);
+
+    // frontend: stack fbank_stride frames (a pure reinterpretation of the
+    // contiguous [n][t_frames][80] buffer), LayerNorm, Linear
+    launch_layernorm(d_fbank, feat, m.fe_ln.g, m.fe_ln.b, h, feat, rows, feat, ACT_NONE, nullptr, 1, m.stream);
+    linear(m, h, feat, m.fe_proj, nullptr, 0, x, M, rows, ACT_NONE, 1.f);
+
+    for (int li = 0; li < c.enc_layers; ++li) {
+        const ConformerLayer& l = m.enc[li];
+        // x += 0.5 * FFN1(LN(x))
+        layernorm(m, x, l.ffn1_ln, h, rows);
+        linear(m, h, M, l.ffn1_in, nullptr, 0, wide, c.enc_ffn_dim, rows, ACT_SILU, 1.f);
+        linear(m, wide, c.enc_ffn_dim, l.ffn1_out, x, M, x, M, rows, ACT_NONE, 0.5f);
+        // x += MHA_shaw(LN(x))
+        layernorm(m, x, l.attn_ln, h, rows);
+        linear(m, h, M, l.qkv, nullptr, 0, wide, 3 * M, rows, ACT_NONE, 1.f);
+        attention_self(m, wide, M, att, n, S, d_lens, l.rel_k);
+        linear(m, att, M, l.attn_out, x, M, x, M, rows, ACT_NONE, 1.f);
+        // x += Conv(LN(x))
+        layernorm(m, x, l.conv_ln, h, rows);
+        linear(m, h, M, l.pw1, nullptr, 0, wide, 2 * M, rows, ACT_NONE, 1.f);
+        launch_glu_dwconv(wide, 2 * M, l.dw, att, M, n, S, M, c.depthwise_conv_kernel_size, d_lens, m.stream);
+        layernorm(m, att, l.conv_inner_ln, h, rows, ACT_SILU);
+        linear(m, h, M, l.pw2, x, M, x, M, rows, ACT_NONE, 1.f);
+        // x += 0.5 * FFN2(LN(x)); x = LN(x)
+        layernorm(m, x, l.ffn2_ln, h, rows);
+        linear(m, h, M, l.ffn2_in, nullptr, 0, wide, c.enc_ffn_dim, rows, ACT_SILU, 1.f);
+        linear(m, wide, c.enc_ffn_dim, l.ffn2_out, x, M, x, M, rows, ACT_NONE, 0.5f);
+        layernorm(m, x, l.final_ln, x, rows);
+    }
+    // adaptor head (adaptor_block.py:105-109)
+    layernorm(m, x, m.enc_inner_ln, x, rows);
+    linear(m, x, M, m.enc_proj1, nullptr, 0, wide, c.adaptor_proj_dim, rows, ACT_RELU, 1.f);
+    linear(m, wide, c.adaptor_proj_dim, m.enc_proj2, x, M, x, M, rows, ACT_NONE, 0.5f);
+
+    // adaptor layer (adaptor_block.py:249-314)
+    const AdaptorLayer& a = m.adaptor;
+    const int Sa = encoder_out_len(m, t_frames);
+    const int arows = n * Sa;
+    const int k = c.adaptor_kernel_size, st = c.adaptor_stride, pad = k / 2;
+    Buf<float> res(&m.pool, (size_t)arows * M), y(&m.pool, (size_t)arows * M), conv(&m.pool, (size_t)arows * 2 * M),
+        aw(&m.pool, (size_t)arows * std::max(3 * M, c.adaptor_ffn_dim)), ah(&m.pool, (size_t)arows * M);
+    layernorm(m, x, a.res_ln, h, rows);
+    conv1d(m, h, a.res_conv, nullptr, conv, n, S, st, pad, 1, nullptr, IN_NONE, ACT_NONE);
+    launch_glu(conv, 2 * M, res, M, arows, M, m.stream);
+    layernorm(m, x, a.attn_ln, h, rows);
+    conv1d(m, h, a.attn_conv, nullptr, conv, n, S, st, pad, 1, nullptr, IN_NONE, ACT_NONE);
+    launch_glu(conv, 2 * M, y, M, arows, M, m.stream);
+    linear(m, y, M, a.qkv, nullptr, 0, aw, 3 * M, arows, ACT_NONE, 1.f);
+    attention_self(m, aw, M, ah, n, Sa, d_alens, nullptr);
+    linear(m, ah, M, a.attn_out, res, M, y, M, arows, ACT_NONE, 1.f);
+    layernorm(m, y, a.ffn_ln, ah, arows);
+    linear(m, ah, M, a.ffn_in, nullptr, 0, aw, c.adaptor_ffn_dim, arows, ACT_RELU, 1.f);
+    linear(m, aw, c.adaptor_ffn_dim, a.ffn_out, y, M, y, M, arows, ACT_NONE, 1.f);
+    launch_layernorm(y, M, m.enc_final_ln.g, m.enc_final_ln.b, d_out, M, arows, M, ACT_NONE, nullptr, 1, m.stream);
+    SC_HIP(hipStreamSynchronize(m.stream));
+}
+
+}  // namespace sc

@@ -1,0 +1,286 @@
+// UnitY2 non-autoregressive text-to-unit model and the Code-HiFi-GAN vocoder.
+//
+// Reference call sites (src/seamless_communication/...):
+//   models/unity/model.py:379-441                UnitYNART2UModel.forward / project
+//   models/unity/nar_decoder_frontend.py:143-334 char-level host logic + upsampling
+//   models/unity/length_regulator.py:24-39,172-218,275-321 HardUpsampling / VariancePredictor / VarianceAdaptor
+//   models/unity/fft_decoder_layer.py:74-101,177-231 Conv1dBlock / FeedForwardTransformerLayer
+//   inference/generator.py:338-353               argmax, padding, unit decoding
+//   models/vocoder/codehifigan.py:75-101, hifigan.py:114-121,180-196  vocoder
+#include "model.h"
+
+namespace sc {
+
+namespace {
+
+void attention_self(Model& m, const float* qkv, int M, float* out, int nb, int S, const int* d_lens) {
+    AttnArgs a;
+    a.q = qkv;
+    a.k = qkv + M;
+    a.v = qkv + 2 * M;
+    a.out = out;
+    a.ldq = a.ldk = a.ldv = 3 * M;
+    a.ldo = M;
+    a.nb = nb;
+    a.heads = m.cfg.num_heads;
+    a.Sq = S;
+    a.Skv = S;
+    a.kv_lens = d_lens;
+    launch_attention(a, m.stream);
+}
+
+// NARDecoderFrontend.text_to_char_seqs on the precomputed per-token tables
+// (nar_decoder_frontend.py:31-49 TagManager, :158-225 char lengths, :227-259 char ids).
+void text_to_char_seqs(const Model& m, const int32_t* text_seqs, int n, int s_text, std::vector<int32_t>& char_lens,
+                       std::vector<std::vector<int32_t>>& char_ids) {
+    const sc_config& c = m.cfg;
+    SC_CHECK(!m.tok_len.empty(), "sc_t2u_nar: sc_set_nar_tables() has not been called");
+    char_lens.assign((size_t)n * s_text, 0);
+    char_ids.assign(n, {});
+    const int S = s_text - 2;  // after dropping the [</s>, lang] prefix
+    for (int b = 0; b < n; ++b) {
+        std::vector<int32_t> toks;
+        for (int i = 0; i < S; ++i) {
+            int32_t t = text_seqs[(size_t)b * s_text + 2 + i];
+            if (t == c.eos_idx) t = c.pad_idx;  // masked_fill_(EOS -> PAD)
+            SC_CHECK(t >= 0 && t < (int)m.tok_len.size(), "sc_t2u_nar: token id %d out of range", t);
+            toks.push_back(t);
+        }
+        int nsub = 0;
+        for (int32_t t : toks) nsub += (t != c.pad_idx);  // subword_lens = ne(pad).sum()
+        for (int i = 0; i < nsub; ++i) {
+            const int32_t t = toks[i];
+            if (t == c.pad_idx) break;
+            int cl;
+            if (t == c.unk_idx) {
+                cl = 1;
+            } else {
+                cl = m.tok_len[t];
+                const bool next_sp = (i < nsub - 1) && m.starts_space[toks[i + 1]];
+                const bool prev_rule = (i > 0) && m.is_punct[toks[i - 1]] && m.starts_space[toks[i]];
+                if (m.is_punct[t] && next_sp) cl += 1;
+                else if (prev_rule) cl -= 1;
+            }
+            char_lens[(size_t)b * s_text + 1 + i] = cl;  // shifted by the leading zero pad (TagManager)
+        }
+        for (int i = 0; i < nsub; ++i) {
+            const int32_t t = toks[i];
+            if (t == c.unk_idx) {
+                char_ids[b].push_back(c.unk_idx);
+            } else {
+                for (int64_t k = m.char_offsets[t]; k < m.char_offsets[t + 1]; ++k) char_ids[b].push_back(m.char_ids[k]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const int32_t* h_text_lens,
+                 const int32_t* h_text_seqs, float duration_factor, int32_t* h_unit_lens, int32_t* out_su,
+                 int32_t* out_sc) {
+    const sc_config& c = m.cfg;
+    const int M = c.model_dim;
+    SC_CHECK(c.has_t2u, "sc_t2u_nar: the model was loaded without a T2U sub-model");
+    SC_CHECK(n > 0 && s_text >= 2, "sc_t2u_nar: need at least the 2-token prefix (s_text=%d)", s_text);
+    const int rows = n * s_text;
+    Buf<int> d_tlens(&m.pool, n);
+    SC_HIP(hipMemcpyAsync(d_tlens.get(), h_text_lens, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+
+    // ---- T2U encoder (model.py:404-412) --------------------------------------------
+    const int wideN = std::max(3 * M, std::max(c.t2u_ffn_dim, c.t2u_conv_inner_dim));
+    Buf<float> x(&m.pool, (size_t)rows * M);
+    {
+        Buf<float> h(&m.pool, (size_t)rows * M), wide(&m.pool, (size_t)rows * wideN), att(&m.pool, (size_t)rows * M);
+        SC_HIP(hipMemcpyAsync(x.get(), d_dec_hidden, (size_t)rows * M * 4, hipMemcpyDeviceToDevice, m.stream));
+        for (const EncoderLayer& l : m.t2u_enc) {
+            layernorm(m, x, l.attn_ln, h, rows);
+            linear(m, h, M, l.qkv, nullptr, 0, wide, 3 * M, rows, ACT_NONE, 1.f);
+            attention_self(m, wide, M, att, n, s_text, d_tlens);
+            linear(m, att, M, l.attn_out, x, M, x, M, rows, ACT_NONE, 1.f);
+            layernorm(m, x, l.ffn_ln, h, rows);
+            linear(m, h, M, l.ffn_in, nullptr, 0, wide, c.t2u_ffn_dim, rows, ACT_RELU, 1.f);
+            linear(m, wide, c.t2u_ffn_dim, l.ffn_out, x, M, x, M, rows, ACT_NONE, 1.f);
+        }
+        layernorm(m, x, m.t2u_enc_ln, x, rows);
+    }
+
+    // ---- host: characters ---------------------------------------------------------
+    std::vector<int32_t> char_lens;
+    std::vector<std::vector<int32_t>> cids;
+    text_to_char_seqs(m, h_text_seqs, n, s_text, char_lens, cids);
+    int Sc = 0;
+    std::vector<int32_t> cseq_lens(n);
+    for (int b = 0; b < n; ++b) {
+        cseq_lens[b] = (int)cids[b].size();
+        Sc = std::max(Sc, cseq_lens[b]);
+    }
+    SC_CHECK(Sc > 0, "sc_t2u_nar: no characters to synthesise (empty text)");
+    SC_CHECK(Sc <= c.char_max_seq_len, "sc_t2u_nar: %d characters exceed char_max_seq_len=%d", Sc, c.char_max_seq_len);
+    const int crows = n * Sc;
+    std::vector<int32_t> gidx((size_t)crows, -1), cid_flat((size_t)crows, c.pad_idx);
+    for (int b = 0; b < n; ++b) {
+        int pos = 0;
+        for (int i = 0; i < s_text; ++i) {
+            const int cl = char_lens[(size_t)b * s_text + i];
+            for (int k = 0; k < cl; ++k) gidx[(size_t)b * Sc + pos++] = b * s_text + i;
+        }
+        SC_CHECK(pos == cseq_lens[b], "sc_t2u_nar: char length bookkeeping mismatch (%d vs %d)", pos, cseq_lens[b]);
+        for (int k = 0; k < cseq_lens[b]; ++k) cid_flat[(size_t)b * Sc + k] = cids[b][k];
+    }
+    Buf<int> d_gidx(&m.pool, crows), d_cid(&m.pool, crows), d_clens(&m.pool, n), d_dur(&m.pool, crows);
+    SC_HIP(hipMemcpyAsync(d_gidx.get(), gidx.data(), (size_t)crows * 4, hipMemcpyHostToDevice, m.stream));
+    SC_HIP(hipMemcpyAsync(d_cid.get(), cid_flat.data(), (size_t)crows * 4, hipMemcpyHostToDevice, m.stream));
+    SC_HIP(hipMemcpyAsync(d_clens.get(), cseq_lens.data(), (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+
+    // ---- character-level upsampling + duration predictor -----------------------------
+    Buf<float> cs(&m.pool, (size_t)crows * M);
+    launch_gather_rows(x, M, d_gidx, cs, M, crows, M, m.stream);
+    launch_char_embed_add(cs, M, d_cid, m.char_embed, m.char_pos, Sc, m.pos_alpha_char, sqrtf((float)M), crows, M, m.stream);
+    std::vector<int32_t> dur((size_t)crows);
+    {
+        const int H = c.var_pred_hidden_dim, K = c.var_pred_kernel_size;
+        Buf<float> a(&m.pool, (size_t)crows * H), b(&m.pool, (size_t)crows * H);
+        conv1d(m, cs, m.dp_conv1, nullptr, a, n, Sc, 1, K / 2, 1, d_clens, IN_NONE, ACT_RELU);
+        layernorm(m, a, m.dp_ln1, b, crows);
+        conv1d(m, b, m.dp_conv2, nullptr, a, n, Sc, 1, K / 2, 1, d_clens, IN_NONE, ACT_RELU);
+        layernorm(m, a, m.dp_ln2, b, crows);
+        launch_durations(b, H, m.dp_proj_w, m.dp_proj_b, crows, H, Sc, d_clens, duration_factor, 1, d_dur, m.stream);
+        SC_HIP(hipMemcpyAsync(dur.data(), d_dur.get(), (size_t)crows * 4, hipMemcpyDeviceToHost, m.stream));
+        SC_HIP(hipStreamSynchronize(m.stream));
+    }
+
+    // ---- host: unit-level gather index -------------------------------------------------
+    int Su = 0;
+    std::vector<int32_t> ulens(n);
+    for (int b = 0; b < n; ++b) {
+        int64_t tot = 0;
+        for (int k = 0; k < Sc; ++k) tot += dur[(size_t)b * Sc + k];
+        SC_CHECK(tot <= c.unit_max_seq_len, "sc_t2u_nar: %lld units exceed unit_max_seq_len=%d", (long long)tot, c.unit_max_seq_len);
+        ulens[b] = (int)tot;
+        Su = std::max(Su, ulens[b]);
+        if (h_unit_lens) h_unit_lens[b] = ulens[b];
+    }
+    SC_CHECK(Su > 0, "sc_t2u_nar: zero units predicted");
+    const int urows = n * Su;
+    std::vector<int32_t> uidx((size_t)urows, -1);
+    for (int b = 0; b < n; ++b) {
+        int pos = 0;
+        for (int k = 0; k < Sc; ++k)
+            for (int r = 0; r < dur[(size_t)b * Sc + k]; ++r) uidx[(size_t)b * Su + pos++] = b * Sc + k;
+    }
+    Buf<int> d_uidx(&m.pool, urows), d_ulens(&m.pool, n), d_ids(&m.pool, urows);
+    SC_HIP(hipMemcpyAsync(d_uidx.get(), uidx.data(), (size_t)urows * 4, hipMemcpyHostToDevice, m.stream));
+    SC_HIP(hipMemcpyAsync(d_ulens.get(), ulens.data(), (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+
+    // ---- FFT decoder ---------------------------------------------------------------------
+    std::vector<int32_t> ids((size_t)urows);
+    {
+        Buf<float> u(&m.pool, (size_t)urows * M), y(&m.pool, (size_t)urows * M), att(&m.pool, (size_t)urows * M),
+            wide(&m.pool, (size_t)urows * wideN);
+        launch_gather_rows(cs, M, d_uidx, u, M, urows, M, m.stream);
+        launch_pos_add(u, M, m.unit_pos, Su, m.pos_alpha, urows, M, m.stream);
+        const int K = c.t2u_conv_kernel;
+        for (const FFTLayer& l : m.t2u_dec) {
+            linear(m, u, M, l.qkv, nullptr, 0, wide, 3 * M, urows, ACT_NONE, 1.f);
+            attention_self(m, wide, M, att, n, Su, d_ulens);
+            linear(m, att, M, l.attn_out, u, M, y, M, urows, ACT_NONE, 1.f);
+            layernorm(m, y, l.attn_ln, y, urows);
+            conv1d(m, y, l.conv1, nullptr, wide, n, Su, 1, K / 2, 1, d_ulens, IN_NONE, ACT_RELU);
+            conv1d(m, wide, l.conv2, y, u, n, Su, 1, K / 2, 1, d_ulens, IN_NONE, ACT_NONE);
+            layernorm(m, u, l.conv_ln, u, urows);
+        }
+        layernorm(m, u, m.t2u_dec_ln, u, urows);
+        // project + argmax (model.py:438-441, generator.py:346)
+        Buf<float> logits(&m.pool, (size_t)urows * c.unit_vocab_size);
+        Linear proj;
+        proj.w = m.unit_embed;
+        proj.ldw = M;
+        proj.kpad = M;
+        proj.in = M;
+        proj.out = c.unit_vocab_size;
+        linear(m, u, M, proj, nullptr, 0, logits, c.unit_vocab_size, urows, ACT_NONE, 1.f);
+        launch_argmax_rows(logits, c.unit_vocab_size, urows, c.unit_vocab_size, nullptr, -1, -1, -1, -1, -1, 0.f, d_ids,
+                           nullptr, m.stream);
+        SC_HIP(hipMemcpyAsync(ids.data(), d_ids.get(), (size_t)urows * 4, hipMemcpyDeviceToHost, m.stream));
+        SC_HIP(hipStreamSynchronize(m.stream));
+    }
+    // apply_padding_mask(pad) + UnitTokenDecoder NAR branch (unit_tokenizer.py:232-243)
+    m.last_units.assign((size_t)urows, 0);
+    for (int b = 0; b < n; ++b)
+        for (int t = 0; t < Su; ++t) {
+            int32_t v = t < ulens[b] ? ids[(size_t)b * Su + t] : c.unit_pad_idx;
+            if (v == c.unit_eos_idx) v = c.unit_pad_idx;
+            if (v == c.unit_pad_idx) v = c.unit_pad_idx + 4;
+            m.last_units[(size_t)b * Su + t] = v - 4;
+        }
+    m.last_durations = dur;
+    m.last_char_ids = cid_flat;
+    m.last_char_seq_lens = cseq_lens;
+    m.last_n = n;
+    m.last_su = Su;
+    m.last_sc = Sc;
+    if (out_su) *out_su = Su;
+    if (out_sc) *out_sc = Sc;
+}
+
+void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h_lang, const int32_t* h_spkr,
+                float* d_wav) {
+    const sc_config& c = m.cfg;
+    SC_CHECK(c.has_vocoder, "sc_vocode: the model was loaded without a vocoder");
+    SC_CHECK(n > 0 && T > 0, "sc_vocode: empty batch");
+    for (int i = 0; i < n; ++i) {
+        SC_CHECK(h_lang[i] >= 0 && h_lang[i] < c.voc_num_langs, "sc_vocode: lang index %d out of range", h_lang[i]);
+        SC_CHECK(h_spkr[i] >= 0 && h_spkr[i] < c.voc_num_spkrs, "sc_vocode: speaker index %d out of range", h_spkr[i]);
+    }
+    for (int64_t i = 0; i < (int64_t)n * T; ++i)
+        SC_CHECK(h_units[i] >= 0 && h_units[i] < c.voc_num_embeddings, "sc_vocode: unit %d out of range [0,%d)", h_units[i],
+                 c.voc_num_embeddings);
+    const int E = c.voc_embedding_dim, Lg = c.voc_lang_embedding_dim, Sp = c.voc_spkr_embedding_dim;
+    Buf<int> d_units(&m.pool, (size_t)n * T), d_ls(&m.pool, 2 * n);
+    SC_HIP(hipMemcpyAsync(d_units.get(), h_units, (size_t)n * T * 4, hipMemcpyHostToDevice, m.stream));
+    SC_HIP(hipMemcpyAsync(d_ls.get(), h_lang, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+    SC_HIP(hipMemcpyAsync(d_ls.get() + n, h_spkr, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+
+    int ch = c.voc_upsample_initial_channel;
+    int t = T;
+    Buf<float> x;
+    {
+        Buf<float> in(&m.pool, (size_t)n * T * (E + Lg + Sp));
+        launch_vocoder_embed(d_units, n, T, m.voc_dict, E, m.voc_lang, Lg, d_ls, m.voc_spkr, Sp, d_ls.get() + n, in, m.stream);
+        x = Buf<float>(&m.pool, (size_t)n * T * ch);
+        conv1d(m, in, m.voc_pre, nullptr, x, n, T, 1, 3, 1, nullptr, IN_NONE, ACT_NONE);
+    }
+    const int nk = c.voc_num_resblock_kernels;
+    SC_CHECK(nk == 3, "sc_vocode: %d resblock kernels (only 3 is implemented)", nk);
+    for (int i = 0; i < c.voc_num_upsamples; ++i) {
+        const ConvT& up = m.voc_ups[i];
+        const int t2 = t * up.stride;
+        ch = up.cout;
+        const size_t sz = (size_t)n * t2 * ch;
+        Buf<float> y(&m.pool, sz), tmp(&m.pool, sz), ra(&m.pool, sz), rb(&m.pool, sz);
+        Buf<float> rout[3] = {Buf<float>(&m.pool, sz), Buf<float>(&m.pool, sz), Buf<float>(&m.pool, sz)};
+        conv_transpose1d(m, x, up, y, n, t, IN_LRELU_01);
+        for (int j = 0; j < nk; ++j) {
+            const ResBlock& r = m.voc_res[i * nk + j];
+            const float* cur = y;
+            const int nd = (int)r.dil.size();
+            for (int d = 0; d < nd; ++d) {
+                const int k = r.convs1[d].k;
+                float* dst = (d == nd - 1) ? rout[j].get() : ((d & 1) ? rb.get() : ra.get());
+                conv1d(m, cur, r.convs1[d], nullptr, tmp, n, t2, 1, (k * r.dil[d] - r.dil[d]) / 2, r.dil[d], nullptr,
+                       IN_LRELU_01, ACT_NONE);
+                conv1d(m, tmp, r.convs2[d], cur, dst, n, t2, 1, (k - 1) / 2, 1, nullptr, IN_LRELU_01, ACT_NONE);
+                cur = dst;
+            }
+        }
+        x = Buf<float>(&m.pool, sz);
+        launch_avg3(rout[0], rout[1], rout[2], x, (int64_t)sz, m.stream);
+        t = t2;
+    }
+    // F.leaky_relu default slope 0.01, conv_post, tanh (hifigan.py:192-194)
+    conv1d(m, x, m.voc_post, nullptr, d_wav, n, t, 1, 3, 1, nullptr, IN_LRELU_001, ACT_TANH);
+    SC_HIP(hipStreamSynchronize(m.stream));
+}
+
+}  // namespace sc

@@ -1,0 +1,79 @@
+"""Data-parallel sharding of utterance batches over the GPUs of one node.
+
+The reference has no multi-GPU inference path (Translator is single device,
+src/seamless_communication/inference/translator.py:83,113); utterances are
+independent, so each rank (one process per GPU, torchrun) runs the full hot
+path on its shard with a full model replica and the only exchange is one
+all-gather of the decoded text ids and unit ids over RCCL/xGMI at the end
+(SURVEY.md section 8e).  Payloads are a few hundred KB per rank, i.e. latency
+bound; lengths are gathered first, then ids padded to the global maximum.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of rank; sizes differ by at most one."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_ragged_ids(seqs: Sequence[Sequence[int]], device: torch.device, pad: int = -1) -> List[List[int]]:
+    """Gathers every rank's ragged int sequences; returns them in rank order.
+
+    Works on any initialised process group (``nccl`` == RCCL on GPUs, ``gloo``
+    on CPU for the tests).  Without a process group it returns the input."""
+    local = [list(map(int, s)) for s in seqs]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    # 1) shard sizes and the global max length (2 ints per rank)
+    meta = torch.tensor([len(local), max((len(s) for s in local), default=0)], dtype=torch.int64, device=device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    counts = [int(m[0]) for m in metas]
+    max_count, max_len = max(counts), max(int(m[1]) for m in metas)
+    # 2) one fixed-shape all-gather of [max_count, 1 + max_len] (length column + padded ids)
+    buf = np.full((max_count, 1 + max_len), pad, dtype=np.int32)
+    for i, s in enumerate(local):
+        buf[i, 0] = len(s)
+        buf[i, 1 : 1 + len(s)] = s
+    t = torch.from_numpy(buf).to(device)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    result: List[List[int]] = []
+    for r in range(world):
+        a = outs[r].cpu().numpy()
+        for i in range(counts[r]):
+            result.append(a[i, 1 : 1 + int(a[i, 0])].tolist())
+    return result
+
+
+def predict_batch_dp(translator, waveforms: Sequence[torch.Tensor], task_str: str, tgt_lang: str, **predict_kwargs):
+    """Shards ``waveforms`` over the ranks, runs ``translator.predict`` on the
+    local shard (one batched call) and all-gathers text ids / units.
+
+    Returns (texts_local, speech_output_local, all_unit_ids) where
+    ``all_unit_ids`` holds the units of every utterance of the global batch in
+    the original order.  Waveforms stay rank-local (41 MB per 64 utterances)."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    lo, hi = shard_range(len(waveforms), rank, world)
+    shard = waveforms[lo:hi]
+    n = max(int(w.numel()) for w in shard)
+    wav = torch.zeros(len(shard), n, dtype=torch.float32)
+    for i, w in enumerate(shard):
+        wav[i, : w.numel()] = w.reshape(-1)
+    model = translator.model
+    fb, frames = model.fbank(wav.to(translator.device), [int(w.numel()) for w in shard])
+    src = {"seqs": fb, "seq_lens": torch.tensor(frames.astype(np.int64)), "is_ragged": len(set(frames.tolist())) > 1}
+    texts, speech = translator.predict(src, task_str, tgt_lang, **predict_kwargs)
+    units = speech.units if speech is not None else [[] for _ in shard]
+    all_units = all_gather_ragged_ids(units, translator.device)
+    return texts, speech, all_units

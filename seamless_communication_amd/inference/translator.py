@@ -1,0 +1,273 @@
+"""Drop-in ``Translator`` for the speech-input tasks (S2ST / S2TT / ASR) whose
+arithmetic runs in libseamless_hip on one MI355X.
+
+Mirrors src/seamless_communication/inference/translator.py of the reference:
+``Task`` / ``Modality`` (:53-63), ``BatchedSpeechOutput`` (:66-75),
+``Translator.__init__`` (:79-154), ``get_modalities_from_task_str`` (:199-213),
+``predict`` (:216-428) — same argument names, defaults, return types and
+error behaviour for the path it covers.  Text-input tasks (T2ST/T2TT) and
+mintox are outside the S2ST hot path and raise
+``NotImplementedError``.
+
+Models are named by asset cards like in the reference; a card is a dict with
+the reference schema (``model_arch``, ``checkpoint``, ...).  Offline, the
+``checkpoint`` may be ``synthetic://<seed>`` which builds seeded random
+weights with the reference's exact state-dict schema.
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+from enum import Enum, auto
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import cards as _cards
+from .. import synthetic as _syn
+from ..config import S2STConfig, seamless_m4t_v2_large, tiny_config
+from ..runtime import HipS2STModel
+from ..tokenizer import CharTokenizer, NllbTextTokenizer, UnitTokenizer
+from .generator import SequenceGeneratorOptions
+
+logger = logging.getLogger(__name__)
+
+StringLike = str
+SequenceData = Dict[str, Any]
+
+
+class Task(Enum):
+    S2ST = auto()
+    S2TT = auto()
+    T2ST = auto()
+    T2TT = auto()
+    ASR = auto()
+
+
+class Modality(Enum):
+    SPEECH = "speech"
+    TEXT = "text"
+
+
+@dataclass
+class BatchedSpeechOutput:
+    units: List[List[int]]
+    """The batched list of generated units."""
+
+    audio_wavs: List[Tensor]
+    """The batched list of audio waveforms."""
+
+    sample_rate: int = 16000
+    """Sample rate of the audio waveforms."""
+
+
+_ARCHS = {"base_v2": seamless_m4t_v2_large, "tiny_v2": tiny_config}
+
+DEFAULT_CARDS: Dict[str, Dict[str, Any]] = {
+    "seamlessM4T_v2_large": {
+        "name": "seamlessM4T_v2_large", "model_arch": "base_v2", "checkpoint": "synthetic://20240901",
+        "num_units": _cards.NUM_UNITS, "unit_langs": _cards.UNIT_LANGS, "langs": _cards.TEXT_LANGS,
+        "default_lang": "eng",
+    },
+    "vocoder_v2": {
+        "name": "vocoder_v2", "model_arch": "base", "checkpoint": "synthetic://20240901",
+        "model_config": {"lang_spkr_idx_map": _cards.vocoder_lang_spkr_idx_map()},
+    },
+}
+
+
+def _resolve_card(name_or_card: Union[str, Dict[str, Any]]) -> Dict[str, Any]:
+    if isinstance(name_or_card, dict):
+        return name_or_card
+    if name_or_card in DEFAULT_CARDS:
+        return DEFAULT_CARDS[name_or_card]
+    raise ValueError(f"unknown asset card '{name_or_card}'; pass a card dict (reference YAML schema) instead")
+
+
+def _load_state_dict(card: Dict[str, Any], cfg: S2STConfig, kind: str, with_t2u: bool) -> Dict[str, Tensor]:
+    uri = card.get("checkpoint", "")
+    if uri.startswith("synthetic://"):
+        seed = int(uri[len("synthetic://"):] or _syn.DEFAULT_SEED)
+        if kind == "unity":
+            return _syn.make_unity_state_dict(cfg, seed, with_t2u=with_t2u)
+        return _syn.make_vocoder_state_dict(cfg, seed)
+    if uri.startswith("file://"):
+        from ..checkpoint import load_converted_checkpoint
+
+        return load_converted_checkpoint(uri[len("file://"):], kind)
+    raise ValueError(
+        f"card '{card.get('name')}': checkpoint '{uri}' is not reachable offline; use file://<path> or synthetic://<seed>"
+    )
+
+
+class Translator:
+    def __init__(
+        self,
+        model_name_or_card: Union[str, Dict[str, Any]],
+        vocoder_name_or_card: Union[str, Dict[str, Any], None],
+        device: Union[torch.device, str, int],
+        text_tokenizer: Optional[NllbTextTokenizer] = None,
+        apply_mintox: bool = False,
+        dtype: torch.dtype = torch.float16,
+        input_modality: Optional[Modality] = None,
+        output_modality: Optional[Modality] = None,
+    ):
+        if apply_mintox:
+            raise NotImplementedError("mintox is outside the MI355X S2ST hot path (SURVEY.md section 8)")
+        card = _resolve_card(model_name_or_card)
+        arch = card.get("model_arch", "base_v2")
+        if arch not in _ARCHS:
+            raise ValueError(f"unsupported model_arch '{arch}' (supported: {sorted(_ARCHS)})")
+        self.cfg: S2STConfig = _ARCHS[arch]()
+        dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+        if dev.type != "cuda":
+            raise ValueError("the MI355X-native Translator runs on a HIP device only (device='cuda[:N]')")
+        self.device = dev
+        # reference: dtype of weights (fp16 on GPU).  Activations are fp32 in HBM.
+        self.dtype = dtype
+        if input_modality is not None and input_modality != Modality.SPEECH:
+            raise NotImplementedError("text input is outside the MI355X S2ST hot path")
+        with_t2u = output_modality is None or output_modality == Modality.SPEECH
+        unity_sd = _load_state_dict(card, self.cfg, "unity", with_t2u)
+        langs = card.get("langs", _cards.TEXT_LANGS)
+        self.text_tokenizer = text_tokenizer or NllbTextTokenizer(
+            self.cfg.text_vocab_size, langs, card.get("default_lang", "eng"), card.get("tokenizer_path")
+        )
+        self.char_tokenizer = CharTokenizer(self.cfg.char_vocab_size, card.get("char_tokenizer_path"))
+        self.unit_tokenizer: Optional[UnitTokenizer] = None
+        if with_t2u:
+            self.unit_tokenizer = UnitTokenizer(
+                card.get("num_units", _cards.NUM_UNITS), card.get("unit_langs", _cards.UNIT_LANGS), arch
+            )
+        vocoder_sd = None
+        self.lang_spkr_idx_map = None
+        if vocoder_name_or_card is not None and with_t2u:
+            vcard = _resolve_card(vocoder_name_or_card)
+            vocoder_sd = _load_state_dict(vcard, self.cfg, "vocoder", True)
+            self.lang_spkr_idx_map = vcard.get("model_config", {}).get("lang_spkr_idx_map") or _cards.vocoder_lang_spkr_idx_map()
+        self.model = HipS2STModel(self.cfg, unity_sd, vocoder_sd, device=dev.index or 0)
+        if with_t2u:
+            self.model.set_nar_tables(self.text_tokenizer, self.char_tokenizer)
+        self.has_vocoder = vocoder_sd is not None
+        self.apply_mintox = False
+
+    # translator.py:199-213
+    @staticmethod
+    def get_modalities_from_task_str(task_str: str) -> Tuple[Modality, Modality]:
+        try:
+            task = Task[task_str.upper()]
+        except KeyError:
+            raise ValueError(f"Unsupported task: {task_str}")
+        if task == Task.S2ST:
+            return Modality.SPEECH, Modality.SPEECH
+        elif task == Task.S2TT or task == Task.ASR:
+            return Modality.SPEECH, Modality.TEXT
+        elif task == Task.T2TT:
+            return Modality.TEXT, Modality.TEXT
+        else:
+            return Modality.TEXT, Modality.SPEECH
+
+    def _collate_audio(self, audio: Tensor) -> SequenceData:
+        """convert_to_fbank + Collater(pad_value=0, pad_to_multiple=2) (translator.py:135-146, :293)."""
+        wav = audio.to(torch.float32)
+        if wav.size(1) > 1:
+            raise NotImplementedError("multi-channel audio: pass mono (T,) or (T,1) tensors")
+        wav = wav[:, 0].contiguous().unsqueeze(0).to(self.device)
+        fb, frames = self.model.fbank(wav, [wav.shape[1]], standardize=True, pad_to_multiple=2)
+        return {"seqs": fb, "seq_lens": torch.tensor(frames.astype(np.int64)), "is_ragged": False}
+
+    @torch.inference_mode()
+    def predict(
+        self,
+        input: Union[str, Tensor, SequenceData],
+        task_str: str,
+        tgt_lang: str,
+        src_lang: Optional[str] = None,
+        text_generation_opts: Optional[SequenceGeneratorOptions] = None,
+        unit_generation_opts: Optional[SequenceGeneratorOptions] = None,
+        spkr: Optional[int] = -1,
+        sample_rate: int = 16000,
+        unit_generation_ngram_filtering: bool = False,
+        duration_factor: float = 1.0,
+        prosody_encoder_input: Optional[SequenceData] = None,
+        src_text: Optional[StringLike] = None,
+    ) -> Tuple[List[StringLike], Optional[BatchedSpeechOutput]]:
+        input_modality, output_modality = self.get_modalities_from_task_str(task_str)
+        if input_modality != Modality.SPEECH:
+            if src_lang is None:
+                raise ValueError("src_lang must be specified for T2ST, T2TT tasks.")
+            raise NotImplementedError("text input (T2ST/T2TT) is outside the MI355X S2ST hot path")
+        if prosody_encoder_input is not None:
+            raise NotImplementedError("expressive (prosody) models are outside the MI355X S2ST hot path")
+
+        if isinstance(input, dict):
+            src = input
+        else:
+            audio = input
+            if isinstance(audio, str):
+                raise NotImplementedError(
+                    "audio file decoding needs libsndfile (not in this image); pass a waveform tensor or SequenceData"
+                )
+            assert audio.dim() <= 2, "The audio tensor can't be more than 2 dimensions."
+            if audio.dim() == 1:
+                audio = audio.unsqueeze(1)
+            elif audio.dim() == 2 and audio.size(0) < audio.size(1):
+                logger.warning("Transposing audio tensor from (bsz, seq_len) -> (seq_len, bsz).")
+                audio = audio.transpose(0, 1)
+            src = self._collate_audio(audio)
+
+        seqs: Tensor = src["seqs"]
+        seq_lens = src["seq_lens"]
+        if seqs.dim() != 3:
+            raise ValueError("SequenceData['seqs'] must be (N, T, num_fbank_channels)")
+        if seqs.shape[1] % self.cfg.fbank_stride:  # Collater(pad_to_multiple=2)
+            seqs = torch.nn.functional.pad(seqs, (0, 0, 0, self.cfg.fbank_stride - seqs.shape[1] % self.cfg.fbank_stride))
+        seqs = seqs.to(self.device, torch.float32).contiguous()
+        frame_lens = [int(x) for x in (seq_lens.tolist() if isinstance(seq_lens, Tensor) else seq_lens)]
+
+        if text_generation_opts is None:
+            text_generation_opts = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(1, 200))
+        if text_generation_opts.beam_size != 1:
+            raise NotImplementedError(
+                "the HIP path implements greedy search; pass text_generation_opts=SequenceGeneratorOptions(beam_size=1, ...)"
+            )
+        if text_generation_opts.step_processor is not None:
+            raise NotImplementedError("step processors are not implemented on the HIP path")
+
+        want_speech = output_modality == Modality.SPEECH
+        enc, enc_lens = self.model.encode_speech(seqs, frame_lens)
+        prefix = self.text_tokenizer.target_prefix(tgt_lang)
+        ids, out_lens, _scores, hidden = self.model.generate_text(
+            enc, enc_lens.tolist(), prefix,
+            beam_size=1,
+            soft_max_seq_len=text_generation_opts.soft_max_seq_len,
+            hard_max_seq_len=text_generation_opts.hard_max_seq_len,
+            unk_penalty=text_generation_opts.unk_penalty,
+            want_hidden=want_speech,
+        )
+        texts: List[StringLike] = [self.text_tokenizer.decode(ids[b, : out_lens[b]]) for b in range(ids.shape[0])]
+        if not want_speech:
+            return texts, None
+
+        if self.unit_tokenizer is None:
+            raise ValueError("the model was loaded with output_modality=TEXT; speech output is unavailable")
+        # generator.py:281-291: pad_seqs + trim the last column; PaddingMask.trim(1)
+        text_seqs = ids[:, :-1]
+        text_lens = (out_lens - 1).tolist()
+        units, unit_lens, _dur, _cids, _clens = self.model.t2u_nar(hidden, text_seqs, text_lens, duration_factor)
+        pad = self.unit_tokenizer.vocab_info.pad_idx
+        speech_units = [[int(u) for u in units[i] if u != pad] for i in range(units.shape[0])]
+        audio_wavs: List[Tensor] = []
+        if self.has_vocoder:
+            lang_map = self.lang_spkr_idx_map
+            n = units.shape[0]
+            lang_idx = [lang_map["multilingual"][tgt_lang]] * n
+            spkr_list = [spkr if spkr is not None else -1] * n
+            spkr_idx = [lang_map["multispkr"][tgt_lang][0] if s == -1 else s for s in spkr_list]
+            wav = self.model.vocode(units, lang_idx, spkr_idx)
+            for i in range(n):
+                keep = int(wav.size(-1) * len(speech_units[i]) / units.shape[1])
+                audio_wavs.append(wav[i, :, :keep].unsqueeze(0))
+        return texts, BatchedSpeechOutput(units=speech_units, audio_wavs=audio_wavs, sample_rate=sample_rate)

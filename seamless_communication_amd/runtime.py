@@ -1,0 +1,223 @@
+"""Python handle over one GPU-resident model of libseamless_hip.
+
+PyTorch is used here only as plumbing: device buffers (``torch.empty(...,
+device="cuda")``) and host<->device copies.  All arithmetic of the hot path
+runs inside the HIP library through its C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SeamlessHipError, check
+from .config import S2STConfig
+
+
+def sinusoidal_freqs(num_pos: int, dim: int, legacy_pad_idx: Optional[int] = 1) -> torch.Tensor:
+    """The ``freqs`` buffer of fairseq2's SinusoidalPositionEncoder: fairseq
+    layout ``[sin | cos]``, first row is position ``legacy_pad_idx + 1``
+    (reference users: t2u_builder.py:586-612; exported the same way by
+    ggml/ggml_convert.py:370-402)."""
+    start = 0 if legacy_pad_idx is None else 1 + legacy_pad_idx
+    half = dim // 2
+    idx = torch.arange(start, start + num_pos, dtype=torch.float32)
+    fct = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000.0) / (half - 1)))
+    ang = torch.outer(idx, fct)
+    out = torch.zeros(num_pos, dim, dtype=torch.float32)
+    out[:, :half] = torch.sin(ang)
+    out[:, half: 2 * half] = torch.cos(ang)
+    return out
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _ptr(a) -> C.c_void_p:
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, torch.Tensor):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(a.ctypes.data)
+
+
+class HipS2STModel:
+    """Weights of one UnitY2 (+ vocoder) model resident in one GPU's HBM."""
+
+    def __init__(
+        self,
+        cfg: S2STConfig,
+        unity_state_dict: Dict[str, torch.Tensor],
+        vocoder_state_dict: Optional[Dict[str, torch.Tensor]] = None,
+        device: int = 0,
+    ) -> None:
+        self.lib = _lib.load_library()
+        self.cfg = cfg
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        if not torch.cuda.is_available():
+            raise SeamlessHipError("no HIP device is visible; the HIP path has no CPU fallback")
+        has_t2u = any(k.startswith("t2u_model.") for k in unity_state_dict)
+        tensors: Dict[str, torch.Tensor] = {}
+        for k, v in unity_state_dict.items():
+            if k in ("final_proj.weight", "t2u_model.final_proj.weight"):
+                continue  # TiedProjection: same storage as the embedding (builder.py:451)
+            if k.startswith("text_encoder"):
+                continue  # not on the speech-input path (translator.py:97-101)
+            tensors[k] = v
+        tensors["text_decoder_frontend.pos_encoder.freqs"] = sinusoidal_freqs(cfg.text_max_seq_len, cfg.model_dim, 1)
+        if has_t2u:
+            f = "t2u_model.decoder_frontend"
+            tensors[f + ".char_pos_encoder.freqs"] = sinusoidal_freqs(cfg.char_max_seq_len, cfg.model_dim, cfg.unit_pad_idx)
+            tensors[f + ".unit_pos_encoder.freqs"] = sinusoidal_freqs(cfg.unit_max_seq_len, cfg.model_dim, cfg.unit_pad_idx)
+        if vocoder_state_dict is not None:
+            for k, v in vocoder_state_dict.items():
+                if ".dur_predictor." in k:
+                    continue  # unused with dur_prediction=False (translator.py:392-394)
+                tensors[k] = v
+        keep: List[torch.Tensor] = []
+        descs = (_lib.sc_tensor_desc * len(tensors))()
+        for i, (k, v) in enumerate(tensors.items()):
+            if v.dtype not in (torch.float16, torch.float32):
+                v = v.to(torch.float32)
+            v = v.detach().contiguous()
+            keep.append(v)
+            d = descs[i]
+            d.name = k.encode()
+            d.dtype = _lib.SC_F16 if v.dtype == torch.float16 else _lib.SC_F32
+            d.ndim = v.dim()
+            for j, s in enumerate(v.shape):
+                d.shape[j] = s
+            d.data = v.data_ptr()
+            d.on_device = 1 if v.is_cuda else 0
+        ccfg = _lib.make_config(cfg, has_t2u=has_t2u, has_vocoder=vocoder_state_dict is not None)
+        self.handle = self.lib.sc_load(descs, len(tensors), C.byref(ccfg), self.device_index)
+        if not self.handle:
+            msg = self.lib.sc_last_error()
+            raise SeamlessHipError(f"sc_load failed: {msg.decode() if msg else '?'}")
+        self.hop = self.lib.sc_vocoder_hop(self.handle) if vocoder_state_dict is not None else 0
+        self._has_nar_tables = False
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.sc_free(self.handle)
+            self.handle = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ #
+    def set_nar_tables(self, text_tokenizer, char_tokenizer) -> None:
+        tok_len, starts_sp, is_punc, offs, ids = text_tokenizer.nar_tables(char_tokenizer)
+        tl = _i32(tok_len)
+        sp = np.ascontiguousarray(starts_sp.astype(np.uint8))
+        pu = np.ascontiguousarray(is_punc.astype(np.uint8))
+        of = np.ascontiguousarray(offs.astype(np.int64))
+        ci = _i32(ids)
+        check(self.lib.sc_set_nar_tables(self.handle, len(tl), _ptr(tl), _ptr(sp), _ptr(pu), _ptr(of), _ptr(ci)),
+              "sc_set_nar_tables")
+        self._has_nar_tables = True
+
+    def fbank(self, wav: torch.Tensor, num_samples: Sequence[int], standardize: bool = True,
+              pad_to_multiple: int = 2) -> Tuple[torch.Tensor, np.ndarray]:
+        """wav (n, max_samples) fp32 on this device -> (n, T, 80), frames (n,)."""
+        assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.is_contiguous()
+        ns = _i32(num_samples)
+        frames = np.where(ns < 400, 0, 1 + (ns - 400) // 160).astype(np.int32)
+        T = int(frames.max())
+        if pad_to_multiple > 1 and T % pad_to_multiple:
+            T += pad_to_multiple - T % pad_to_multiple
+        out = torch.empty(wav.shape[0], T, self.cfg.num_fbank_channels, dtype=torch.float32, device=self.device)
+        got = np.zeros(wav.shape[0], dtype=np.int32)
+        check(self.lib.sc_fbank(self.handle, _ptr(wav), wav.shape[0], wav.stride(0), _ptr(ns), int(standardize),
+                                _ptr(out), T, _ptr(got)), "sc_fbank")
+        return out, got
+
+    def encode_speech(self, fbank: torch.Tensor, frame_lens: Sequence[int]) -> Tuple[torch.Tensor, np.ndarray]:
+        assert fbank.is_cuda and fbank.dtype == torch.float32 and fbank.is_contiguous() and fbank.dim() == 3
+        n, T, _ = fbank.shape
+        sa = self.lib.sc_encoder_out_len(self.handle, T)
+        out = torch.empty(n, sa, self.cfg.model_dim, dtype=torch.float32, device=self.device)
+        lens = _i32(frame_lens)
+        out_lens = np.zeros(n, dtype=np.int32)
+        check(self.lib.sc_encode_speech(self.handle, _ptr(fbank), n, T, _ptr(lens), _ptr(out), _ptr(out_lens)),
+              "sc_encode_speech")
+        return out, out_lens
+
+    def _gen_opts(self, beam_size, soft_max_seq_len, hard_max_seq_len, min_seq_len, unk_penalty, use_graph):
+        o = _lib.sc_gen_opts()
+        o.beam_size = int(beam_size)
+        o.soft_max_seq_len_a = float(soft_max_seq_len[0])
+        o.soft_max_seq_len_b = int(soft_max_seq_len[1])
+        o.hard_max_seq_len = int(hard_max_seq_len)
+        o.min_seq_len = int(min_seq_len)
+        o.unk_penalty = float(unk_penalty)
+        o.use_graph = int(use_graph)
+        return o
+
+    def generate_text(self, enc: torch.Tensor, enc_lens: Sequence[int], prefix: Sequence[int], beam_size: int = 1,
+                      soft_max_seq_len=(1, 200), hard_max_seq_len: int = 1024, min_seq_len: int = 1,
+                      unk_penalty: float = 0.0, use_graph: bool = True, want_hidden: bool = True):
+        """-> (ids (n, max_len) int32, lens (n,), scores (n,), hidden (n, max_len-1, M) or None)."""
+        assert enc.is_cuda and enc.is_contiguous()
+        n, s_enc, M = enc.shape
+        o = self._gen_opts(beam_size, soft_max_seq_len, hard_max_seq_len, min_seq_len, unk_penalty, use_graph)
+        max_len = self.lib.sc_text_max_len(self.handle, C.byref(o), s_enc)
+        ids = np.zeros((n, max_len), dtype=np.int32)
+        lens = np.zeros(n, dtype=np.int32)
+        scores = np.zeros(n, dtype=np.float32)
+        hidden = torch.empty(n, max_len - 1, M, dtype=torch.float32, device=self.device) if want_hidden else None
+        pre = _i32(prefix)
+        el = _i32(enc_lens)
+        check(self.lib.sc_generate_text(self.handle, _ptr(enc), n, s_enc, _ptr(el), C.byref(o), _ptr(pre), len(pre),
+                                        _ptr(ids), _ptr(lens), _ptr(scores), _ptr(hidden)), "sc_generate_text")
+        return ids, lens, scores, hidden
+
+    def decode_text(self, enc: torch.Tensor, enc_lens: Sequence[int], tokens: np.ndarray) -> torch.Tensor:
+        """Teacher-forced decoder pass: tokens (n, s_text) -> hidden (n, s_text, M)."""
+        n, s_enc, M = enc.shape
+        tok = _i32(tokens)
+        assert tok.shape[0] == n
+        hidden = torch.empty(n, tok.shape[1], M, dtype=torch.float32, device=self.device)
+        el = _i32(enc_lens)
+        check(self.lib.sc_decode_text(self.handle, _ptr(enc), n, s_enc, _ptr(el), _ptr(tok), tok.shape[1], _ptr(hidden)),
+              "sc_decode_text")
+        return hidden
+
+    def t2u_nar(self, dec_hidden: torch.Tensor, text_seqs: np.ndarray, text_lens: Sequence[int],
+                duration_factor: float = 1.0):
+        """-> units (n, S_u) int32 (pad = unit_pad_idx), unit_lens, durations (n, S_c), char ids, char_seq_lens."""
+        if not self._has_nar_tables:
+            raise SeamlessHipError("set_nar_tables() must be called before t2u_nar()")
+        assert dec_hidden.is_cuda and dec_hidden.is_contiguous()
+        n, s_text, _ = dec_hidden.shape
+        ts = _i32(text_seqs)
+        assert ts.shape == (n, s_text), (ts.shape, (n, s_text))
+        tl = _i32(text_lens)
+        ulens = np.zeros(n, dtype=np.int32)
+        su, sc_ = C.c_int32(0), C.c_int32(0)
+        check(self.lib.sc_t2u_nar(self.handle, _ptr(dec_hidden), n, s_text, _ptr(tl), _ptr(ts), float(duration_factor),
+                                  _ptr(ulens), C.byref(su), C.byref(sc_)), "sc_t2u_nar")
+        units = np.zeros((n, su.value), dtype=np.int32)
+        check(self.lib.sc_get_units(self.handle, _ptr(units)), "sc_get_units")
+        dur = np.zeros((n, sc_.value), dtype=np.int32)
+        cids = np.zeros((n, sc_.value), dtype=np.int32)
+        clens = np.zeros(n, dtype=np.int32)
+        check(self.lib.sc_get_durations(self.handle, _ptr(dur), _ptr(cids), _ptr(clens)), "sc_get_durations")
+        return units, ulens, dur, cids, clens
+
+    def vocode(self, units: np.ndarray, lang_idx: Sequence[int], spkr_idx: Sequence[int]) -> torch.Tensor:
+        u = _i32(units)
+        n, s_u = u.shape
+        wav = torch.empty(n, 1, s_u * self.hop, dtype=torch.float32, device=self.device)
+        li, si = _i32(lang_idx), _i32(spkr_idx)
+        check(self.lib.sc_vocode(self.handle, _ptr(u), n, s_u, _ptr(li), _ptr(si), _ptr(wav)), "sc_vocode")
+        return wav

@@ -1,0 +1,68 @@
+"""Shared fixtures for the parity tests: a tiny seeded model, its oracle and
+(on a GPU box) the HIP handle."""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+import torch
+
+from seamless_communication_amd import cards, synthetic as syn
+from seamless_communication_amd.config import S2STConfig, tiny_config
+from seamless_communication_amd.tokenizer import CharTokenizer, NllbTextTokenizer
+
+
+@functools.lru_cache(maxsize=4)
+def tiny_bundle(seed: int = 20240901):
+    cfg = tiny_config()
+    sd = syn.make_unity_state_dict(cfg, seed)
+    vsd = syn.make_vocoder_state_dict(cfg, seed)
+    tt = NllbTextTokenizer(cfg.text_vocab_size, cards.TEXT_LANGS)
+    ct = CharTokenizer(cfg.char_vocab_size)
+    return cfg, sd, vsd, tt, ct
+
+
+def make_oracle(seed: int = 20240901):
+    from oracle.pipeline import OracleS2ST
+
+    cfg, sd, vsd, tt, ct = tiny_bundle(seed)
+    return OracleS2ST(cfg, sd, vsd, tt, ct, cards.vocoder_lang_spkr_idx_map())
+
+
+@functools.lru_cache(maxsize=2)
+def make_hip(seed: int = 20240901):
+    from seamless_communication_amd.runtime import HipS2STModel
+
+    cfg, sd, vsd, tt, ct = tiny_bundle(seed)
+    m = HipS2STModel(cfg, sd, vsd, device=0)
+    m.set_nar_tables(tt, ct)
+    return m
+
+
+def waves(seconds=(2.0, 1.37), start: int = 0):
+    return [syn.synthetic_waveform(start + i, s).numpy() for i, s in enumerate(seconds)]
+
+
+def pad_waves(ws):
+    n = max(len(w) for w in ws)
+    out = np.zeros((len(ws), n), dtype=np.float32)
+    for i, w in enumerate(ws):
+        out[i, : len(w)] = w
+    return out, [len(w) for w in ws]
+
+
+def random_text_seqs(cfg: S2STConfig, tt, n: int, lens, seed: int = 0):
+    """[</s>, lang, w1..wk] rows (EOS already trimmed), pad filled; ids avoid control symbols mostly."""
+    rng = np.random.RandomState(seed)
+    L = max(lens)
+    out = np.full((n, L), cfg.pad_idx, dtype=np.int64)
+    for b in range(n):
+        out[b, 0] = cfg.eos_idx
+        out[b, 1] = tt.lang_token_idx("fra")
+        body = rng.randint(4, cfg.text_vocab_size - 110, size=lens[b] - 2)
+        if lens[b] > 6:
+            body[2] = cfg.unk_idx  # exercise the UNK rule
+        out[b, 2 : lens[b]] = body
+        if lens[b] < L:
+            out[b, lens[b]] = cfg.eos_idx  # shorter items keep their EOS inside the trimmed matrix
+    return out

@@ -1,0 +1,295 @@
+"""Kernel-level parity: every HIP op of libseamless_hip against a plain PyTorch
+fp32 CPU restatement of the same op (called through the C ABI, sc_op_*).
+
+Tolerances are stated per test.  The dense products use an fp32-activation x
+fp16-weight split-MFMA scheme whose error is ~2^-22 relative per product, so
+GEMM results are expected to agree with fp32 to ~1e-5 relative.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from seamless_communication_amd import _lib
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    return _lib.load_library()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+_KEEP = []
+
+
+def dev(t):
+    """Device copy that stays alive until the end of the test: the raw pointer
+    handed to the C ABI must not be recycled by the caching allocator."""
+    d = t.contiguous().cuda()
+    _KEEP.append(d)
+    return d
+
+
+@pytest.fixture(autouse=True)
+def _release_device_copies():
+    yield
+    _KEEP.clear()
+
+
+def check(lib, st):
+    assert st == 0, lib.sc_last_error().decode()
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _log(report_dir, name, **kw):
+    with open(report_dir / "ops_report.txt", "a") as f:
+        f.write(name + " " + " ".join(f"{k}={v}" for k, v in kw.items()) + "\n")
+
+
+@pytest.mark.parametrize("rows,C_", [(7, 160), (499, 1024), (33, 256), (5, 2048), (3, 128)])
+@pytest.mark.parametrize("act", [0, 2])
+def test_layernorm(lib, report_dir, rows, C_, act):
+    g = torch.Generator().manual_seed(rows * 1000 + C_)
+    x = torch.randn(rows, C_, generator=g) * 3 + 0.5
+    w = torch.rand(C_, generator=g) + 0.5
+    b = torch.randn(C_, generator=g) * 0.1
+    ref = F.layer_norm(x, (C_,), w, b, 1e-5)
+    if act == 2:
+        ref = F.silu(ref)
+    y = torch.empty(rows, C_, device="cuda")
+    check(lib, lib.sc_op_layernorm(P(dev(x)), P(dev(w)), P(dev(b)), P(y), rows, C_, act))
+    err = float((y.cpu() - ref).abs().max())
+    _log(report_dir, "layernorm", rows=rows, C=C_, act=act, err=err)
+    assert err < 2e-5
+
+
+GEMM_SHAPES = [
+    (499, 4096, 1024),  # encoder FFN inner, 64x64 tiles
+    (998, 1024, 4096),
+    (5, 1024, 1024),  # skinny tile (M <= 32)
+    (40, 3072, 1024),
+    (63, 2048, 1024),
+    (2048, 2048, 1024),  # 128x128 tiles
+    (130, 100, 160),  # ragged N, K = 160
+    (257, 1, 352),  # N = 1
+    (31, 10082, 1024),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_linear_mfma_split(lib, report_dir, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    x = torch.randn(M, K, generator=g) * 2.0
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half()
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g)
+    ref = 0.5 * F.silu(x.double() @ w.double().t() + b.double()) + r.double()
+    y = torch.empty(M, N, device="cuda")
+    check(lib, lib.sc_op_linear(P(dev(x)), P(dev(w)), P(dev(b)), P(dev(r)), P(y), M, N, K, 2, 0.5, 1, 0))
+    err = rel_err(y.cpu(), ref)
+    # transpose-detecting: asymmetric random operands; fp32-class accuracy expected
+    ref32 = 0.5 * F.silu(x @ w.float().t() + b) + r
+    err32 = rel_err(ref32, ref)
+    _log(report_dir, "linear_split", M=M, N=N, K=K, err=err, fp32_cpu_err=err32)
+    assert err < 2e-6, (err, err32)
+
+
+def test_linear_mfma_nosplit_is_fp16_class(lib, report_dir):
+    M, N, K = 300, 512, 1024
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(M, K, generator=g)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half()
+    ref = x.double() @ w.double().t()
+    y = torch.empty(M, N, device="cuda")
+    check(lib, lib.sc_op_linear(P(dev(x)), P(dev(w)), None, None, P(y), M, N, K, 0, 1.0, 0, 0))
+    err = rel_err(y.cpu(), ref)
+    _log(report_dir, "linear_nosplit", err=err)
+    assert 1e-6 < err < 2e-3  # fp16 rounding of the activations is visible, as designed
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 8])
+@pytest.mark.parametrize("N,K", [(1024, 1024), (8192, 1024), (1024, 8192), (1003, 1024)])
+def test_gemv(lib, report_dir, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half()
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g)
+    ref = F.relu(x.double() @ w.double().t() + b.double()) + r.double()
+    y = torch.empty(M, N, device="cuda")
+    check(lib, lib.sc_op_linear(P(dev(x)), P(dev(w)), P(dev(b)), P(dev(r)), P(y), M, N, K, 1, 1.0, 1, 1))
+    err = rel_err(y.cpu(), ref)
+    _log(report_dir, "gemv", M=M, N=N, K=K, err=err)
+    assert err < 2e-6
+
+
+CONV_CASES = [
+    # nb, T, cin, cout, k, stride, pad, dil, in_act, act, lens
+    (2, 50, 1024, 256, 3, 1, 1, 1, 0, 1, [50, 37]),  # duration predictor conv1 (+ReLU, masked)
+    (2, 61, 128, 128, 7, 1, 3, 1, 0, 0, [61, 20]),  # NAR conv k7
+    (2, 499, 128, 256, 8, 8, 4, 1, 0, 0, None),  # adaptor strided conv
+    (1, 300, 64, 64, 11, 1, 25, 5, 1, 0, None),  # resblock dilated conv, LeakyReLU(0.1) on input
+    (2, 200, 16, 16, 3, 1, 3, 3, 1, 0, None),  # narrow channels (generic A path)
+    (1, 333, 16, 1, 7, 1, 3, 1, 2, 3, None),  # conv_post: lrelu(0.01) in, tanh out
+    (1, 40, 1792, 512, 7, 1, 3, 1, 0, 0, None),  # conv_pre
+    (3, 17, 8, 4, 3, 1, 1, 1, 0, 0, None),  # tiny
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv1d(lib, report_dir, case):
+    nb, T, cin, cout, k, stride, pad, dil, in_act, act, lens = case
+    g = torch.Generator().manual_seed(T * 31 + cin)
+    x = torch.randn(nb, T, cin, generator=g)
+    w = (torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)).half()
+    b = torch.randn(cout, generator=g) * 0.1
+    xin = x.clone()
+    if lens is not None:
+        for i, l in enumerate(lens):
+            xin[i, l:] = 0
+    if in_act == 1:
+        xin = F.leaky_relu(xin, 0.1)
+    elif in_act == 2:
+        xin = F.leaky_relu(xin, 0.01)
+    ref = F.conv1d(xin.transpose(1, 2).double(), w.double(), b.double(), stride=stride, padding=pad, dilation=dil).transpose(1, 2)
+    t_out = ref.shape[1]
+    res = torch.randn(nb, t_out, cout, generator=g)
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 3:
+        ref = torch.tanh(ref)
+    ref = ref + res.double()
+    kpad = (cin * k + 31) // 32 * 32
+    wp = torch.zeros(cout, kpad, dtype=torch.float16, device="cuda")
+    check(lib, lib.sc_op_pack_conv_weight(P(dev(w)), P(wp), cout, cin, k))
+    d_lens = dev(torch.tensor(lens, dtype=torch.int32)) if lens is not None else None
+    y = torch.full((nb, t_out, cout), float("nan"), device="cuda")
+    check(lib, lib.sc_op_conv1d(P(dev(x)), P(wp), P(dev(b)), P(dev(res)), P(y), nb, T, cin, cout, k, stride, pad, dil,
+                                P(d_lens), in_act, act))
+    err = rel_err(y.cpu(), ref)
+    _log(report_dir, "conv1d", case=case, err=err)
+    assert err < 3e-6
+
+
+CONVT_CASES = [(2, 25, 64, 32, 11, 5), (1, 100, 32, 16, 8, 4), (2, 77, 16, 8, 4, 2), (1, 13, 512, 256, 11, 5)]
+
+
+@pytest.mark.parametrize("nb,T,cin,cout,k,s", CONVT_CASES)
+def test_conv_transpose1d_weight_norm(lib, report_dir, nb, T, cin, cout, k, s):
+    g = torch.Generator().manual_seed(T + cin + k)
+    x = torch.randn(nb, T, cin, generator=g)
+    v = (torch.randn(cin, cout, k, generator=g) / math.sqrt(cin * k)).half()
+    gg = (torch.rand(cin, 1, 1, generator=g) + 0.5).half()
+    b = torch.randn(cout, generator=g) * 0.1
+    pad = (k - s) // 2
+    wn = gg.double() * v.double() / v.double().reshape(cin, -1).norm(dim=1).reshape(cin, 1, 1)
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1).transpose(1, 2).double(), wn, b.double(), stride=s, padding=pad).transpose(1, 2)
+    y = torch.full((nb, T * s, cout), float("nan"), device="cuda")
+    check(lib, lib.sc_op_conv_transpose1d(P(dev(x)), P(dev(v)), P(dev(gg)), P(dev(b)), P(y), nb, T, cin, cout, k, s, pad, 1))
+    err = rel_err(y.cpu(), ref)
+    _log(report_dir, "conv_transpose1d", nb=nb, T=T, cin=cin, cout=cout, k=k, s=s, err=err)
+    # folded weights are rounded to fp16 once (2^-11 relative per weight)
+    assert err < 1e-3
+    assert not torch.isnan(y).any()
+
+
+def _attn_ref(q, k, v, lens, causal, rel, left, right):
+    # q (nb,H,Sq,64) ...
+    nb, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    w = (q.double() @ k.double().transpose(-1, -2)) * D ** -0.5
+    if rel is not None:
+        idx = torch.arange(Skv)[None, :] - torch.arange(Skv)[:, None]
+        idx = idx.clamp(-left, right) + left
+        rk = rel.double()[idx][-Sq:]
+        w = w + torch.einsum("nhsm,stm->nhst", q.double(), rk) * D ** -0.5
+    if causal:
+        cm = torch.ones(Sq, Skv, dtype=torch.bool).tril(diagonal=Skv - Sq)
+        w = w.masked_fill(~cm, float("-inf"))
+    if lens is not None:
+        km = torch.arange(Skv)[None, :] < torch.tensor(lens)[:, None]
+        w = w.masked_fill(~km[:, None, None, :], float("-inf"))
+    return torch.softmax(w, -1) @ v.double()
+
+
+ATTN_CASES = [
+    # nb, H, Sq, Skv, lens, causal, shaw
+    (2, 4, 499, 499, [499, 310], False, True),
+    (1, 16, 63, 63, None, False, False),
+    (2, 2, 40, 40, [40, 17], True, False),
+    (1, 2, 130, 130, None, False, True),
+    (2, 2, 5, 70, [70, 3], False, False),
+    (1, 3, 200, 200, [129], True, False),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention(lib, report_dir, case):
+    nb, H, Sq, Skv, lens, causal, shaw = case
+    g = torch.Generator().manual_seed(Sq * 13 + Skv)
+    M = H * 64
+    q = torch.randn(nb, Sq, M, generator=g)
+    k = torch.randn(nb, Skv, M, generator=g)
+    v = torch.randn(nb, Skv, M, generator=g)
+    rel = torch.randn(73, 64, generator=g) * 0.3 if shaw else None
+
+    def heads(t, S):
+        return t.view(nb, S, H, 64).transpose(1, 2)
+
+    ref = _attn_ref(heads(q, Sq), heads(k, Skv), heads(v, Skv), lens, causal, rel, 64, 8).transpose(1, 2).reshape(nb, Sq, M)
+    out = torch.full((nb, Sq, M), float("nan"), device="cuda")
+    d_lens = dev(torch.tensor(lens, dtype=torch.int32)) if lens is not None else None
+    check(lib, lib.sc_op_attention(P(dev(q)), P(dev(k)), P(dev(v)), P(out), nb, H, Sq, Skv, M, M, M, M, P(d_lens),
+                                   int(causal), P(dev(rel)) if shaw else None, 64 if shaw else 0, 8 if shaw else 0))
+    err = float((out.cpu().double() - ref).abs().max())
+    _log(report_dir, "attention", case=case, err=err)
+    assert err < 2e-5
+
+
+@pytest.mark.parametrize("nb,T,C_,lens", [(2, 70, 256, [70, 33]), (1, 499, 1024, None), (3, 5, 128, [5, 1, 3])])
+def test_glu_dwconv(lib, report_dir, nb, T, C_, lens):
+    g = torch.Generator().manual_seed(T + C_)
+    x = torch.randn(nb, T, 2 * C_, generator=g)
+    w = torch.randn(C_, 31, generator=g) * 0.2
+    gl = F.glu(x.double(), dim=-1)
+    if lens is not None:
+        for i, l in enumerate(lens):
+            gl[i, l:] = 0
+    ref = F.conv1d(F.pad(gl.transpose(1, 2), (30, 0)), w.double().unsqueeze(1), groups=C_).transpose(1, 2)
+    y = torch.full((nb, T, C_), float("nan"), device="cuda")
+    d_lens = dev(torch.tensor(lens, dtype=torch.int32)) if lens is not None else None
+    check(lib, lib.sc_op_glu_dwconv(P(dev(x)), P(dev(w)), P(y), nb, T, C_, 31, P(d_lens)))
+    err = float((y.cpu().double() - ref).abs().max())
+    _log(report_dir, "glu_dwconv", nb=nb, T=T, C=C_, err=err)
+    assert err < 2e-5
+
+
+@pytest.mark.parametrize("rows,V", [(1, 256102), (7, 10082), (64, 1200)])
+def test_argmax_lprob(lib, report_dir, rows, V):
+    g = torch.Generator().manual_seed(V)
+    x = torch.randn(rows, V, generator=g) * 3
+    x[0, 5] = x[0].max() + 1.0
+    x[0, 9] = x[0, 5]  # tie -> lowest index wins
+    idx = torch.empty(rows, dtype=torch.int32, device="cuda")
+    lp = torch.empty(rows, device="cuda")
+    check(lib, lib.sc_op_argmax(P(dev(x)), rows, V, P(idx), P(lp)))
+    ref_lp = torch.log_softmax(x.double(), -1).max(-1).values
+    assert idx.cpu().tolist() == x.argmax(-1).tolist()
+    assert int(idx[0]) == 5
+    err = float((lp.cpu().double() - ref_lp).abs().max())
+    _log(report_dir, "argmax", rows=rows, V=V, err=err)
+    assert err < 1e-5

@@ -1,0 +1,173 @@
+"""Stage-level parity of the HIP path (through the C ABI) against the CPU oracle
+on a tiny seeded model: fbank, speech encoder, greedy text generation, teacher
+forced decoding, NAR T2U, vocoder, and the whole S2ST chain.
+
+Bars: token / unit / duration ids bit-exact; floating-point tensors within the
+tolerance written in each test.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+
+def _log(report_dir, name, **kw):
+    with open(report_dir / "stages_report.txt", "a") as f:
+        f.write(name + " " + " ".join(f"{k}={v}" for k, v in kw.items()) + "\n")
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    cfg, sd, vsd, tt, ct = common.tiny_bundle()
+    return cfg, tt, ct, common.make_oracle(), common.make_hip()
+
+
+def test_fbank_matches_oracle(env, report_dir):
+    cfg, tt, ct, orc, hip = env
+    ws = common.waves((2.0, 1.37, 0.5))
+    fb_ref, lens_ref = orc.collate_fbank(ws)
+    wav, ns = common.pad_waves(ws)
+    fb, frames = hip.fbank(torch.from_numpy(wav).cuda(), ns)
+    assert frames.tolist() == lens_ref.tolist()
+    assert tuple(fb.shape) == tuple(fb_ref.shape)
+    err = float((fb.cpu() - fb_ref).abs().max())
+    _log(report_dir, "fbank", err=err)
+    assert err < 2e-3  # log-mel, standardised (fp32 FFT vs float64 FFT)
+
+
+def test_fbank_raw_unstandardized(env, report_dir):
+    from oracle import fbank as ofb
+
+    cfg, tt, ct, orc, hip = env
+    ws = common.waves((1.0,))
+    wav, ns = common.pad_waves(ws)
+    fb, frames = hip.fbank(torch.from_numpy(wav).cuda(), ns, standardize=False, pad_to_multiple=1)
+    ref = ofb.fbank_raw(ws[0])
+    err = float(np.abs(fb.cpu().numpy()[0, : ref.shape[0]] - ref).max())
+    _log(report_dir, "fbank_raw", err=err)
+    assert err < 2e-3
+
+
+def test_encoder_matches_oracle(env, report_dir):
+    from oracle import unity as ou
+
+    cfg, tt, ct, orc, hip = env
+    fb, lens = orc.collate_fbank(common.waves((2.0, 1.37)))
+    ref, ref_lens = ou.encode_speech(orc.P, cfg, fb, lens)
+    out, out_lens = hip.encode_speech(fb.cuda().contiguous(), lens.tolist())
+    assert out_lens.tolist() == ref_lens.tolist()
+    errs = []
+    for b in range(fb.shape[0]):
+        n = int(ref_lens[b])
+        errs.append(float((out[b, :n].cpu() - ref[b, :n]).abs().max()))
+    _log(report_dir, "encoder", errs=errs, ref_absmax=float(ref.abs().max()))
+    assert max(errs) < 2e-4
+
+
+def test_greedy_text_ids_bit_exact(env, report_dir):
+    cfg, tt, ct, orc, hip = env
+    fb, lens = orc.collate_fbank(common.waves((2.0, 1.37)))
+    seqs, enc, enc_lens, margins = orc.s2tt(fb, lens, "fra", (1, 200), 20)
+    prefix = tt.target_prefix("fra")
+    for use_graph in (False, True):
+        ids, out_lens, scores, hidden = hip.generate_text(
+            enc.cuda().contiguous(), enc_lens.tolist(), prefix, soft_max_seq_len=(1, 200), hard_max_seq_len=20,
+            use_graph=use_graph,
+        )
+        got = [ids[b, : out_lens[b]].tolist() for b in range(len(seqs))]
+        _log(report_dir, "greedy", use_graph=use_graph, got=got, ref=seqs, min_margin=min(min(m) for m in margins))
+        assert got == seqs
+
+
+def test_generated_hidden_equals_teacher_forced_pass(env, report_dir):
+    from oracle import unity as ou
+
+    cfg, tt, ct, orc, hip = env
+    fb, lens = orc.collate_fbank(common.waves((2.0, 1.37)))
+    seqs, enc, enc_lens, _ = orc.s2tt(fb, lens, "fra", (1, 200), 16)
+    ids, out_lens, _, hidden = hip.generate_text(enc.cuda().contiguous(), enc_lens.tolist(), tt.target_prefix("fra"),
+                                                 hard_max_seq_len=16)
+    L = max(len(s) for s in seqs)
+    text = torch.full((len(seqs), L), cfg.pad_idx, dtype=torch.int64)
+    for i, s in enumerate(seqs):
+        text[i, : len(s)] = torch.tensor(s)
+    text = text[:, :-1]
+    tl = torch.tensor([len(s) - 1 for s in seqs])
+    ref = ou.decode_text(orc.P, cfg, text, tl, enc, enc_lens, orc.pos_table)
+    errs = [float((hidden[b, : tl[b]].cpu() - ref[b, : tl[b]]).abs().max()) for b in range(len(seqs))]
+    _log(report_dir, "hidden_capture", errs=errs)
+    assert max(errs) < 2e-4
+
+
+def test_teacher_forced_decode_matches_oracle(env, report_dir):
+    from oracle import unity as ou
+
+    cfg, tt, ct, orc, hip = env
+    fb, lens = orc.collate_fbank(common.waves((1.0, 0.8)))
+    enc, enc_lens = ou.encode_speech(orc.P, cfg, fb, lens)
+    tl = [11, 7]
+    text = common.random_text_seqs(cfg, tt, 2, tl, seed=3)
+    ref = ou.decode_text(orc.P, cfg, torch.from_numpy(text), torch.tensor(tl), enc, enc_lens, orc.pos_table)
+    hid = hip.decode_text(enc.cuda().contiguous(), enc_lens.tolist(), text)
+    errs = [float((hid[b, : tl[b]].cpu() - ref[b, : tl[b]]).abs().max()) for b in range(2)]
+    _log(report_dir, "decode_forced", errs=errs)
+    assert max(errs) < 2e-4
+
+
+def test_t2u_units_and_durations_bit_exact(env, report_dir):
+    from oracle import unity as ou
+
+    cfg, tt, ct, orc, hip = env
+    fb, lens = orc.collate_fbank(common.waves((1.0, 0.8)))
+    enc, enc_lens = ou.encode_speech(orc.P, cfg, fb, lens)
+    tl = [12, 8]
+    text = common.random_text_seqs(cfg, tt, 2, tl, seed=5)
+    dec = ou.decode_text(orc.P, cfg, torch.from_numpy(text), torch.tensor(tl), enc, enc_lens, orc.pos_table)
+    ref_units, aux = ou.t2u_nar(orc.P, cfg, dec, torch.tensor(tl), torch.from_numpy(text.copy()), tt, ct, 1.0)
+    units, ulens, dur, cids, clens = hip.t2u_nar(dec.cuda().contiguous(), text, tl, 1.0)
+    _log(report_dir, "t2u", unit_lens=ulens.tolist(), ref_unit_lens=aux["unit_lens"].tolist(),
+         n_mismatch=int((units != ref_units.numpy()).sum()) if units.shape == tuple(ref_units.shape) else -1)
+    assert clens.tolist() == aux["char_seq_lens"].tolist()
+    assert cids.tolist() == aux["char_seqs"].tolist()
+    assert dur.tolist() == aux["durations"].tolist()
+    assert ulens.tolist() == aux["unit_lens"].tolist()
+    assert units.tolist() == ref_units.tolist()
+
+
+def test_vocoder_waveform(env, report_dir):
+    from oracle import vocoder as ov
+
+    cfg, tt, ct, orc, hip = env
+    rng = np.random.RandomState(0)
+    units = rng.randint(0, cfg.vocoder.num_embeddings, size=(2, 37)).astype(np.int64)
+    lang_idx, spkr_idx = ov.resolve_lang_spkr(orc.lang_spkr_idx_map, ["fra", "fra"], [-1, 3])
+    ref = ov.vocode(orc.vocoder_sd, cfg.vocoder, torch.from_numpy(units), lang_idx, spkr_idx)
+    wav = hip.vocode(units, lang_idx, spkr_idx)
+    assert tuple(wav.shape) == tuple(ref.shape)
+    err = float((wav.cpu() - ref).abs().max())
+    _log(report_dir, "vocoder", err=err, ref_absmax=float(ref.abs().max()))
+    # fp16 rounding of the weight-norm-folded weights: stated tolerance 2e-3 absolute on [-1,1] audio
+    assert err < 2e-3
+
+
+def test_s2st_end_to_end(env, report_dir):
+    cfg, tt, ct, orc, hip = env
+    ws = common.waves((2.0, 1.37))
+    fb_ref, lens_ref = orc.collate_fbank(ws)
+    seqs, speech_units, wavs, units_ref, aux = orc.s2st(fb_ref, lens_ref, "fra", (1, 200), 14)
+    wav, ns = common.pad_waves(ws)
+    fb, frames = hip.fbank(torch.from_numpy(wav).cuda(), ns)
+    enc, enc_lens = hip.encode_speech(fb, frames.tolist())
+    ids, out_lens, _, hidden = hip.generate_text(enc, enc_lens.tolist(), tt.target_prefix("fra"), hard_max_seq_len=14)
+    got = [ids[b, : out_lens[b]].tolist() for b in range(len(seqs))]
+    assert got == seqs
+    text = ids[:, :-1].copy()
+    units, ulens, dur, cids, clens = hip.t2u_nar(hidden, text, (out_lens - 1).tolist(), 1.0)
+    _log(report_dir, "e2e", text=got, unit_lens=ulens.tolist(), ref_unit_lens=aux["unit_lens"].tolist())
+    assert dur.tolist() == aux["durations"].tolist()
+    assert units.tolist() == units_ref.tolist()
