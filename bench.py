@@ -1,0 +1,286 @@
+#!/usr/bin/env python
+"""S2ST throughput / real-time-factor benchmark of the MI355X-native hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path (fbank -> Conformer-Shaw encoder ->
+greedy NLLB text decoding -> UnitY2 NAR T2U -> Code-HiFi-GAN vocoder, plus for
+N > 1 the RCCL all-gather of text/unit ids) over one batch of ``--batch``
+synthetic 10 s / 16 kHz utterances per GPU that are already resident in HBM
+(BASELINE.json configs[2]: S2ST 10 s audio, seamlessM4T_v2_large).  Weights are
+seeded random tensors with the reference's checkpoint schema (no checkpoints
+are reachable offline); such a model never emits EOS, so the text length is
+fixed by ``SequenceGeneratorOptions.hard_max_seq_len`` (``--text-len``,
+default 42 = 40 generated tokens, the length BASELINE.md prices the path at).
+
+Rank 0 prints ONE JSON line.  ``value`` is utterances/s over all GPUs (weak
+scaling: per-GPU batch fixed).  ``roofline`` describes the kernel family with
+the largest share of GPU time, from per-launch HIP events recorded on the
+library's own stream in one extra profiled step after the timed region;
+``cpu_baseline`` is the CPU oracle (a port of the reference's fairseq2 path,
+the reference itself is not runnable offline) on ONE utterance of the same
+workload on this host's cores (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+AUDIO_SECONDS = 10.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (no sparsity)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
+    ap.add_argument("--text-len", type=int, default=42, help="hard_max_seq_len of the greedy text search (prompt included)")
+    ap.add_argument("--arch", default="base_v2", choices=["base_v2", "tiny_v2"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-step", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch decoder steps eagerly instead of hipGraph replay")
+    return ap.parse_args()
+
+
+def prof_report(lib):
+    n = lib.sc_prof_report(None, 0)
+    buf = ctypes.create_string_buffer(int(n) + 16)
+    lib.sc_prof_report(buf, len(buf))
+    fams = {}
+    for line in buf.value.decode().splitlines():
+        name, launches, ms, flops, byts = line.split()
+        fams[name] = {"launches": int(launches), "ms": float(ms), "flops": float(flops), "bytes": float(byts)}
+    return fams
+
+
+def roofline_of(fams):
+    if not fams:
+        return None, {}
+    name = max(fams, key=lambda k: fams[k]["ms"])
+    f = fams[name]
+    sec = f["ms"] * 1e-3
+    avg_us = 1e3 * f["ms"] / max(1, f["launches"])
+    if name.startswith("gemv"):
+        ach = f["bytes"] / sec / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    else:
+        ach = f["flops"] / sec / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / MFMA_F16_PEAK_TFLOPS}
+    roof.update({"traffic": None, "kernel": name, "launches": f["launches"], "avg_launch_us": avg_us,
+                 "algorithmic_flops_per_launch": f["flops"] / max(1, f["launches"]),
+                 "algorithmic_bytes_per_launch": f["bytes"] / max(1, f["launches"])})
+    total = sum(v["ms"] for v in fams.values())
+    shares = {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
+                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
+                  "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
+              for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])}
+    shares["_profiled_total_ms"] = round(total, 3)
+    return roof, shares
+
+
+def cpu_baseline(cfg, unity_sd, vocoder_sd, tt, ct, lang_map, wav_np, text_len):
+    """The CPU oracle on ONE utterance of the bench workload (a port: the
+    reference's fairseq2 path itself cannot be run offline)."""
+    from oracle.pipeline import OracleS2ST
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    orc = OracleS2ST(cfg, unity_sd, vocoder_sd, tt, ct, lang_map)
+    t0 = time.perf_counter()
+    fb, lens = orc.collate_fbank([wav_np])
+    seqs, speech_units, wavs, units, aux = orc.s2st(fb, lens, "fra", (1, 200), text_len)
+    dt = time.perf_counter() - t0
+    return {
+        "value": 1.0 / dt, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"1 utterance (10 s audio, {len(seqs[0])} text tokens, {len(speech_units[0])} units), "
+                  f"fp32 PyTorch oracle of the fairseq2 path, one pass, no warm-up",
+        "seconds": dt, "rtf": dt / AUDIO_SECONDS,
+    }, seqs, speech_units
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from seamless_communication_amd import cards, synthetic as syn
+    from seamless_communication_amd.distributed import all_gather_ragged_ids
+    from seamless_communication_amd.inference import SequenceGeneratorOptions, Translator
+    from seamless_communication_amd.inference.translator import DEFAULT_CARDS
+
+    t_load = time.perf_counter()
+    card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch=args.arch)
+    translator = Translator(card, "vocoder_v2", device=device)
+    translator.use_graph = not args.no_graph
+    model = translator.model
+    cfg = translator.cfg
+    load_s = time.perf_counter() - t_load
+
+    B = args.batch
+    n_samples = int(AUDIO_SECONDS * 16000)
+    wav_host = torch.stack([syn.synthetic_waveform(rank * B + i, AUDIO_SECONDS) for i in range(B)])
+    wav_dev = wav_host.to(device)  # inputs resident in HBM before the timed region
+    ns = [n_samples] * B
+    opts = SequenceGeneratorOptions(beam_size=1, soft_max_seq_len=(1, 200), hard_max_seq_len=args.text_len)
+    stage_ms = {}
+
+    def step():
+        t0 = time.perf_counter()
+        fb, frames = model.fbank(wav_dev, ns, standardize=True, pad_to_multiple=2)
+        t1 = time.perf_counter()
+        src = {"seqs": fb, "seq_lens": torch.from_numpy(frames.astype(np.int64)), "is_ragged": False}
+        texts, speech = translator.predict(src, "S2ST", "fra", text_generation_opts=opts)
+        stage_ms.clear()
+        stage_ms["fbank"] = (t1 - t0) * 1e3
+        stage_ms.update(translator.last_stage_ms)
+        if world > 1:  # the only exchange of the data-parallel path: ids, a few hundred KB
+            all_text = all_gather_ragged_ids(translator.last_text_ids, device)
+            all_units = all_gather_ragged_ids(speech.units, device)
+            assert len(all_text) == len(all_units) == world * B
+        return texts, speech
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        texts, speech = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stage_snapshot = dict(stage_ms)
+    unit_counts = [len(u) for u in speech.units]
+    text_lens = [len(t) for t in translator.last_text_ids]
+    wav_secs = [w.shape[-1] / 16000.0 for w in speech.audio_wavs]
+
+    result = None
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / max(1, args.steps)
+        utt_per_s = world * B * args.steps / elapsed
+        result = {
+            "metric": "S2ST utterances/sec (and real-time factor), seamlessM4T_v2_large, 10 s audio",
+            "value": utt_per_s, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 activations x f16 weights, f32 accumulate", "data": "synthetic",
+            "rtf": (elapsed / args.steps) / (B * AUDIO_SECONDS),
+            "config": {
+                "workload": "S2ST 10 s 16 kHz audio -> text -> units -> 16 kHz waveform (BASELINE configs[2])",
+                "arch": args.arch, "weights": "synthetic://20240901 (reference state-dict schema, fp16)",
+                "batch_per_gpu": B, "global_batch": world * B, "tgt_lang": "fra",
+                "text_search": f"greedy, soft_max_seq_len=(1,200), hard_max_seq_len={args.text_len}",
+                "text_tokens_per_utt": float(np.mean(text_lens)), "units_per_utt": float(np.mean(unit_counts)),
+                "out_audio_seconds_per_utt": float(np.mean(wav_secs)),
+                "parallelism": f"dp{world} (utterances sharded, full replica per GPU, all-gather of ids)",
+                "hip_graph_decoder_step": bool(translator.use_graph),
+            },
+            "stage_ms_last_step": {k: round(v, 3) for k, v in stage_snapshot.items()},
+            "load_seconds": round(load_s, 1),
+        }
+
+    # ---- one extra profiled step: per-launch HIP events on the library's stream ----------
+    if not args.no_profile_step:
+        lib = model.lib
+        lib.sc_prof_reset()
+        lib.sc_prof_enable(1)
+        translator.use_graph = False  # launches inside a captured graph cannot carry events
+        step()
+        torch.cuda.synchronize()
+        lib.sc_prof_enable(0)
+        fams = prof_report(lib)
+        translator.use_graph = not args.no_graph
+        if rank == 0:
+            roof, shares = roofline_of(fams)
+            result["roofline"] = roof
+            result["kernel_families_profiled_step"] = shares
+            result["stage_ms_profiled_step"] = {k: round(v, 3) for k, v in stage_ms.items()}
+    elif rank == 0:
+        result["roofline"] = None
+
+    # ---- batch-1 latency (RTF of a single utterance) ---------------------------------------
+    if rank == 0:
+        w1 = wav_dev[:1].contiguous()
+        def one():
+            fb, frames = model.fbank(w1, ns[:1])
+            translator.predict({"seqs": fb, "seq_lens": torch.from_numpy(frames.astype(np.int64)), "is_ragged": False},
+                               "S2ST", "fra", text_generation_opts=opts)
+        one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t0) / 3
+        result["latency_batch1"] = {"seconds": lat, "rtf": lat / AUDIO_SECONDS,
+                                    "stage_ms": {k: round(v, 3) for k, v in translator.last_stage_ms.items()}}
+
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            tt, ct = translator.text_tokenizer, translator.char_tokenizer
+            unity_sd = syn.make_unity_state_dict(cfg, syn.DEFAULT_SEED)
+            voc_sd = syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED)
+            base, seqs, sunits = cpu_baseline(cfg, unity_sd, voc_sd, tt, ct, cards.vocoder_lang_spkr_idx_map(),
+                                              wav_host[0].numpy(), args.text_len)
+            base["ids_match_gpu"] = {
+                "text": seqs[0] == translator_first_text(translator, texts, model, wav_dev, ns, opts),
+            }
+            result["cpu_baseline"] = base
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def translator_first_text(translator, texts, model, wav_dev, ns, opts):
+    """Text ids of utterance 0 from the HIP path (re-run at batch 1 so that the
+    comparison with the CPU oracle is on identical input)."""
+    fb, frames = model.fbank(wav_dev[:1].contiguous(), ns[:1])
+    translator.predict({"seqs": fb, "seq_lens": torch.from_numpy(frames.astype(np.int64)), "is_ragged": False},
+                       "S2ST", "fra", text_generation_opts=opts)
+    return translator.last_text_ids[0]
+
+
+if __name__ == "__main__":
+    main()

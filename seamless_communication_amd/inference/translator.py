@@ -17,6 +17,7 @@ weights with the reference's exact state-dict schema.
 from __future__ import annotations
 
 import logging
+import time
 from dataclasses import dataclass
 from enum import Enum, auto
 from typing import Any, Dict, List, Optional, Tuple, Union
@@ -152,6 +153,10 @@ class Translator:
             self.model.set_nar_tables(self.text_tokenizer, self.char_tokenizer)
         self.has_vocoder = vocoder_sd is not None
         self.apply_mintox = False
+        # introspection for the batch driver / bench (not part of the reference API)
+        self.use_graph = True  # replay the decoder step from a captured hipGraph
+        self.last_text_ids: List[List[int]] = []
+        self.last_stage_ms: Dict[str, float] = {}
 
     # translator.py:199-213
     @staticmethod
@@ -237,7 +242,10 @@ class Translator:
             raise NotImplementedError("step processors are not implemented on the HIP path")
 
         want_speech = output_modality == Modality.SPEECH
+        # every sc_* stage call returns with its stream drained, so host timers are stage times
+        t0 = time.perf_counter()
         enc, enc_lens = self.model.encode_speech(seqs, frame_lens)
+        t1 = time.perf_counter()
         prefix = self.text_tokenizer.target_prefix(tgt_lang)
         ids, out_lens, _scores, hidden = self.model.generate_text(
             enc, enc_lens.tolist(), prefix,
@@ -245,9 +253,13 @@ class Translator:
             soft_max_seq_len=text_generation_opts.soft_max_seq_len,
             hard_max_seq_len=text_generation_opts.hard_max_seq_len,
             unk_penalty=text_generation_opts.unk_penalty,
+            use_graph=self.use_graph,
             want_hidden=want_speech,
         )
-        texts: List[StringLike] = [self.text_tokenizer.decode(ids[b, : out_lens[b]]) for b in range(ids.shape[0])]
+        t2 = time.perf_counter()
+        self.last_text_ids = [ids[b, : out_lens[b]].tolist() for b in range(ids.shape[0])]
+        texts: List[StringLike] = [self.text_tokenizer.decode(t) for t in self.last_text_ids]
+        self.last_stage_ms = {"encoder": (t1 - t0) * 1e3, "text_decoder": (t2 - t1) * 1e3}
         if not want_speech:
             return texts, None
 
@@ -256,7 +268,10 @@ class Translator:
         # generator.py:281-291: pad_seqs + trim the last column; PaddingMask.trim(1)
         text_seqs = ids[:, :-1]
         text_lens = (out_lens - 1).tolist()
+        t3 = time.perf_counter()
         units, unit_lens, _dur, _cids, _clens = self.model.t2u_nar(hidden, text_seqs, text_lens, duration_factor)
+        t4 = time.perf_counter()
+        self.last_stage_ms["t2u"] = (t4 - t3) * 1e3
         pad = self.unit_tokenizer.vocab_info.pad_idx
         speech_units = [[int(u) for u in units[i] if u != pad] for i in range(units.shape[0])]
         audio_wavs: List[Tensor] = []
@@ -267,6 +282,7 @@ class Translator:
             spkr_list = [spkr if spkr is not None else -1] * n
             spkr_idx = [lang_map["multispkr"][tgt_lang][0] if s == -1 else s for s in spkr_list]
             wav = self.model.vocode(units, lang_idx, spkr_idx)
+            self.last_stage_ms["vocoder"] = (time.perf_counter() - t4) * 1e3
             for i in range(n):
                 keep = int(wav.size(-1) * len(speech_units[i]) / units.shape[1])
                 audio_wavs.append(wav[i, :, :keep].unsqueeze(0))

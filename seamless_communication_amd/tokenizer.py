@@ -21,6 +21,16 @@ import numpy as np
 SPACE = "▁"  # nar_decoder_frontend.py:28
 
 
+def _is_tensor(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _like(ref, arr: np.ndarray):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(ref.device)
+
+
 @dataclass(frozen=True)
 class VocabularyInfo:
     size: int
@@ -76,7 +86,9 @@ class UnitTokenizer:
             )
         return self.langs[relative_idx]
 
-    def create_encoder(self, lang: str) -> "UnitTokenEncoder":
+    def create_encoder(self, lang: str, device=None) -> "UnitTokenEncoder":
+        """``device`` is accepted for signature parity (unit_tokenizer.py:96-107);
+        tensors are returned on the device of the input."""
         return UnitTokenEncoder(self, lang, self.is_nar_decoder)
 
     def create_decoder(self) -> "UnitTokenDecoder":
@@ -102,7 +114,10 @@ class UnitTokenEncoder:
         else:
             self.prefix_indices = None
 
-    def __call__(self, units: np.ndarray) -> np.ndarray:
+    def __call__(self, units):
+        """int64 array or tensor (N, S) -> same kind, (N, S [+2])."""
+        if _is_tensor(units):
+            return _like(units, self(units.detach().cpu().numpy()))
         units = np.asarray(units, dtype=np.int64)
         n = units.shape[0]
         if self.prefix_indices is not None:
@@ -124,7 +139,9 @@ class UnitTokenDecoder:
         self.pad_idx = tokenizer.vocab_info.pad_idx
         self.is_nar_decoder = is_nar_decoder
 
-    def __call__(self, token_indices: np.ndarray) -> np.ndarray:
+    def __call__(self, token_indices):
+        if _is_tensor(token_indices):
+            return _like(token_indices, self(token_indices.detach().cpu().numpy()))
         token_indices = np.asarray(token_indices, dtype=np.int64)
         if token_indices.shape[1] == 0:
             return token_indices
