@@ -23,6 +23,16 @@ GOLDEN = ROOT / "tests" / "golden" / "fbank_knf.npz"
 TOL = 2e-3
 
 
+def close_logmel(got: np.ndarray, ref: np.ndarray) -> bool:
+    """|dlog| < TOL, except in bins that sit at the fp32 noise floor of the
+    frame (energy < 1e-10 x the frame's largest bin: there the reference's own
+    float32 FFT rounding decides the value, e.g. the band-limited "ramp" case)."""
+    e_got, e_ref = np.exp(got.astype(np.float64)), np.exp(ref.astype(np.float64))
+    floor = 1e-10 * e_ref.max(axis=1, keepdims=True)
+    ok = (np.abs(got - ref) < TOL) | (np.abs(e_got - e_ref) < floor)
+    return bool(ok.all())
+
+
 def _knf(wav: np.ndarray) -> np.ndarray:
     lib = ctypes.CDLL(str(REF_LIB))
     lib.knf_ref_num_frames.restype = ctypes.c_int32
@@ -47,7 +57,7 @@ def test_oracle_fbank_matches_knf_golden(key):
     wav, ref = g[key + "_wav"], g[key + "_fbank"]
     got = ofb.fbank_raw(wav)
     assert got.shape == ref.shape == (ofb.num_frames(len(wav)), 80)
-    assert np.abs(got - ref).max() < TOL
+    assert close_logmel(got, ref)
 
 
 def test_num_frames_rule_and_short_inputs():
@@ -66,7 +76,7 @@ def test_oracle_fbank_matches_compiled_reference_live():
         ref = _knf(wav)
         got = ofb.fbank_raw(wav)
         assert got.shape == ref.shape
-        assert np.abs(got - ref).max() < TOL
+        assert close_logmel(got, ref)
 
 
 def test_standardize_is_unbiased_per_bin():
