@@ -55,6 +55,9 @@ def parse_args():
     ap.add_argument("--text-len", type=int, default=42, help="hard_max_seq_len of the greedy text search (prompt included)")
     ap.add_argument("--arch", default="base_v2", choices=["base_v2", "tiny_v2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default min(32, usable cpus))")
+    ap.add_argument("--cpu-baseline-timeout", type=int, default=240)
     ap.add_argument("--no-profile-step", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch decoder steps eagerly instead of hipGraph replay")
     return ap.parse_args()
@@ -97,27 +100,68 @@ def roofline_of(fams):
     return roof, shares
 
 
-def cpu_baseline(cfg, unity_sd, vocoder_sd, tt, ct, lang_map, wav_np, text_len):
-    """The CPU oracle on ONE utterance of the bench workload (a port: the
-    reference's fairseq2 path itself cannot be run offline)."""
-    from oracle.pipeline import OracleS2ST
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    torch.set_num_threads(os.cpu_count() or 1)
-    orc = OracleS2ST(cfg, unity_sd, vocoder_sd, tt, ct, lang_map)
+
+def usable_cpus() -> int:
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2 quota, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline_worker(args):
+    """Child process: the CPU oracle (a port of the reference's fairseq2 path; the
+    reference itself cannot be run offline) on ONE utterance of the bench workload."""
+    from oracle.pipeline import OracleS2ST
+    from seamless_communication_amd import cards, synthetic as syn
+    from seamless_communication_amd.inference.translator import _ARCHS
+    from seamless_communication_amd.tokenizer import CharTokenizer, NllbTextTokenizer
+
+    torch.set_num_threads(args.cpu_threads)
+    cfg = _ARCHS[args.arch]()
+    tt = NllbTextTokenizer(cfg.text_vocab_size, cards.TEXT_LANGS)
+    ct = CharTokenizer(cfg.char_vocab_size)
+    orc = OracleS2ST(cfg, syn.make_unity_state_dict(cfg, syn.DEFAULT_SEED), syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED),
+                     tt, ct, cards.vocoder_lang_spkr_idx_map())
+    wav = syn.synthetic_waveform(0, AUDIO_SECONDS).numpy()
     t0 = time.perf_counter()
-    fb, lens = orc.collate_fbank([wav_np])
-    seqs, speech_units, wavs, units, aux = orc.s2st(fb, lens, "fra", (1, 200), text_len)
+    fb, lens = orc.collate_fbank([wav])
+    seqs, speech_units, wavs, units, aux = orc.s2st(fb, lens, "fra", (1, 200), args.text_len)
     dt = time.perf_counter() - t0
-    return {
+    print(json.dumps({
         "value": 1.0 / dt, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
         "sample": f"1 utterance (10 s audio, {len(seqs[0])} text tokens, {len(speech_units[0])} units), "
                   f"fp32 PyTorch oracle of the fairseq2 path, one pass, no warm-up",
-        "seconds": dt, "rtf": dt / AUDIO_SECONDS,
-    }, seqs, speech_units
+        "seconds": dt, "rtf": dt / AUDIO_SECONDS, "text_ids": seqs[0], "units": speech_units[0],
+    }), flush=True)
+
+
+def cpu_baseline(args):
+    import subprocess
+
+    threads = args.cpu_threads or min(32, usable_cpus())
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-worker", "--arch", args.arch, "--text-len",
+           str(args.text_len), "--cpu-threads", str(threads)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_baseline_timeout)
+        if r.returncode != 0:
+            return {"value": None, "error": (r.stderr or "")[-400:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "utterances/s", "cores": threads, "kind": "port",
+                "sample": f"1 utterance did not finish within {args.cpu_baseline_timeout} s"}
 
 
 def main():
     args = parse_args()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -136,6 +180,7 @@ def main():
     from seamless_communication_amd.inference import SequenceGeneratorOptions, Translator
     from seamless_communication_amd.inference.translator import DEFAULT_CARDS
 
+    log(f"rank {rank}/{world}: building weights + loading the model ...")
     t_load = time.perf_counter()
     card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch=args.arch)
     translator = Translator(card, "vocoder_v2", device=device)
@@ -143,6 +188,7 @@ def main():
     model = translator.model
     cfg = translator.cfg
     load_s = time.perf_counter() - t_load
+    log(f"model resident in HBM after {load_s:.1f} s")
 
     B = args.batch
     n_samples = int(AUDIO_SECONDS * 16000)
@@ -173,14 +219,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        log(f"warmup step {i}: {stage_ms}")
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         texts, speech = step()
     fence()
     elapsed = time.perf_counter() - t0
+    log(f"timed region: {args.steps} steps in {elapsed:.3f} s; last step {stage_ms}")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,6 +272,7 @@ def main():
         torch.cuda.synchronize()
         lib.sc_prof_enable(0)
         fams = prof_report(lib)
+        log("profiled step done")
         translator.use_graph = not args.no_graph
         if rank == 0:
             roof, shares = roofline_of(fams)
@@ -255,14 +304,11 @@ def main():
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            tt, ct = translator.text_tokenizer, translator.char_tokenizer
-            unity_sd = syn.make_unity_state_dict(cfg, syn.DEFAULT_SEED)
-            voc_sd = syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED)
-            base, seqs, sunits = cpu_baseline(cfg, unity_sd, voc_sd, tt, ct, cards.vocoder_lang_spkr_idx_map(),
-                                              wav_host[0].numpy(), args.text_len)
-            base["ids_match_gpu"] = {
-                "text": seqs[0] == translator_first_text(translator, texts, model, wav_dev, ns, opts),
-            }
+            log("CPU baseline (oracle, 1 utterance) in a child process ...")
+            base = cpu_baseline(args)
+            if base.get("value"):
+                gpu_text, gpu_units = first_utterance_ids(translator, model, wav_dev, ns, opts)
+                base["ids_match_gpu"] = {"text": base.pop("text_ids") == gpu_text, "units": base.pop("units") == gpu_units}
             result["cpu_baseline"] = base
         else:
             result["cpu_baseline"] = None
@@ -273,13 +319,13 @@ def main():
         dist.destroy_process_group()
 
 
-def translator_first_text(translator, texts, model, wav_dev, ns, opts):
-    """Text ids of utterance 0 from the HIP path (re-run at batch 1 so that the
-    comparison with the CPU oracle is on identical input)."""
+def first_utterance_ids(translator, model, wav_dev, ns, opts):
+    """Text ids and units of utterance 0 from the HIP path at batch 1 (the CPU
+    oracle runs the same single utterance)."""
     fb, frames = model.fbank(wav_dev[:1].contiguous(), ns[:1])
-    translator.predict({"seqs": fb, "seq_lens": torch.from_numpy(frames.astype(np.int64)), "is_ragged": False},
-                       "S2ST", "fra", text_generation_opts=opts)
-    return translator.last_text_ids[0]
+    _, speech = translator.predict({"seqs": fb, "seq_lens": torch.from_numpy(frames.astype(np.int64)), "is_ragged": False},
+                                   "S2ST", "fra", text_generation_opts=opts)
+    return translator.last_text_ids[0], speech.units[0]
 
 
 if __name__ == "__main__":
