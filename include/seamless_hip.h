@@ -174,6 +174,14 @@ int sc_op_layernorm(const float* d_x, const float* d_gamma, const float* d_beta,
                     int32_t act);
 int sc_op_linear(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y,
                  int32_t M, int32_t N, int32_t K, int32_t act, float alpha, int32_t split, int32_t force_gemv);
+/* Decoder-step products for 1..64 rows (k_skinny.hip).  sc_op_skinny_linear: y = alpha*act(x.W^T+b)+res.
+ * sc_op_skinny_res_ln: x += in.W^T + b computed as `splits` K-range partials (0 = pick automatically)
+ * summed in fixed order, then h = LayerNorm(x) (d_h may be NULL). */
+int sc_op_skinny_linear(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y,
+                        int32_t M, int32_t N, int32_t K, int32_t act, float alpha);
+int sc_op_skinny_res_ln(const float* d_in, const void* d_w_f16, const float* d_bias, float* d_x_inout,
+                        const float* d_gamma, const float* d_beta, float* d_h, int32_t M, int32_t N, int32_t K,
+                        int32_t splits);
 int sc_op_conv1d(const float* d_x, const void* d_w_f16_packed, const float* d_bias, const float* d_res, float* d_y,
                  int32_t nb, int32_t t_in, int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t pad,
                  int32_t dil, const int32_t* d_in_lens, int32_t in_act, int32_t act);

@@ -97,6 +97,8 @@ SIGNATURES = {
     "sc_prof_report": (C.c_int64, [C.c_char_p, C.c_int64]),
     "sc_op_layernorm": (C.c_int, [_P, _P, _P, _P, _i, _i, _i]),
     "sc_op_linear": (C.c_int, [_P, _P, _P, _P, _P, _i, _i, _i, _i, C.c_float, _i, _i]),
+    "sc_op_skinny_linear": (C.c_int, [_P, _P, _P, _P, _P, _i, _i, _i, _i, C.c_float]),
+    "sc_op_skinny_res_ln": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i]),
     "sc_op_conv1d": (C.c_int, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i, _i, _i, _P, _i, _i]),
     "sc_op_pack_conv_weight": (C.c_int, [_P, _P, _i, _i, _i]),
     "sc_op_conv_transpose1d": (C.c_int, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i, _i, _i]),

@@ -228,6 +228,57 @@ int sc_op_linear(const float* d_x, const void* d_w_f16, const float* d_bias, con
     SC_API_END
 }
 
+int sc_op_skinny_linear(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y,
+                        int32_t M, int32_t N, int32_t K, int32_t act, float alpha) {
+    SC_API_BEGIN
+    SkinnyArgs a;
+    a.A = d_x;
+    a.lda = K;
+    a.W = static_cast<const __half*>(d_w_f16);
+    a.ldw = K;
+    a.bias = d_bias;
+    a.res = d_res;
+    a.ldr = N;
+    a.C = d_y;
+    a.ldc = N;
+    a.M = M;
+    a.N = N;
+    a.K = K;
+    a.act = act;
+    a.alpha = alpha;
+    launch_skinny(a, g_op_stream);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+int sc_op_skinny_res_ln(const float* d_in, const void* d_w_f16, const float* d_bias, float* d_x_inout,
+                        const float* d_gamma, const float* d_beta, float* d_h, int32_t M, int32_t N, int32_t K,
+                        int32_t splits) {
+    SC_API_BEGIN
+    SkinnyArgs a;
+    a.A = d_in;
+    a.lda = K;
+    a.W = static_cast<const __half*>(d_w_f16);
+    a.ldw = K;
+    a.M = M;
+    a.N = N;
+    a.K = K;
+    a.splits = splits > 0 ? splits : skinny_splits(M, N, K, 1);
+    float* partial = nullptr;
+    SC_HIP(hipMalloc(&partial, (size_t)a.splits * M * N * sizeof(float)));
+    a.partial = partial;
+    try {
+        launch_skinny(a, g_op_stream);
+        launch_reduce_res_ln(partial, a.splits, d_bias, d_x_inout, d_gamma, d_beta, d_h, M, N, g_op_stream);
+        SC_HIP(hipStreamSynchronize(g_op_stream));
+    } catch (...) {
+        (void)hipFree(partial);
+        throw;
+    }
+    (void)hipFree(partial);
+    SC_API_END
+}
+
 int sc_op_pack_conv_weight(const void* d_w_f16, void* d_dst_f16, int32_t cout, int32_t cin, int32_t k) {
     SC_API_BEGIN
     const int kpad = (int)align_up((int64_t)cin * k, 32);

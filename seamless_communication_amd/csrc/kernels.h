@@ -55,6 +55,33 @@ void launch_gemv(const float* x, int64_t ldx, const __half* W, int64_t ldw, cons
                  const float* res, int64_t ldr, float* out, int64_t ldo, int M, int N, int K,
                  int act, float alpha, hipStream_t s);
 
+// Skinny product for 1..64 rows (decoder step), see k_skinny.hip.  With partial != nullptr the
+// kernel writes raw K-range partial sums to partial[split][M][N] (no epilogue); otherwise
+// C = alpha*act(A.W^T + bias) + res.
+struct SkinnyArgs {
+    const float* A = nullptr;
+    int64_t lda = 0;
+    const __half* W = nullptr;
+    int64_t ldw = 0;
+    const float* bias = nullptr;
+    const float* res = nullptr;
+    int64_t ldr = 0;
+    float* C = nullptr;
+    int64_t ldc = 0;
+    float* partial = nullptr;
+    int M = 0, N = 0, K = 0;
+    int act = ACT_NONE;
+    float alpha = 1.0f;
+    int splits = 1;
+    int kc = 0;  // filled by the launcher
+};
+void launch_skinny(const SkinnyArgs& a, hipStream_t s);
+// number of K ranges that brings the grid to >= 256 workgroups (1 when want_split == 0)
+int skinny_splits(int M, int N, int K, int want_split);
+// x[row] += bias + sum_s partial[s][row]; h[row] = LayerNorm(x[row]) (h may be null)
+void launch_reduce_res_ln(const float* partial, int splits, const float* bias, float* x, const float* gamma,
+                          const float* beta, float* h, int rows, int C, hipStream_t s);
+
 // y = act(LayerNorm(x) * gamma + beta); rows masked to zero when t >= lens[n] (optional).
 void launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
                       int64_t ldy, int rows, int C, int act, const int* lens, int t_per_batch,

@@ -34,6 +34,7 @@ struct StepCtx {
     std::vector<float*> kcache, vcache;  // per layer [nb][cap][M]
     std::vector<float*> cross_kv;        // per layer [nb*s_enc][2M]
     float* dec_hidden = nullptr;         // [nb][cap-1][M] or null
+    float* partial = nullptr;            // split-K partial sums [splits][nb][M]
     int min_seq_len = 1, force_eos_step = -1;
     float unk_penalty = 0.f;
 };
@@ -48,29 +49,53 @@ __global__ void store_hidden_kernel(const float* __restrict__ hN, float* __restr
     for (int c = threadIdx.x; c < M / 4; c += blockDim.x) d[c] = s[c];
 }
 
+// out-projection + residual + the NEXT LayerNorm:  x += in . W^T + b ;  h_out = LN_next(x).
+// Up to 64 rows: split-K skinny product into K-range partials, summed in fixed order by the fused
+// reduce + residual + LayerNorm kernel.  More rows: the MFMA GEMM with a residual epilogue + LayerNorm.
+void out_proj_res_ln(Model& m, StepCtx& c, const float* in, int64_t ld_in, const Linear& L, const LNorm& next,
+                     float* h_out) {
+    const int nb = c.nb, M = m.cfg.model_dim;
+    if (nb <= 64 && L.in % 64 == 0 && L.out == M && M % 4 == 0) {
+        SkinnyArgs a;
+        a.A = in;
+        a.lda = ld_in;
+        a.W = L.w;
+        a.ldw = L.ldw;
+        a.M = nb;
+        a.N = L.out;
+        a.K = L.in;
+        a.splits = skinny_splits(nb, L.out, L.in, 1);
+        a.partial = c.partial;
+        launch_skinny(a, m.stream);
+        launch_reduce_res_ln(c.partial, a.splits, L.b, c.x, next.g, next.b, h_out, nb, M, m.stream);
+    } else {
+        linear(m, in, ld_in, L, c.x, M, c.x, M, nb, ACT_NONE, 1.f);
+        layernorm(m, c.x, next, h_out, nb);
+    }
+}
+
 // One decoder step for all batch rows: feeds d_tok at position *d_pos.
 void decoder_step(Model& m, StepCtx& c, bool project) {
     const sc_config& cfg = m.cfg;
     const int M = cfg.model_dim, nb = c.nb;
     launch_embed_tokens(c.d_tok, nb, m.text_embed, M, sqrtf((float)M), m.text_pos, c.d_pos, 0, c.x, M, m.stream);
+    layernorm(m, c.x, m.dec[0].self_ln, c.h, nb);
     for (int li = 0; li < cfg.dec_layers; ++li) {
         const DecoderLayer& l = m.dec[li];
-        layernorm(m, c.x, l.self_ln, c.h, nb);
+        const bool last = li + 1 == cfg.dec_layers;
         linear(m, c.h, M, l.qkv, nullptr, 0, c.wide, 3 * M, nb, ACT_NONE, 1.f);
         launch_decode_attention(c.wide, 3 * M, c.wide + M, c.wide + 2 * M, 3 * M, c.kcache[li], c.vcache[li], M,
                                 (int64_t)c.cap * M, c.cap, c.att, M, nb, cfg.num_heads, c.d_pos, nullptr, 0, m.stream);
-        linear(m, c.att, M, l.self_out, c.x, M, c.x, M, nb, ACT_NONE, 1.f);
-        layernorm(m, c.x, l.cross_ln, c.h, nb);
+        out_proj_res_ln(m, c, c.att, M, l.self_out, l.cross_ln, c.h);
         linear(m, c.h, M, l.cross_q, nullptr, 0, c.wide, M, nb, ACT_NONE, 1.f);
         launch_decode_attention(c.wide, M, nullptr, nullptr, 0, c.cross_kv[li], c.cross_kv[li] + M, 2 * M,
                                 (int64_t)c.s_enc * 2 * M, c.s_enc, c.att, M, nb, cfg.num_heads, nullptr, c.d_enc_lens, 1,
                                 m.stream);
-        linear(m, c.att, M, l.cross_out, c.x, M, c.x, M, nb, ACT_NONE, 1.f);
-        layernorm(m, c.x, l.ffn_ln, c.h, nb);
+        out_proj_res_ln(m, c, c.att, M, l.cross_out, l.ffn_ln, c.h);
         linear(m, c.h, M, l.ffn_in, nullptr, 0, c.wide, cfg.dec_ffn_dim, nb, ACT_RELU, 1.f);
-        linear(m, c.wide, cfg.dec_ffn_dim, l.ffn_out, c.x, M, c.x, M, nb, ACT_NONE, 1.f);
+        out_proj_res_ln(m, c, c.wide, cfg.dec_ffn_dim, l.ffn_out, last ? m.dec_final_ln : m.dec[li + 1].self_ln,
+                        last ? c.hN : c.h);
     }
-    layernorm(m, c.x, m.dec_final_ln, c.hN, nb);
     if (c.dec_hidden) {
         hipLaunchKernelGGL(store_hidden_kernel, dim3(nb), dim3(256), 0, m.stream, c.hN, c.dec_hidden, M, c.cap - 1, c.d_pos);
         SC_LAUNCH_CHECK();
@@ -140,6 +165,8 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
     Buf<float> x(&m.pool, (size_t)n * M), h(&m.pool, (size_t)n * M), wide(&m.pool, (size_t)n * wideN), att(&m.pool, (size_t)n * M),
         hN(&m.pool, (size_t)n * M), logits(&m.pool, forced ? 4 : (size_t)n * cfg.text_vocab_size);
+    Buf<float> partial(&m.pool, (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * n * M);
+    c.partial = partial;
     c.x = x;
     c.h = h;
     c.wide = wide;

@@ -431,8 +431,23 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
 void linear(Model& m, const float* x, int64_t ldx, const Linear& L, const float* res, int64_t ldr, float* y,
             int64_t ldy, int rows, int act, float alpha) {
     if (rows <= 0) return;
-    if (rows <= 8 && L.in % 8 == 0 && ldx % 4 == 0) {
-        launch_gemv(x, ldx, L.w, L.ldw, L.b, res, ldr, y, ldy, rows, L.out, L.in, act, alpha, m.stream);
+    if (rows <= 64 && L.in % 64 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        SkinnyArgs a;
+        a.A = x;
+        a.lda = ldx;
+        a.W = L.w;
+        a.ldw = L.ldw;
+        a.bias = L.b;
+        a.res = res;
+        a.ldr = ldr;
+        a.C = y;
+        a.ldc = ldy;
+        a.M = rows;
+        a.N = L.out;
+        a.K = L.in;
+        a.act = act;
+        a.alpha = alpha;
+        launch_skinny(a, m.stream);
         return;
     }
     GemmArgs a;

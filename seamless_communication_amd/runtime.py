@@ -137,7 +137,9 @@ class HipS2STModel:
             T += pad_to_multiple - T % pad_to_multiple
         out = torch.empty(wav.shape[0], T, self.cfg.num_fbank_channels, dtype=torch.float32, device=self.device)
         got = np.zeros(wav.shape[0], dtype=np.int32)
-        check(self.lib.sc_fbank(self.handle, _ptr(wav), wav.shape[0], wav.stride(0), _ptr(ns), int(standardize),
+        # a size-1 batch dimension may carry an arbitrary stride
+        stride = wav.stride(0) if wav.shape[0] > 1 else wav.shape[1]
+        check(self.lib.sc_fbank(self.handle, _ptr(wav), wav.shape[0], stride, _ptr(ns), int(standardize),
                                 _ptr(out), T, _ptr(got)), "sc_fbank")
         return out, got
 

@@ -178,9 +178,11 @@ def make_unity_state_dict(
     g.layer_norm(f"{d}.ln1", H)
     g.conv1d(f"{d}.conv2.0", H, H, K)
     g.layer_norm(f"{d}.ln2", H)
-    # log(dur+1) ~ N(1.25, 0.3): durations of 2..4 units per character.
+    # log(dur+1) ~ N(1.8, 0.3): durations of about 3..7 units per character, so that the ~100
+    # characters of a 40-token synthetic hypothesis give the ~500 units (10 s of speech) that
+    # BASELINE.md prices the path at.
     g.uniform(f"{d}.proj.weight", (1, H), 0.3 * math.sqrt(3.0 / H))
-    g.sd[f"{d}.proj.bias"] = torch.tensor([1.25], dtype=dtype)
+    g.sd[f"{d}.proj.bias"] = torch.tensor([1.8], dtype=dtype)
     for i in range(cfg.t2u_dec_layers):
         p = f"t2u_model.decoder.layers.{i}"
         g.mha(f"{p}.self_attn", M)
