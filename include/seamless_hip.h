@@ -182,6 +182,12 @@ int sc_op_skinny_linear(const float* d_x, const void* d_w_f16, const float* d_bi
 int sc_op_skinny_res_ln(const float* d_in, const void* d_w_f16, const float* d_bias, float* d_x_inout,
                         const float* d_gamma, const float* d_beta, float* d_h, int32_t M, int32_t N, int32_t K,
                         int32_t splits);
+/* Fused vocabulary projection + arg-max under the generation step rules (PAD never, EOS masked while
+ * step < min_step_for_eos, EOS forced at step == force_eos_step, UNK penalty); d_lprob receives the
+ * log-softmax value of the winner.  step is a host value here. */
+int sc_op_skinny_argmax(const float* d_x, const void* d_w_f16, int32_t M, int32_t N, int32_t K, int32_t step,
+                        int32_t min_step_for_eos, int32_t force_eos_step, int32_t pad_idx, int32_t eos_idx,
+                        int32_t unk_idx, float unk_penalty, int32_t* d_idx, float* d_lprob);
 int sc_op_conv1d(const float* d_x, const void* d_w_f16_packed, const float* d_bias, const float* d_res, float* d_y,
                  int32_t nb, int32_t t_in, int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t pad,
                  int32_t dil, const int32_t* d_in_lens, int32_t in_act, int32_t act);

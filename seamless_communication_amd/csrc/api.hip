@@ -279,6 +279,58 @@ int sc_op_skinny_res_ln(const float* d_in, const void* d_w_f16, const float* d_b
     SC_API_END
 }
 
+int sc_op_skinny_argmax(const float* d_x, const void* d_w_f16, int32_t M, int32_t N, int32_t K, int32_t step,
+                        int32_t min_step_for_eos, int32_t force_eos_step, int32_t pad_idx, int32_t eos_idx,
+                        int32_t unk_idx, float unk_penalty, int32_t* d_idx, float* d_lprob) {
+    SC_API_BEGIN
+    SC_CHECK(M >= 1 && M <= 64, "sc_op_skinny_argmax: M=%d out of range", M);
+    const int tiles = skinny_argmax_tiles(M, N);
+    // scratch: records | eos logit | pos | hist[M][step+2] | finished | out_len
+    const int hist_ld = step + 2;
+    char* buf = nullptr;
+    const size_t bytes = (size_t)tiles * M * 16 + (size_t)M * 4 + 16 + (size_t)M * hist_ld * 4 + (size_t)M * 8;
+    SC_HIP(hipMalloc(&buf, bytes));
+    try {
+        SC_HIP(hipMemsetAsync(buf, 0, bytes, g_op_stream));
+        float4* part = reinterpret_cast<float4*>(buf);
+        float* eos_logit = reinterpret_cast<float*>(buf + (size_t)tiles * M * 16);
+        int* d_pos = reinterpret_cast<int*>(eos_logit + M);
+        int* hist = d_pos + 4;
+        int* finished = hist + (size_t)M * hist_ld;
+        int* out_len = finished + M;
+        SC_HIP(hipMemcpyAsync(d_pos, &step, 4, hipMemcpyHostToDevice, g_op_stream));
+        SC_HIP(hipMemsetAsync(d_lprob, 0, (size_t)M * 4, g_op_stream));
+        SkinnyArgs a;
+        a.A = d_x;
+        a.lda = K;
+        a.W = static_cast<const __half*>(d_w_f16);
+        a.ldw = K;
+        a.M = M;
+        a.N = N;
+        a.K = K;
+        a.am_part = part;
+        a.am_tiles_cap = tiles;
+        a.am_eos_logit = eos_logit;
+        a.am_pos = d_pos;
+        a.am_min_step_for_eos = min_step_for_eos;
+        a.am_force_eos_step = force_eos_step;
+        a.am_pad_idx = pad_idx;
+        a.am_eos_idx = eos_idx;
+        a.am_unk_idx = unk_idx;
+        a.am_unk_penalty = unk_penalty;
+        launch_skinny(a, g_op_stream);
+        // score accumulates the winner's log-probability: d_lprob starts at zero
+        launch_argmax_finalize(part, tiles, M, eos_logit, d_pos, force_eos_step, pad_idx, eos_idx, d_idx, hist, hist_ld,
+                               finished, out_len, d_lprob, g_op_stream);
+        SC_HIP(hipStreamSynchronize(g_op_stream));
+    } catch (...) {
+        (void)hipFree(buf);
+        throw;
+    }
+    (void)hipFree(buf);
+    SC_API_END
+}
+
 int sc_op_pack_conv_weight(const void* d_w_f16, void* d_dst_f16, int32_t cout, int32_t cin, int32_t k) {
     SC_API_BEGIN
     const int kpad = (int)align_up((int64_t)cin * k, 32);

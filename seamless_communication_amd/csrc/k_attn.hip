@@ -250,7 +250,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     const float* __restrict__ q, int64_t ldq, const float* __restrict__ k_new,
     const float* __restrict__ v_new, int64_t ldkv, float* __restrict__ kcache,
     float* __restrict__ vcache, int64_t cache_ld, int64_t cache_bs, int cap, float* __restrict__ out,
-    int64_t ldo, int heads, const int* __restrict__ d_pos, const int* __restrict__ kv_lens, int use_lens) {
+    int64_t ldo, int heads, const int* __restrict__ d_pos, const int* __restrict__ kv_lens, int use_lens,
+    int in_splits, int64_t in_split_stride, const float* __restrict__ bias_q,
+    const float* __restrict__ bias_k, const float* __restrict__ bias_v) {
     __shared__ float s_q[HD];
     __shared__ float s_sc[MAX_CACHE];
     __shared__ float s_red[8];
@@ -263,11 +265,20 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     // key/value row j of (batch b, head h) lives at base + b*cache_bs + j*cache_ld + h*64
     float* kc = kcache + (int64_t)b * cache_bs + h * HD;
     float* vc = vcache + (int64_t)b * cache_bs + h * HD;
-    if (tid < HD) {
-        s_q[tid] = q[(int64_t)b * ldq + h * HD + tid];
-        if (k_new) {
-            kc[(int64_t)pos * cache_ld + tid] = k_new[(int64_t)b * ldkv + h * HD + tid];
-            vc[(int64_t)pos * cache_ld + tid] = v_new[(int64_t)b * ldkv + h * HD + tid];
+    // q / new k / new v may arrive as split-K partial sums of the projection (k_skinny.hip): they are
+    // added here in split order, bias last, instead of in a separate reduction launch.
+    if (tid < 3 * HD) {
+        const int which = tid >> 6, d = tid & 63;  // 0: q, 1: k_new, 2: v_new
+        if (which == 0 || k_new) {
+            const float* src = which == 0 ? q : (which == 1 ? k_new : v_new);
+            const int64_t ld = which == 0 ? ldq : ldkv;
+            const float* bias = which == 0 ? bias_q : (which == 1 ? bias_k : bias_v);
+            float v = 0.f;
+            for (int sp = 0; sp < in_splits; ++sp) v += src[(int64_t)sp * in_split_stride + (int64_t)b * ld + h * HD + d];
+            if (bias) v += bias[h * HD + d];
+            if (which == 0) s_q[d] = v;
+            else if (which == 1) kc[(int64_t)pos * cache_ld + d] = v;
+            else vc[(int64_t)pos * cache_ld + d] = v;
         }
     }
     __syncthreads();
@@ -323,11 +334,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
 void launch_decode_attention(const float* q, int64_t ldq, const float* k_new, const float* v_new,
                              int64_t ldkv, float* kcache, float* vcache, int64_t cache_ld, int64_t cache_bs,
                              int cap, float* out, int64_t ldo, int nb, int heads, const int* d_pos,
-                             const int* kv_lens, int use_lens, hipStream_t s) {
+                             const int* kv_lens, int use_lens, hipStream_t s, int in_splits,
+                             int64_t in_split_stride, const float* bias_q, const float* bias_k,
+                             const float* bias_v) {
     SC_CHECK(cap <= MAX_CACHE, "decode attention: cache capacity %d > %d", cap, MAX_CACHE);
     SC_CHECK(nb > 0 && heads > 0, "decode attention: empty problem");
     hipLaunchKernelGGL(decode_attn_kernel, dim3(heads, nb), dim3(256), 0, s, q, ldq, k_new, v_new, ldkv,
-                       kcache, vcache, cache_ld, cache_bs, cap, out, ldo, heads, d_pos, kv_lens, use_lens);
+                       kcache, vcache, cache_ld, cache_bs, cap, out, ldo, heads, d_pos, kv_lens, use_lens,
+                       in_splits < 1 ? 1 : in_splits, in_split_stride, bias_q, bias_k, bias_v);
     SC_LAUNCH_CHECK();
 }
 

@@ -39,7 +39,8 @@ __device__ __forceinline__ float apply_in_act(float v, int in_act) {
     return v;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool FASTA, bool SPLIT>
+// AMODE 0: any cin (scalar loads); 1: cin % 32 == 0 (a K slab lies in one tap); 2: cin % 4 == 0 (a float4 lies in one tap)
+template <int BM, int BN, int WGM, int WGN, int AMODE, bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -87,10 +88,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     uint4 b_reg[B_IT];
 
     auto load_tile = [&](int k0) {
-        if (FASTA) {
+        if (AMODE == 1) {
             // cin % 32 == 0: the whole slab lies inside one tap.
             const int tap = k0 / p.cin;
             const int c0 = k0 - tap * p.cin + a_kq * 4;
+            const bool tap_ok = tap < p.taps;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int src_t = a_q[i] * p.stride + tap * p.dil - p.pad;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (tap_ok && src_t >= 0 && src_t < a_len[i]) {
+                    v = *reinterpret_cast<const float4*>(
+                        p.A + ((int64_t)a_n[i] * p.t_in + src_t) * p.lda + c0);
+                }
+                a_reg[i] = v;
+            }
+        } else if (AMODE == 2) {
+            // cin % 4 == 0: each thread's 4 consecutive k sit in one tap
+            const int kk = k0 + a_kq * 4;
+            const int tap = kk / p.cin;
+            const int c0 = kk - tap * p.cin;
             const bool tap_ok = tap < p.taps;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
@@ -232,25 +249,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 template <int BM, int BN, int WGM, int WGN>
 static void launch_cfg(const GemmArgs& a, hipStream_t s) {
     dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.phases);
-    const bool fast = (a.cin % 32 == 0) && (a.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
+    const bool vec_ok = (a.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
+    const int amode = (vec_ok && a.cin % 32 == 0) ? 1 : (vec_ok && a.cin % 4 == 0) ? 2 : 0;
     char name[64];
-    snprintf(name, sizeof(name), "gemm_%dx%d_%s_%s", BM, BN, fast ? "vecA" : "genA", a.split ? "split" : "f16");
+    snprintf(name, sizeof(name), "gemm_%dx%d_%s_%s", BM, BN, amode == 1 ? "vecA" : amode == 2 ? "vec4A" : "genA",
+             a.split ? "split" : "f16");
     const double kreal = (double)a.taps * a.cin;
     const double flops = a.algo_flops > 0 ? a.algo_flops : 2.0 * a.M * a.N * kreal * a.phases;
     const double bytes = 4.0 * a.M * (double)a.cin * (a.stride < a.taps ? 1.0 : (double)a.taps) +
                          2.0 * a.N * (double)a.K * a.phases + 4.0 * a.M * (double)a.N * (a.res ? 2.0 : 1.0);
     prof::Scope scope(name, flops, bytes, s);
-    if (fast) {
-        if (a.split)
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, true, true>), grid, dim3(256), 0, s, a);
-        else
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, true, false>), grid, dim3(256), 0, s, a);
+#define SC_GEMM_LAUNCH(AM, SP) hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, AM, SP>), grid, dim3(256), 0, s, a)
+    if (a.split) {
+        if (amode == 1) SC_GEMM_LAUNCH(1, true);
+        else if (amode == 2) SC_GEMM_LAUNCH(2, true);
+        else SC_GEMM_LAUNCH(0, true);
     } else {
-        if (a.split)
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, false, true>), grid, dim3(256), 0, s, a);
-        else
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, false, false>), grid, dim3(256), 0, s, a);
+        if (amode == 1) SC_GEMM_LAUNCH(1, false);
+        else if (amode == 2) SC_GEMM_LAUNCH(2, false);
+        else SC_GEMM_LAUNCH(0, false);
     }
+#undef SC_GEMM_LAUNCH
 }
 
 void launch_gemm(const GemmArgs& a, hipStream_t s) {
@@ -261,6 +280,13 @@ void launch_gemm(const GemmArgs& a, hipStream_t s) {
     const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * a.phases;
     if (a.M <= 32) {
         launch_cfg<32, 128, 1, 4>(a, s);
+    } else if (a.N <= 32) {
+        // narrow outputs (late vocoder stages, duration predictor): all four waves along M
+        if ((int64_t)cdiv(a.M, 256) * a.phases >= 512) launch_cfg<256, 32, 4, 1>(a, s);
+        else launch_cfg<128, 32, 4, 1>(a, s);
+    } else if (a.N <= 64) {
+        if ((int64_t)cdiv(a.M, 128) * a.phases >= 512) launch_cfg<128, 64, 2, 2>(a, s);
+        else launch_cfg<64, 64, 2, 2>(a, s);
     } else if (tiles128 >= 256) {
         launch_cfg<128, 128, 2, 2>(a, s);
     } else {

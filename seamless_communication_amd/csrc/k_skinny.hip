@@ -37,7 +37,8 @@ __device__ __forceinline__ float sk_act(float v, int act) {
     return v;
 }
 
-template <int MT, int NT>
+// PF = slabs whose weights are requested before the first MFMA (loads in flight per wave).
+template <int MT, int NT, int PF>
 __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs p) {
     __shared__ float red[4][32 * 32];
 
@@ -76,50 +77,49 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
-    u32x4_t wv[NT][4];
-    auto load_w = [&](int k0) {
+    // this wave's slabs: k = kbeg + (wave + 4*s) * 64, s = 0, 1, ...
+    for (int kb = kbeg + wave * 64; kb < kend; kb += 256 * PF) {
+        u32x4_t wv[PF][NT][4];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int s = 0; s < PF; ++s) {
+            const int k0 = kb + 256 * s;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                u32x4_t v = {0u, 0u, 0u, 0u};
-                if (wok[t]) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow[t] + k0 + 8 * j));
-                wv[t][j] = v;
-            }
-    };
-
-    int k0 = kbeg + wave * 64;
-    if (k0 < kend) load_w(k0);
-    for (; k0 < kend; k0 += 256) {
-        // current slab's weights -> MFMA operands; then prefetch the next slab
-        half8_t bf[NT][4];
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bf[t][j] = *reinterpret_cast<const half8_t*>(&wv[t][j]);
-        if (k0 + 256 < kend) load_w(k0 + 256);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            float4 av[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                av[q] = aok[i] ? *reinterpret_cast<const float4*>(arow[i] + k0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float x[8] = {av[2 * j].x,     av[2 * j].y,     av[2 * j].z,     av[2 * j].w,
-                                    av[2 * j + 1].x, av[2 * j + 1].y, av[2 * j + 1].z, av[2 * j + 1].w};
-                half8_t hi, lo;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const _Float16 h = (_Float16)x[e];
-                    hi[e] = h;
-                    lo[e] = (_Float16)(x[e] - (float)h);
+                for (int j = 0; j < 4; ++j) {
+                    u32x4_t v = {0u, 0u, 0u, 0u};
+                    if (wok[t] && k0 < kend) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow[t] + k0 + 8 * j));
+                    wv[s][t][j] = v;
                 }
+        }
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bf[t][j], acc[i][t], 0, 0, 0);
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, bf[t][j], acc[i][t], 0, 0, 0);
+        for (int s = 0; s < PF; ++s) {
+            const int k0 = kb + 256 * s;
+            if (k0 < kend) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    float4 av[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        av[q] = aok[i] ? *reinterpret_cast<const float4*>(arow[i] + k0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x[8] = {av[2 * j].x,     av[2 * j].y,     av[2 * j].z,     av[2 * j].w,
+                                            av[2 * j + 1].x, av[2 * j + 1].y, av[2 * j + 1].z, av[2 * j + 1].w};
+                        half8_t hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const _Float16 h = (_Float16)x[e];
+                            hi[e] = h;
+                            lo[e] = (_Float16)(x[e] - (float)h);
+                        }
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const half8_t bf = *reinterpret_cast<const half8_t*>(&wv[s][t][j]);
+                            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bf, acc[i][t], 0, 0, 0);
+                            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, bf, acc[i][t], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
@@ -128,6 +128,25 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs p) {
     // ---- cross-wave reduction + epilogue, one 32x32 tile at a time -----------------------
     const int col = tid & 31;
     const int rbase = tid >> 5;  // 0..7
+    // arg-max mode state: this thread's rows are 32*i + rbase + 8*q
+    float am_best[MT][4], am_m[MT][4], am_s[MT][4];
+    int am_idx[MT][4];
+    int am_step = 0;
+    bool am_force = false, am_no_eos = false;
+    if (p.am_part) {
+        am_step = p.am_pos ? *p.am_pos : 0;
+        am_force = (p.am_force_eos_step >= 0 && am_step == p.am_force_eos_step);
+        am_no_eos = am_step < p.am_min_step_for_eos;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                am_best[i][q] = -INFINITY;
+                am_idx[i][q] = 0x7fffffff;
+                am_m[i][q] = -INFINITY;
+                am_s[i][q] = 0.f;
+            }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -147,7 +166,26 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs p) {
                 const int o = row * 32 + col;
                 float v = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
                 if (m < p.M && n < p.N) {
-                    if (p.partial) {
+                    if (p.am_part) {
+                        // generation step rules on the logit of column n (see argmax_rows_kernel)
+                        if (p.bias) v += p.bias[n];
+                        if (n == p.am_eos_idx) p.am_eos_logit[m] = v;
+                        if (v > am_m[i][q]) {
+                            am_s[i][q] = am_s[i][q] * expf(am_m[i][q] - v) + 1.f;
+                            am_m[i][q] = v;
+                        } else {
+                            am_s[i][q] += expf(v - am_m[i][q]);
+                        }
+                        float tv = v;
+                        if (n == p.am_unk_idx) tv -= p.am_unk_penalty;
+                        if (n == p.am_pad_idx) tv = -INFINITY;
+                        if (am_no_eos && n == p.am_eos_idx) tv = -INFINITY;
+                        if (am_force && n != p.am_eos_idx) tv = -INFINITY;
+                        if (tv > am_best[i][q] || (tv == am_best[i][q] && n < am_idx[i][q])) {
+                            am_best[i][q] = tv;
+                            am_idx[i][q] = n;
+                        }
+                    } else if (p.partial) {
                         p.partial[((int64_t)split * p.M + m) * p.N + n] = v;
                     } else {
                         if (p.bias) v += p.bias[n];
@@ -159,17 +197,63 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs p) {
             }
         }
     }
+    if (p.am_part) {
+        // the 32 lanes of a half-wave share a row: reduce over the columns
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float best = am_best[i][q], mm = am_m[i][q], ss = am_s[i][q];
+                int bidx = am_idx[i][q];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    const float ob = __shfl_xor(best, o);
+                    const int oi = __shfl_xor(bidx, o);
+                    if (ob > best || (ob == best && oi < bidx)) {
+                        best = ob;
+                        bidx = oi;
+                    }
+                    const float om = __shfl_xor(mm, o);
+                    const float os = __shfl_xor(ss, o);
+                    const float nm = fmaxf(mm, om);
+                    const float a = (mm == -INFINITY) ? 0.f : ss * expf(mm - nm);
+                    const float b = (om == -INFINITY) ? 0.f : os * expf(om - nm);
+                    ss = a + b;
+                    mm = nm;
+                }
+                const int m = 32 * i + rbase + 8 * q;
+                if (col == 0 && m < p.M) {
+                    float4 rec;
+                    rec.x = best;
+                    rec.y = __int_as_float(bidx);
+                    rec.z = mm;
+                    rec.w = ss;
+                    p.am_part[(int64_t)blockIdx.x * p.M + m] = rec;
+                }
+            }
+    }
 }
 
 int skinny_splits(int M, int N, int K, int want_split) {
-    // K ranges are multiples of 256 (4 waves x 64-wide slabs)
+    // K ranges are multiples of 256 (4 waves x 64-wide slabs); smallest divisor of K/256 that
+    // brings the grid to >= 256 workgroups, else the largest one.
+    (void)M;
     if (!want_split || K % 256 != 0) return 1;
     const int tiles = cdiv(N, 32);
-    int s = cdiv(256, tiles);
-    const int maxs = K / 256;
-    if (s > maxs) s = maxs;
-    while (s > 1 && (K / 256) % s != 0) --s;
-    return s < 1 ? 1 : s;
+    const int units = K / 256;
+    int best = 1;
+    for (int s = 1; s <= units; ++s) {
+        if (units % s) continue;
+        best = s;
+        if (tiles * s >= 256) break;
+    }
+    return best;
+}
+
+int skinny_argmax_tiles(int M, int N) {
+    const int tiles = cdiv(N, 32);
+    const int nt = (M <= 32 && tiles >= 2048) ? 4 : 1;
+    return cdiv(tiles, nt);
 }
 
 void launch_skinny(const SkinnyArgs& a0, hipStream_t s) {
@@ -186,13 +270,17 @@ void launch_skinny(const SkinnyArgs& a0, hipStream_t s) {
     const int tiles = cdiv(a.N, 32);
     const int nt = (a.M <= 32 && tiles >= 2048) ? 4 : 1;
     dim3 grid(cdiv(tiles, nt), a.splits);
+    SC_CHECK(!a.am_part || a.am_tiles_cap >= (int)grid.x, "skinny gemm: arg-max partial buffer holds %d tiles, need %d",
+             a.am_tiles_cap, (int)grid.x);
     prof::Scope scope(a.M <= 32 ? "skinny_m32" : "skinny_m64", 2.0 * a.M * (double)a.N * a.K,
                       2.0 * a.N * (double)a.K + 4.0 * a.M * ((double)a.K + (double)a.N * a.splits), s);
+    SC_CHECK(!a.am_part || a.splits == 1, "skinny gemm: arg-max epilogue cannot be combined with split-K");
+    if (a.am_part) a.am_tiles = (int)grid.x;
     if (a.M <= 32) {
-        if (nt == 4) hipLaunchKernelGGL((skinny_kernel<1, 4>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((skinny_kernel<1, 1>), grid, dim3(256), 0, s, a);
+        if (nt == 4) hipLaunchKernelGGL((skinny_kernel<1, 4, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((skinny_kernel<1, 1, 4>), grid, dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL((skinny_kernel<2, 1>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((skinny_kernel<2, 1, 2>), grid, dim3(256), 0, s, a);
     }
     SC_LAUNCH_CHECK();
 }
@@ -220,13 +308,23 @@ __global__ __launch_bounds__(256) void reduce_res_ln_kernel(const float* __restr
         const int idx = lane + 64 * i;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (idx < nv) {
-            // same association as the unsplit epilogue: (sum of partials + bias) + residual
-            for (int sp = 0; sp < splits; ++sp) {
-                const float4 pv = reinterpret_cast<const float4*>(partial + ((int64_t)sp * rows + row) * C)[idx];
-                a.x += pv.x;
-                a.y += pv.y;
-                a.z += pv.z;
-                a.w += pv.w;
+            // (sum of partials in split order + bias) + residual; loads batched 8 deep so that the
+            // round trips to the previous kernel's output overlap
+            for (int sp0 = 0; sp0 < splits; sp0 += 8) {
+                float4 pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    pv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (sp0 + u < splits)
+                        pv[u] = reinterpret_cast<const float4*>(partial + ((int64_t)(sp0 + u) * rows + row) * C)[idx];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    a.x += pv[u].x;
+                    a.y += pv[u].y;
+                    a.z += pv[u].z;
+                    a.w += pv[u].w;
+                }
             }
             if (bias) {
                 const float4 bb = b4[idx];
@@ -288,6 +386,102 @@ void launch_reduce_res_ln(const float* partial, int splits, const float* bias, f
     if (C <= 256) hipLaunchKernelGGL((reduce_res_ln_kernel<1>), grid, dim3(256), 0, s, partial, splits, bias, x, gamma, beta, h, rows, C);
     else if (C <= 1024) hipLaunchKernelGGL((reduce_res_ln_kernel<4>), grid, dim3(256), 0, s, partial, splits, bias, x, gamma, beta, h, rows, C);
     else hipLaunchKernelGGL((reduce_res_ln_kernel<16>), grid, dim3(256), 0, s, partial, splits, bias, x, gamma, beta, h, rows, C);
+    SC_LAUNCH_CHECK();
+}
+
+
+// --------------------------------------------------------------------------- //
+// Final stage of the fused vocabulary projection + arg-max: combines the per-tile
+// (best, idx, max, sumexp) records of one row, applies the forced-EOS rule, and performs the
+// generation bookkeeping of step_update_kernel for that row.  One workgroup per batch row.
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void argmax_finalize_kernel(const float4* __restrict__ part, int tiles, int nb,
+                                                              const float* __restrict__ eos_logit,
+                                                              const int* __restrict__ d_pos, int force_eos_step,
+                                                              int pad_idx, int eos_idx, int* __restrict__ next_tok,
+                                                              int* __restrict__ hist, int hist_ld,
+                                                              int* __restrict__ finished, int* __restrict__ out_len,
+                                                              float* __restrict__ score) {
+    __shared__ float s_v[4], s_m[4], s_s[4];
+    __shared__ int s_i[4];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float best = -INFINITY, m = -INFINITY, ssum = 0.f;
+    int bidx = 0x7fffffff;
+    for (int t = tid; t < tiles; t += 256) {
+        const float4 r = part[(int64_t)t * nb + b];
+        const int oi = __float_as_int(r.y);
+        if (r.x > best || (r.x == best && oi < bidx)) {
+            best = r.x;
+            bidx = oi;
+        }
+        const float nm = fmaxf(m, r.z);
+        const float a = (m == -INFINITY) ? 0.f : ssum * expf(m - nm);
+        const float c = (r.z == -INFINITY) ? 0.f : r.w * expf(r.z - nm);
+        ssum = a + c;
+        m = nm;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bidx, o);
+        if (ob > best || (ob == best && oi < bidx)) {
+            best = ob;
+            bidx = oi;
+        }
+        const float om = __shfl_xor(m, o);
+        const float os = __shfl_xor(ssum, o);
+        const float nm = fmaxf(m, om);
+        const float a = (m == -INFINITY) ? 0.f : ssum * expf(m - nm);
+        const float c = (om == -INFINITY) ? 0.f : os * expf(om - nm);
+        ssum = a + c;
+        m = nm;
+    }
+    if (lane == 0) {
+        s_v[wave] = best;
+        s_i[wave] = bidx;
+        s_m[wave] = m;
+        s_s[wave] = ssum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) {
+            if (s_v[w] > best || (s_v[w] == best && s_i[w] < bidx)) {
+                best = s_v[w];
+                bidx = s_i[w];
+            }
+            const float nm = fmaxf(m, s_m[w]);
+            const float a = (m == -INFINITY) ? 0.f : ssum * expf(m - nm);
+            const float c = (s_m[w] == -INFINITY) ? 0.f : s_s[w] * expf(s_m[w] - nm);
+            ssum = a + c;
+            m = nm;
+        }
+        const int pos = *d_pos;
+        if (force_eos_step >= 0 && pos == force_eos_step) {
+            best = eos_logit[b];
+            bidx = eos_idx;
+        }
+        const float lprob = best - (m + logf(ssum));
+        int tok = bidx;
+        if (finished[b]) {
+            tok = pad_idx;
+        } else {
+            if (score) score[b] += lprob;
+            if (tok == eos_idx) {
+                finished[b] = 1;
+                out_len[b] = pos + 2;
+            }
+        }
+        next_tok[b] = tok;
+        hist[(int64_t)b * hist_ld + pos + 1] = tok;
+    }
+}
+
+void launch_argmax_finalize(const float4* part, int tiles, int nb, const float* eos_logit, const int* d_pos,
+                            int force_eos_step, int pad_idx, int eos_idx, int* next_tok, int* hist, int hist_ld,
+                            int* finished, int* out_len, float* score, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_finalize_kernel, dim3(nb), dim3(256), 0, s, part, tiles, nb, eos_logit, d_pos,
+                       force_eos_step, pad_idx, eos_idx, next_tok, hist, hist_ld, finished, out_len, score);
     SC_LAUNCH_CHECK();
 }
 

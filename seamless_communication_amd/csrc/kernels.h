@@ -74,7 +74,23 @@ struct SkinnyArgs {
     float alpha = 1.0f;
     int splits = 1;
     int kc = 0;  // filled by the launcher
+    // fused arg-max epilogue (vocabulary projection of the decoder step): when am_part != nullptr no
+    // logits are written; per workgroup and row one record {best tweaked logit, its index, max, sumexp}
+    // goes to am_part[tile][M] and the raw EOS logit to am_eos_logit[M]; launch_argmax_finalize combines them.
+    float4* am_part = nullptr;
+    int am_tiles_cap = 0;  // capacity of am_part in tiles
+    int am_tiles = 0;      // filled by the launcher: tiles written
+    float* am_eos_logit = nullptr;
+    const int* am_pos = nullptr;
+    int am_min_step_for_eos = 0, am_force_eos_step = -1;
+    int am_pad_idx = -1, am_eos_idx = -1, am_unk_idx = -1;
+    float am_unk_penalty = 0.f;
 };
+// number of am_part tiles launch_skinny will write for N output features and M rows
+int skinny_argmax_tiles(int M, int N);
+void launch_argmax_finalize(const float4* part, int tiles, int nb, const float* eos_logit, const int* d_pos,
+                            int force_eos_step, int pad_idx, int eos_idx, int* next_tok, int* hist, int hist_ld,
+                            int* finished, int* out_len, float* score, hipStream_t s);
 void launch_skinny(const SkinnyArgs& a, hipStream_t s);
 // number of K ranges that brings the grid to >= 256 workgroups (1 when want_split == 0)
 int skinny_splits(int M, int N, int K, int want_split);
@@ -114,7 +130,9 @@ void launch_attention(const AttnArgs& a, hipStream_t s);
 void launch_decode_attention(const float* q, int64_t ldq, const float* k_new, const float* v_new,
                              int64_t ldkv, float* kcache, float* vcache, int64_t cache_ld, int64_t cache_bs,
                              int cap, float* out, int64_t ldo, int nb, int heads, const int* d_pos,
-                             const int* kv_lens, int use_lens, hipStream_t s);
+                             const int* kv_lens, int use_lens, hipStream_t s, int in_splits = 1,
+                             int64_t in_split_stride = 0, const float* bias_q = nullptr,
+                             const float* bias_k = nullptr, const float* bias_v = nullptr);
 
 // fbank front-end
 // consts = window[400] | melT[256][80] | twiddle cos[256] | twiddle sin[256]

@@ -34,7 +34,10 @@ struct StepCtx {
     std::vector<float*> kcache, vcache;  // per layer [nb][cap][M]
     std::vector<float*> cross_kv;        // per layer [nb*s_enc][2M]
     float* dec_hidden = nullptr;         // [nb][cap-1][M] or null
-    float* partial = nullptr;            // split-K partial sums [splits][nb][M]
+    float* partial = nullptr;            // split-K partial sums [splits][nb][<=3M]
+    float4* am_part = nullptr;           // fused arg-max records [tiles][nb]
+    int am_tiles = 0;
+    float* am_eos_logit = nullptr;       // [nb]
     int min_seq_len = 1, force_eos_step = -1;
     float unk_penalty = 0.f;
 };
@@ -74,6 +77,25 @@ void out_proj_res_ln(Model& m, StepCtx& c, const float* in, int64_t ld_in, const
     }
 }
 
+// in . W^T as `*splits` K-range partial sums in c.partial (no bias): the consumer adds them up.
+// Returns false when the shape is outside the skinny kernel's domain (caller falls back to linear()).
+bool proj_partials(Model& m, StepCtx& c, const float* in, int64_t ld_in, const Linear& L, int* splits) {
+    if (c.nb > 64 || L.in % 64 != 0) return false;
+    SkinnyArgs a;
+    a.A = in;
+    a.lda = ld_in;
+    a.W = L.w;
+    a.ldw = L.ldw;
+    a.M = c.nb;
+    a.N = L.out;
+    a.K = L.in;
+    a.splits = skinny_splits(c.nb, L.out, L.in, 1);
+    a.partial = c.partial;
+    launch_skinny(a, m.stream);
+    *splits = a.splits;
+    return true;
+}
+
 // One decoder step for all batch rows: feeds d_tok at position *d_pos.
 void decoder_step(Model& m, StepCtx& c, bool project) {
     const sc_config& cfg = m.cfg;
@@ -83,14 +105,30 @@ void decoder_step(Model& m, StepCtx& c, bool project) {
     for (int li = 0; li < cfg.dec_layers; ++li) {
         const DecoderLayer& l = m.dec[li];
         const bool last = li + 1 == cfg.dec_layers;
-        linear(m, c.h, M, l.qkv, nullptr, 0, c.wide, 3 * M, nb, ACT_NONE, 1.f);
-        launch_decode_attention(c.wide, 3 * M, c.wide + M, c.wide + 2 * M, 3 * M, c.kcache[li], c.vcache[li], M,
-                                (int64_t)c.cap * M, c.cap, c.att, M, nb, cfg.num_heads, c.d_pos, nullptr, 0, m.stream);
+        int sp = 1;
+        // self attention: q/k/v partials are summed (+bias) by the attention kernel itself
+        if (proj_partials(m, c, c.h, M, l.qkv, &sp)) {
+            const int64_t stride = (int64_t)nb * 3 * M;
+            launch_decode_attention(c.partial, 3 * M, c.partial + M, c.partial + 2 * M, 3 * M, c.kcache[li], c.vcache[li], M,
+                                    (int64_t)c.cap * M, c.cap, c.att, M, nb, cfg.num_heads, c.d_pos, nullptr, 0, m.stream, sp,
+                                    stride, l.qkv.b, l.qkv.b ? l.qkv.b + M : nullptr, l.qkv.b ? l.qkv.b + 2 * M : nullptr);
+        } else {
+            linear(m, c.h, M, l.qkv, nullptr, 0, c.wide, 3 * M, nb, ACT_NONE, 1.f);
+            launch_decode_attention(c.wide, 3 * M, c.wide + M, c.wide + 2 * M, 3 * M, c.kcache[li], c.vcache[li], M,
+                                    (int64_t)c.cap * M, c.cap, c.att, M, nb, cfg.num_heads, c.d_pos, nullptr, 0, m.stream);
+        }
         out_proj_res_ln(m, c, c.att, M, l.self_out, l.cross_ln, c.h);
-        linear(m, c.h, M, l.cross_q, nullptr, 0, c.wide, M, nb, ACT_NONE, 1.f);
-        launch_decode_attention(c.wide, M, nullptr, nullptr, 0, c.cross_kv[li], c.cross_kv[li] + M, 2 * M,
-                                (int64_t)c.s_enc * 2 * M, c.s_enc, c.att, M, nb, cfg.num_heads, nullptr, c.d_enc_lens, 1,
-                                m.stream);
+        // encoder-decoder attention over the K/V projected once per utterance
+        if (proj_partials(m, c, c.h, M, l.cross_q, &sp)) {
+            launch_decode_attention(c.partial, M, nullptr, nullptr, 0, c.cross_kv[li], c.cross_kv[li] + M, 2 * M,
+                                    (int64_t)c.s_enc * 2 * M, c.s_enc, c.att, M, nb, cfg.num_heads, nullptr, c.d_enc_lens, 1,
+                                    m.stream, sp, (int64_t)nb * M, l.cross_q.b, nullptr, nullptr);
+        } else {
+            linear(m, c.h, M, l.cross_q, nullptr, 0, c.wide, M, nb, ACT_NONE, 1.f);
+            launch_decode_attention(c.wide, M, nullptr, nullptr, 0, c.cross_kv[li], c.cross_kv[li] + M, 2 * M,
+                                    (int64_t)c.s_enc * 2 * M, c.s_enc, c.att, M, nb, cfg.num_heads, nullptr, c.d_enc_lens, 1,
+                                    m.stream);
+        }
         out_proj_res_ln(m, c, c.att, M, l.cross_out, l.ffn_ln, c.h);
         linear(m, c.h, M, l.ffn_in, nullptr, 0, c.wide, cfg.dec_ffn_dim, nb, ACT_RELU, 1.f);
         out_proj_res_ln(m, c, c.wide, cfg.dec_ffn_dim, l.ffn_out, last ? m.dec_final_ln : m.dec[li + 1].self_ln,
@@ -101,17 +139,43 @@ void decoder_step(Model& m, StepCtx& c, bool project) {
         SC_LAUNCH_CHECK();
     }
     if (project) {
-        Linear proj;
-        proj.w = m.text_embed;
-        proj.ldw = M;
-        proj.kpad = M;
-        proj.in = M;
-        proj.out = cfg.text_vocab_size;
-        linear(m, c.hN, M, proj, nullptr, 0, c.logits, cfg.text_vocab_size, nb, ACT_NONE, 1.f);
-        launch_argmax_rows(c.logits, cfg.text_vocab_size, nb, cfg.text_vocab_size, c.d_pos, c.min_seq_len, c.force_eos_step,
-                           cfg.pad_idx, cfg.eos_idx, cfg.unk_idx, c.unk_penalty, c.d_tok, c.d_lprob, m.stream);
-        launch_step_update(c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len, c.d_lprob, c.d_score, nb, c.d_pos,
-                           cfg.pad_idx, cfg.eos_idx, nullptr, m.stream);
+        if (nb <= 64 && M % 64 == 0) {
+            // vocabulary projection with the arg-max folded into its epilogue: no logits in HBM
+            SkinnyArgs a;
+            a.A = c.hN;
+            a.lda = M;
+            a.W = m.text_embed;
+            a.ldw = M;
+            a.M = nb;
+            a.N = cfg.text_vocab_size;
+            a.K = M;
+            a.am_part = c.am_part;
+            a.am_tiles_cap = c.am_tiles;
+            a.am_eos_logit = c.am_eos_logit;
+            a.am_pos = c.d_pos;
+            a.am_min_step_for_eos = c.min_seq_len;
+            a.am_force_eos_step = c.force_eos_step;
+            a.am_pad_idx = cfg.pad_idx;
+            a.am_eos_idx = cfg.eos_idx;
+            a.am_unk_idx = cfg.unk_idx;
+            a.am_unk_penalty = c.unk_penalty;
+            launch_skinny(a, m.stream);
+            launch_argmax_finalize(c.am_part, c.am_tiles, nb, c.am_eos_logit, c.d_pos, c.force_eos_step, cfg.pad_idx,
+                                   cfg.eos_idx, c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len, c.d_score, m.stream);
+        } else {
+            Linear proj;
+            proj.w = m.text_embed;
+            proj.ldw = M;
+            proj.kpad = M;
+            proj.in = M;
+            proj.out = cfg.text_vocab_size;
+            linear(m, c.hN, M, proj, nullptr, 0, c.logits, cfg.text_vocab_size, nb, ACT_NONE, 1.f);
+            launch_argmax_rows(c.logits, cfg.text_vocab_size, nb, cfg.text_vocab_size, c.d_pos, c.min_seq_len,
+                               c.force_eos_step, cfg.pad_idx, cfg.eos_idx, cfg.unk_idx, c.unk_penalty, c.d_tok, c.d_lprob,
+                               m.stream);
+            launch_step_update(c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len, c.d_lprob, c.d_score, nb, c.d_pos,
+                               cfg.pad_idx, cfg.eos_idx, nullptr, m.stream);
+        }
     }
     launch_add_i32(c.d_pos, 1, m.stream);
 }
@@ -127,6 +191,7 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     const sc_config& cfg = m.cfg;
     const int M = cfg.model_dim;
     SC_CHECK(n > 0 && s_enc > 0, "sc_generate_text: empty batch");
+    prof::set_tag("dec");
     const bool forced = h_forced_tokens != nullptr;
     int max_len;
     if (forced) {
@@ -163,10 +228,17 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     c.d_lprob = fl;
     c.d_score = fl.get() + n;
     const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
+    const bool fused_argmax = !forced && n <= 64 && M % 64 == 0;
     Buf<float> x(&m.pool, (size_t)n * M), h(&m.pool, (size_t)n * M), wide(&m.pool, (size_t)n * wideN), att(&m.pool, (size_t)n * M),
-        hN(&m.pool, (size_t)n * M), logits(&m.pool, forced ? 4 : (size_t)n * cfg.text_vocab_size);
-    Buf<float> partial(&m.pool, (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * n * M);
+        hN(&m.pool, (size_t)n * M), logits(&m.pool, (forced || fused_argmax) ? 4 : (size_t)n * cfg.text_vocab_size);
+    // worst case: K/256 ranges of an [n][M] out-projection, or M/256 ranges of the [n][3M] q/k/v projection
+    Buf<float> partial(&m.pool, (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * n * 3 * M);
     c.partial = partial;
+    c.am_tiles = fused_argmax ? skinny_argmax_tiles(n, cfg.text_vocab_size) : 0;
+    Buf<float4> am_part(&m.pool, (size_t)std::max(1, c.am_tiles) * n);
+    Buf<float> am_eos(&m.pool, (size_t)n);
+    c.am_part = am_part;
+    c.am_eos_logit = am_eos;
     c.x = x;
     c.h = h;
     c.wide = wide;

@@ -73,6 +73,7 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
     const sc_config& c = m.cfg;
     const int M = c.model_dim;
     SC_CHECK(n > 0 && t_frames > 0, "sc_encode_speech: empty batch");
+    prof::set_tag("enc");
     SC_CHECK(t_frames % c.fbank_stride == 0, "sc_encode_speech: t_frames=%d must be a multiple of fbank_stride=%d (Collater pad_to_multiple)",
              t_frames, c.fbank_stride);
     const int S = t_frames / c.fbank_stride;

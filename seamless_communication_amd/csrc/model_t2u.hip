@@ -82,6 +82,7 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
     const sc_config& c = m.cfg;
     const int M = c.model_dim;
     SC_CHECK(c.has_t2u, "sc_t2u_nar: the model was loaded without a T2U sub-model");
+    prof::set_tag("t2u");
     SC_CHECK(n > 0 && s_text >= 2, "sc_t2u_nar: need at least the 2-token prefix (s_text=%d)", s_text);
     const int rows = n * s_text;
     Buf<int> d_tlens(&m.pool, n);
@@ -228,6 +229,7 @@ void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h
                 float* d_wav) {
     const sc_config& c = m.cfg;
     SC_CHECK(c.has_vocoder, "sc_vocode: the model was loaded without a vocoder");
+    prof::set_tag("voc");
     SC_CHECK(n > 0 && T > 0, "sc_vocode: empty batch");
     for (int i = 0; i < n; ++i) {
         SC_CHECK(h_lang[i] >= 0 && h_lang[i] < c.voc_num_langs, "sc_vocode: lang index %d out of range", h_lang[i]);

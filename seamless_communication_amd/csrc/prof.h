@@ -10,6 +10,8 @@ namespace prof {
 bool enabled();
 void enable(bool on);
 void reset();
+// Stage tag prefixed to every kernel family name recorded from now on ("enc", "dec", "t2u", "voc", ...).
+void set_tag(const char* tag);
 // Record a start event on `s` for kernel family `name` (algorithmic flops / bytes of this launch).
 // Returns a token >= 0 to pass to end(), or -1 when profiling is off / the stream is capturing.
 int begin(const char* name, double flops, double bytes, hipStream_t s);

@@ -20,6 +20,7 @@ struct Agg {
     double ms = 0, flops = 0, bytes = 0;
 };
 bool g_on = false;
+std::string g_tag;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_free;
 std::map<std::string, Agg> g_agg;
@@ -54,6 +55,7 @@ void drain() {
 
 bool enabled() { return g_on; }
 void enable(bool on) { g_on = on; }
+void set_tag(const char* tag) { g_tag = tag ? tag : ""; }
 void reset() {
     drain();
     g_agg.clear();
@@ -65,7 +67,7 @@ int begin(const char* name, double flops, double bytes, hipStream_t s) {
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return -1;
     if (g_recs.size() > 200000) drain();
     Rec r;
-    r.name = name;
+    r.name = g_tag.empty() ? std::string(name) : g_tag + ":" + name;
     r.flops = flops;
     r.bytes = bytes;
     r.a = get_event();
