@@ -105,6 +105,11 @@ int sc_abi_version(void);
  * folds weight-norm, fuses QKV.  Replaces load_unity_model/load_vocoder_model +
  * model.to(device) (inference/translator.py:113-154). */
 sc_model* sc_load(const sc_tensor_desc* tensors, size_t n_tensors, const sc_config* cfg, int device);
+/* A second handle on the SAME weights with its own HIP stream, scratch pool and result slots, so that
+ * several micro-batches can be in flight on one GPU (one host thread per handle).  The parent must
+ * outlive its forks; freeing a fork releases only its own scratch.  NAR tables set on the parent
+ * before the fork are inherited. */
+sc_model* sc_fork(sc_model* parent);
 void sc_free(sc_model* m);
 int sc_synchronize(sc_model* m);
 

@@ -78,6 +78,7 @@ SIGNATURES = {
     "sc_last_error": (C.c_char_p, []),
     "sc_abi_version": (C.c_int, []),
     "sc_load": (_P, [C.POINTER(sc_tensor_desc), C.c_size_t, C.POINTER(sc_config), C.c_int]),
+    "sc_fork": (_P, [_P]),
     "sc_free": (None, [_P]),
     "sc_synchronize": (C.c_int, [_P]),
     "sc_set_nar_tables": (C.c_int, [_P, _i, _P, _P, _P, _P, _P]),

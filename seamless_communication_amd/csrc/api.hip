@@ -50,6 +50,23 @@ sc_model* sc_load(const sc_tensor_desc* tensors, size_t n_tensors, const sc_conf
     return nullptr;
 }
 
+sc_model* sc_fork(sc_model* parent) {
+    sc_model* h = nullptr;
+    try {
+        SC_CHECK(parent, "sc_fork: null handle");
+        SC_HIP(hipSetDevice(parent->m.device));
+        h = new sc_model();
+        static_cast<ModelData&>(h->m) = static_cast<const ModelData&>(parent->m);
+        SC_HIP(hipStreamCreateWithFlags(&h->m.stream, hipStreamNonBlocking));
+        return h;
+    } catch (const sc::Error&) {
+    } catch (const std::exception& e) {
+        sc::set_error("sc_fork: unexpected C++ exception: %s", e.what());
+    }
+    delete h;
+    return nullptr;
+}
+
 void sc_free(sc_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->m.device);

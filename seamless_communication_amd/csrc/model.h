@@ -111,12 +111,11 @@ struct ResBlock {
     std::vector<int> dil;
 };
 
-struct Model {
+// Everything that describes the loaded model: views into the weight allocations and the host-side
+// NAR tables.  Plain copyable data: a forked handle (sc_fork) copies it and shares the allocations.
+struct ModelData {
     sc_config cfg{};
     int device = 0;
-    hipStream_t stream = nullptr;
-    DevicePool pool;
-    std::vector<void*> owned;  // weight allocations
 
     // raw uploaded tensors by name
     struct Raw {
@@ -166,6 +165,13 @@ struct Model {
     Conv voc_pre, voc_post;
     std::vector<ConvT> voc_ups;
     std::vector<ResBlock> voc_res;
+};
+
+// One handle: the model description plus its own stream, scratch pool and per-call results.
+struct Model : ModelData {
+    hipStream_t stream = nullptr;
+    DevicePool pool;
+    std::vector<void*> owned;  // weight allocations (empty for a forked handle: the parent owns them)
 
     // results of the last sc_t2u_nar call
     std::vector<int32_t> last_units, last_durations, last_char_ids, last_char_seq_lens;
@@ -175,6 +181,9 @@ struct Model {
     hipGraph_t step_graph = nullptr;
     hipGraphExec_t step_exec = nullptr;
 
+    Model() = default;
+    Model(const Model&) = delete;
+    Model& operator=(const Model&) = delete;
     ~Model();
 };
 

@@ -77,3 +77,52 @@ def predict_batch_dp(translator, waveforms: Sequence[torch.Tensor], task_str: st
     units = speech.units if speech is not None else [[] for _ in shard]
     all_units = all_gather_ragged_ids(units, translator.device)
     return texts, speech, all_units
+
+
+class MicroBatcher:
+    """Runs ``Translator.predict`` on ``groups`` contiguous slices of a batch concurrently, one host
+    thread and one forked handle (own HIP stream) per slice.  Utterances are independent, so the
+    results are those of one big batch; what changes is the schedule on the GPU: the decoder steps of
+    one slice (a chain of ~270 short dependent kernels per token, latency bound) run underneath the
+    GEMM-bound encoder / T2U / vocoder stages of another slice instead of leaving the chip idle."""
+
+    def __init__(self, translator, groups: int) -> None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.groups = max(1, int(groups))
+        self.views = [translator] + [translator.fork() for _ in range(self.groups - 1)]
+        self.pool = ThreadPoolExecutor(max_workers=self.groups) if self.groups > 1 else None
+
+    def _one(self, view, wav_dev: torch.Tensor, num_samples, task_str, tgt_lang, kwargs):
+        fb, frames = view.model.fbank(wav_dev, num_samples, standardize=True, pad_to_multiple=2)
+        src = {"seqs": fb, "seq_lens": torch.from_numpy(frames.astype(np.int64)), "is_ragged": len(set(frames.tolist())) > 1}
+        texts, speech = view.predict(src, task_str, tgt_lang, **kwargs)
+        return texts, speech, list(view.last_text_ids), dict(view.last_stage_ms)
+
+    def predict(self, wav_dev: torch.Tensor, num_samples: Sequence[int], task_str: str, tgt_lang: str, **kwargs):
+        """wav_dev (n, max_samples) fp32 on the translator's device.  Returns (texts, units, audio_wavs,
+        text_ids, stage_ms of the first slice)."""
+        n = wav_dev.shape[0]
+        g = min(self.groups, n)
+        spans = [shard_range(n, i, g) for i in range(g)]
+        if g == 1:
+            outs = [self._one(self.views[0], wav_dev, list(num_samples), task_str, tgt_lang, kwargs)]
+        else:
+            futs = [self.pool.submit(self._one, self.views[i], wav_dev[lo:hi].contiguous(), list(num_samples[lo:hi]),
+                                     task_str, tgt_lang, kwargs) for i, (lo, hi) in enumerate(spans)]
+            outs = [f.result() for f in futs]
+        texts: List[str] = []
+        units: List[List[int]] = []
+        wavs: List[torch.Tensor] = []
+        text_ids: List[List[int]] = []
+        for t, speech, ids, _ in outs:
+            texts += t
+            text_ids += ids
+            if speech is not None:
+                units += speech.units
+                wavs += speech.audio_wavs
+        return texts, units, wavs, text_ids, outs[0][3]
+
+    def close(self) -> None:
+        if self.pool is not None:
+            self.pool.shutdown(wait=True)

@@ -158,6 +158,16 @@ class Translator:
         self.last_text_ids: List[List[int]] = []
         self.last_stage_ms: Dict[str, float] = {}
 
+    def fork(self) -> "Translator":
+        """A view of this translator for another host thread: same weights and tokenizers, own HIP
+        stream / scratch (not part of the reference API; used by the micro-batched batch driver)."""
+        import copy
+
+        view = copy.copy(self)
+        view.model = self.model.fork()
+        view.last_text_ids, view.last_stage_ms = [], {}
+        return view
+
     # translator.py:199-213
     @staticmethod
     def get_modalities_from_task_str(task_str: str) -> Tuple[Modality, Modality]:

@@ -103,6 +103,22 @@ class HipS2STModel:
         self.hop = self.lib.sc_vocoder_hop(self.handle) if vocoder_state_dict is not None else 0
         self._has_nar_tables = False
 
+    def fork(self) -> "HipS2STModel":
+        """A second handle on the same HBM-resident weights with its own HIP stream and scratch pool
+        (``sc_fork``): one per host thread, so that several micro-batches are in flight on the GPU and the
+        latency-bound decoder steps of one overlap the GEMM-bound stages of another."""
+        child = object.__new__(HipS2STModel)
+        child.lib, child.cfg = self.lib, self.cfg
+        child.device_index, child.device = self.device_index, self.device
+        child.handle = self.lib.sc_fork(self.handle)
+        if not child.handle:
+            msg = self.lib.sc_last_error()
+            raise SeamlessHipError(f"sc_fork failed: {msg.decode() if msg else '?'}")
+        child.hop = self.hop
+        child._has_nar_tables = self._has_nar_tables
+        child._parent = self  # the parent owns the weights and must outlive the fork
+        return child
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             self.lib.sc_free(self.handle)

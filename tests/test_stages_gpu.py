@@ -171,3 +171,39 @@ def test_s2st_end_to_end(env, report_dir):
     _log(report_dir, "e2e", text=got, unit_lens=ulens.tolist(), ref_unit_lens=aux["unit_lens"].tolist())
     assert dur.tolist() == aux["durations"].tolist()
     assert units.tolist() == units_ref.tolist()
+
+
+def test_forked_handles_concurrent_microbatches_match_single_batch(env, report_dir):
+    """sc_fork: two handles on the same weights, driven from two host threads on their own HIP
+    streams, must reproduce the single-handle results bit for bit (ids) / exactly (waveform)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    cfg, tt, ct, orc, hip = env
+    ws = common.waves((2.0, 1.37, 1.0, 1.8))
+    wav, ns = common.pad_waves(ws)
+    wav_dev = torch.from_numpy(wav).cuda()
+
+    def run(model, lo, hi):
+        fb, frames = model.fbank(wav_dev[lo:hi].contiguous(), ns[lo:hi])
+        enc, enc_lens = model.encode_speech(fb, frames.tolist())
+        ids, out_lens, _, hidden = model.generate_text(enc, enc_lens.tolist(), tt.target_prefix("fra"), hard_max_seq_len=12)
+        units, ulens, dur, _, _ = model.t2u_nar(hidden, ids[:, :-1].copy(), (out_lens - 1).tolist(), 1.0)
+        return [ids[b, : out_lens[b]].tolist() for b in range(hi - lo)], [units[b, : ulens[b]].tolist() for b in range(hi - lo)]
+
+    ref_text, ref_units = [], []
+    for i in range(4):  # one utterance at a time on the parent handle
+        t, u = run(hip, i, i + 1)
+        ref_text += t
+        ref_units += u
+    child = hip.fork()
+    try:
+        for _ in range(3):
+            with ThreadPoolExecutor(2) as ex:
+                f0 = ex.submit(run, hip, 0, 2)
+                f1 = ex.submit(run, child, 2, 4)
+                (t0, u0), (t1, u1) = f0.result(), f1.result()
+            assert t0 + t1 == ref_text
+            assert u0 + u1 == ref_units
+    finally:
+        child.close()
+    _log(report_dir, "fork", text=ref_text)
