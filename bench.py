@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default min(32, usable cpus))")
     ap.add_argument("--cpu-baseline-timeout", type=int, default=240)
     ap.add_argument("--no-profile-step", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement")
     ap.add_argument("--no-graph", action="store_true", help="launch decoder steps eagerly instead of hipGraph replay")
     return ap.parse_args()
 
@@ -296,7 +297,7 @@ def main():
         result["roofline"] = None
 
     # ---- batch-1 latency (RTF of a single utterance) ---------------------------------------
-    if rank == 0:
+    if rank == 0 and not args.no_latency:
         w1 = wav_dev[:1].contiguous()
         def one():
             fb, frames = model.fbank(w1, ns[:1])

@@ -112,6 +112,11 @@ sc_model* sc_load(const sc_tensor_desc* tensors, size_t n_tensors, const sc_conf
 sc_model* sc_fork(sc_model* parent);
 void sc_free(sc_model* m);
 int sc_synchronize(sc_model* m);
+/* Orders the handle's stream after everything enqueued so far on `producer_stream` (a hipStream_t; NULL = the
+ * legacy default stream) without blocking the host: event record + hipStreamWaitEvent.  The handle's stream is
+ * non-blocking, so a caller that fills device inputs on another stream (PyTorch's current stream in the Python
+ * host) calls this before the stage that reads them.  Every stage returns only after its outputs are complete. */
+int sc_wait_stream(sc_model* m, void* producer_stream);
 
 /* Per-vocabulary tables for NARDecoderFrontend's string rules
  * (models/unity/nar_decoder_frontend.py:158-259), built once by the host from

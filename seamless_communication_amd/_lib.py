@@ -81,6 +81,7 @@ SIGNATURES = {
     "sc_fork": (_P, [_P]),
     "sc_free": (None, [_P]),
     "sc_synchronize": (C.c_int, [_P]),
+    "sc_wait_stream": (C.c_int, [_P, _P]),
     "sc_set_nar_tables": (C.c_int, [_P, _i, _P, _P, _P, _P, _P]),
     "sc_fbank": (C.c_int, [_P, _P, _i, C.c_int64, _P, _i, _P, _i, _P]),
     "sc_encoder_out_len": (_i, [_P, _i]),

@@ -81,6 +81,18 @@ int sc_synchronize(sc_model* m) {
     SC_API_END
 }
 
+int sc_wait_stream(sc_model* m, void* producer_stream) {
+    SC_API_BEGIN
+    SC_CHECK(m, "null handle");
+    SC_HIP(hipSetDevice(m->m.device));
+    hipStream_t prod = static_cast<hipStream_t>(producer_stream);
+    if (prod == m->m.stream) return SC_OK;
+    if (!m->m.order_event) SC_HIP(hipEventCreateWithFlags(&m->m.order_event, hipEventDisableTiming));
+    SC_HIP(hipEventRecord(m->m.order_event, prod));
+    SC_HIP(hipStreamWaitEvent(m->m.stream, m->m.order_event, 0));
+    SC_API_END
+}
+
 int sc_set_nar_tables(sc_model* m, int32_t vocab, const int32_t* tok_len, const uint8_t* starts_space,
                       const uint8_t* is_punct, const int64_t* offs, const int32_t* ids) {
     SC_API_BEGIN

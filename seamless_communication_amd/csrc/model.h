@@ -170,6 +170,7 @@ struct ModelData {
 // One handle: the model description plus its own stream, scratch pool and per-call results.
 struct Model : ModelData {
     hipStream_t stream = nullptr;
+    hipEvent_t order_event = nullptr;  // sc_wait_stream: orders this handle's stream after a producer stream
     DevicePool pool;
     std::vector<void*> owned;  // weight allocations (empty for a forked handle: the parent owns them)
 

@@ -7,9 +7,13 @@
 //   inference/generator.py:281-299           teacher-forced second decoder pass
 // Step rules restated from ggml/examples/unity/fairseq2.cpp:1097-1126 (max length),
 // :1269-1305 (_tweak_lprobs), :1463-1594 (step loop).
+#include <mutex>
+
 #include "model.h"
 
 namespace sc {
+
+static std::mutex g_capture_mutex;
 
 int text_max_len(const Model& m, const sc_gen_opts& o, int s_enc) {
     int max_len;
@@ -295,8 +299,18 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     for (int step = first; step <= max_len - 2; ++step) {
         if (use_graph) {
             if (!exec) {
-                SC_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeGlobal));
-                decoder_step(m, c, true);
+                // Thread-local capture: another handle's host thread may allocate scratch (hipMalloc) while
+                // this one records; captures and instantiations are serialised process-wide.
+                std::lock_guard<std::mutex> lock(g_capture_mutex);
+                SC_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeThreadLocal));
+                try {
+                    decoder_step(m, c, true);
+                } catch (...) {
+                    hipGraph_t dead = nullptr;
+                    (void)hipStreamEndCapture(m.stream, &dead);
+                    if (dead) (void)hipGraphDestroy(dead);
+                    throw;
+                }
                 SC_HIP(hipStreamEndCapture(m.stream, &graph));
                 SC_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
             }

@@ -39,6 +39,7 @@ Model::~Model() {
     if (step_exec) (void)hipGraphExecDestroy(step_exec);
     if (step_graph) (void)hipGraphDestroy(step_graph);
     if (stream) (void)hipStreamSynchronize(stream);
+    if (order_event) (void)hipEventDestroy(order_event);
     pool.release_all();
     for (void* p : owned) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);

@@ -130,6 +130,12 @@ class HipS2STModel:
         except Exception:
             pass
 
+    def _after_torch(self) -> None:
+        """Orders the handle's (non-blocking) stream after PyTorch's current stream, where the caller's
+        input tensors may still be being produced (slices, ``.contiguous()``, H2D copies)."""
+        check(self.lib.sc_wait_stream(self.handle, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+              "sc_wait_stream")
+
     # ------------------------------------------------------------------ #
     def set_nar_tables(self, text_tokenizer, char_tokenizer) -> None:
         tok_len, starts_sp, is_punc, offs, ids = text_tokenizer.nar_tables(char_tokenizer)
@@ -155,6 +161,7 @@ class HipS2STModel:
         got = np.zeros(wav.shape[0], dtype=np.int32)
         # a size-1 batch dimension may carry an arbitrary stride
         stride = wav.stride(0) if wav.shape[0] > 1 else wav.shape[1]
+        self._after_torch()
         check(self.lib.sc_fbank(self.handle, _ptr(wav), wav.shape[0], stride, _ptr(ns), int(standardize),
                                 _ptr(out), T, _ptr(got)), "sc_fbank")
         return out, got
@@ -166,6 +173,7 @@ class HipS2STModel:
         out = torch.empty(n, sa, self.cfg.model_dim, dtype=torch.float32, device=self.device)
         lens = _i32(frame_lens)
         out_lens = np.zeros(n, dtype=np.int32)
+        self._after_torch()
         check(self.lib.sc_encode_speech(self.handle, _ptr(fbank), n, T, _ptr(lens), _ptr(out), _ptr(out_lens)),
               "sc_encode_speech")
         return out, out_lens
@@ -195,6 +203,7 @@ class HipS2STModel:
         hidden = torch.empty(n, max_len - 1, M, dtype=torch.float32, device=self.device) if want_hidden else None
         pre = _i32(prefix)
         el = _i32(enc_lens)
+        self._after_torch()
         check(self.lib.sc_generate_text(self.handle, _ptr(enc), n, s_enc, _ptr(el), C.byref(o), _ptr(pre), len(pre),
                                         _ptr(ids), _ptr(lens), _ptr(scores), _ptr(hidden)), "sc_generate_text")
         return ids, lens, scores, hidden
@@ -206,6 +215,7 @@ class HipS2STModel:
         assert tok.shape[0] == n
         hidden = torch.empty(n, tok.shape[1], M, dtype=torch.float32, device=self.device)
         el = _i32(enc_lens)
+        self._after_torch()
         check(self.lib.sc_decode_text(self.handle, _ptr(enc), n, s_enc, _ptr(el), _ptr(tok), tok.shape[1], _ptr(hidden)),
               "sc_decode_text")
         return hidden
@@ -222,6 +232,7 @@ class HipS2STModel:
         tl = _i32(text_lens)
         ulens = np.zeros(n, dtype=np.int32)
         su, sc_ = C.c_int32(0), C.c_int32(0)
+        self._after_torch()
         check(self.lib.sc_t2u_nar(self.handle, _ptr(dec_hidden), n, s_text, _ptr(tl), _ptr(ts), float(duration_factor),
                                   _ptr(ulens), C.byref(su), C.byref(sc_)), "sc_t2u_nar")
         units = np.zeros((n, su.value), dtype=np.int32)
