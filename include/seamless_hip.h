@@ -180,6 +180,9 @@ int64_t sc_prof_report(char* buf, int64_t cap);
 
 /* Kernel-level entry points used by the parity tests (tests/test_ops_gpu.py).
  * All pointers are device pointers; weights fp16, activations fp32. */
+/* 1: route every dense product to the general MFMA kernel instead of the double-buffered fast path
+ * (the two produce identical bits; used by the parity tests and for A/B timing). */
+int sc_op_force_general_gemm(int on);
 int sc_op_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float* d_y, int32_t rows, int32_t C,
                     int32_t act);
 int sc_op_linear(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y,

@@ -437,19 +437,26 @@ def fft_layer(P: Params, cfg, prefix: str, x: Tensor, lens: Tensor) -> Tensor:
     return P.layer_norm(h.transpose(1, 2) + x, prefix + ".conv1d_layer_norm")
 
 
+def t2u_encoder(P: Params, cfg, x: Tensor, lens: Optional[Tensor]) -> Tensor:
+    """UnitYNART2UModel.encode (models/unity/model.py:404-412): pre-LN StandardTransformerEncoder
+    layers + final LayerNorm (t2u_builder.py:521-551).  Pinned against the reference's
+    StandardTransformerEncoder_forward (ggml/examples/unity/fairseq2.cpp:955-977) by
+    tests/test_oracle_ggml_ref.py."""
+    for i in range(cfg.t2u_enc_layers):
+        p = f"t2u_model.encoder.layers.{i}"
+        h = P.layer_norm(x, p + ".self_attn_layer_norm")
+        x = x + mha(P, p + ".self_attn", h, h, cfg.num_heads, key_lens=lens)
+        x = x + ffn(P, p + ".ffn", P.layer_norm(x, p + ".ffn_layer_norm"), "relu")
+    return P.layer_norm(x, "t2u_model.encoder.layer_norm")
+
+
 def t2u_nar(
     P: Params, cfg, dec_out: Tensor, dec_lens: Tensor, text_seqs: Tensor, text_tok, char_tok,
     duration_factor: float = 1.0,
 ):
     """UnitYNART2UModel.forward (models/unity/model.py:379-441) + arg-max,
     padding and unit decoding of generator.py:338-353."""
-    x = dec_out
-    for i in range(cfg.t2u_enc_layers):
-        p = f"t2u_model.encoder.layers.{i}"
-        h = P.layer_norm(x, p + ".self_attn_layer_norm")
-        x = x + mha(P, p + ".self_attn", h, h, cfg.num_heads, key_lens=dec_lens)
-        x = x + ffn(P, p + ".ffn", P.layer_norm(x, p + ".ffn_layer_norm"), "relu")
-    x = P.layer_norm(x, "t2u_model.encoder.layer_norm")
+    x = t2u_encoder(P, cfg, dec_out, dec_lens)
     char_pos = sinusoidal_table(cfg.char_max_seq_len, cfg.model_dim, cfg.unit_pad_idx)
     unit_pos = sinusoidal_table(cfg.unit_max_seq_len, cfg.model_dim, cfg.unit_pad_idx)
     seqs, unit_lens, dur, char_seqs, char_seq_lens, char_lens = nar_decoder_frontend(

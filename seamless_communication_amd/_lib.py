@@ -97,6 +97,7 @@ SIGNATURES = {
     "sc_prof_enable": (C.c_int, [C.c_int]),
     "sc_prof_reset": (C.c_int, []),
     "sc_prof_report": (C.c_int64, [C.c_char_p, C.c_int64]),
+    "sc_op_force_general_gemm": (C.c_int, [C.c_int]),
     "sc_op_layernorm": (C.c_int, [_P, _P, _P, _P, _i, _i, _i]),
     "sc_op_linear": (C.c_int, [_P, _P, _P, _P, _P, _i, _i, _i, _i, C.c_float, _i, _i]),
     "sc_op_skinny_linear": (C.c_int, [_P, _P, _P, _P, _P, _i, _i, _i, _i, C.c_float]),

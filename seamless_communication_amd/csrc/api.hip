@@ -216,6 +216,11 @@ int64_t sc_prof_report(char* buf, int64_t cap) { return (int64_t)sc::prof::repor
 // --------------------------------------------------------------------------- //
 // kernel-level entry points for the parity tests (default stream, synchronous)
 // --------------------------------------------------------------------------- //
+int sc_op_force_general_gemm(int on) {
+    sc::g_force_general_gemm.store(on ? 1 : 0);
+    return SC_OK;
+}
+
 int sc_op_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float* d_y, int32_t rows, int32_t C,
                     int32_t act) {
     SC_API_BEGIN

@@ -15,9 +15,14 @@
 // K-slab's global loads in flight during the MFMA phase.  LDS rows are padded
 // to 40 halfs (80 B) so that the 16-byte fragment reads of a 16-lane group
 // fall on distinct banks.
+#include <atomic>
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace sc {
+
+std::atomic<int> g_force_general_gemm{0};
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
@@ -277,6 +282,12 @@ void launch_gemm(const GemmArgs& a, hipStream_t s) {
     SC_CHECK(a.ldw % 8 == 0, "gemm: ldw=%lld must be a multiple of 8", (long long)a.ldw);
     SC_CHECK(a.M > 0 && a.N > 0, "gemm: empty problem M=%d N=%d", a.M, a.N);
     SC_CHECK(a.rows_per_batch > 0 && a.cin > 0, "gemm: rows_per_batch/cin unset");
+    // SC_GEMM_GENERAL=1 forces the general kernel (A/B timing of the two paths; same bits either way)
+    static const bool env_general = getenv("SC_GEMM_GENERAL") != nullptr;
+    if (!env_general && !g_force_general_gemm.load(std::memory_order_relaxed) && gemm_fast_eligible(a)) {
+        launch_gemm_fast(a, s);
+        return;
+    }
     const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * a.phases;
     if (a.M <= 32) {
         launch_cfg<32, 128, 1, 4>(a, s);

@@ -1,0 +1,329 @@
+// Fast path of the dense product  C = alpha * act(A x W^T + bias) + res  (see k_gemm.hip for the
+// general kernel and the meaning of GemmArgs).  Same arithmetic, same K order and therefore the
+// same bits as gemm_kernel<.., AMODE=1, SPLIT=true>, restricted to what the big launches of the
+// path use:  split (hi+lo) fp32 x fp16 product, cin % 32 == 0 (a 32-wide K slab lies inside one
+// convolution tap), 16-byte aligned A rows.
+//
+// What differs from the general kernel (why it is faster on gfx950):
+//   * two LDS stages and ONE barrier per K slab: the global loads of slab s+1 are issued before the
+//     MFMA phase of slab s and are converted/stored into the other stage after it;
+//   * all per-row convolution addressing (batch item, source row, validity against the item length)
+//     is hoisted to tap boundaries; the slab loop holds only pointer bumps, 16-byte loads and selects;
+//   * the LeakyReLU-on-load is a compile-time variant (fmax/fmin form, no branches);
+//   * the epilogue's bias / activation / residual switches are resolved once per tile, bias values
+//     are loaded once per column fragment;
+//   * 1-D grid with an XCD-aware tile order: workgroup id b runs on XCD b % 8, so XCD x gets the
+//     contiguous tile range [x * tiles/8, (x+1) * tiles/8) in n-fastest order: the workgroups that
+//     share an XCD's 4 MiB L2 share A row tiles (and walk W once per row tile) instead of every XCD
+//     streaming every A tile.
+#include "kernels.h"
+
+namespace sc {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int FBK = 32;
+constexpr int FLD = 40;  // halfs per LDS row (32 + 8 pad): 16-byte fragment reads of a lane group hit distinct banks
+
+template <int ACT>
+__device__ __forceinline__ float act_fn(float v) {
+    if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == ACT_SILU) return v / (1.f + expf(-v));
+    if (ACT == ACT_TANH) return tanhf(v);
+    return v;
+}
+
+template <int TM, int TN, int WM, int WN, int ACT, bool HAS_RES>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, float16_t (&acc)[TM][TN], int m0w, int n0w, int lane,
+                                         int out_off, bool plain_rows) {
+    float bcol[TN];
+    int col[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        col[j] = n0w + j * 32 + (lane & 31);
+        bcol[j] = (p.bias && col[j] < p.N) ? p.bias[col[j]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0w + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= p.M) continue;
+            int64_t row;
+            if (plain_rows) {
+                row = m;
+            } else {
+                const int n = m / p.rows_per_batch;
+                const int q = m - n * p.rows_per_batch;
+                const int dst_t = q * p.out_mul + out_off;
+                if (dst_t < 0 || dst_t >= p.t_out) continue;
+                row = (int64_t)n * p.t_out + dst_t;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (col[j] >= p.N) continue;
+                float v = act_fn<ACT>(acc[i][j][r] + bcol[j]) * p.alpha;
+                if (HAS_RES) v += p.res[row * p.ldr + col[j]];
+                p.C[row * p.ldc + col[j]] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool IN_ACT, bool CONV>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p, int tiles_n, int tiles_mn, int tiles_total,
+                                                        int tiles_per_xcd, float in_slope) {
+    static_assert(WGM * WGN == 4, "4 waves per block");
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 fragment");
+    constexpr int A_IT = BM / 32;               // float4 loads per thread for the A slab
+    constexpr int B_IT = (BN * 4 + 255) / 256;  // 16-byte loads per thread for the W slab
+
+    __shared__ __attribute__((aligned(16))) _Float16 sAh[2][BM * FLD];
+    __shared__ __attribute__((aligned(16))) _Float16 sAl[2][BM * FLD];
+    __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * FLD];
+
+    // ---- XCD-aware tile order ------------------------------------------------------------
+    const int bid = blockIdx.x;
+    const int tile = (bid & 7) * tiles_per_xcd + (bid >> 3);
+    if (tile >= tiles_total) return;
+    const int phase = tile / tiles_mn;
+    const int rem = tile - phase * tiles_mn;
+    const int tm = rem / tiles_n;
+    const int tn = rem - tm * tiles_n;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+    const __half* __restrict__ W = p.W + (int64_t)phase * p.w_phase_stride;
+    const int out_off = p.out_off + phase * p.out_off_phase_step;
+
+    // ---- per-thread A rows: batch item, first source row, valid length ----------------------
+    const int a_kq = tid & 7;  // which float4 of the 32-wide K slab
+    const int a_r = tid >> 3;  // 0..31
+    const float* a_base[A_IT];  // &A[item n][row 0][a_kq*4]
+    int a_t0[A_IT], a_len[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + a_r + 32 * i;
+        if (m < p.M) {
+            const int n = m / p.rows_per_batch;
+            const int q = m - n * p.rows_per_batch;
+            a_base[i] = p.A + (int64_t)n * p.t_in * p.lda + a_kq * 4;
+            a_t0[i] = q * p.stride - p.pad;
+            a_len[i] = p.in_lens ? min(p.in_lens[n], p.t_in) : p.t_in;
+        } else {
+            a_base[i] = p.A + a_kq * 4;
+            a_t0[i] = 0;
+            a_len[i] = 0;  // nothing valid
+        }
+    }
+    const int b_r = tid >> 2;  // 0..63
+    const int b_kc = tid & 3;  // which 8-half chunk
+    const __half* b_ptr[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        // rows beyond N are clamped: they only feed accumulator columns that are never stored
+        const int row = min(n0 + b_r + 64 * i, p.N - 1);
+        b_ptr[i] = W + (int64_t)row * p.ldw + b_kc * 8;
+    }
+
+    // tap state (recomputed at tap boundaries only)
+    const float* a_ptr[A_IT];
+    bool a_ok[A_IT];
+    auto set_tap = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int src_t = a_t0[i] + tap * p.dil;
+            a_ok[i] = src_t >= 0 && src_t < a_len[i];
+            a_ptr[i] = a_base[i] + (int64_t)(a_ok[i] ? src_t : 0) * p.lda;
+        }
+    };
+
+    f32x4_t a_reg[A_IT];
+    u32x4_t b_reg[B_IT];
+    constexpr bool B_GUARD = (BN % 64) != 0;  // BN = 32: only half of the threads carry a W row
+
+    float16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 8;
+    const int a_frag = (wm * WM + frag_row) * FLD + frag_k;
+    const int b_frag = (wn * WN + frag_row) * FLD + frag_k;
+
+// global -> registers: unconditional 16-byte loads (invalid rows read row 0 of their item and are
+// zeroed at the LDS store, after the MFMA phase, so that nothing here waits on the loads)
+#define SC_LOAD_SLAB(C0, K0)                                                                    \
+    do {                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i)                                        \
+            a_reg[i] = *reinterpret_cast<const f32x4_t*>(a_ptr[i] + (C0));                       \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i)                                        \
+            b_reg[i] = *reinterpret_cast<const u32x4_t*>(b_ptr[i] + (K0));                        \
+    } while (0)
+
+// registers -> LDS stage ST: zero invalid rows (convolutions only), optional LeakyReLU, hi/lo split of A
+#define SC_STORE_SLAB(ST)                                                                       \
+    do {                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                      \
+            f32x4_t x = a_reg[i];                                                               \
+            if (CONV) x = a_ok[i] ? x : f32x4_t{0.f, 0.f, 0.f, 0.f};                            \
+            if (IN_ACT) {                                                                       \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                   \
+                    x[j] = fmaxf(x[j], 0.f) + in_slope * fminf(x[j], 0.f);                      \
+            }                                                                                   \
+            const half4_t hi = __builtin_convertvector(x, half4_t);                             \
+            const f32x4_t back = __builtin_convertvector(hi, f32x4_t);                          \
+            const half4_t lo = __builtin_convertvector(x - back, half4_t);                      \
+            const int off = (a_r + 32 * i) * FLD + a_kq * 4;                                    \
+            *reinterpret_cast<half4_t*>(&sAh[ST][off]) = hi;                                    \
+            *reinterpret_cast<half4_t*>(&sAl[ST][off]) = lo;                                    \
+        }                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                      \
+            const int row = b_r + 64 * i;                                                       \
+            if (!B_GUARD || row < BN) *reinterpret_cast<u32x4_t*>(&sB[ST][row * FLD + b_kc * 8]) = b_reg[i]; \
+        }                                                                                       \
+    } while (0)
+
+// one K slab (two 16-wide MFMA steps, hi then lo for every fragment pair) from LDS stage ST
+#define SC_COMPUTE_SLAB(ST)                                                                     \
+    do {                                                                                        \
+        _Pragma("unroll") for (int kb = 0; kb < FBK; kb += 16) {                                \
+            half8_t ah[TM], al[TM], bf[TN];                                                     \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                    \
+                ah[i] = *reinterpret_cast<const half8_t*>(&sAh[ST][a_frag + i * 32 * FLD + kb]); \
+                al[i] = *reinterpret_cast<const half8_t*>(&sAl[ST][a_frag + i * 32 * FLD + kb]); \
+            }                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+                bf[j] = *reinterpret_cast<const half8_t*>(&sB[ST][b_frag + j * 32 * FLD + kb]); \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                      \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bf[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bf[j], acc[i][j], 0, 0, 0); \
+                }                                                                               \
+        }                                                                                       \
+    } while (0)
+
+    const int nslab = p.K / FBK;
+    const int slabs_per_tap = p.cin / FBK;
+    int tap = 0, cs = 0;  // position of the slab being LOADED
+    set_tap(0);
+    SC_LOAD_SLAB(0, 0);
+    SC_STORE_SLAB(0);
+    __syncthreads();
+    // steady state: loads of slab s+1 in flight during the MFMA phase of slab s; one barrier per slab
+    for (int s = 0; s + 1 < nslab; ++s) {
+        const int st = s & 1;
+        if (++cs == slabs_per_tap) {
+            cs = 0;
+            set_tap(++tap);
+        }
+        SC_LOAD_SLAB(cs * FBK, (s + 1) * FBK);
+        // keep the loads above and their consumers below the MFMA phase (the machine scheduler would
+        // otherwise sink each load next to its first use and stall the wave mid-phase)
+        __builtin_amdgcn_sched_barrier(0);
+        SC_COMPUTE_SLAB(st);
+        __builtin_amdgcn_sched_barrier(0);
+        SC_STORE_SLAB(st ^ 1);
+        __syncthreads();
+    }
+    {
+        const int st = (nslab - 1) & 1;
+        SC_COMPUTE_SLAB(st);
+    }
+#undef SC_LOAD_SLAB
+#undef SC_STORE_SLAB
+#undef SC_COMPUTE_SLAB
+
+    // ---- epilogue: C/D fragment map col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ------
+    const bool plain_rows = (p.rows_per_batch == p.M) && p.out_mul == 1 && out_off == 0 && p.t_out == p.M;
+    const int m0w = m0 + wm * WM, n0w = n0 + wn * WN;
+#define SC_EPI(ACT)                                                                               \
+    do {                                                                                          \
+        if (p.res) epilogue<TM, TN, WM, WN, ACT, true>(p, acc, m0w, n0w, lane, out_off, plain_rows); \
+        else epilogue<TM, TN, WM, WN, ACT, false>(p, acc, m0w, n0w, lane, out_off, plain_rows);    \
+    } while (0)
+    if (p.act == ACT_NONE) SC_EPI(ACT_NONE);
+    else if (p.act == ACT_RELU) SC_EPI(ACT_RELU);
+    else if (p.act == ACT_SILU) SC_EPI(ACT_SILU);
+    else SC_EPI(ACT_TANH);
+#undef SC_EPI
+}
+
+template <int BM, int BN, int WGM, int WGN>
+void launch_fast_cfg(const GemmArgs& a, hipStream_t s) {
+    const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
+    const int tiles_mn = tiles_m * tiles_n;
+    const int64_t total64 = (int64_t)tiles_mn * a.phases;
+    SC_CHECK(total64 < (1ll << 30), "gemm: %lld tiles", (long long)total64);
+    const int tiles_total = (int)total64;
+    const int tiles_per_xcd = cdiv(tiles_total, 8);
+    char name[64];
+    snprintf(name, sizeof(name), "gemm_%dx%d_fast_split", BM, BN);
+    const double kreal = (double)a.taps * a.cin;
+    const double flops = a.algo_flops > 0 ? a.algo_flops : 2.0 * a.M * a.N * kreal * a.phases;
+    const double bytes = 4.0 * a.M * (double)a.cin * (a.stride < a.taps ? 1.0 : (double)a.taps) +
+                         2.0 * a.N * (double)a.K * a.phases + 4.0 * a.M * (double)a.N * (a.res ? 2.0 : 1.0);
+    prof::Scope scope(name, flops, bytes, s);
+    const dim3 grid(tiles_per_xcd * 8);
+    // plain product: one tap, no stride/padding/length mask -> every row below M is valid and rows
+    // >= M only feed accumulator rows that are never stored, so the validity selects are compiled out
+    const bool conv = a.taps != 1 || a.stride != 1 || a.pad != 0 || a.in_lens != nullptr;
+    if (a.in_act == IN_NONE) {
+        if (conv)
+            hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WGM, WGN, false, true>), grid, dim3(256), 0, s, a, tiles_n,
+                               tiles_mn, tiles_total, tiles_per_xcd, 0.f);
+        else
+            hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WGM, WGN, false, false>), grid, dim3(256), 0, s, a, tiles_n,
+                               tiles_mn, tiles_total, tiles_per_xcd, 0.f);
+    } else {
+        const float slope = a.in_act == IN_LRELU_01 ? 0.1f : 0.01f;
+        hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WGM, WGN, true, true>), grid, dim3(256), 0, s, a, tiles_n, tiles_mn,
+                           tiles_total, tiles_per_xcd, slope);
+    }
+}
+
+}  // namespace
+
+bool gemm_fast_eligible(const GemmArgs& a) {
+    return a.split == 1 && a.cin % FBK == 0 && a.K == a.taps * a.cin && a.lda % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && a.ldw % 8 == 0 && a.M > 32 &&
+           // N <= 32 (late vocoder stages) is HBM-bound; two LDS stages of a 256-row tile leave one workgroup
+           // per CU and measured slower than the general kernel (profiles/r1_gemm_ab.txt)
+           a.N > 32 &&
+           (a.in_act == IN_NONE || a.in_act == IN_LRELU_01 || a.in_act == IN_LRELU_001);
+}
+
+// Tile choice mirrors launch_gemm (k_gemm.hip) so that both paths cover the same shapes.
+void launch_gemm_fast(const GemmArgs& a, hipStream_t s) {
+    const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * a.phases;
+    if (a.N <= 32) {
+        if ((int64_t)cdiv(a.M, 256) * a.phases >= 512) launch_fast_cfg<256, 32, 4, 1>(a, s);
+        else launch_fast_cfg<128, 32, 4, 1>(a, s);
+    } else if (a.N <= 64) {
+        if ((int64_t)cdiv(a.M, 128) * a.phases >= 512) launch_fast_cfg<128, 64, 2, 2>(a, s);
+        else launch_fast_cfg<64, 64, 2, 2>(a, s);
+    } else if (tiles128 >= 256) {
+        launch_fast_cfg<128, 128, 2, 2>(a, s);
+    } else {
+        launch_fast_cfg<64, 64, 2, 2>(a, s);
+    }
+    SC_LAUNCH_CHECK();
+}
+
+}  // namespace sc

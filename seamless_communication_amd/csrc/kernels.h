@@ -11,6 +11,8 @@
 //     fp32 x fp16 product to ~2^-22 relative (needed for bit-exact greedy ids
 //     against the fp32 CPU reference) at 2x the fp16 MFMA cost.
 #pragma once
+#include <atomic>
+
 #include "common.h"
 #include "prof.h"
 
@@ -49,6 +51,10 @@ struct GemmArgs {
 };
 
 void launch_gemm(const GemmArgs& a, hipStream_t s);
+// k_gemm2.hip: double-buffered, XCD-aware fast path for split products with cin % 32 == 0 (same bits)
+extern std::atomic<int> g_force_general_gemm;  // tests / A-B timing: 1 routes every product to the general kernel
+bool gemm_fast_eligible(const GemmArgs& a);
+void launch_gemm_fast(const GemmArgs& a, hipStream_t s);
 
 // out[m][n] = alpha*act(sum_k x[m][k]*W[n][k] + bias[n]) + res[m][n], exact fp32 FMA, M <= 8.
 void launch_gemv(const float* x, int64_t ldx, const __half* W, int64_t ldw, const float* bias,

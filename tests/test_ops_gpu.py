@@ -185,6 +185,99 @@ def test_conv1d(lib, report_dir, case):
     assert err < 3e-6
 
 
+FAST_LINEAR_SHAPES = [
+    (7984, 4096, 1024),  # encoder FFN inner at batch 16: 128x128 tiles, XCD-ordered 1-D grid
+    (2048, 1024, 4096),
+    (499, 1024, 1024),  # 64x64 tiles
+    (70000, 32, 96),  # narrow output: 256x32 tiles
+    (3000, 32, 160),  # 128x32 tiles
+    (70000, 64, 192),  # 128x64 tiles
+    (333, 48, 64),  # ragged N below one tile
+    (129, 130, 32),  # a single K slab
+]
+
+
+@pytest.mark.parametrize("M,N,K", FAST_LINEAR_SHAPES)
+@pytest.mark.parametrize("act,with_res", [(0, False), (2, True)])
+def test_fast_gemm_bit_identical_to_general_linear(lib, report_dir, M, N, K, act, with_res):
+    """k_gemm2.hip (double-buffered, XCD-ordered) must reproduce the general kernel bit for bit:
+    same hi/lo split, same K order, same epilogue arithmetic."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    x = dev(torch.randn(M, K, generator=g) * 2.0)
+    w = dev((torch.randn(N, K, generator=g) / math.sqrt(K)).half())
+    b = dev(torch.randn(N, generator=g) * 0.1)
+    r = dev(torch.randn(M, N, generator=g)) if with_res else None
+    out = []
+    for general in (1, 0):
+        check(lib, lib.sc_op_force_general_gemm(general))
+        y = torch.full((M, N), float("nan"), device="cuda")
+        check(lib, lib.sc_op_linear(P(x), P(w), P(b), P(r), P(y), M, N, K, act, 0.5, 1, 0))
+        out.append(y.cpu())
+    check(lib, lib.sc_op_force_general_gemm(0))
+    ref = x.cpu().double() @ w.cpu().double().t() + b.cpu().double()
+    ref = 0.5 * (F.silu(ref) if act == 2 else ref) + (r.cpu().double() if with_res else 0)
+    err = rel_err(out[1], ref)
+    _log(report_dir, "fast_vs_general_linear", M=M, N=N, K=K, act=act, err=err)
+    assert torch.equal(out[0], out[1])
+    assert err < 2e-6
+
+
+FAST_CONV_CASES = [
+    # nb, T, cin, cout, k, stride, pad, dil, in_act, act, lens
+    (2, 50, 1024, 256, 3, 1, 1, 1, 0, 1, [50, 37]),
+    (3, 520, 128, 128, 7, 1, 3, 1, 0, 0, [520, 20, 333]),
+    (2, 499, 128, 256, 8, 8, 4, 1, 0, 0, None),
+    (1, 3000, 64, 64, 11, 1, 25, 5, 1, 0, None),
+    (2, 9000, 32, 32, 3, 1, 3, 3, 1, 0, None),
+    (1, 4000, 32, 1, 7, 1, 3, 1, 2, 3, None),
+    (1, 40, 1792, 512, 7, 1, 3, 1, 0, 0, None),
+]
+
+
+@pytest.mark.parametrize("case", FAST_CONV_CASES)
+def test_fast_gemm_bit_identical_to_general_conv(lib, report_dir, case):
+    nb, T, cin, cout, k, stride, pad, dil, in_act, act, lens = case
+    g = torch.Generator().manual_seed(T * 31 + cin + k)
+    x = dev(torch.randn(nb, T, cin, generator=g))
+    w = (torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)).half()
+    b = dev(torch.randn(cout, generator=g) * 0.1)
+    t_out = (T + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    res = dev(torch.randn(nb, t_out, cout, generator=g))
+    wp = torch.zeros(cout, cin * k, dtype=torch.float16, device="cuda")
+    check(lib, lib.sc_op_pack_conv_weight(P(dev(w)), P(wp), cout, cin, k))
+    d_lens = dev(torch.tensor(lens, dtype=torch.int32)) if lens is not None else None
+    out = []
+    for general in (1, 0):
+        check(lib, lib.sc_op_force_general_gemm(general))
+        y = torch.full((nb, t_out, cout), float("nan"), device="cuda")
+        check(lib, lib.sc_op_conv1d(P(x), P(wp), P(b), P(res), P(y), nb, T, cin, cout, k, stride, pad, dil, P(d_lens), in_act, act))
+        out.append(y.cpu())
+    check(lib, lib.sc_op_force_general_gemm(0))
+    _log(report_dir, "fast_vs_general_conv", case=case)
+    assert not torch.isnan(out[1]).any()
+    assert torch.equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("nb,T,cin,cout,k,s", [(2, 250, 512, 256, 11, 5), (1, 4000, 64, 32, 4, 2), (3, 77, 32, 16, 8, 4)])
+def test_fast_gemm_bit_identical_to_general_conv_transpose(lib, report_dir, nb, T, cin, cout, k, s):
+    g = torch.Generator().manual_seed(T + cin + k)
+    x = dev(torch.randn(nb, T, cin, generator=g))
+    v = dev((torch.randn(cin, cout, k, generator=g) / math.sqrt(cin * k)).half())
+    gg = dev((torch.rand(cin, 1, 1, generator=g) + 0.5).half())
+    b = dev(torch.randn(cout, generator=g) * 0.1)
+    pad = (k - s) // 2
+    t_out = (T - 1) * s - 2 * pad + k
+    out = []
+    for general in (1, 0):
+        check(lib, lib.sc_op_force_general_gemm(general))
+        y = torch.full((nb, t_out, cout), float("nan"), device="cuda")
+        check(lib, lib.sc_op_conv_transpose1d(P(x), P(v), P(gg), P(b), P(y), nb, T, cin, cout, k, s, pad, 1))
+        out.append(y.cpu())
+    check(lib, lib.sc_op_force_general_gemm(0))
+    assert not torch.isnan(out[1]).any()
+    assert torch.equal(out[0], out[1])
+
+
 CONVT_CASES = [(2, 25, 64, 32, 11, 5), (1, 100, 32, 16, 8, 4), (2, 77, 16, 8, 4, 2), (1, 13, 512, 256, 11, 5)]
 
 
