@@ -208,6 +208,12 @@ int sc_op_pack_conv_weight(const void* d_w_f16, void* d_dst_f16, int32_t cout, i
 int sc_op_conv_transpose1d(const float* d_x, const void* d_v_f16, const void* d_g_f16, const float* d_bias,
                            float* d_y, int32_t nb, int32_t t_in, int32_t cin, int32_t cout, int32_t k,
                            int32_t stride, int32_t pad, int32_t in_act);
+/* One HiFi-GAN ResBlock dilation pair (hifigan.py:114-121) fused in one kernel for C in {16, 32, 64}:
+ * out = x + conv2_{k,1}(lrelu(conv1_{k,dil}(lrelu(x)) + b1)) + b2, weights packed by sc_op_pack_conv_weight
+ * (rows padded to a multiple of 32); with d_avg_a/d_avg_b: out = ((a + b) + that) / 3. */
+int sc_op_resblock_pair(const float* d_x, const void* d_w1_packed, const float* d_b1, const void* d_w2_packed,
+                        const float* d_b2, float* d_out, int32_t nb, int32_t T, int32_t C, int32_t k, int32_t dil,
+                        float slope, const float* d_avg_a, const float* d_avg_b);
 int sc_op_attention(const float* d_q, const float* d_k, const float* d_v, float* d_out, int32_t nb, int32_t heads,
                     int32_t sq, int32_t skv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                     const int32_t* d_kv_lens, int32_t causal, const float* d_rel_k, int32_t rel_left,

@@ -421,6 +421,32 @@ int sc_op_conv_transpose1d(const float* d_x, const void* d_v_f16, const void* d_
     SC_API_END
 }
 
+int sc_op_resblock_pair(const float* d_x, const void* d_w1_packed, const float* d_b1, const void* d_w2_packed,
+                        const float* d_b2, float* d_out, int32_t nb, int32_t T, int32_t C, int32_t k, int32_t dil,
+                        float slope, const float* d_avg_a, const float* d_avg_b) {
+    SC_API_BEGIN
+    SC_CHECK(d_x && d_w1_packed && d_w2_packed && d_out, "sc_op_resblock_pair: null argument");
+    ResPairArgs a;
+    a.x = d_x;
+    a.out = d_out;
+    a.w1 = static_cast<const __half*>(d_w1_packed);
+    a.w2 = static_cast<const __half*>(d_w2_packed);
+    a.ldw1 = a.ldw2 = align_up((int64_t)C * k, 32);
+    a.b1 = d_b1;
+    a.b2 = d_b2;
+    a.nb = nb;
+    a.T = T;
+    a.C = C;
+    a.k = k;
+    a.dil = dil;
+    a.slope = slope;
+    a.avg_a = d_avg_a;
+    a.avg_b = d_avg_b;
+    launch_resblock_pair(a, g_op_stream);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
 int sc_op_attention(const float* d_q, const float* d_k, const float* d_v, float* d_out, int32_t nb, int32_t heads,
                     int32_t sq, int32_t skv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* d_kv_lens,
                     int32_t causal, const float* d_rel_k, int32_t rel_left, int32_t rel_right) {

@@ -56,6 +56,25 @@ extern std::atomic<int> g_force_general_gemm;  // tests / A-B timing: 1 routes e
 bool gemm_fast_eligible(const GemmArgs& a);
 void launch_gemm_fast(const GemmArgs& a, hipStream_t s);
 
+// k_resblock.hip: out = x + conv2_{k,1}(lrelu(conv1_{k,dil}(lrelu(x)) + b1)) + b2 for C in {16, 32, 64}, the
+// intermediate kept in LDS; optionally out = ((avg_a + avg_b) + that) / 3.  Weights packed [C][ldw], tap-major.
+struct ResPairArgs {
+    const float* x = nullptr;  // [nb][T][C]
+    float* out = nullptr;      // [nb][T][C]
+    const __half* w1 = nullptr;
+    int64_t ldw1 = 0;
+    const float* b1 = nullptr;
+    const __half* w2 = nullptr;
+    int64_t ldw2 = 0;
+    const float* b2 = nullptr;
+    int nb = 0, T = 0, C = 0, k = 0, dil = 1;
+    float slope = 0.1f;
+    const float* avg_a = nullptr;
+    const float* avg_b = nullptr;
+};
+bool resblock_pair_supported(int C, int k, int dil);
+void launch_resblock_pair(const ResPairArgs& a, hipStream_t s);
+
 // out[m][n] = alpha*act(sum_k x[m][k]*W[n][k] + bias[n]) + res[m][n], exact fp32 FMA, M <= 8.
 void launch_gemv(const float* x, int64_t ldx, const __half* W, int64_t ldw, const float* bias,
                  const float* res, int64_t ldr, float* out, int64_t ldo, int M, int N, int K,

@@ -263,6 +263,10 @@ void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h
         Buf<float> y(&m.pool, sz), tmp(&m.pool, sz), ra(&m.pool, sz), rb(&m.pool, sz);
         Buf<float> rout[3] = {Buf<float>(&m.pool, sz), Buf<float>(&m.pool, sz), Buf<float>(&m.pool, sz)};
         conv_transpose1d(m, x, up, y, n, t, IN_LRELU_01);
+        // narrow stages: each dilation pair is one kernel with the intermediate in LDS, and the last pair of
+        // the third ResBlock also applies the average over the three ResBlocks (k_resblock.hip)
+        bool fused_avg = false;
+        x = Buf<float>(&m.pool, sz);
         for (int j = 0; j < nk; ++j) {
             const ResBlock& r = m.voc_res[i * nk + j];
             const float* cur = y;
@@ -270,14 +274,41 @@ void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h
             for (int d = 0; d < nd; ++d) {
                 const int k = r.convs1[d].k;
                 float* dst = (d == nd - 1) ? rout[j].get() : ((d & 1) ? rb.get() : ra.get());
-                conv1d(m, cur, r.convs1[d], nullptr, tmp, n, t2, 1, (k * r.dil[d] - r.dil[d]) / 2, r.dil[d], nullptr,
-                       IN_LRELU_01, ACT_NONE);
-                conv1d(m, tmp, r.convs2[d], cur, dst, n, t2, 1, (k - 1) / 2, 1, nullptr, IN_LRELU_01, ACT_NONE);
+                const bool fuse = g_force_general_gemm.load(std::memory_order_relaxed) == 0 && r.convs2[d].k == k &&
+                                  r.convs1[d].cin == ch && r.convs1[d].cout == ch && r.convs2[d].cin == ch &&
+                                  r.convs2[d].cout == ch && resblock_pair_supported(ch, k, r.dil[d]);
+                if (fuse) {
+                    ResPairArgs a;
+                    a.x = cur;
+                    a.w1 = r.convs1[d].w;
+                    a.ldw1 = r.convs1[d].kpad;
+                    a.b1 = r.convs1[d].b;
+                    a.w2 = r.convs2[d].w;
+                    a.ldw2 = r.convs2[d].kpad;
+                    a.b2 = r.convs2[d].b;
+                    a.nb = n;
+                    a.T = t2;
+                    a.C = ch;
+                    a.k = k;
+                    a.dil = r.dil[d];
+                    a.slope = 0.1f;
+                    if (j == nk - 1 && d == nd - 1) {
+                        a.avg_a = rout[0];
+                        a.avg_b = rout[1];
+                        dst = x.get();
+                        fused_avg = true;
+                    }
+                    a.out = dst;
+                    launch_resblock_pair(a, m.stream);
+                } else {
+                    conv1d(m, cur, r.convs1[d], nullptr, tmp, n, t2, 1, (k * r.dil[d] - r.dil[d]) / 2, r.dil[d], nullptr,
+                           IN_LRELU_01, ACT_NONE);
+                    conv1d(m, tmp, r.convs2[d], cur, dst, n, t2, 1, (k - 1) / 2, 1, nullptr, IN_LRELU_01, ACT_NONE);
+                }
                 cur = dst;
             }
         }
-        x = Buf<float>(&m.pool, sz);
-        launch_avg3(rout[0], rout[1], rout[2], x, (int64_t)sz, m.stream);
+        if (!fused_avg) launch_avg3(rout[0], rout[1], rout[2], x, (int64_t)sz, m.stream);
         t = t2;
     }
     // F.leaky_relu default slope 0.01, conv_post, tanh (hifigan.py:192-194)

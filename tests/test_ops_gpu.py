@@ -278,6 +278,59 @@ def test_fast_gemm_bit_identical_to_general_conv_transpose(lib, report_dir, nb, 
     assert torch.equal(out[0], out[1])
 
 
+RESPAIR_CASES = [
+    # nb, T, C, k, dil, avg
+    (2, 1000, 32, 3, 1, False),
+    (2, 1000, 32, 11, 5, True),
+    (1, 257, 32, 7, 3, False),
+    (3, 777, 16, 11, 5, False),
+    (2, 4100, 16, 3, 3, True),
+    (1, 100, 16, 7, 1, False),  # shorter than one tile
+    (2, 900, 64, 11, 5, True),
+    (1, 1300, 64, 7, 3, False),
+    (2, 118, 64, 3, 1, False),
+]
+
+
+@pytest.mark.parametrize("nb,T,C_,k,dil,avg", RESPAIR_CASES)
+def test_resblock_pair_bit_identical_to_two_convs(lib, report_dir, nb, T, C_, k, dil, avg):
+    """k_resblock.hip (one ResBlock dilation pair, intermediate in LDS) against the two implicit-GEMM launches
+    it replaces: identical bits; and against F.conv1d in float64 within the split-product accuracy."""
+    g = torch.Generator().manual_seed(T * 13 + C_ * 5 + k + dil)
+    x = torch.randn(nb, T, C_, generator=g)
+    w1 = (torch.randn(C_, C_, k, generator=g) / math.sqrt(C_ * k)).half()
+    w2 = (torch.randn(C_, C_, k, generator=g) / math.sqrt(C_ * k)).half()
+    b1, b2 = torch.randn(C_, generator=g) * 0.1, torch.randn(C_, generator=g) * 0.1
+    ra, rb = torch.randn(nb, T, C_, generator=g), torch.randn(nb, T, C_, generator=g)
+    kpad = (C_ * k + 31) // 32 * 32
+    wp1 = torch.zeros(C_, kpad, dtype=torch.float16, device="cuda")
+    wp2 = torch.zeros(C_, kpad, dtype=torch.float16, device="cuda")
+    check(lib, lib.sc_op_pack_conv_weight(P(dev(w1)), P(wp1), C_, C_, k))
+    check(lib, lib.sc_op_pack_conv_weight(P(dev(w2)), P(wp2), C_, C_, k))
+    dx, db1, db2 = dev(x), dev(b1), dev(b2)
+    tmp = torch.full((nb, T, C_), float("nan"), device="cuda")
+    two = torch.full((nb, T, C_), float("nan"), device="cuda")
+    check(lib, lib.sc_op_conv1d(P(dx), P(wp1), P(db1), None, P(tmp), nb, T, C_, C_, k, 1, dil * (k - 1) // 2, dil, None, 1, 0))
+    check(lib, lib.sc_op_conv1d(P(tmp), P(wp2), P(db2), P(dx), P(two), nb, T, C_, C_, k, 1, (k - 1) // 2, 1, None, 1, 0))
+    want = two.cpu()
+    if avg:
+        want = torch.from_numpy(((ra.numpy() + rb.numpy()) + want.numpy()) / np.float32(3.0))
+    got = torch.full((nb, T, C_), float("nan"), device="cuda")
+    check(lib, lib.sc_op_resblock_pair(P(dx), P(wp1), P(db1), P(wp2), P(db2), P(got), nb, T, C_, k, dil, 0.1,
+                                       P(dev(ra)) if avg else None, P(dev(rb)) if avg else None))
+    got = got.cpu()
+    assert not torch.isnan(got).any()
+    xt = F.leaky_relu(x, 0.1).transpose(1, 2).double()
+    h = F.conv1d(xt, w1.double(), b1.double(), padding=dil * (k - 1) // 2, dilation=dil)
+    ref = F.conv1d(F.leaky_relu(h, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2).transpose(1, 2) + x.double()
+    if avg:
+        ref = (ra.double() + rb.double() + ref) / 3.0
+    err = rel_err(got, ref)
+    _log(report_dir, "resblock_pair", nb=nb, T=T, C=C_, k=k, dil=dil, avg=avg, err=err, bit_identical=bool(torch.equal(got, want)))
+    assert err < 3e-6
+    assert torch.equal(got, want)
+
+
 CONVT_CASES = [(2, 25, 64, 32, 11, 5), (1, 100, 32, 16, 8, 4), (2, 77, 16, 8, 4, 2), (1, 13, 512, 256, 11, 5)]
 
 
