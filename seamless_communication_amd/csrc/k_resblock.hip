@@ -11,7 +11,7 @@
 //      into hi/lo fp16 planes and staged in LDS (halo: H1 = d(k-1)/2 for conv1, H2 = (k-1)/2 for conv2);
 //   2. conv1 for the 128 rows [t0-H2, t0+TT+H2) runs on MFMA straight out of LDS (A fragment = 8
 //      consecutive channels of row j + tap*d; B fragments = weights from L1/L2), the result gets
-//      bias + LeakyReLU + hi/lo split in registers and goes to a second LDS tile - it never sees HBM;
+//      bias + LeakyReLU + hi/lo split in registers and goes back to LDS over the x tile - it never sees HBM;
 //      rows outside [0, T) are forced to zero (conv2's zero padding);
 //   3. conv2 for the TT = 128 - 2*H2 output rows runs out of that tile; bias, the residual x (re-read,
 //      L2 resident) and optionally the (a + b + v) / 3 average over the three ResBlocks of the stage
@@ -94,11 +94,13 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
     const int H2 = (k - 1) / 2, H1 = dil * (k - 1) / 2;
     const int TT = RB_M1 - 2 * H2;  // output rows per workgroup
     const int R0 = RB_M1 + 2 * H1;  // staged x rows
-    const int R1 = RB_M1 + k - 1;   // tmp rows addressed by conv2 (rows >= RB_M1 only feed outputs that are not stored)
+    // conv2 addresses tmp rows [0, RB_M1 + k - 1) <= R0; rows >= RB_M1 only feed outputs that are not stored.
+    // The tmp tile reuses the x planes (conv1 has consumed them by then), which keeps the workgroup at
+    // 2 * R0 * CS halfs of LDS: 3 workgroups per CU at C = 64 instead of 1.
     _Float16* xh = reinterpret_cast<_Float16*>(rb_smem);
     _Float16* xl = xh + R0 * CS;
-    _Float16* th = xl + R0 * CS;
-    _Float16* tl = th + R1 * CS;
+    _Float16* th = xh;
+    _Float16* tl = xl;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.x / tiles;
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
         conv_from_lds<C, NF>(xh, xl, 32 * wave, dil, k, p.w1, p.ldw1, lane, acc);
+        __syncthreads();  // every wave is done reading x before the tmp tile overwrites it
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
             const int col = nf * 32 + (lane & 31);
@@ -191,7 +194,7 @@ void launch_cfg(const ResPairArgs& a, hipStream_t s) {
     const int H2 = (a.k - 1) / 2, H1 = a.dil * (a.k - 1) / 2;
     const int TT = RB_M1 - 2 * H2;
     const int tiles = cdiv(a.T, TT);
-    const size_t lds = (size_t)2 * ((RB_M1 + 2 * H1) + (RB_M1 + a.k - 1)) * (C + 8) * sizeof(_Float16);
+    const size_t lds = (size_t)2 * (RB_M1 + 2 * H1) * (C + 8) * sizeof(_Float16);
     SC_CHECK(lds <= 120 * 1024, "resblock pair: %zu bytes of LDS (C=%d k=%d dil=%d)", lds, C, a.k, a.dil);
     char name[48];
     snprintf(name, sizeof(name), "resblock_pair_c%d", C);
@@ -206,7 +209,7 @@ void launch_cfg(const ResPairArgs& a, hipStream_t s) {
 bool resblock_pair_supported(int C, int k, int dil) {
     if (!(C == 16 || C == 32 || C == 64) || k < 1 || (k & 1) == 0 || dil < 1) return false;
     const int H1 = dil * (k - 1) / 2;
-    const size_t lds = (size_t)2 * ((RB_M1 + 2 * H1) + (RB_M1 + k - 1)) * (C + 8) * sizeof(_Float16);
+    const size_t lds = (size_t)2 * (RB_M1 + 2 * H1) * (C + 8) * sizeof(_Float16);
     return RB_M1 - (k - 1) >= 32 && lds <= 120 * 1024;
 }
 

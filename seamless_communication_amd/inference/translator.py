@@ -87,7 +87,8 @@ def _resolve_card(name_or_card: Union[str, Dict[str, Any]]) -> Dict[str, Any]:
     raise ValueError(f"unknown asset card '{name_or_card}'; pass a card dict (reference YAML schema) instead")
 
 
-def _load_state_dict(card: Dict[str, Any], cfg: S2STConfig, kind: str, with_t2u: bool) -> Dict[str, Tensor]:
+def _load_state_dict(card: Dict[str, Any], cfg: S2STConfig, kind: str, with_t2u: bool,
+                     char_pieces: Optional[List[str]] = None) -> Dict[str, Tensor]:
     uri = card.get("checkpoint", "")
     if uri.startswith("synthetic://"):
         seed = int(uri[len("synthetic://"):] or _syn.DEFAULT_SEED)
@@ -97,7 +98,9 @@ def _load_state_dict(card: Dict[str, Any], cfg: S2STConfig, kind: str, with_t2u:
     if uri.startswith("file://"):
         from ..checkpoint import load_converted_checkpoint
 
-        return load_converted_checkpoint(uri[len("file://"):], kind)
+        # fairseq-keyed checkpoints (what the model cards publish) are converted like the reference's
+        # convert_unity_checkpoint / convert_vocoder_checkpoint do
+        return load_converted_checkpoint(uri[len("file://"):], kind, char_spm_tokens=char_pieces)
     raise ValueError(
         f"card '{card.get('name')}': checkpoint '{uri}' is not reachable offline; use file://<path> or synthetic://<seed>"
     )
@@ -131,12 +134,12 @@ class Translator:
         if input_modality is not None and input_modality != Modality.SPEECH:
             raise NotImplementedError("text input is outside the MI355X S2ST hot path")
         with_t2u = output_modality is None or output_modality == Modality.SPEECH
-        unity_sd = _load_state_dict(card, self.cfg, "unity", with_t2u)
+        self.char_tokenizer = CharTokenizer(self.cfg.char_vocab_size, card.get("char_tokenizer_path"))
+        unity_sd = _load_state_dict(card, self.cfg, "unity", with_t2u, self.char_tokenizer.pieces())
         langs = card.get("langs", _cards.TEXT_LANGS)
         self.text_tokenizer = text_tokenizer or NllbTextTokenizer(
             self.cfg.text_vocab_size, langs, card.get("default_lang", "eng"), card.get("tokenizer_path")
         )
-        self.char_tokenizer = CharTokenizer(self.cfg.char_vocab_size, card.get("char_tokenizer_path"))
         self.unit_tokenizer: Optional[UnitTokenizer] = None
         if with_t2u:
             self.unit_tokenizer = UnitTokenizer(

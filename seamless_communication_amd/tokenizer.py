@@ -305,6 +305,13 @@ class CharTokenizer:
                 raise ValueError("char vocabulary too small")
             self._map = {c: 4 + i for i, c in enumerate(chars)}
 
+    def pieces(self) -> Optional[List[str]]:
+        """The SentencePiece pieces in model order (None for the built-in synthetic alphabet): what
+        ``_get_char_index_mapping`` (models/unity/loader.py:158-176) re-orders the char embedding by."""
+        if self._spm is None:
+            return None
+        return [self._spm.id_to_piece(i) for i in range(self._spm.get_piece_size())]
+
     def token_to_index(self, ch: str) -> int:
         if self._spm is not None:
             return int(self._spm.piece_to_id(ch))
