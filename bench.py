@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step (BASELINE configs[3]: 64 per GPU)")
     ap.add_argument("--microbatches", type=int, default=2,
                     help="concurrent slices of the per-GPU batch (one host thread + one HIP stream each)")
     ap.add_argument("--text-len", type=int, default=42, help="hard_max_seq_len of the greedy text search (prompt included)")
@@ -84,14 +84,19 @@ def roofline_of(fams):
     f = fams[name]
     sec = f["ms"] * 1e-3
     avg_us = 1e3 * f["ms"] / max(1, f["launches"])
-    if name.startswith("gemv"):
+    base = name.split(":")[-1]
+    if base.startswith(("gemv", "skinny", "resblock_pair_c16", "resblock_pair_c32")):
+        # weight streaming (decoder step) / narrow vocoder stages: HBM-bound kernels
         ach = f["bytes"] / sec / 1e9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
     else:
         ach = f["flops"] / sec / 1e12
+        # algorithmic flops (2*M*N*K).  The product is fp32-activation x fp16-weight: every fragment issues
+        # TWO fp16 MFMAs (hi and lo half of the activation), so the matrix pipe is busy at 2x this rate.
         roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / MFMA_F16_PEAK_TFLOPS}
-    roof.update({"traffic": None, "kernel": name, "launches": f["launches"], "avg_launch_us": avg_us,
+                "frac": ach / MFMA_F16_PEAK_TFLOPS, "mfma_issue_tflops": 2.0 * ach,
+                "mfma_issue_frac": 2.0 * ach / MFMA_F16_PEAK_TFLOPS}
+    roof.update({"traffic": pmc_traffic(name), "kernel": name, "launches": f["launches"], "avg_launch_us": avg_us,
                  "algorithmic_flops_per_launch": f["flops"] / max(1, f["launches"]),
                  "algorithmic_bytes_per_launch": f["bytes"] / max(1, f["launches"])})
     total = sum(v["ms"] for v in fams.values())
@@ -101,6 +106,28 @@ def roofline_of(fams):
               for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])}
     shares["_profiled_total_ms"] = round(total, 3)
     return roof, shares
+
+
+def pmc_traffic(family: str):
+    """HBM bytes per launch of the kernel family from the newest committed rocprofv3 PMC summary under
+    profiles/ (FETCH_SIZE / WRITE_SIZE collected in separate passes, FETCH_SIZE doubled per the gfx950
+    correction; scripts/pmc_summary.py).  bench.py cannot run the PMC passes on itself; null when absent."""
+    import csv
+    import glob
+
+    key = {"gemm_128x128_fast_split": "gemm_fast_kernel<128, 128", "gemm_128x128_vecA_split": "gemm_kernel<128, 128, 2, 2, 1, true>",
+           "skinny_m32": "skinny_kernel<1, 1", "skinny_m64": "skinny_kernel<2, 1"}.get(family.split(":")[-1])
+    files = sorted(glob.glob(str(ROOT / "profiles" / "*pmc_hbm_traffic*.csv")))
+    if not key or not files:
+        return None
+    try:
+        with open(files[-1], newline="") as fh:
+            for row in csv.DictReader(fh):
+                if key in row["kernel"]:
+                    return float(row["hbm_bytes_per_launch_corrected"])
+    except Exception:
+        return None
+    return None
 
 
 def log(msg):

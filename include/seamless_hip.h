@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 1
+#define SC_ABI_VERSION 2
 #define SC_MAX_UPSAMPLES 8
 #define SC_MAX_RESBLOCK_KERNELS 4
 #define SC_MAX_RESBLOCK_DILATIONS 4
@@ -87,13 +87,15 @@ typedef struct sc_config {
 /* Text generation options: the fields of SequenceGeneratorOptions
  * (inference/generator.py:59-84) that the greedy path honours. */
 typedef struct sc_gen_opts {
-    int32_t beam_size;        /* must be 1 (greedy); >1 is rejected with SC_ERR_INVALID */
+    int32_t beam_size;        /* 1: greedy arg-max with a graph-captured step; 2..8: beam search (host-driven steps) */
     float soft_max_seq_len_a; /* max_len = min(hard, int(a*S_src) + b), prefix included */
     int32_t soft_max_seq_len_b;
     int32_t hard_max_seq_len;
     int32_t min_seq_len;
     float unk_penalty;
-    int32_t use_graph; /* replay the decoder step from a captured hipGraph */
+    int32_t use_graph; /* replay the decoder step from a captured hipGraph (greedy only) */
+    float len_penalty;        /* beam search: hypothesis score / (len)^len_penalty (generator.py:81-84) */
+    int32_t normalize_scores; /* beam search: apply the length normalisation (fairseq2 default: true) */
 } sc_gen_opts;
 
 typedef struct sc_model sc_model;

@@ -41,9 +41,13 @@ class OracleS2ST:
 
     @torch.inference_mode()
     def s2tt(self, fbank: Tensor, lens: Tensor, tgt_lang: str, soft_max_seq_len=(1, 200),
-             hard_max_seq_len: int = 1024):
+             hard_max_seq_len: int = 1024, beam_size: int = 1):
         enc, enc_lens = ou.encode_speech(self.P, self.cfg, fbank, lens)
         prefix = self.text_tok.target_prefix(tgt_lang)
+        if beam_size > 1:
+            seqs = ou.beam_search_generate(self.P, self.cfg, enc, enc_lens, prefix, beam_size, soft_max_seq_len,
+                                           hard_max_seq_len, pos_table=self.pos_table)
+            return seqs, enc, enc_lens, None
         seqs, margins = ou.greedy_generate(
             self.P, self.cfg, enc, enc_lens, prefix, soft_max_seq_len, hard_max_seq_len,
             pos_table=self.pos_table, return_margins=True,
@@ -53,9 +57,9 @@ class OracleS2ST:
     @torch.inference_mode()
     def s2st(self, fbank: Tensor, lens: Tensor, tgt_lang: str, soft_max_seq_len=(1, 200),
              hard_max_seq_len: int = 1024, duration_factor: float = 1.0, spkr: int = -1,
-             vocode: bool = True):
+             vocode: bool = True, beam_size: int = 1):
         cfg = self.cfg
-        seqs, enc, enc_lens, margins = self.s2tt(fbank, lens, tgt_lang, soft_max_seq_len, hard_max_seq_len)
+        seqs, enc, enc_lens, margins = self.s2tt(fbank, lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size)
         # generator.py:281-291: pad_seqs + trim the final EOS column
         L = max(len(s) for s in seqs)
         text_seqs = torch.full((len(seqs), L), cfg.pad_idx, dtype=torch.int64)

@@ -321,6 +321,109 @@ def greedy_generate(
     return (out, margins) if return_margins else out
 
 
+def beam_search_generate(
+    P: Params, cfg, enc: Tensor, enc_lens: Tensor, prefix: Sequence[int], beam_size: int = 5,
+    soft_max_seq_len: Tuple[float, int] = (1, 200), hard_max_seq_len: int = 1024, min_seq_len: int = 1,
+    len_penalty: float = 1.0, unk_penalty: float = 0.0, normalize_scores: bool = True,
+    pos_table: Optional[Tensor] = None, return_all: bool = False,
+):
+    """BeamSearchSeq2SeqGenerator as the reference constructs it (inference/generator.py:147-156,
+    beam_size=5 by default translator.py:311-313), restated from the in-tree C++ port of fairseq2's
+    algorithm, ggml/examples/unity/fairseq2.cpp:1371-1608:
+      * the encoder output is fanned out to `beam_size` rows, the prompt is echoed and its cumulative
+        log-probabilities seed the scores (`_bootstrap_seqs_and_scores` :1161-1247);
+      * every step: log-softmax, `_tweak_lprobs` (:1269-1305), + cumulative score (first step: beam 0 only),
+        the best 2*beam candidates over (beam, token) (:1249-1267); candidates are visited best first:
+        an EOS candidate is finalised with score / (step+1)^len_penalty (:1310-1348), others continue
+        until `beam_size` beams are refilled; the search of an utterance ends when `beam_size`
+        hypotheses are finished (:1546-1560); beams (sequences, scores, KV cache) are re-ordered;
+      * hypotheses sorted by score, best first (:1597-1602).
+    Uses log-probabilities throughout (the intent of the port; see tests/test_oracle_ggml_ref.py for what
+    the compiled C++ actually does to them).  Ties between equal candidates: lower (beam, token) index.
+    Returns the best hypothesis per utterance (and all finished ones with return_all)."""
+    N = enc.shape[0]
+    if pos_table is None:
+        pos_table = sinusoidal_table(cfg.text_max_seq_len, cfg.model_dim, 1)
+    W = P["final_proj.weight"]
+    V = W.shape[0]
+    B = beam_size
+    best: List[List[int]] = []
+    everything = []
+    for n in range(N):
+        max_len = min(max_seq_len_rule(soft_max_seq_len[0], soft_max_seq_len[1], hard_max_seq_len, enc.shape[1]), cfg.text_max_seq_len)
+        enc_b = enc[n : n + 1].expand(B, -1, -1)
+        lens_b = enc_lens[n : n + 1].expand(B)
+        dec = IncrementalDecoder(P, cfg, enc_b, lens_b, pos_table)
+        seqs = torch.zeros(B, max_len, dtype=torch.int64)
+        scores = torch.zeros(B, max_len, dtype=torch.float32)
+        seqs[:, : len(prefix)] = torch.tensor(list(prefix))
+        # bootstrap: feed prefix[:-1]; score[i] = sum_{j<=i} lprob(prefix[j] | prefix[<j])
+        if len(prefix) > 1:
+            h = dec(seqs[:, : len(prefix) - 1])
+            lp = torch.log_softmax(F.linear(h[0], W), dim=-1)  # (S_pfx-1, V), beam 0
+            acc = 0.0
+            for i in range(1, len(prefix)):
+                acc = acc + float(lp[i - 1, prefix[i]])
+                scores[:, i] = acc
+        finished: List[Tuple[float, List[int]]] = []
+        start = len(prefix) - 1
+        for step_nr in range(start, max_len - 1):
+            h = dec(seqs[:, step_nr : step_nr + 1])
+            lprobs = torch.log_softmax(F.linear(h[:, -1], W), dim=-1)  # (B, V)
+            if step_nr < min_seq_len:
+                lprobs[:, cfg.eos_idx] = -math.inf
+            if step_nr == max_len - 2:
+                lprobs[:, : cfg.eos_idx] = -math.inf
+                lprobs[:, cfg.eos_idx + 1 :] = -math.inf
+            lprobs[:, cfg.pad_idx] = -math.inf
+            if unk_penalty != 0:
+                lprobs[:, cfg.unk_idx] -= unk_penalty
+            if step_nr == start:
+                cand = lprobs[0:1] + (scores[0:1, step_nr : step_nr + 1] if step_nr > 0 else 0.0)
+            else:
+                cand = lprobs + scores[:, step_nr : step_nr + 1]
+            flat = cand.reshape(-1)
+            K = min(2 * B, V - 1, flat.numel())
+            # best K, ties -> lower flattened index
+            order = sorted(range(flat.numel()), key=lambda i: (-float(flat[i]), i))[:K] if flat.numel() <= 4096 else None
+            if order is None:
+                vals, idx = torch.topk(flat, K)
+                pairs = sorted(zip(vals.tolist(), idx.tolist()), key=lambda p: (-p[0], p[1]))
+                order = [i for _, i in pairs]
+            beams, toks, scs = [], [], []
+            done = False
+            for c in order:
+                beam, token, s = c // V, c % V, float(flat[c])
+                if token == cfg.eos_idx and s != -math.inf:
+                    final = s / float((step_nr + 1) ** len_penalty) if normalize_scores else s
+                    finished.append((final, seqs[beam, : step_nr + 1].tolist() + [token]))
+                    if len(finished) == B:
+                        done = True
+                        break
+                    continue
+                beams.append(beam)
+                toks.append(token)
+                scs.append(s)
+                if len(beams) >= B:
+                    break
+            if done:
+                break
+            while len(beams) < B:  # fewer live candidates than beams: pad with dead copies of beam 0
+                beams.append(beams[0] if beams else 0)
+                toks.append(cfg.pad_idx)
+                scs.append(-math.inf)
+            bi = torch.tensor(beams)
+            seqs = seqs[bi].clone()
+            scores = scores[bi].clone()
+            dec.cache = [c[bi] for c in dec.cache]
+            seqs[:, step_nr + 1] = torch.tensor(toks)
+            scores[:, step_nr + 1] = torch.tensor(scs)
+        finished.sort(key=lambda f: -f[0])
+        best.append(finished[0][1])
+        everything.append(finished)
+    return (best, everything) if return_all else best
+
+
 # --------------------------------------------------------------------------- #
 # NAR T2U (a12..a17)
 # --------------------------------------------------------------------------- #

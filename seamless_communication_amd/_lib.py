@@ -11,7 +11,7 @@ from typing import Optional
 
 LIB_PATH = Path(__file__).resolve().parent / "libseamless_hip.so"
 
-SC_ABI_VERSION = 1
+SC_ABI_VERSION = 2
 SC_MAX_UPSAMPLES = 8
 SC_MAX_RESBLOCK_KERNELS = 4
 SC_MAX_RESBLOCK_DILATIONS = 4
@@ -67,6 +67,7 @@ class sc_gen_opts(C.Structure):
     _fields_ = [
         ("beam_size", _i), ("soft_max_seq_len_a", C.c_float), ("soft_max_seq_len_b", _i),
         ("hard_max_seq_len", _i), ("min_seq_len", _i), ("unk_penalty", C.c_float), ("use_graph", _i),
+        ("len_penalty", C.c_float), ("normalize_scores", _i),
     ]
 
 

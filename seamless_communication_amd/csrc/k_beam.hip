@@ -1,0 +1,189 @@
+// Device side of beam search over the text decoder (BeamSearchSeq2SeqGenerator, beam_size > 1;
+// reference: inference/generator.py:147-156, algorithm restated from the in-tree port
+// ggml/examples/unity/fairseq2.cpp:1249-1305, :1463-1594).
+//
+// beam_candidates_kernel: one workgroup per utterance.  For the utterance's `beams` logit rows:
+//   log-softmax (row max + log-sum-exp by block reductions), the generation step rules
+//   (`_tweak_lprobs`: EOS masked before min_seq_len, only EOS at the length limit, PAD never, UNK
+//   penalty), + the beam's cumulative score, then the best K = 2*beam candidates over the flattened
+//   (beam, token) space (first step: beam 0 only), best first, ties to the lower flattened index.
+//   HBM traffic: each logit row is read three times (max, sum, scan), L2 resident (1 MB per row).
+// row_token_lprob_kernel: log-softmax value of ONE given token per row (scores of the echoed prompt).
+// gather_cache_kernel: K/V cache rows re-ordered by the surviving beams (all layers in one launch).
+#include "kernels.h"
+
+namespace sc {
+
+namespace {
+
+constexpr int BEAM_MAX_K = 16;
+
+__device__ __forceinline__ float block_reduce_max(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__device__ __forceinline__ float block_reduce_sum(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ __forceinline__ bool better(float v, int i, float w, int j) { return v > w || (v == w && i < j); }
+
+__global__ __launch_bounds__(256) void beam_candidates_kernel(const float* __restrict__ logits, int64_t ld, int beams, int V,
+                                                              const float* __restrict__ cum, int first_step, int no_eos,
+                                                              int force_eos, int pad_idx, int eos_idx, int unk_idx,
+                                                              float unk_penalty, int K, float* __restrict__ cand_val,
+                                                              int* __restrict__ cand_idx) {
+    __shared__ float red[4];
+    __shared__ float lse[BEAM_MAX_K];
+    __shared__ float s_val[256];
+    __shared__ int s_idx[256];
+    __shared__ int s_winner;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int nb = first_step ? 1 : beams;
+    for (int b = 0; b < nb; ++b) {
+        const float* row = logits + ((int64_t)n * beams + b) * ld;
+        float mx = -INFINITY;
+        for (int i = tid; i < V; i += 256) mx = fmaxf(mx, row[i]);
+        mx = block_reduce_max(mx, red);
+        float sm = 0.f;
+        for (int i = tid; i < V; i += 256) sm += expf(row[i] - mx);
+        sm = block_reduce_sum(sm, red);
+        if (tid == 0) lse[b] = mx + logf(sm);
+    }
+    __syncthreads();
+    // per-thread best-K list, sorted best first
+    float tv[BEAM_MAX_K];
+    int ti[BEAM_MAX_K];
+#pragma unroll
+    for (int q = 0; q < BEAM_MAX_K; ++q) {
+        tv[q] = -INFINITY;
+        ti[q] = 0x7fffffff;
+    }
+    float wv = -INFINITY;  // the list's current K-th entry (kept in scalars: no dynamic register indexing)
+    int wi = 0x7fffffff;
+    for (int b = 0; b < nb; ++b) {
+        const float* row = logits + ((int64_t)n * beams + b) * ld;
+        const float base = cum[(int64_t)n * beams + b];
+        const float l = lse[b];
+        for (int t = tid; t < V; t += 256) {
+            float lp = row[t] - l;
+            if (no_eos && t == eos_idx) lp = -INFINITY;
+            if (force_eos && t != eos_idx) lp = -INFINITY;
+            if (t == pad_idx) lp = -INFINITY;
+            if (t == unk_idx) lp -= unk_penalty;
+            const float v = lp + base;
+            const int idx = b * V + t;
+            if (better(v, idx, wv, wi)) {
+                // insertion into the sorted list (K <= 16, fully unrolled compare-and-shift)
+                float cv = v;
+                int ci = idx;
+#pragma unroll
+                for (int q = 0; q < BEAM_MAX_K; ++q) {
+                    if (q < K && better(cv, ci, tv[q], ti[q])) {
+                        const float ov = tv[q];
+                        const int oi = ti[q];
+                        tv[q] = cv;
+                        ti[q] = ci;
+                        cv = ov;
+                        ci = oi;
+                    }
+                    if (q == K - 1) {
+                        wv = tv[q];
+                        wi = ti[q];
+                    }
+                }
+            }
+        }
+    }
+    // K rounds of block-wide arg-best over the list heads
+    int head = 0;
+    for (int r = 0; r < K; ++r) {
+        float hv = -INFINITY;
+        int hi = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < BEAM_MAX_K; ++q)
+            if (q == head) {
+                hv = tv[q];
+                hi = ti[q];
+            }
+        s_val[tid] = hv;
+        s_idx[tid] = hi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o && better(s_val[tid + o], s_idx[tid + o], s_val[tid], s_idx[tid])) {
+                s_val[tid] = s_val[tid + o];
+                s_idx[tid] = s_idx[tid + o];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            cand_val[(int64_t)n * K + r] = s_val[0];
+            cand_idx[(int64_t)n * K + r] = s_idx[0];
+            s_winner = s_idx[0];
+        }
+        __syncthreads();
+        if (hi == s_winner && hi != 0x7fffffff) ++head;  // flattened indices are unique: exactly one list advances
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void row_token_lprob_kernel(const float* __restrict__ logits, int64_t ld, int V,
+                                                              int row_stride, int token, float* __restrict__ out) {
+    __shared__ float red[4];
+    const float* row = logits + (int64_t)blockIdx.x * row_stride * ld;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += 256) mx = fmaxf(mx, row[i]);
+    mx = block_reduce_max(mx, red);
+    float sm = 0.f;
+    for (int i = threadIdx.x; i < V; i += 256) sm += expf(row[i] - mx);
+    sm = block_reduce_sum(sm, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = row[token] - (mx + logf(sm));
+}
+
+// dst[l][r][t][:] = src[l][src_row[r]][t][:] for t < len; blockIdx = (t, r, l)
+__global__ __launch_bounds__(256) void gather_cache_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           const int* __restrict__ src_row, int cap, int M, int64_t layer_stride) {
+    const int t = blockIdx.x, r = blockIdx.y, l = blockIdx.z;
+    const float4* s4 = reinterpret_cast<const float4*>(src + l * layer_stride + ((int64_t)src_row[r] * cap + t) * M);
+    float4* d4 = reinterpret_cast<float4*>(dst + l * layer_stride + ((int64_t)r * cap + t) * M);
+    for (int c = threadIdx.x; c < (M >> 2); c += 256) d4[c] = s4[c];
+}
+
+}  // namespace
+
+void launch_beam_candidates(const float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step,
+                            int no_eos, int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K,
+                            float* cand_val, int* cand_idx, hipStream_t s) {
+    SC_CHECK(K >= 1 && K <= BEAM_MAX_K && beams >= 1 && beams <= BEAM_MAX_K, "beam search: beam_size %d / K %d out of range (max %d candidates)",
+             beams, K, BEAM_MAX_K);
+    SC_CHECK((int64_t)beams * V < (1ll << 31) - 1, "beam search: beam * vocabulary overflows the candidate index");
+    hipLaunchKernelGGL(beam_candidates_kernel, dim3(n_utt), dim3(256), 0, s, logits, ld, beams, V, cum, first_step, no_eos, force_eos,
+                       pad_idx, eos_idx, unk_idx, unk_penalty, K, cand_val, cand_idx);
+    SC_LAUNCH_CHECK();
+}
+
+void launch_row_token_lprob(const float* logits, int64_t ld, int rows, int V, int row_stride, int token, float* out, hipStream_t s) {
+    SC_CHECK(token >= 0 && token < V, "row_token_lprob: token %d out of range", token);
+    hipLaunchKernelGGL(row_token_lprob_kernel, dim3(rows), dim3(256), 0, s, logits, ld, V, row_stride, token, out);
+    SC_LAUNCH_CHECK();
+}
+
+void launch_gather_cache(const float* src, float* dst, const int* src_row, int rows, int len, int cap, int M, int layers,
+                         int64_t layer_stride, hipStream_t s) {
+    SC_CHECK(M % 4 == 0 && rows <= 65535 && layers <= 65535, "gather_cache: bad geometry");
+    if (len <= 0) return;
+    hipLaunchKernelGGL(gather_cache_kernel, dim3(len, rows, layers), dim3(256), 0, s, src, dst, src_row, cap, M, layer_stride);
+    SC_LAUNCH_CHECK();
+}
+
+}  // namespace sc

@@ -159,6 +159,14 @@ void launch_decode_attention(const float* q, int64_t ldq, const float* k_new, co
                              int64_t in_split_stride = 0, const float* bias_q = nullptr,
                              const float* bias_k = nullptr, const float* bias_v = nullptr);
 
+// beam search (k_beam.hip)
+void launch_beam_candidates(const float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step,
+                            int no_eos, int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K,
+                            float* cand_val, int* cand_idx, hipStream_t s);
+void launch_row_token_lprob(const float* logits, int64_t ld, int rows, int V, int row_stride, int token, float* out, hipStream_t s);
+void launch_gather_cache(const float* src, float* dst, const int* src_row, int rows, int len, int cap, int M, int layers,
+                         int64_t layer_stride, hipStream_t s);
+
 // fbank front-end
 // consts = window[400] | melT[256][80] | twiddle cos[256] | twiddle sin[256]
 void launch_fbank(const float* wav, int64_t wav_stride, const int* num_samples, int nb, float* out,

@@ -22,6 +22,10 @@ int text_max_len(const Model& m, const sc_gen_opts& o, int s_enc) {
     return std::min(max_len, m.cfg.text_max_seq_len);
 }
 
+void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens, const sc_gen_opts& o,
+                            const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids, int32_t* h_out_lens, float* h_scores,
+                            float* d_dec_hidden);
+
 namespace {
 
 struct StepCtx {
@@ -201,7 +205,12 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     if (forced) {
         max_len = forced_len + 1;  // hidden buffer has max_len-1 = forced_len rows
     } else {
-        SC_CHECK(o.beam_size == 1, "sc_generate_text: beam_size=%d is not supported by the greedy HIP path (use 1)", o.beam_size);
+        SC_CHECK(o.beam_size >= 1, "sc_generate_text: beam_size=%d", o.beam_size);
+        if (o.beam_size > 1) {
+            run_generate_text_beam(m, d_enc, n, s_enc, h_enc_lens, o, h_prefix, prefix_len, h_out_ids, h_out_lens, h_scores,
+                                   d_dec_hidden);
+            return;
+        }
         SC_CHECK(prefix_len >= 1, "sc_generate_text: the prompt must hold at least one token");
         max_len = text_max_len(m, o, s_enc);
         SC_CHECK(o.min_seq_len <= max_len, "sc_generate_text: min_seq_len %d > effective max length %d", o.min_seq_len, max_len);
@@ -339,6 +348,252 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
         for (int t = 0; t < max_len; ++t) h_out_ids[(size_t)b * max_len + t] = t < len ? hist[(size_t)b * max_len + t] : cfg.pad_idx;
         h_out_lens[b] = len;
         if (h_scores) h_scores[b] = scores[b];
+    }
+}
+
+// --------------------------------------------------------------------------------------------- //
+// Beam search (beam_size > 1): BeamSearchSeq2SeqGenerator as the reference constructs it
+// (inference/generator.py:147-156; beam_size=5 is the API default, translator.py:311-313).  Algorithm
+// restated from ggml/examples/unity/fairseq2.cpp:1371-1608 (see oracle/unity.py: beam_search_generate).
+// Row r = utterance * beam + b of every decoder buffer is one live beam.  Per step: decoder step for all
+// rows, vocabulary projection, beam_candidates_kernel (log-softmax + step rules + cumulative score +
+// best 2*beam candidates per utterance), then the host walks the candidates (finalise EOS hypotheses,
+// refill the beams), and the K/V caches are re-ordered on the device (double buffered, all layers in one
+// launch).  One host round trip per step; not graph-captured (the beam bookkeeping lives on the host).
+// --------------------------------------------------------------------------------------------- //
+void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens, const sc_gen_opts& o,
+                            const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids, int32_t* h_out_lens, float* h_scores,
+                            float* d_dec_hidden) {
+    const sc_config& cfg = m.cfg;
+    const int M = cfg.model_dim, V = cfg.text_vocab_size, B = o.beam_size, L = cfg.dec_layers;
+    const int nb = n * B;
+    const int K = std::min(2 * B, V - 1);
+    SC_CHECK(B <= 8, "sc_generate_text: beam_size %d > 8", B);
+    SC_CHECK(prefix_len >= 1, "sc_generate_text: the prompt must hold at least one token");
+    const int max_len = text_max_len(m, o, s_enc);
+    SC_CHECK(o.min_seq_len <= max_len, "sc_generate_text: min_seq_len %d > effective max length %d", o.min_seq_len, max_len);
+    SC_CHECK(prefix_len < max_len, "sc_generate_text: prompt length %d >= effective max length %d", prefix_len, max_len);
+    SC_CHECK(max_len <= 4096 && max_len <= cfg.text_max_seq_len + 1, "sc_generate_text: length %d exceeds the decoder limit", max_len);
+    SC_CHECK(s_enc <= 4096, "sc_generate_text: encoder length %d > 4096", s_enc);
+    for (int i = 0; i < n; ++i)
+        SC_CHECK(h_enc_lens[i] > 0 && h_enc_lens[i] <= s_enc, "sc_generate_text: enc_lens[%d]=%d out of range", i, h_enc_lens[i]);
+    const float len_penalty = o.len_penalty;
+    const bool normalize = o.normalize_scores != 0;
+
+    // ---- fan the encoder output out to the beams (fairseq2.cpp `_fan_out_encoder_output`) ----------
+    Buf<float> enc_rep(&m.pool, (size_t)nb * s_enc * M);
+    {
+        std::vector<int32_t> idx((size_t)nb * s_enc);
+        for (int r = 0; r < nb; ++r)
+            for (int t = 0; t < s_enc; ++t) idx[(size_t)r * s_enc + t] = (r / B) * s_enc + t;
+        Buf<int> d_idx(&m.pool, idx.size());
+        SC_HIP(hipMemcpyAsync(d_idx.get(), idx.data(), idx.size() * 4, hipMemcpyHostToDevice, m.stream));
+        launch_gather_rows(d_enc, M, d_idx, enc_rep, M, nb * s_enc, M, m.stream);
+        SC_HIP(hipStreamSynchronize(m.stream));  // idx is a host temporary
+    }
+
+    StepCtx c;
+    c.nb = nb;
+    c.cap = max_len;
+    c.s_enc = s_enc;
+    c.min_seq_len = o.min_seq_len;
+    c.force_eos_step = max_len - 2;
+    c.unk_penalty = o.unk_penalty;
+    Buf<int> ints(&m.pool, (size_t)8 + 5 * nb);
+    c.d_pos = ints;
+    c.d_tok = ints.get() + 8;
+    c.d_finished = c.d_tok + nb;
+    c.d_out_len = c.d_finished + nb;
+    c.d_enc_lens = c.d_out_len + nb;
+    int* d_src_row = c.d_enc_lens + nb;
+    const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
+    Buf<float> x(&m.pool, (size_t)nb * M), h(&m.pool, (size_t)nb * M), wide(&m.pool, (size_t)nb * wideN), att(&m.pool, (size_t)nb * M),
+        hN(&m.pool, (size_t)nb * M), logits(&m.pool, (size_t)nb * V);
+    Buf<float> partial(&m.pool, (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * nb * 3 * M);
+    Buf<float> d_cum(&m.pool, (size_t)nb), d_cand_val(&m.pool, (size_t)n * K), d_pref(&m.pool, (size_t)n);
+    Buf<int> d_cand_idx(&m.pool, (size_t)n * K);
+    c.partial = partial;
+    c.x = x;
+    c.h = h;
+    c.wide = wide;
+    c.att = att;
+    c.hN = hN;
+    c.logits = logits;
+    // self-attention K/V caches of all layers in one allocation, twice (re-ordered from one into the other)
+    const int64_t layer_stride = (int64_t)nb * max_len * M;
+    Buf<float> kv_a(&m.pool, (size_t)2 * L * layer_stride), kv_b(&m.pool, (size_t)2 * L * layer_stride);
+    float* kv_cur = kv_a;
+    float* kv_alt = kv_b;
+    auto bind_caches = [&](float* base) {
+        c.kcache.clear();
+        c.vcache.clear();
+        for (int li = 0; li < L; ++li) {
+            c.kcache.push_back(base + (int64_t)(2 * li) * layer_stride);
+            c.vcache.push_back(base + (int64_t)(2 * li + 1) * layer_stride);
+        }
+    };
+    bind_caches(kv_cur);
+    std::vector<Buf<float>> cross;
+    cross.reserve(L);
+    for (int li = 0; li < L; ++li) {
+        cross.emplace_back(&m.pool, (size_t)nb * s_enc * 2 * M);
+        c.cross_kv.push_back(cross.back());
+        linear(m, enc_rep, M, m.dec[li].cross_kv, nullptr, 0, c.cross_kv.back(), 2 * M, nb * s_enc, ACT_NONE, 1.f);
+    }
+    Linear proj;
+    proj.w = m.text_embed;
+    proj.ldw = M;
+    proj.kpad = M;
+    proj.in = M;
+    proj.out = V;
+
+    // ---- host state: sequences, cumulative scores, finished hypotheses ------------------------------
+    std::vector<int32_t> seqs((size_t)nb * max_len, cfg.pad_idx), init(8 + 5 * nb, 0), tok(nb), src_row(nb);
+    std::vector<float> scores((size_t)nb * max_len, 0.f), cum(nb, 0.f);
+    for (int r = 0; r < nb; ++r) {
+        for (int t = 0; t < prefix_len; ++t) seqs[(size_t)r * max_len + t] = h_prefix[t];
+        init[8 + r] = h_prefix[0];
+        init[8 + 3 * nb + r] = h_enc_lens[r / B];
+    }
+    SC_HIP(hipMemcpyAsync(ints.get(), init.data(), init.size() * 4, hipMemcpyHostToDevice, m.stream));
+    struct Hyp {
+        float score;
+        std::vector<int32_t> seq;
+    };
+    std::vector<std::vector<Hyp>> finished(n);
+    std::vector<char> done(n, 0);
+    std::vector<float> cand_val((size_t)n * K), pref(n);
+    std::vector<int32_t> cand_idx((size_t)n * K);
+
+    // ---- prompt echo: feed prefix[:-1]; scores[i] = sum_{j<=i} lprob(prefix[j] | prefix[<j]) ---------
+    for (int t = 0; t + 1 < prefix_len; ++t) {
+        decoder_step(m, c, /*project=*/false);
+        linear(m, c.hN, M, proj, nullptr, 0, c.logits, V, nb, ACT_NONE, 1.f);
+        launch_row_token_lprob(c.logits, V, n, V, B, h_prefix[t + 1], d_pref, m.stream);
+        for (int r = 0; r < nb; ++r) tok[r] = h_prefix[t + 1];
+        SC_HIP(hipMemcpyAsync(pref.data(), d_pref.get(), (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
+        SC_HIP(hipMemcpyAsync(c.d_tok, tok.data(), (size_t)nb * 4, hipMemcpyHostToDevice, m.stream));
+        SC_HIP(hipStreamSynchronize(m.stream));
+        for (int r = 0; r < nb; ++r) {
+            const float prev = scores[(size_t)r * max_len + t];
+            scores[(size_t)r * max_len + t + 1] = prev + pref[r / B];
+        }
+    }
+
+    // ---- search ------------------------------------------------------------------------------------
+    const int start = prefix_len - 1;
+    int remaining = n;
+    for (int step = start; step <= max_len - 2 && remaining > 0; ++step) {
+        decoder_step(m, c, /*project=*/false);  // feeds d_tok at position `step`, advances *d_pos
+        linear(m, c.hN, M, proj, nullptr, 0, c.logits, V, nb, ACT_NONE, 1.f);
+        for (int r = 0; r < nb; ++r) cum[r] = scores[(size_t)r * max_len + step];
+        SC_HIP(hipMemcpyAsync(d_cum.get(), cum.data(), (size_t)nb * 4, hipMemcpyHostToDevice, m.stream));
+        launch_beam_candidates(c.logits, V, n, B, V, d_cum, step == start, step < o.min_seq_len, step == max_len - 2, cfg.pad_idx,
+                               cfg.eos_idx, cfg.unk_idx, o.unk_penalty, K, d_cand_val, d_cand_idx, m.stream);
+        SC_HIP(hipMemcpyAsync(cand_val.data(), d_cand_val.get(), cand_val.size() * 4, hipMemcpyDeviceToHost, m.stream));
+        SC_HIP(hipMemcpyAsync(cand_idx.data(), d_cand_idx.get(), cand_idx.size() * 4, hipMemcpyDeviceToHost, m.stream));
+        SC_HIP(hipStreamSynchronize(m.stream));
+        bool reorder = false;
+        std::vector<int32_t> new_seqs(seqs);
+        std::vector<float> new_scores(scores);
+        for (int u = 0; u < n; ++u) {
+            if (done[u]) {  // finished utterance: its rows keep running on their own caches, results ignored
+                for (int b = 0; b < B; ++b) {
+                    src_row[u * B + b] = u * B + b;
+                    tok[u * B + b] = cfg.eos_idx;
+                }
+                continue;
+            }
+            int live = 0;
+            int beams[8], toks[8];
+            float scs[8];
+            for (int i = 0; i < K && !done[u]; ++i) {
+                const int cidx = cand_idx[(size_t)u * K + i];
+                const float sc = cand_val[(size_t)u * K + i];
+                const int beam = cidx / V, token = cidx % V;
+                if (token == cfg.eos_idx && sc != -INFINITY) {
+                    Hyp hy;
+                    hy.score = normalize ? sc / powf((float)(step + 1), len_penalty) : sc;
+                    const int32_t* sp = &seqs[(size_t)(u * B + beam) * max_len];
+                    hy.seq.assign(sp, sp + step + 1);
+                    hy.seq.push_back(token);
+                    finished[u].push_back(std::move(hy));
+                    if ((int)finished[u].size() == B) {
+                        done[u] = 1;
+                        --remaining;
+                    }
+                    continue;
+                }
+                if (live < B) {
+                    beams[live] = beam;
+                    toks[live] = token;
+                    scs[live] = sc;
+                    ++live;
+                }
+                if (live >= B) break;
+            }
+            if (done[u]) {
+                for (int b = 0; b < B; ++b) {
+                    src_row[u * B + b] = u * B + b;
+                    tok[u * B + b] = cfg.eos_idx;
+                }
+                continue;
+            }
+            for (; live < B; ++live) {  // fewer live candidates than beams: dead copies of the first one
+                beams[live] = live > 0 ? beams[0] : 0;
+                toks[live] = cfg.pad_idx;
+                scs[live] = -INFINITY;
+            }
+            for (int b = 0; b < B; ++b) {
+                const int r = u * B + b, sr = u * B + beams[b];
+                src_row[r] = sr;
+                tok[r] = toks[b];
+                if (sr != r) reorder = true;
+                std::copy(&seqs[(size_t)sr * max_len], &seqs[(size_t)sr * max_len] + max_len, &new_seqs[(size_t)r * max_len]);
+                std::copy(&scores[(size_t)sr * max_len], &scores[(size_t)sr * max_len] + max_len, &new_scores[(size_t)r * max_len]);
+                new_seqs[(size_t)r * max_len + step + 1] = toks[b];
+                new_scores[(size_t)r * max_len + step + 1] = scs[b];
+            }
+        }
+        seqs.swap(new_seqs);
+        scores.swap(new_scores);
+        if (remaining == 0) break;
+        SC_HIP(hipMemcpyAsync(c.d_tok, tok.data(), (size_t)nb * 4, hipMemcpyHostToDevice, m.stream));
+        if (reorder) {
+            SC_HIP(hipMemcpyAsync(d_src_row, src_row.data(), (size_t)nb * 4, hipMemcpyHostToDevice, m.stream));
+            launch_gather_cache(kv_cur, kv_alt, d_src_row, nb, step + 1, max_len, M, 2 * L, layer_stride, m.stream);
+            std::swap(kv_cur, kv_alt);
+            bind_caches(kv_cur);
+        }
+        SC_HIP(hipStreamSynchronize(m.stream));  // tok / src_row are reused by the next iteration
+    }
+
+    // ---- best hypothesis per utterance (sorted by score, fairseq2.cpp:1597-1602) ----------------------
+    int longest = 0;
+    for (int u = 0; u < n; ++u) {
+        SC_CHECK(!finished[u].empty(), "sc_generate_text: beam search returned no hypothesis for item %d", u);
+        size_t best = 0;
+        for (size_t i = 1; i < finished[u].size(); ++i)
+            if (finished[u][i].score > finished[u][best].score) best = i;
+        const Hyp& hy = finished[u][best];
+        const int len = (int)hy.seq.size();
+        for (int t = 0; t < max_len; ++t) h_out_ids[(size_t)u * max_len + t] = t < len ? hy.seq[t] : cfg.pad_idx;
+        h_out_lens[u] = len;
+        if (h_scores) h_scores[u] = hy.score;
+        longest = std::max(longest, len);
+    }
+    // ---- decoder outputs of the chosen hypotheses: the reference's teacher-forced pass (generator.py:281-299)
+    if (d_dec_hidden) {
+        const int fl = longest - 1;  // text_seqs[:, :-1]
+        std::vector<int32_t> forced((size_t)n * fl, cfg.pad_idx);
+        for (int u = 0; u < n; ++u)
+            for (int t = 0; t < fl && t < h_out_lens[u]; ++t) forced[(size_t)u * fl + t] = h_out_ids[(size_t)u * max_len + t];
+        Buf<float> hid(&m.pool, (size_t)n * fl * M);
+        run_generate_text(m, d_enc, n, s_enc, h_enc_lens, o, nullptr, 0, nullptr, nullptr, nullptr, hid, forced.data(), fl);
+        SC_HIP(hipMemsetAsync(d_dec_hidden, 0, (size_t)n * (max_len - 1) * M * 4, m.stream));
+        SC_HIP(hipMemcpy2DAsync(d_dec_hidden, (size_t)(max_len - 1) * M * 4, hid.get(), (size_t)fl * M * 4, (size_t)fl * M * 4, n,
+                                hipMemcpyDeviceToDevice, m.stream));
+        SC_HIP(hipStreamSynchronize(m.stream));
     }
 }
 

@@ -247,10 +247,8 @@ class Translator:
 
         if text_generation_opts is None:
             text_generation_opts = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(1, 200))
-        if text_generation_opts.beam_size != 1:
-            raise NotImplementedError(
-                "the HIP path implements greedy search; pass text_generation_opts=SequenceGeneratorOptions(beam_size=1, ...)"
-            )
+        if not 1 <= text_generation_opts.beam_size <= 8:
+            raise ValueError("beam_size must be in [1, 8] on the HIP path")
         if text_generation_opts.step_processor is not None:
             raise NotImplementedError("step processors are not implemented on the HIP path")
 
@@ -262,7 +260,8 @@ class Translator:
         prefix = self.text_tokenizer.target_prefix(tgt_lang)
         ids, out_lens, _scores, hidden = self.model.generate_text(
             enc, enc_lens.tolist(), prefix,
-            beam_size=1,
+            beam_size=text_generation_opts.beam_size,
+            len_penalty=text_generation_opts.len_penalty,
             soft_max_seq_len=text_generation_opts.soft_max_seq_len,
             hard_max_seq_len=text_generation_opts.hard_max_seq_len,
             unk_penalty=text_generation_opts.unk_penalty,

@@ -213,3 +213,51 @@ def test_forked_handles_concurrent_microbatches_match_single_batch(env, report_d
     finally:
         child.close()
     _log(report_dir, "fork", text=ref_text)
+
+
+@pytest.mark.parametrize("beam,hard_max,min_len", [(2, 12, 1), (5, 14, 1), (5, 10, 6), (3, 9, 1)])
+def test_beam_search_ids_match_oracle(env, report_dir, beam, hard_max, min_len):
+    """beam_size > 1 (the API default is 5): best hypothesis per utterance, ids exact, against
+    oracle.beam_search_generate on the SAME encoder output; three utterances of different lengths so that
+    the searches finish at different steps."""
+    from oracle import unity as ou
+
+    cfg, tt, ct, orc, hip = env
+    fb, lens = orc.collate_fbank(common.waves((2.0, 1.37, 0.9)))
+    enc, enc_lens = hip.encode_speech(fb.cuda(), lens.tolist())
+    prefix = tt.target_prefix("fra")
+    want, every = ou.beam_search_generate(orc.P, cfg, enc.cpu(), torch.from_numpy(enc_lens.astype(np.int64)), prefix, beam,
+                                          hard_max_seq_len=hard_max, min_seq_len=min_len, pos_table=orc.pos_table,
+                                          return_all=True)
+    ids, out_lens, scores, hidden = hip.generate_text(enc, enc_lens.tolist(), prefix, beam_size=beam, hard_max_seq_len=hard_max,
+                                                      min_seq_len=min_len)
+    got = [ids[b, : out_lens[b]].tolist() for b in range(len(want))]
+    _log(report_dir, "beam", beam=beam, got=got, want=want, scores=scores.tolist(),
+         ref_scores=[[round(f[0], 5) for f in e] for e in every])
+    assert got == want
+    for b in range(len(want)):
+        assert abs(float(scores[b]) - every[b][0][0]) < 2e-4
+    # decoder outputs of the chosen hypotheses = the teacher-forced pass over them (generator.py:281-299)
+    L = max(len(s) for s in want) - 1
+    toks = np.full((len(want), L), cfg.pad_idx, dtype=np.int32)
+    for b, s in enumerate(want):
+        toks[b, : len(s) - 1] = s[:-1]
+    forced = hip.decode_text(enc, enc_lens.tolist(), toks)
+    for b, s in enumerate(want):
+        err = float((hidden[b, : len(s) - 1] - forced[b, : len(s) - 1]).abs().max())
+        assert err < 1e-5, err
+
+
+def test_beam_size_one_equals_greedy(env):
+    from oracle import unity as ou
+
+    cfg, tt, ct, orc, hip = env
+    fb, lens = orc.collate_fbank(common.waves((1.2,)))
+    enc, enc_lens = hip.encode_speech(fb.cuda(), lens.tolist())
+    prefix = tt.target_prefix("fra")
+    a = ou.beam_search_generate(orc.P, cfg, enc.cpu(), torch.from_numpy(enc_lens.astype(np.int64)), prefix, 1, hard_max_seq_len=11,
+                                pos_table=orc.pos_table)
+    b = ou.greedy_generate(orc.P, cfg, enc.cpu(), torch.from_numpy(enc_lens.astype(np.int64)), prefix, hard_max_seq_len=11,
+                           pos_table=orc.pos_table)
+    ids, out_lens, _, _ = hip.generate_text(enc, enc_lens.tolist(), prefix, beam_size=1, hard_max_seq_len=11)
+    assert a == b == [ids[0, : out_lens[0]].tolist()]
