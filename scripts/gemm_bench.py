@@ -3,6 +3,7 @@ shapes the S2ST path launches at batch 16, through the C ABI (sc_op_linear / sc_
 the library's own per-launch HIP-event profiler.  Prints one line per shape and path."""
 import ctypes as C
 import math
+import os
 import sys
 from pathlib import Path
 
@@ -31,7 +32,7 @@ def report():
 
 def timed(fn, reps=6):
     res = {}
-    for general in (1, 0):
+    for general in ((0,) if QUICK else (1, 0)):
         lib.sc_op_force_general_gemm(general)
         fn()  # warm-up
         lib.sc_prof_reset()
@@ -49,7 +50,7 @@ def timed(fn, reps=6):
 
 def show(label, res):
     for path, (name, ms, flops, byts) in res.items():
-        print(f"{label:44s} {path:8s} {name:34s} {ms*1e3:9.1f} us  {flops/ms/1e9:8.1f} TFLOP/s  {byts/ms/1e6:8.1f} GB/s", flush=True)
+        print(f"gm={os.environ.get('SC_GEMM_GROUP_M', '-'):3s} {label:44s} {path:8s} {name:34s} {ms*1e3:9.1f} us  {flops/ms/1e9:8.1f} TFLOP/s  {byts/ms/1e6:8.1f} GB/s", flush=True)
 
 
 LINEAR = [  # (M, N, K) at batch 16: S=499 rows per utterance
@@ -67,6 +68,10 @@ CONV = [  # (nb, T, cin, cout, k, stride, pad, dil, in_act)
     (16, 83200, 32, 32, 3, 1, 1, 1, 1),
 ]
 
+QUICK = "--quick" in sys.argv
+if QUICK:
+    LINEAR = [(7984, 4096, 1024), (7984, 1024, 4096), (7984, 1024, 1024), (8320, 8192, 1024), (31936, 4096, 1024)]
+    CONV = [(16, 520, 1024, 1024, 7, 1, 3, 1, 0), (16, 2600, 256, 256, 11, 1, 25, 5, 1)]
 for M, N, K in LINEAR:
     x = torch.randn(M, K, device="cuda")
     w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).half()

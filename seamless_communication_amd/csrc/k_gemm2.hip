@@ -16,6 +16,9 @@
 //     contiguous tile range [x * tiles/8, (x+1) * tiles/8) in n-fastest order: the workgroups that
 //     share an XCD's 4 MiB L2 share A row tiles (and walk W once per row tile) instead of every XCD
 //     streaming every A tile.
+#include <algorithm>
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace sc {
@@ -28,6 +31,8 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 namespace {
 
+constexpr int GEMM_GROUP_M_DEFAULT = 1;
+constexpr int GEMM_PF2_DEFAULT = 1;
 constexpr int FBK = 32;
 constexpr int FLD = 40;  // halfs per LDS row (32 + 8 pad): 16-byte fragment reads of a lane group hit distinct banks
 
@@ -78,7 +83,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, float16_t (&acc)[TM]
 
 template <int BM, int BN, int WGM, int WGN, bool IN_ACT, bool CONV>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p, int tiles_n, int tiles_mn, int tiles_total,
-                                                        int tiles_per_xcd, float in_slope) {
+                                                        int tiles_per_xcd, float in_slope, int group_m) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -96,8 +101,18 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p, int tiles_n,
     if (tile >= tiles_total) return;
     const int phase = tile / tiles_mn;
     const int rem = tile - phase * tiles_mn;
-    const int tm = rem / tiles_n;
-    const int tn = rem - tm * tiles_n;
+    // inside a phase: groups of `group_m` row tiles, walked m-fastest (the tiles in flight on one XCD then
+    // form a group_m x (in-flight / group_m) patch: both A row tiles and W column tiles are re-used from L2)
+    int tm, tn;
+    {
+        const int per_group = group_m * tiles_n;
+        const int g = rem / per_group;
+        const int in_g = rem - g * per_group;
+        const int tiles_m = tiles_mn / tiles_n;
+        const int gm = min(group_m, tiles_m - g * group_m);  // last group may be shorter
+        tn = in_g / gm;
+        tm = g * group_m + (in_g - tn * gm);
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -265,6 +280,206 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p, int tiles_n,
 #undef SC_EPI
 }
 
+// ------------------------------------------------------------------------------------------------- //
+// Variant with prefetch distance 2.  Operands come in through raw buffer loads: per-thread byte offsets
+// (VGPR) are fixed for a whole tap, the slab position is a scalar offset, so the slab loop issues loads
+// without any vector address arithmetic, and rows that are padding / beyond M get an out-of-range
+// offset and read as zero in hardware (no validity selects).  Two register staging sets alternate:
+// while slab s is multiplied out of LDS, slab s+1 is in one set and the loads of slab s+2 go into the
+// other, so a load has two MFMA phases to arrive.  Same arithmetic and K order as the kernels above.
+// ------------------------------------------------------------------------------------------------- //
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+template <int BM, int BN, int WGM, int WGN, bool IN_ACT>
+__global__ __launch_bounds__(256) void gemm_fast2_kernel(GemmArgs p, int tiles_n, int tiles_mn, int tiles_total,
+                                                         int tiles_per_xcd, float in_slope, uint32_t a_bytes, uint32_t w_bytes) {
+    static_assert(WGM * WGN == 4, "4 waves per block");
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_IT = BM / 32;
+    constexpr int B_IT = (BN * 4 + 255) / 256;
+    constexpr uint32_t OOB = 0x80000000u;  // >= num_records of either buffer: the load returns zeros
+
+    __shared__ __attribute__((aligned(16))) _Float16 sAh[2][BM * FLD];
+    __shared__ __attribute__((aligned(16))) _Float16 sAl[2][BM * FLD];
+    __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * FLD];
+
+    const int bid = blockIdx.x;
+    const int tile = (bid & 7) * tiles_per_xcd + (bid >> 3);
+    if (tile >= tiles_total) return;
+    const int phase = tile / tiles_mn;
+    const int rem = tile - phase * tiles_mn;
+    const int tm = rem / tiles_n;
+    const int tn = rem - tm * tiles_n;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = tm * BM;
+    const int n0 = tn * BN;
+    const int out_off = p.out_off + phase * p.out_off_phase_step;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.W + (int64_t)phase * p.w_phase_stride, w_bytes);
+
+    const int a_kq = tid & 7;
+    const int a_r = tid >> 3;
+    int a_row0[A_IT], a_t0[A_IT], a_len[A_IT];  // first row of the item, first source row, valid rows
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + a_r + 32 * i;
+        if (m < p.M) {
+            const int n = m / p.rows_per_batch;
+            const int q = m - n * p.rows_per_batch;
+            a_row0[i] = n * p.t_in;
+            a_t0[i] = q * p.stride - p.pad;
+            a_len[i] = p.in_lens ? min(p.in_lens[n], p.t_in) : p.t_in;
+        } else {
+            a_row0[i] = 0;
+            a_t0[i] = 0;
+            a_len[i] = 0;
+        }
+    }
+    const int b_r = tid >> 2;
+    const int b_kc = tid & 3;
+    uint32_t b_voff[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int row = n0 + b_r + 64 * i;
+        b_voff[i] = row < p.N ? (uint32_t)(((int64_t)row * p.ldw + b_kc * 8) * 2) : OOB;
+    }
+    uint32_t a_voff[A_IT];
+    auto set_tap = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int src_t = a_t0[i] + tap * p.dil;
+            const bool ok = src_t >= 0 && src_t < a_len[i];
+            a_voff[i] = ok ? (uint32_t)((((int64_t)a_row0[i] + src_t) * p.lda + a_kq * 4) * 4) : OOB;
+        }
+    };
+
+    f32x4_t a_reg0[A_IT], a_reg1[A_IT];
+    u32x4_t b_reg0[B_IT], b_reg1[B_IT];
+    constexpr bool B_GUARD = (BN % 64) != 0;
+
+    float16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 8;
+    const int a_frag = (wm * WM + frag_row) * FLD + frag_k;
+    const int b_frag = (wn * WN + frag_row) * FLD + frag_k;
+
+// KILL = OOB turns the loads into no-ops that return zeros (tail of the pipeline): the loads are issued
+// UNCONDITIONALLY every step so that the compiler's s_waitcnt bookkeeping sees a fixed number of loads
+// between a load and its use (with conditional loads it falls back to vmcnt(0) and the prefetch is lost)
+#define SC2_LOAD(AR, BR, ASOFF, BSOFF, KILL)                                                                  \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i)                                                      \
+            AR[i] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ra, a_voff[i] | (KILL), (ASOFF), 0)); \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i)                                                      \
+            BR[i] = __builtin_amdgcn_raw_buffer_load_b128(rb, b_voff[i] | (KILL), (BSOFF), 0);                \
+    } while (0)
+
+#define SC2_STORE(AR, BR, ST)                                                                   \
+    do {                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                      \
+            f32x4_t x = AR[i];                                                                  \
+            if (IN_ACT) {                                                                       \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                   \
+                    x[j] = fmaxf(x[j], 0.f) + in_slope * fminf(x[j], 0.f);                      \
+            }                                                                                   \
+            const half4_t hi = __builtin_convertvector(x, half4_t);                             \
+            const f32x4_t back = __builtin_convertvector(hi, f32x4_t);                          \
+            const half4_t lo = __builtin_convertvector(x - back, half4_t);                      \
+            const int off = (a_r + 32 * i) * FLD + a_kq * 4;                                    \
+            *reinterpret_cast<half4_t*>(&sAh[ST][off]) = hi;                                    \
+            *reinterpret_cast<half4_t*>(&sAl[ST][off]) = lo;                                    \
+        }                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                      \
+            const int row = b_r + 64 * i;                                                       \
+            if (!B_GUARD || row < BN) *reinterpret_cast<u32x4_t*>(&sB[ST][row * FLD + b_kc * 8]) = BR[i]; \
+        }                                                                                       \
+    } while (0)
+
+#define SC2_COMPUTE(ST)                                                                         \
+    do {                                                                                        \
+        _Pragma("unroll") for (int kb = 0; kb < FBK; kb += 16) {                                \
+            half8_t ah[TM], al[TM], bf[TN];                                                     \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                    \
+                ah[i] = *reinterpret_cast<const half8_t*>(&sAh[ST][a_frag + i * 32 * FLD + kb]); \
+                al[i] = *reinterpret_cast<const half8_t*>(&sAl[ST][a_frag + i * 32 * FLD + kb]); \
+            }                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+                bf[j] = *reinterpret_cast<const half8_t*>(&sB[ST][b_frag + j * 32 * FLD + kb]); \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                      \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bf[j], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bf[j], acc[i][j], 0, 0, 0); \
+                }                                                                               \
+        }                                                                                       \
+    } while (0)
+
+    const int nslab = p.K / FBK;  // even (gemm_fast2_eligible)
+    const int slabs_per_tap = p.cin / FBK;
+    int tap = 0, cs = 0;  // position of the slab being LOADED
+#define SC2_ADVANCE()                \
+    do {                             \
+        if (++cs == slabs_per_tap) { \
+            cs = 0;                  \
+            set_tap(++tap);          \
+        }                            \
+    } while (0)
+// LDS stage S&1 holds slab S, set NEXT holds slab S+1, set FREE is loaded with slab S+2
+#define SC2_STEP(S, AFREE, BFREE, ANEXT, BNEXT)                                   \
+    do {                                                                          \
+        const bool more2 = (S) + 2 < nslab;                                       \
+        if (more2) SC2_ADVANCE();                                                 \
+        SC2_LOAD(AFREE, BFREE, cs * (FBK * 4), more2 ? ((S) + 2) * (FBK * 2) : 0, more2 ? 0u : OOB); \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        SC2_COMPUTE((S) & 1);                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        if ((S) + 1 < nslab) SC2_STORE(ANEXT, BNEXT, ((S) + 1) & 1);              \
+        __syncthreads();                                                          \
+    } while (0)
+
+    set_tap(0);
+    SC2_LOAD(a_reg0, b_reg0, 0, 0, 0u);
+    SC2_STORE(a_reg0, b_reg0, 0);
+    SC2_ADVANCE();
+    SC2_LOAD(a_reg1, b_reg1, cs * (FBK * 4), FBK * 2, 0u);
+    __syncthreads();
+    for (int s = 0; s < nslab; s += 2) {
+        SC2_STEP(s, a_reg0, b_reg0, a_reg1, b_reg1);
+        SC2_STEP(s + 1, a_reg1, b_reg1, a_reg0, b_reg0);
+    }
+#undef SC2_STEP
+#undef SC2_ADVANCE
+#undef SC2_LOAD
+#undef SC2_STORE
+#undef SC2_COMPUTE
+
+    const bool plain_rows = (p.rows_per_batch == p.M) && p.out_mul == 1 && out_off == 0 && p.t_out == p.M;
+    const int m0w = m0 + wm * WM, n0w = n0 + wn * WN;
+#define SC_EPI(ACT)                                                                               \
+    do {                                                                                          \
+        if (p.res) epilogue<TM, TN, WM, WN, ACT, true>(p, acc, m0w, n0w, lane, out_off, plain_rows); \
+        else epilogue<TM, TN, WM, WN, ACT, false>(p, acc, m0w, n0w, lane, out_off, plain_rows);    \
+    } while (0)
+    if (p.act == ACT_NONE) SC_EPI(ACT_NONE);
+    else if (p.act == ACT_RELU) SC_EPI(ACT_RELU);
+    else if (p.act == ACT_SILU) SC_EPI(ACT_SILU);
+    else SC_EPI(ACT_TANH);
+#undef SC_EPI
+}
+
 template <int BM, int BN, int WGM, int WGN>
 void launch_fast_cfg(const GemmArgs& a, hipStream_t s) {
     const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
@@ -281,20 +496,36 @@ void launch_fast_cfg(const GemmArgs& a, hipStream_t s) {
                          2.0 * a.N * (double)a.K * a.phases + 4.0 * a.M * (double)a.N * (a.res ? 2.0 : 1.0);
     prof::Scope scope(name, flops, bytes, s);
     const dim3 grid(tiles_per_xcd * 8);
+    // prefetch-distance-2 variant (raw buffer loads): both operands must be addressable with 31-bit byte offsets
+    static const int env_pf2 = getenv("SC_GEMM_PF2") ? atoi(getenv("SC_GEMM_PF2")) : GEMM_PF2_DEFAULT;
+    const int64_t a_bytes64 = (int64_t)(a.M / a.rows_per_batch) * a.t_in * a.lda * 4;
+    const int64_t w_bytes64 = (int64_t)a.N * a.ldw * 2;
+    if (env_pf2 && a.K % (2 * FBK) == 0 && a.M % a.rows_per_batch == 0 && a_bytes64 < (1ll << 31) && w_bytes64 < (1ll << 31)) {
+        const float slope = a.in_act == IN_LRELU_01 ? 0.1f : a.in_act == IN_LRELU_001 ? 0.01f : 0.f;
+        if (a.in_act == IN_NONE)
+            hipLaunchKernelGGL((gemm_fast2_kernel<BM, BN, WGM, WGN, false>), grid, dim3(256), 0, s, a, tiles_n, tiles_mn,
+                               tiles_total, tiles_per_xcd, slope, (uint32_t)a_bytes64, (uint32_t)w_bytes64);
+        else
+            hipLaunchKernelGGL((gemm_fast2_kernel<BM, BN, WGM, WGN, true>), grid, dim3(256), 0, s, a, tiles_n, tiles_mn,
+                               tiles_total, tiles_per_xcd, slope, (uint32_t)a_bytes64, (uint32_t)w_bytes64);
+        return;
+    }
+    static const int env_gm = getenv("SC_GEMM_GROUP_M") ? atoi(getenv("SC_GEMM_GROUP_M")) : 0;
+    const int group_m = std::max(1, std::min(env_gm > 0 ? env_gm : GEMM_GROUP_M_DEFAULT, tiles_m));
     // plain product: one tap, no stride/padding/length mask -> every row below M is valid and rows
     // >= M only feed accumulator rows that are never stored, so the validity selects are compiled out
     const bool conv = a.taps != 1 || a.stride != 1 || a.pad != 0 || a.in_lens != nullptr;
     if (a.in_act == IN_NONE) {
         if (conv)
             hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WGM, WGN, false, true>), grid, dim3(256), 0, s, a, tiles_n,
-                               tiles_mn, tiles_total, tiles_per_xcd, 0.f);
+                               tiles_mn, tiles_total, tiles_per_xcd, 0.f, group_m);
         else
             hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WGM, WGN, false, false>), grid, dim3(256), 0, s, a, tiles_n,
-                               tiles_mn, tiles_total, tiles_per_xcd, 0.f);
+                               tiles_mn, tiles_total, tiles_per_xcd, 0.f, group_m);
     } else {
         const float slope = a.in_act == IN_LRELU_01 ? 0.1f : 0.01f;
         hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WGM, WGN, true, true>), grid, dim3(256), 0, s, a, tiles_n, tiles_mn,
-                           tiles_total, tiles_per_xcd, slope);
+                           tiles_total, tiles_per_xcd, slope, group_m);
     }
 }
 
@@ -319,7 +550,10 @@ void launch_gemm_fast(const GemmArgs& a, hipStream_t s) {
         if ((int64_t)cdiv(a.M, 128) * a.phases >= 512) launch_fast_cfg<128, 64, 2, 2>(a, s);
         else launch_fast_cfg<64, 64, 2, 2>(a, s);
     } else if (tiles128 >= 256) {
-        launch_fast_cfg<128, 128, 2, 2>(a, s);
+        static const int env_tile = getenv("SC_GEMM_TILE") ? atoi(getenv("SC_GEMM_TILE")) : 0;  // experiments only
+        if (env_tile == 1) launch_fast_cfg<128, 64, 2, 2>(a, s);
+        else if (env_tile == 2) launch_fast_cfg<64, 64, 2, 2>(a, s);
+        else launch_fast_cfg<128, 128, 2, 2>(a, s);
     } else {
         launch_fast_cfg<64, 64, 2, 2>(a, s);
     }
