@@ -115,15 +115,16 @@ def pmc_traffic(family: str):
     import csv
     import glob
 
-    key = {"gemm_128x128_fast_split": "gemm_fast_kernel<128, 128", "gemm_128x128_vecA_split": "gemm_kernel<128, 128, 2, 2, 1, true>",
-           "skinny_m32": "skinny_kernel<1, 1", "skinny_m64": "skinny_kernel<2, 1"}.get(family.split(":")[-1])
+    keys = {"gemm_128x128_fast_split": ("gemm_fast", "<128, 128, 2, 2, false"), "gemm_128x128_vecA_split": ("gemm_kernel<128, 128, 2, 2, 1, true>",),
+            "skinny_m32": ("skinny_kernel<1, 1",), "skinny_m64": ("skinny_kernel<2, 1",)}.get(family.split(":")[-1])
     files = sorted(glob.glob(str(ROOT / "profiles" / "*pmc_hbm_traffic*.csv")))
-    if not key or not files:
+    files = [f for f in files if "early" not in f]
+    if not keys or not files:
         return None
     try:
         with open(files[-1], newline="") as fh:
             for row in csv.DictReader(fh):
-                if key in row["kernel"]:
+                if all(k in row["kernel"] for k in keys):
                     return float(row["hbm_bytes_per_launch_corrected"])
     except Exception:
         return None
