@@ -171,32 +171,27 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) sP[(ty + 16 * r) * QS + tx + 16 * c] = sc_[r][c];
         __syncthreads();
-        // ---- O = alpha*O + P V : thread owns rows ty+16r, dims tx+16c -----------
+        // ---- O = alpha*O + P V : thread owns rows ty+16r, dims 4*tx .. 4*tx+3 ------
+        // (contiguous dims: one 16-byte LDS read per V row instead of four 4-byte ones; the 16 lanes of a
+        // row group read 256 contiguous bytes, the 4 row groups of a wave read the same address)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[r][c] *= alpha[r];
 #pragma unroll 4
         for (int j = 0; j < BKV; j += 4) {
-            float4 pa[4];
+            float4 pa[4], vb[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) pa[r] = *reinterpret_cast<const float4*>(&sP[(ty + 16 * r) * QS + j]);
-            float vb[4][4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < 4; ++jj) vb[jj] = *reinterpret_cast<const float4*>(&sV[(j + jj) * HD + 4 * tx]);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) vb[jj][c] = sV[(j + jj) * HD + tx + 16 * c];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float a = o[r][c];
-                    a = fmaf(pa[r].x, vb[0][c], a);
-                    a = fmaf(pa[r].y, vb[1][c], a);
-                    a = fmaf(pa[r].z, vb[2][c], a);
-                    a = fmaf(pa[r].w, vb[3][c], a);
-                    o[r][c] = a;
-                }
+            for (int r = 0; r < 4; ++r) {
+                o[r][0] = fmaf(pa[r].w, vb[3].x, fmaf(pa[r].z, vb[2].x, fmaf(pa[r].y, vb[1].x, fmaf(pa[r].x, vb[0].x, o[r][0]))));
+                o[r][1] = fmaf(pa[r].w, vb[3].y, fmaf(pa[r].z, vb[2].y, fmaf(pa[r].y, vb[1].y, fmaf(pa[r].x, vb[0].y, o[r][1]))));
+                o[r][2] = fmaf(pa[r].w, vb[3].z, fmaf(pa[r].z, vb[2].z, fmaf(pa[r].y, vb[1].z, fmaf(pa[r].x, vb[0].z, o[r][2]))));
+                o[r][3] = fmaf(pa[r].w, vb[3].w, fmaf(pa[r].z, vb[2].w, fmaf(pa[r].y, vb[1].w, fmaf(pa[r].x, vb[0].w, o[r][3]))));
+            }
         }
         __syncthreads();  // before the next tile overwrites sK / sV
     }
@@ -207,8 +202,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         if (qi >= p.Sq) continue;
         const float inv = l_i[r] > 0.f ? 1.0f / l_i[r] : 0.f;
         float* orow = p.out + ((int64_t)n * p.Sq + qi) * p.ldo + h * HD;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) orow[tx + 16 * c] = o[r][c] * inv;
+        *reinterpret_cast<float4*>(orow + 4 * tx) = make_float4(o[r][0] * inv, o[r][1] * inv, o[r][2] * inv, o[r][3] * inv);
     }
 }
 
@@ -216,7 +210,8 @@ static bool g_attn_attr_set = false;
 
 void launch_attention(const AttnArgs& a, hipStream_t s) {
     SC_CHECK(a.nb > 0 && a.heads > 0 && a.Sq > 0 && a.Skv > 0, "attention: empty problem");
-    SC_CHECK(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0, "attention: row strides must be multiples of 4");
+    SC_CHECK(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0,
+             "attention: row strides must be multiples of 4 and the output 16-byte aligned");
     const int npos = a.rel_left + 1 + a.rel_right;
     SC_CHECK(!a.rel_k || npos <= MAX_REL, "attention: %d relative positions > %d", npos, MAX_REL);
     if (!g_attn_attr_set) {
