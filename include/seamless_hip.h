@@ -210,6 +210,11 @@ int sc_op_pack_conv_weight(const void* d_w_f16, void* d_dst_f16, int32_t cout, i
 int sc_op_conv_transpose1d(const float* d_x, const void* d_v_f16, const void* d_g_f16, const float* d_bias,
                            float* d_y, int32_t nb, int32_t t_in, int32_t cin, int32_t cout, int32_t k,
                            int32_t stride, int32_t pad, int32_t in_act);
+/* y = alpha*act(x.W^T + b) + res through the PRE-SPLIT product kernel (k_gemm_ps.hip): x is first split into two
+ * fp16 planes on the device, the operands then reach LDS by DMA.  d_y (fp32) and/or d_yh/d_yl (the result as two
+ * fp16 planes, the format the next product consumes) may be requested.  Same bits as sc_op_linear(split=1). */
+int sc_op_linear_presplit(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y,
+                          void* d_yh_f16, void* d_yl_f16, int32_t M, int32_t N, int32_t K, int32_t act, float alpha);
 /* One HiFi-GAN ResBlock dilation pair (hifigan.py:114-121) fused in one kernel for C in {16, 32, 64}:
  * out = x + conv2_{k,1}(lrelu(conv1_{k,dil}(lrelu(x)) + b1)) + b2, weights packed by sc_op_pack_conv_weight
  * (rows padded to a multiple of 32); with d_avg_a/d_avg_b: out = ((a + b) + that) / 3. */

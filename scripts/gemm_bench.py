@@ -72,12 +72,27 @@ QUICK = "--quick" in sys.argv
 if QUICK:
     LINEAR = [(7984, 4096, 1024), (7984, 1024, 4096), (7984, 1024, 1024), (8320, 8192, 1024), (31936, 4096, 1024)]
     CONV = [(16, 520, 1024, 1024, 7, 1, 3, 1, 0), (16, 2600, 256, 256, 11, 1, 25, 5, 1)]
+def timed_presplit(fn, reps=6):
+    fn()
+    lib.sc_prof_reset()
+    lib.sc_prof_enable(1)
+    for _ in range(reps):
+        fn()
+    lib.sc_prof_enable(0)
+    rep = {k: v for k, v in report().items() if "presplit" in k}
+    name = max(rep, key=lambda k: rep[k][1])
+    launches, ms, flops, byts = rep[name]
+    return {"presplit": (name, ms / launches, flops / launches, byts / launches)}
+
+
 for M, N, K in LINEAR:
     x = torch.randn(M, K, device="cuda")
     w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).half()
     b = torch.randn(N, device="cuda")
     y = torch.empty(M, N, device="cuda")
+    torch.cuda.synchronize()
     show(f"linear M={M} N={N} K={K}", timed(lambda: lib.sc_op_linear(P(x), P(w), P(b), None, P(y), M, N, K, 0, 1.0, 1, 0)))
+    show(f"linear M={M} N={N} K={K}", timed_presplit(lambda: lib.sc_op_linear_presplit(P(x), P(w), P(b), None, P(y), None, None, M, N, K, 0, 1.0)))
 for nb, T, cin, cout, k, stride, pad, dil, in_act in CONV:
     x = torch.randn(nb, T, cin, device="cuda")
     wp = (torch.randn(cout, cin * k, device="cuda") / math.sqrt(cin * k)).half()

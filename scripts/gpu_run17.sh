@@ -1,0 +1,5 @@
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+( timeout 300 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "presplit" > gpurun_out/pytest_ps.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_ps.log )
+grep -E "^FAILED|passed|failed|^E  " gpurun_out/pytest_ps.log | head -20
+grep presplit gpurun_out/ops_report.txt | tail -20

@@ -421,6 +421,46 @@ int sc_op_conv_transpose1d(const float* d_x, const void* d_v_f16, const void* d_
     SC_API_END
 }
 
+int sc_op_linear_presplit(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y,
+                          void* d_yh_f16, void* d_yl_f16, int32_t M, int32_t N, int32_t K, int32_t act, float alpha) {
+    SC_API_BEGIN
+    SC_CHECK(d_x && d_w_f16 && (d_y || d_yh_f16), "sc_op_linear_presplit: null argument");
+    __half *hi = nullptr, *lo = nullptr;
+    SC_HIP(hipMalloc(&hi, (size_t)M * K * 2));
+    SC_HIP(hipMalloc(&lo, (size_t)M * K * 2));
+    try {
+        launch_split_f32(d_x, hi, lo, (int64_t)M * K, g_op_stream);
+        GemmPsArgs a;
+        a.Ah = hi;
+        a.Al = lo;
+        a.lda = K;
+        a.W = static_cast<const __half*>(d_w_f16);
+        a.ldw = K;
+        a.bias = d_bias;
+        a.res = d_res;
+        a.ldr = N;
+        a.C = d_y;
+        a.ldc = N;
+        a.Ch = static_cast<__half*>(d_yh_f16);
+        a.Cl = static_cast<__half*>(d_yl_f16);
+        a.ldcs = N;
+        a.M = M;
+        a.N = N;
+        a.K = K;
+        a.act = act;
+        a.alpha = alpha;
+        launch_gemm_presplit(a, g_op_stream);
+        SC_HIP(hipStreamSynchronize(g_op_stream));
+    } catch (...) {
+        (void)hipFree(hi);
+        (void)hipFree(lo);
+        throw;
+    }
+    (void)hipFree(hi);
+    (void)hipFree(lo);
+    SC_API_END
+}
+
 int sc_op_resblock_pair(const float* d_x, const void* d_w1_packed, const float* d_b1, const void* d_w2_packed,
                         const float* d_b2, float* d_out, int32_t nb, int32_t T, int32_t C, int32_t k, int32_t dil,
                         float slope, const float* d_avg_a, const float* d_avg_b) {

@@ -201,6 +201,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         const int qi = q0 + ty + 16 * r;
         if (qi >= p.Sq) continue;
         const float inv = l_i[r] > 0.f ? 1.0f / l_i[r] : 0.f;
+        if (p.out_hi) {  // two fp16 planes for launch_gemm_presplit (the output projection) instead of fp32
+            typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+            typedef float f4_t __attribute__((ext_vector_type(4)));
+            const f4_t of = {o[r][0] * inv, o[r][1] * inv, o[r][2] * inv, o[r][3] * inv};
+            const h4_t hi = __builtin_convertvector(of, h4_t);
+            const f4_t back = __builtin_convertvector(hi, f4_t);
+            const int64_t off = ((int64_t)n * p.Sq + qi) * p.ldoh + h * HD + 4 * tx;
+            *reinterpret_cast<h4_t*>(p.out_hi + off) = hi;
+            *reinterpret_cast<h4_t*>(p.out_lo + off) = __builtin_convertvector(of - back, h4_t);
+            continue;
+        }
         float* orow = p.out + ((int64_t)n * p.Sq + qi) * p.ldo + h * HD;
         *reinterpret_cast<float4*>(orow + 4 * tx) = make_float4(o[r][0] * inv, o[r][1] * inv, o[r][2] * inv, o[r][3] * inv);
     }
@@ -210,6 +221,7 @@ static bool g_attn_attr_set = false;
 
 void launch_attention(const AttnArgs& a, hipStream_t s) {
     SC_CHECK(a.nb > 0 && a.heads > 0 && a.Sq > 0 && a.Skv > 0, "attention: empty problem");
+    SC_CHECK(a.out || (a.out_hi && a.out_lo && a.ldoh % 4 == 0), "attention: no output");
     SC_CHECK(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0,
              "attention: row strides must be multiples of 4 and the output 16-byte aligned");
     const int npos = a.rel_left + 1 + a.rel_right;

@@ -1,0 +1,308 @@
+// Dense product with a PRE-SPLIT activation operand:  C = alpha * act(A x W^T + bias) + res, where the
+// fp32 activation matrix A is stored by its producer (LayerNorm, a previous product's epilogue, attention)
+// as two fp16 planes  A_hi = fp16(A),  A_lo = fp16(A - A_hi)  -- the same split the other product
+// kernels (k_gemm.hip, k_gemm2.hip) compute on the fly, so the results are bit-identical to theirs.
+//
+// With fp16 operands on both sides nothing has to pass through registers on the way in: all three
+// operand tiles (A_hi, A_lo, W; 128 x 32 halfs = 8 KB each) are moved global -> LDS by the buffer
+// unit itself (`buffer_load_dwordx4 ... lds`, 1 KB per wave instruction).  The slab loop then holds only
+// ds_read_b128 + MFMA + 6 DMA issues per wave: no conversion VALU, no ds_write, no staging VGPRs.
+//
+//   * LDS layout of a tile: [rows][32 halfs] unpadded (the DMA writes lane order: lane p of a 1 KB
+//     chunk lands at byte 16 p), with the four 16-byte segments of a row XOR-swizzled by (row>>2)&3 -
+//     each lane fetches the global segment that belongs at its fixed LDS position - so that the
+//     ds_read_b128 fragment reads of a 16-lane group hit 16 distinct 16-byte slots;
+//   * three LDS stages (72 KB, two workgroups per CU), prefetch distance 2, ONE s_barrier per K slab;
+//     DMA completion is awaited with explicit s_waitcnt vmcnt(6) (the six DMAs of the next slab may
+//     stay in flight) - __syncthreads() would drain them all;
+//   * rows beyond M / N get an out-of-range buffer offset and arrive as zeros;
+//   * same MFMA order as the other kernels: per 16-wide K chunk and fragment pair, hi then lo.
+#include "kernels.h"
+
+namespace sc {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int PBK = 32;
+#define SC_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int ACT>
+__device__ __forceinline__ float ps_act(float v) {
+    if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == ACT_SILU) return v / (1.f + expf(-v));
+    if (ACT == ACT_TANH) return tanhf(v);
+    return v;
+}
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+// raw buffer resource: base (48 bit), stride 0, num_records = bytes, dword 3 as for every gfx9 raw buffer
+__device__ __forceinline__ i32x4_t make_rsrc_words(const void* base, uint32_t bytes) {
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    i32x4_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((b >> 32) & 0xffff));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+// byte offset of (row, 16-byte segment s) inside an unpadded [rows][64 B] tile
+__device__ __forceinline__ int swz(int row, int s) { return row * 64 + ((s ^ ((row >> 2) & 3)) << 4); }
+
+// Reads the wave's fp32 tile back row-major: the four 16-lane groups of a ds_read_b128 ({0-3,12-15,20-27},
+// {4-11,16-19,28-31} and the same +32) each take whole rows, 16 bytes per lane, so that the LDS reads are
+// conflict free and every global access is a run of 16-byte pieces of one output row.
+template <int WM, int WN, int EP_LD, int ACT>
+__device__ __forceinline__ void ps_epilogue(const GemmPsArgs& p, const float* ep, int m0w, int n0w, int lane) {
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    constexpr int LPR = WN / 4;        // lanes per row
+    constexpr int RPG = 16 / LPR;      // rows per 16-lane group
+    constexpr int RPI = 4 * RPG;       // rows per wave instruction
+    const int l5 = lane & 31;
+    const bool g1 = (l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28;
+    const int rank = g1 ? (l5 < 12 ? l5 - 4 : l5 < 20 ? l5 - 8 : l5 - 16) : (l5 < 4 ? l5 : l5 < 16 ? l5 - 8 : l5 - 12);
+    const int grp = (lane >> 5) * 2 + (g1 ? 1 : 0);
+    const int row_in = grp * RPG + rank / LPR;
+    const int c0 = (rank % LPR) * 4;
+    const int col = n0w + c0;
+    const bool vec_ok = (col + 3 < p.N) && ((p.ldc | p.ldr | p.ldcs) % 4 == 0) && (n0w % 4 == 0);
+    f4_t b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b4[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < WM / RPI; ++it) {
+        const int row = it * RPI + row_in;
+        const int64_t m = m0w + row;
+        const f4_t a = *reinterpret_cast<const f4_t*>(ep + row * EP_LD + c0);
+        if (m >= p.M || col >= p.N) continue;
+        f4_t v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ps_act<ACT>(a[e] + b4[e]) * p.alpha;
+        if (vec_ok) {
+            if (p.res) v += *reinterpret_cast<const f4_t*>(p.res + m * p.ldr + col);
+            if (p.C) *reinterpret_cast<f4_t*>(p.C + m * p.ldc + col) = v;
+            if (p.Ch) {
+                const h4_t hi = __builtin_convertvector(v, h4_t);
+                *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(p.Ch) + m * p.ldcs + col) = hi;
+                *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(p.Cl) + m * p.ldcs + col) =
+                    __builtin_convertvector(v - __builtin_convertvector(hi, f4_t), h4_t);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (col + e >= p.N) continue;
+                float x = v[e];
+                if (p.res) x += p.res[m * p.ldr + col + e];
+                if (p.C) p.C[m * p.ldc + col + e] = x;
+                if (p.Ch) {
+                    const _Float16 h = (_Float16)x;
+                    reinterpret_cast<_Float16*>(p.Ch)[m * p.ldcs + col + e] = h;
+                    reinterpret_cast<_Float16*>(p.Cl)[m * p.ldcs + col + e] = (_Float16)(x - (float)h);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_ps_kernel(GemmPsArgs p, int tiles_n, int tiles_total, int tiles_per_xcd,
+                                                      uint32_t a_bytes, uint32_t w_bytes) {
+    constexpr int WM = BM / 2, WN = BN / 2;  // 2 x 2 waves
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int ACH = BM / 64;  // 1 KB chunks (16 rows) of the A tile per wave
+    constexpr int BCH = BN / 64;
+    constexpr uint32_t OOB = 0x80000000u;
+    constexpr int A_TILE = BM * 32, B_TILE = BN * 32;  // halfs per stage
+
+    // three stages of [A_hi | A_lo | W] tiles; after the K loop the same memory holds one fp32 tile per wave for the
+    // transposed (row-major, 16 bytes per lane) epilogue
+    constexpr int STAGE_BYTES = (2 * A_TILE + B_TILE) * 2;
+    constexpr int EP_LD = WN + 4;  // floats per row of a wave's epilogue tile
+    static_assert(4 * WM * EP_LD * 4 <= 3 * STAGE_BYTES, "epilogue tiles must fit in the stage memory");
+    __shared__ __attribute__((aligned(16))) char smem[3 * STAGE_BYTES];
+    _Float16* const sAh0 = reinterpret_cast<_Float16*>(smem);
+    _Float16* const sAl0 = sAh0 + A_TILE;
+    _Float16* const sB0 = sAl0 + A_TILE;
+    _Float16* const sAh1 = reinterpret_cast<_Float16*>(smem + STAGE_BYTES);
+    _Float16* const sAl1 = sAh1 + A_TILE;
+    _Float16* const sB1 = sAl1 + A_TILE;
+    _Float16* const sAh2 = reinterpret_cast<_Float16*>(smem + 2 * STAGE_BYTES);
+    _Float16* const sAl2 = sAh2 + A_TILE;
+    _Float16* const sB2 = sAl2 + A_TILE;
+
+    const int bid = blockIdx.x;
+    const int tile = (bid & 7) * tiles_per_xcd + (bid >> 3);
+    if (tile >= tiles_total) return;
+    const int tm = tile / tiles_n;
+    const int tn = tile - tm * tiles_n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const i32x4_t rah = make_rsrc_words(p.Ah, a_bytes);
+    const i32x4_t ral = make_rsrc_words(p.Al, a_bytes);
+    const i32x4_t rw = make_rsrc_words(p.W, w_bytes);
+
+    // this lane's fixed LDS position inside a chunk: row (lane >> 2), segment slot (lane & 3); it fetches the
+    // global segment that the swizzle maps to that slot
+    uint32_t a_voff[ACH], b_voff[BCH];
+#pragma unroll
+    for (int j = 0; j < ACH; ++j) {
+        const int row = 16 * (wave * ACH + j) + (lane >> 2);
+        const int seg = (lane & 3) ^ ((row >> 2) & 3);
+        a_voff[j] = (m0 + row) < p.M ? (uint32_t)(((int64_t)(m0 + row) * p.lda + seg * 8) * 2) : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+        const int row = 16 * (wave * BCH + j) + (lane >> 2);
+        const int seg = (lane & 3) ^ ((row >> 2) & 3);
+        b_voff[j] = (n0 + row) < p.N ? (uint32_t)(((int64_t)(n0 + row) * p.ldw + seg * 8) * 2) : OOB;
+    }
+
+    float16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets (bytes) per 16-wide K chunk kc = 0, 1
+    int a_off[TM][2], b_off[TN][2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+        const int s = kc * 2 + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a_off[i][kc] = swz(wm * WM + i * 32 + (lane & 31), s);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b_off[j][kc] = swz(wn * WN + j * 32 + (lane & 31), s);
+    }
+
+// One LDS-DMA instruction: M0 = LDS byte address of this wave's 1 KB chunk, lane p lands at +16 p.  Issued as
+// inline asm on purpose: the compiler cannot tell which LDS stage an in-flight DMA targets and would drain
+// every outstanding DMA (s_waitcnt vmcnt(0)) before each ds_read; completion is awaited explicitly in PS_STEP.
+#define PS_DMA(RSRC, LDSP, VOFF, SOFF)                                                                        \
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"                              \
+                 :                                                                                            \
+                 : "s"(__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)SC_LDS_PTR(LDSP))), "v"(VOFF), \
+                   "s"(RSRC), "s"((int)(SOFF))                                                                \
+                 : "memory")
+#define PS_ISSUE(AH, AL, BB, KOFF)                                                             \
+    do {                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < ACH; ++j) {                                      \
+            PS_DMA(rah, &AH[(wave * ACH + j) * 512], a_voff[j], (KOFF));                       \
+            PS_DMA(ral, &AL[(wave * ACH + j) * 512], a_voff[j], (KOFF));                       \
+        }                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < BCH; ++j)                                        \
+            PS_DMA(rw, &BB[(wave * BCH + j) * 512], b_voff[j], (KOFF));                        \
+    } while (0)
+
+#define PS_COMPUTE(AH, AL, BB)                                                                                         \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int kc = 0; kc < 2; ++kc) {                                                             \
+            half8_t ah[TM], al[TM], bf[TN];                                                                            \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                           \
+                ah[i] = *reinterpret_cast<const half8_t*>(reinterpret_cast<const char*>(AH) + a_off[i][kc]);            \
+                al[i] = *reinterpret_cast<const half8_t*>(reinterpret_cast<const char*>(AL) + a_off[i][kc]);            \
+            }                                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
+                bf[j] = *reinterpret_cast<const half8_t*>(reinterpret_cast<const char*>(BB) + b_off[j][kc]);            \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                       \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bf[j], acc[i][j], 0, 0, 0);               \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bf[j], acc[i][j], 0, 0, 0);               \
+                }                                                                                                      \
+        }                                                                                                              \
+    } while (0)
+
+    constexpr int NDMA = 2 * ACH + BCH;  // DMA instructions per wave and slab
+    static_assert(NDMA == 6 || NDMA == 3, "s_waitcnt immediates below assume 6 or 3 DMAs per slab");
+// Slab S sits in stage (CUR); the DMAs of slab S+1 (if any) are the youngest outstanding ones: wait until only
+// those remain, make the landed data visible to every wave, then refill the stage that was read at slab S-1.
+#define PS_STEP(S, CAH, CAL, CB, NAH, NAL, NB)                                                 \
+    do {                                                                                       \
+        if ((S) + 1 < nslab) {                                                                 \
+            if (NDMA == 6) __builtin_amdgcn_s_waitcnt(0x0076); /* vmcnt(6) lgkmcnt(0) */       \
+            else __builtin_amdgcn_s_waitcnt(0x0073);           /* vmcnt(3) lgkmcnt(0) */       \
+        } else {                                                                               \
+            __builtin_amdgcn_s_waitcnt(0x0070); /* vmcnt(0) lgkmcnt(0) */                      \
+        }                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                          \
+        asm volatile("" ::: "memory");                                                         \
+        if ((S) + 2 < nslab) PS_ISSUE(NAH, NAL, NB, ((S) + 2) * (PBK * 2));                    \
+        PS_COMPUTE(CAH, CAL, CB);                                                              \
+        asm volatile("" ::: "memory");                                                         \
+    } while (0)
+
+    const int nslab = p.K / PBK;
+    PS_ISSUE(sAh0, sAl0, sB0, 0);
+    if (nslab > 1) PS_ISSUE(sAh1, sAl1, sB1, PBK * 2);
+    for (int s = 0; s < nslab; s += 3) {
+        PS_STEP(s, sAh0, sAl0, sB0, sAh2, sAl2, sB2);
+        if (s + 1 < nslab) PS_STEP(s + 1, sAh1, sAl1, sB1, sAh0, sAl0, sB0);
+        if (s + 2 < nslab) PS_STEP(s + 2, sAh2, sAl2, sB2, sAh1, sAl1, sB1);
+    }
+#undef PS_STEP
+#undef PS_COMPUTE
+#undef PS_ISSUE
+#undef PS_DMA
+
+    // ---- epilogue through LDS: accumulators (column per lane) -> row-major tile of this wave -> 16-byte rows ----
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage
+    asm volatile("" ::: "memory");
+    float* ep = reinterpret_cast<float*>(smem) + wave * (WM * EP_LD);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+    const int m0w = m0 + wm * WM, n0w = n0 + wn * WN;
+    if (p.act == ACT_NONE) ps_epilogue<WM, WN, EP_LD, ACT_NONE>(p, ep, m0w, n0w, lane);
+    else if (p.act == ACT_RELU) ps_epilogue<WM, WN, EP_LD, ACT_RELU>(p, ep, m0w, n0w, lane);
+    else if (p.act == ACT_SILU) ps_epilogue<WM, WN, EP_LD, ACT_SILU>(p, ep, m0w, n0w, lane);
+    else ps_epilogue<WM, WN, EP_LD, ACT_TANH>(p, ep, m0w, n0w, lane);
+}
+
+template <int BM, int BN>
+void launch_ps_cfg(const GemmPsArgs& a, hipStream_t s) {
+    const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
+    const int tiles_total = tiles_m * tiles_n;
+    const int tiles_per_xcd = cdiv(tiles_total, 8);
+    char name[64];
+    snprintf(name, sizeof(name), "gemm_%dx%d_presplit", BM, BN);
+    prof::Scope scope(name, 2.0 * a.M * (double)a.N * a.K,
+                      4.0 * a.M * (double)a.K + 2.0 * a.N * (double)a.K + 4.0 * a.M * (double)a.N * (a.res ? 2.0 : 1.0), s);
+    hipLaunchKernelGGL((gemm_ps_kernel<BM, BN>), dim3(tiles_per_xcd * 8), dim3(256), 0, s, a, tiles_n, tiles_total, tiles_per_xcd,
+                       (uint32_t)((int64_t)a.M * a.lda * 2), (uint32_t)((int64_t)a.N * a.ldw * 2));
+}
+
+}  // namespace
+
+void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s) {
+    SC_CHECK(a.Ah && a.Al && a.W && (a.C || a.Ch), "presplit gemm: null operand");
+    SC_CHECK((a.Ch == nullptr) == (a.Cl == nullptr), "presplit gemm: Ch/Cl must be given together");
+    SC_CHECK(a.M > 0 && a.N > 0 && a.K > 0 && a.K % PBK == 0, "presplit gemm: M=%d N=%d K=%d (K must be a multiple of 32)", a.M, a.N, a.K);
+    SC_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.lda >= a.K && a.ldw >= a.K, "presplit gemm: lda=%lld ldw=%lld", (long long)a.lda,
+             (long long)a.ldw);
+    SC_CHECK(((reinterpret_cast<uintptr_t>(a.Ah) | reinterpret_cast<uintptr_t>(a.Al) | reinterpret_cast<uintptr_t>(a.W) |
+               reinterpret_cast<uintptr_t>(a.C) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0 &&
+                 ((reinterpret_cast<uintptr_t>(a.Ch) | reinterpret_cast<uintptr_t>(a.Cl)) & 7) == 0,
+             "presplit gemm: operands must be 16-byte aligned");
+    SC_CHECK((int64_t)a.M * a.lda * 2 < (1ll << 31) && (int64_t)a.N * a.ldw * 2 < (1ll << 31), "presplit gemm: operand larger than 2 GB");
+    const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
+    if (tiles128 >= 256) launch_ps_cfg<128, 128>(a, s);
+    else launch_ps_cfg<64, 64>(a, s);
+    SC_LAUNCH_CHECK();
+}
+
+}  // namespace sc

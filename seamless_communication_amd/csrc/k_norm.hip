@@ -24,18 +24,31 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ beta,
                                                         float* __restrict__ y, int64_t ldy, int rows,
                                                         int C, int act, const int* __restrict__ lens,
-                                                        int t_per_batch) {
+                                                        int t_per_batch, __half* __restrict__ yh = nullptr,
+                                                        __half* __restrict__ yl = nullptr, int64_t ldh = 0) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nv = C >> 2;  // float4 per row
     const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
     float4* yr = reinterpret_cast<float4*>(y + (int64_t)row * ldy);
+    // yh != null: the result is written as two fp16 planes (hi, lo) for launch_gemm_presplit instead of fp32
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    h4_t* yhr = reinterpret_cast<h4_t*>(yh + (yh ? (int64_t)row * ldh : 0));
+    h4_t* ylr = reinterpret_cast<h4_t*>(yl + (yl ? (int64_t)row * ldh : 0));
     if (lens) {
         const int n = row / t_per_batch;
         const int t = row - n * t_per_batch;
         if (t >= lens[n]) {
-            for (int i = lane; i < nv; i += 64) yr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = lane; i < nv; i += 64) {
+                if (yh) {
+                    yhr[i] = h4_t{0, 0, 0, 0};
+                    ylr[i] = h4_t{0, 0, 0, 0};
+                } else {
+                    yr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
             return;
         }
     }
@@ -71,9 +84,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             o.y = act_f((v[i].y - mean) * rstd * g.y + b.y, act);
             o.z = act_f((v[i].z - mean) * rstd * g.z + b.z, act);
             o.w = act_f((v[i].w - mean) * rstd * g.w + b.w, act);
-            yr[idx] = o;
+            if (yh) {
+                const f4_t of = {o.x, o.y, o.z, o.w};
+                const h4_t hi = __builtin_convertvector(of, h4_t);
+                const f4_t back = __builtin_convertvector(hi, f4_t);
+                yhr[idx] = hi;
+                ylr[idx] = __builtin_convertvector(of - back, h4_t);
+            } else {
+                yr[idx] = o;
+            }
         }
     }
+}
+
+void launch_layernorm_split(const float* x, int64_t ldx, const float* gamma, const float* beta, __half* yh, __half* yl,
+                            int64_t ldh, int rows, int C, int act, const int* lens, int t_per_batch, hipStream_t s) {
+    SC_CHECK(C % 4 == 0 && ldx % 4 == 0 && ldh % 4 == 0 && C <= 4096 && yh && yl, "layernorm_split: C=%d ldx=%lld ldh=%lld", C,
+             (long long)ldx, (long long)ldh);
+    if (rows <= 0) return;
+    dim3 grid(cdiv(rows, 4));
+    float* none = nullptr;
+    if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
+    else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
+    else hipLaunchKernelGGL((layernorm_kernel<16>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
+    SC_LAUNCH_CHECK();
 }
 
 void launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
@@ -85,11 +119,11 @@ void launch_layernorm(const float* x, int64_t ldx, const float* gamma, const flo
     if (rows <= 0) return;
     dim3 grid(cdiv(rows, 4));
     if (C <= 256) {
-        hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch);
+        hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch, (__half*)nullptr, (__half*)nullptr, (int64_t)0);
     } else if (C <= 1024) {
-        hipLaunchKernelGGL((layernorm_kernel<4>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch);
+        hipLaunchKernelGGL((layernorm_kernel<4>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch, (__half*)nullptr, (__half*)nullptr, (int64_t)0);
     } else {
-        hipLaunchKernelGGL((layernorm_kernel<16>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch);
+        hipLaunchKernelGGL((layernorm_kernel<16>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch, (__half*)nullptr, (__half*)nullptr, (int64_t)0);
     }
     SC_LAUNCH_CHECK();
 }

@@ -56,6 +56,29 @@ extern std::atomic<int> g_force_general_gemm;  // tests / A-B timing: 1 routes e
 bool gemm_fast_eligible(const GemmArgs& a);
 void launch_gemm_fast(const GemmArgs& a, hipStream_t s);
 
+// k_gemm_ps.hip: product with a PRE-SPLIT activation operand (two fp16 planes hi = fp16(a), lo = fp16(a - hi),
+// written by the producer kernel); operands go global -> LDS by DMA.  C (fp32) and/or Ch/Cl (split planes for the
+// next product) receive alpha * act(A.W^T + bias) + res.  Bit-identical to launch_gemm on the same values.
+struct GemmPsArgs {
+    const __half* Ah = nullptr;
+    const __half* Al = nullptr;
+    int64_t lda = 0;  // halfs between rows of Ah / Al
+    const __half* W = nullptr;
+    int64_t ldw = 0;
+    const float* bias = nullptr;
+    const float* res = nullptr;
+    int64_t ldr = 0;
+    float* C = nullptr;
+    int64_t ldc = 0;
+    __half* Ch = nullptr;
+    __half* Cl = nullptr;
+    int64_t ldcs = 0;
+    int M = 0, N = 0, K = 0;
+    int act = ACT_NONE;
+    float alpha = 1.0f;
+};
+void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s);
+
 // k_resblock.hip: out = x + conv2_{k,1}(lrelu(conv1_{k,dil}(lrelu(x)) + b1)) + b2 for C in {16, 32, 64}, the
 // intermediate kept in LDS; optionally out = ((avg_a + avg_b) + that) / 3.  Weights packed [C][ldw], tap-major.
 struct ResPairArgs {
@@ -128,6 +151,12 @@ void launch_layernorm(const float* x, int64_t ldx, const float* gamma, const flo
                       int64_t ldy, int rows, int C, int act, const int* lens, int t_per_batch,
                       hipStream_t s);
 
+// same, result written as two fp16 planes hi = fp16(y), lo = fp16(y - hi) (the A operand of launch_gemm_presplit)
+void launch_layernorm_split(const float* x, int64_t ldx, const float* gamma, const float* beta, __half* yh, __half* yl,
+                            int64_t ldh, int rows, int C, int act, const int* lens, int t_per_batch, hipStream_t s);
+// hi = fp16(x), lo = fp16(x - hi), elementwise over n values (n % 4 == 0)
+void launch_split_f32(const float* x, __half* hi, __half* lo, int64_t n, hipStream_t s);
+
 // y[r][c] = x[r][c] * sigmoid(x[r][C + c])
 void launch_glu(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int C, hipStream_t s);
 
@@ -146,6 +175,10 @@ struct AttnArgs {
     int causal = 0;                // key j visible iff j <= i + (Skv - Sq)
     const float* rel_k = nullptr;  // Shaw relative keys [left+1+right][64] (nullable)
     int rel_left = 0, rel_right = 0;
+    // optional: write the result as two fp16 planes (hi, lo) for launch_gemm_presplit instead of `out`
+    __half* out_hi = nullptr;
+    __half* out_lo = nullptr;
+    int64_t ldoh = 0;
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 

@@ -7,6 +7,8 @@
 //   models/unity/adaptor_block.py:98-125 UnitYEncoderAdaptor.forward
 //   models/unity/adaptor_block.py:237-314 UnitYTransformerAdaptorLayer
 //   models/conformer_shaw/builder.py:127-156 Shaw SDPA + causal depthwise conv
+#include <cstdlib>
+
 #include "model.h"
 
 namespace sc {
@@ -99,8 +101,92 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
     launch_layernorm(d_fbank, feat, m.fe_ln.g, m.fe_ln.b, h, feat, rows, feat, ACT_NONE, nullptr, 1, m.stream);
     linear(m, h, feat, m.fe_proj, nullptr, 0, x, M, rows, ACT_NONE, 1.f);
 
+    // Operands of the products are kept as two fp16 planes (hi, lo) written by their producers - LayerNorm, the FFN
+    // inner product's epilogue, the attention kernel - and consumed by the DMA-fed product kernel (k_gemm_ps.hip);
+    // the residual stream x and the tensors read by element-wise kernels stay fp32.  SC_PRESPLIT=0 selects the
+    // on-the-fly split path (same bits).
+    static const bool presplit = !(getenv("SC_PRESPLIT") && atoi(getenv("SC_PRESPLIT")) == 0);
+    const bool ps_ok = presplit && M % 32 == 0 && c.enc_ffn_dim % 32 == 0 && (int64_t)rows * std::max(M, c.enc_ffn_dim) * 2 < (1ll << 31);
+    Buf<__half> hs(&m.pool, ps_ok ? (size_t)2 * rows * M : 0), ws(&m.pool, ps_ok ? (size_t)2 * rows * c.enc_ffn_dim : 0),
+        as(&m.pool, ps_ok ? (size_t)2 * rows * M : 0);
+    __half* hs_hi = hs.get();
+    __half* hs_lo = ps_ok ? hs.get() + (size_t)rows * M : nullptr;
+    __half* ws_hi = ws.get();
+    __half* ws_lo = ps_ok ? ws.get() + (size_t)rows * c.enc_ffn_dim : nullptr;
+    __half* as_hi = as.get();
+    __half* as_lo = ps_ok ? as.get() + (size_t)rows * M : nullptr;
+    auto ln_split = [&](const float* src, const LNorm& L, int act) {
+        launch_layernorm_split(src, L.dim, L.g, L.b, hs_hi, hs_lo, L.dim, rows, L.dim, act, nullptr, 1, m.stream);
+    };
+    // C (fp32) and/or Ch/Cl (split planes) = alpha * act(A . W^T + b) + res
+    auto ps = [&](const __half* ah, const __half* al, const Linear& L, int act, float alpha, const float* res, float* C,
+                  __half* Ch, __half* Cl) {
+        GemmPsArgs a;
+        a.Ah = ah;
+        a.Al = al;
+        a.lda = L.in;
+        a.W = L.w;
+        a.ldw = L.ldw;
+        a.bias = L.b;
+        a.res = res;
+        a.ldr = L.out;
+        a.C = C;
+        a.ldc = L.out;
+        a.Ch = Ch;
+        a.Cl = Cl;
+        a.ldcs = L.out;
+        a.M = rows;
+        a.N = L.out;
+        a.K = L.in;
+        a.act = act;
+        a.alpha = alpha;
+        launch_gemm_presplit(a, m.stream);
+    };
+
     for (int li = 0; li < c.enc_layers; ++li) {
         const ConformerLayer& l = m.enc[li];
+        if (ps_ok) {
+            // x += 0.5 * FFN1(LN(x))
+            ln_split(x, l.ffn1_ln, ACT_NONE);
+            ps(hs_hi, hs_lo, l.ffn1_in, ACT_SILU, 1.f, nullptr, nullptr, ws_hi, ws_lo);
+            ps(ws_hi, ws_lo, l.ffn1_out, ACT_NONE, 0.5f, x, x, nullptr, nullptr);
+            // x += MHA_shaw(LN(x))
+            ln_split(x, l.attn_ln, ACT_NONE);
+            ps(hs_hi, hs_lo, l.qkv, ACT_NONE, 1.f, nullptr, wide, nullptr, nullptr);
+            {
+                AttnArgs a;
+                a.q = wide;
+                a.k = wide.get() + M;
+                a.v = wide.get() + 2 * M;
+                a.out_hi = as_hi;
+                a.out_lo = as_lo;
+                a.ldoh = M;
+                a.ldq = a.ldk = a.ldv = 3 * M;
+                a.ldo = M;
+                a.nb = n;
+                a.heads = c.num_heads;
+                a.Sq = S;
+                a.Skv = S;
+                a.kv_lens = d_lens;
+                a.rel_k = l.rel_k;
+                a.rel_left = c.shaw_max_left;
+                a.rel_right = c.shaw_max_right;
+                launch_attention(a, m.stream);
+            }
+            ps(as_hi, as_lo, l.attn_out, ACT_NONE, 1.f, x, x, nullptr, nullptr);
+            // x += Conv(LN(x))
+            ln_split(x, l.conv_ln, ACT_NONE);
+            ps(hs_hi, hs_lo, l.pw1, ACT_NONE, 1.f, nullptr, wide, nullptr, nullptr);
+            launch_glu_dwconv(wide, 2 * M, l.dw, att, M, n, S, M, c.depthwise_conv_kernel_size, d_lens, m.stream);
+            ln_split(att, l.conv_inner_ln, ACT_SILU);
+            ps(hs_hi, hs_lo, l.pw2, ACT_NONE, 1.f, x, x, nullptr, nullptr);
+            // x += 0.5 * FFN2(LN(x)); x = LN(x)
+            ln_split(x, l.ffn2_ln, ACT_NONE);
+            ps(hs_hi, hs_lo, l.ffn2_in, ACT_SILU, 1.f, nullptr, nullptr, ws_hi, ws_lo);
+            ps(ws_hi, ws_lo, l.ffn2_out, ACT_NONE, 0.5f, x, x, nullptr, nullptr);
+            layernorm(m, x, l.final_ln, x, rows);
+            continue;
+        }
         // x += 0.5 * FFN1(LN(x))
         layernorm(m, x, l.ffn1_ln, h, rows);
         linear(m, h, M, l.ffn1_in, nullptr, 0, wide, c.enc_ffn_dim, rows, ACT_SILU, 1.f);

@@ -278,6 +278,51 @@ def test_fast_gemm_bit_identical_to_general_conv_transpose(lib, report_dir, nb, 
     assert torch.equal(out[0], out[1])
 
 
+PRESPLIT_SHAPES = [
+    (7984, 4096, 1024),  # 128x128 tiles, 32 slabs
+    (4100, 1024, 4096),  # ragged M
+    (20000, 2048, 96),   # 3 slabs
+    (20000, 2048, 64),   # 2 slabs
+    (20000, 2048, 32),   # 1 slab
+    (499, 1024, 1024),   # 64x64 tiles
+    (333, 100, 160),     # ragged N, 5 slabs
+    (40, 3072, 1024),
+    (1, 64, 32),
+]
+
+
+@pytest.mark.parametrize("M,N,K", PRESPLIT_SHAPES)
+@pytest.mark.parametrize("act,with_res", [(0, False), (2, True)])
+def test_presplit_gemm_bit_identical_to_split_gemm(lib, report_dir, M, N, K, act, with_res):
+    """k_gemm_ps.hip (activation pre-split into two fp16 planes, operands DMA'd global -> LDS, XOR-swizzled tiles,
+    three stages) against the on-the-fly split product: identical bits; the split-plane output of the epilogue is
+    hi = fp16(y), lo = fp16(y - hi)."""
+    g = torch.Generator().manual_seed(M + 5 * N + 11 * K)
+    x = dev(torch.randn(M, K, generator=g) * 2.0)
+    w = dev((torch.randn(N, K, generator=g) / math.sqrt(K)).half())
+    b = dev(torch.randn(N, generator=g) * 0.1)
+    r = dev(torch.randn(M, N, generator=g)) if with_res else None
+    want = torch.full((M, N), float("nan"), device="cuda")
+    check(lib, lib.sc_op_linear(P(x), P(w), P(b), P(r), P(want), M, N, K, act, 0.5, 1, 0))
+    got = torch.full((M, N), float("nan"), device="cuda")
+    gh = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
+    gl = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
+    check(lib, lib.sc_op_linear_presplit(P(x), P(w), P(b), P(r), P(got), P(gh), P(gl), M, N, K, act, 0.5))
+    got, want = got.cpu(), want.cpu()
+    _log(report_dir, "presplit_gemm", M=M, N=N, K=K, act=act, equal=bool(torch.equal(got, want)),
+         maxdiff=float((got - want).abs().max()))
+    assert not torch.isnan(got).any()
+    assert torch.equal(got, want)
+    hi = got.half()
+    assert torch.equal(gh.cpu(), hi)
+    assert torch.equal(gl.cpu(), (got - hi.float()).half())
+    # split planes only (no fp32 output)
+    gh2 = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
+    gl2 = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float16)
+    check(lib, lib.sc_op_linear_presplit(P(x), P(w), P(b), P(r), None, P(gh2), P(gl2), M, N, K, act, 0.5))
+    assert torch.equal(gh2.cpu(), hi)
+
+
 RESPAIR_CASES = [
     # nb, T, C, k, dil, avg
     (2, 1000, 32, 3, 1, False),
