@@ -63,6 +63,11 @@ def parse_args():
     ap.add_argument("--no-profile-step", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement")
     ap.add_argument("--no-graph", action="store_true", help="launch decoder steps eagerly instead of hipGraph replay")
+    ap.add_argument("--free-run", action="store_true",
+                    help="let the micro-batch slices free-run over the K steps (joined once) instead of joining them after "
+                         "every step; measured no faster on MI355X (profiles/r1_microbatch_schedule.txt), kept for experiments")
+    ap.add_argument("--stagger", type=float, default=-1.0,
+                    help="start offset between micro-batch threads in the timed region, seconds (<0: warm-up step time / threads)")
     return ap.parse_args()
 
 
@@ -260,13 +265,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    warm_s = 0.0
     for i in range(args.warmup):
+        tw = time.perf_counter()
         step()
+        torch.cuda.synchronize()
+        warm_s = time.perf_counter() - tw
         log(f"warmup step {i}: {stage_ms}")
+    free_run = args.free_run and batcher.groups > 1
+    stagger = args.stagger if args.stagger >= 0 else (warm_s / batcher.groups if args.warmup > 0 else 0.0)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if free_run:
+        # K passes over the per-GPU batch; the micro-batch slices free-run (joined once), the all-gathers of the K
+        # passes follow.  Same work as K lock-step passes, see MicroBatcher.predict_steps.
+        outs = batcher.predict_steps(wav_dev, ns, args.steps, "S2ST", "fra", stagger_s=stagger, text_generation_opts=opts)
+        for texts, units, wavs, text_ids, st in outs:
+            if world > 1:
+                all_text = all_gather_ragged_ids(text_ids, device)
+                all_units = all_gather_ragged_ids(units, device)
+                assert len(all_text) == len(all_units) == world * B
+        texts, units, wavs, text_ids, st = outs[-1]
+        stage_ms.clear()
+        stage_ms.update(st)
+        last.update(texts=texts, units=units, wavs=wavs, text_ids=text_ids)
+    else:
+        for _ in range(args.steps):
+            step()
     fence()
     elapsed = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s; last step {stage_ms}")
@@ -299,6 +324,7 @@ def main():
                 "parallelism": f"dp{world} (utterances sharded, full replica per GPU, all-gather of ids)",
                 "hip_graph_decoder_step": bool(translator.use_graph),
                 "microbatches_in_flight": batcher.groups,
+                "microbatch_schedule": (f"free-running slices, start offsets {stagger * 1e3:.0f} ms" if free_run else "lock-step (join per pass)"),
             },
             "stage_ms_last_step_slice0": {k: round(v, 3) for k, v in stage_snapshot.items()},
             "load_seconds": round(load_s, 1),

@@ -123,6 +123,43 @@ class MicroBatcher:
                 wavs += speech.audio_wavs
         return texts, units, wavs, text_ids, outs[0][3]
 
+    def predict_steps(self, wav_dev: torch.Tensor, num_samples: Sequence[int], steps: int, task_str: str, tgt_lang: str,
+                      stagger_s: float = 0.0, **kwargs):
+        """``steps`` passes over the same batch with the slices FREE-RUNNING: every worker thread runs its slice
+        ``steps`` times back to back and the threads are only joined at the end, worker i starting ``i * stagger_s``
+        late.  The slices then drift out of phase, so that the latency-bound decoder steps of one slice overlap the
+        GEMM-bound stages of the others instead of all slices sitting in their decoder phase together (which is
+        what a join after every pass produces).  Returns one ``predict``-style tuple per pass."""
+        import time as _time
+
+        n = wav_dev.shape[0]
+        g = min(self.groups, n)
+        spans = [shard_range(n, i, g) for i in range(g)]
+        if g == 1:
+            return [self.predict(wav_dev, num_samples, task_str, tgt_lang, **kwargs) for _ in range(steps)]
+        slices = [wav_dev[lo:hi].contiguous() for lo, hi in spans]
+
+        def worker(i):
+            if stagger_s > 0 and i > 0:
+                _time.sleep(i * stagger_s)
+            lo, hi = spans[i]
+            return [self._one(self.views[i], slices[i], list(num_samples[lo:hi]), task_str, tgt_lang, kwargs) for _ in range(steps)]
+
+        futs = [self.pool.submit(worker, i) for i in range(g)]
+        per_worker = [f.result() for f in futs]
+        results = []
+        for k in range(steps):
+            texts, units, wavs, text_ids = [], [], [], []
+            for w in per_worker:
+                t, speech, ids, _ = w[k]
+                texts += t
+                text_ids += ids
+                if speech is not None:
+                    units += speech.units
+                    wavs += speech.audio_wavs
+            results.append((texts, units, wavs, text_ids, per_worker[0][k][3]))
+        return results
+
     def close(self) -> None:
         if self.pool is not None:
             self.pool.shutdown(wait=True)
