@@ -11,6 +11,8 @@
 //
 // fp32 everywhere: attention is < 6 % of the encoder FLOPs and the parity
 // target is the fp32 CPU reference; see DESIGN.md for the MFMA follow-up.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace sc {
@@ -217,6 +219,198 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------- //
+// attn_mfma_kernel: the same attention on the matrix cores with fp32 operands
+// (v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation, 64 FLOP/clk/SIMD = the fp32 vector rate,
+// but the operands of a 32x32x2 step are 2 values per lane instead of LDS traffic for every fmaf).
+// A workgroup = 4 waves x 32 queries; K/V tiles of 32 keys in LDS.  Everything is kept TRANSPOSED so that a
+// query is a LANE (column) in every accumulator:
+//   S^T[key][query] = K . Q^T      A = K tile from LDS (16-byte reads: 4 contraction steps per read),
+//                                  B = Q^T held in 32 registers per lane for the whole kernel;
+//   O^T[dim][query] += V^T . P^T   A = V^T from LDS, B = P^T = the S^T accumulator registers themselves
+//                                  (step s of half h contracts the key that register s of that half holds),
+// so the soft-max runs per lane (16 registers + one cross-half shuffle), the probabilities never leave the
+// registers, and the running rescale of O is a per-lane multiply.  Shaw term: q.R table per query in LDS
+// (computed once per workgroup), indexed by clamp(j - i).  The result goes through LDS once for 16-byte row stores.
+// ------------------------------------------------------------------------------------------------- //
+static constexpr int MQ = 128;   // queries per workgroup
+static constexpr int MKV = 32;   // keys per iteration
+static constexpr int KS = 68;    // padded row stride of the K tile / R staging / output tile (floats)
+
+template <bool SHAW>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs p) {
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sK = smem;                    // [MKV][KS]; after the loop: output tiles [4 waves][32][KS] start here
+    float* sV = sK + MKV * KS;           // [MKV][HD]
+    float* sQR = smem + 4 * 32 * KS;     // [MQ][npos]   (SHAW only; placed behind the output-tile region)
+    float* sR = smem;                    // [npos][KS] staging of the relative keys before the loop (over the K/V tiles)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const int q0 = blockIdx.x * MQ + wave * 32;
+    const int qi = q0 + ql;
+    const int kv_len = p.kv_lens ? min(p.kv_lens[n], p.Skv) : p.Skv;
+    const int shift = p.Skv - p.Sq;
+    const int qabs = qi + shift;
+    const int npos = p.rel_left + 1 + p.rel_right;
+    const float scale = 0.125f;
+
+    // Q^T operand: step s (0..31) of half hh contracts dim 8*(s>>2) + 4*hh + (s&3)
+    float qreg[32];
+    {
+        const bool qok = qi < p.Sq;
+        const float* qp = p.q + ((int64_t)n * p.Sq + (qok ? qi : 0)) * p.ldq + h * HD + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f4v v = {0.f, 0.f, 0.f, 0.f};
+            if (qok) v = *reinterpret_cast<const f4v*>(qp + 8 * g);
+            qreg[4 * g + 0] = v[0];
+            qreg[4 * g + 1] = v[1];
+            qreg[4 * g + 2] = v[2];
+            qreg[4 * g + 3] = v[3];
+        }
+    }
+    if (SHAW) {
+        for (int idx = tid; idx < npos * (HD / 4); idx += 256) {
+            const int r = idx >> 4, c4 = idx & 15;
+            *reinterpret_cast<f4v*>(&sR[r * KS + c4 * 4]) = *reinterpret_cast<const f4v*>(p.rel_k + r * HD + c4 * 4);
+        }
+        __syncthreads();
+        // qR[e] = sum_d q[d] R[e][d]: each half-lane holds 32 of the 64 dims of its query
+        for (int e = 0; e < npos; ++e) {
+            float acc = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f4v r4 = *reinterpret_cast<const f4v*>(&sR[e * KS + 8 * g + 4 * hh]);
+                acc = fmaf(qreg[4 * g + 0], r4[0], acc);
+                acc = fmaf(qreg[4 * g + 1], r4[1], acc);
+                acc = fmaf(qreg[4 * g + 2], r4[2], acc);
+                acc = fmaf(qreg[4 * g + 3], r4[3], acc);
+            }
+            acc += __shfl_xor(acc, 32);
+            if (hh == 0) sQR[(wave * 32 + ql) * npos + e] = acc;
+        }
+    }
+
+    f16v o0, o1;  // O^T: dims 0..31 / 32..63 (rows) x queries (lanes)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        o0[r] = 0.f;
+        o1[r] = 0.f;
+    }
+    float m_i = -1e30f, l_i = 0.f;
+
+    // keys beyond this bound are masked for every query of the workgroup
+    int k_end = kv_len;
+    if (p.causal) k_end = min(k_end, (int)(blockIdx.x * MQ) + MQ - 1 + shift + 1);
+
+    for (int k0 = 0; k0 < k_end; k0 += MKV) {
+        __syncthreads();  // previous tile fully consumed (also orders the sQR writes before their first use)
+        for (int idx = tid; idx < MKV * (HD / 4); idx += 256) {
+            const int r = idx >> 4, c4 = idx & 15;
+            f4v kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+            if (k0 + r < kv_len) {
+                const int64_t row = (int64_t)n * p.Skv + k0 + r;
+                kv = *reinterpret_cast<const f4v*>(p.k + row * p.ldk + h * HD + c4 * 4);
+                vv = *reinterpret_cast<const f4v*>(p.v + row * p.ldv + h * HD + c4 * 4);
+            }
+            *reinterpret_cast<f4v*>(&sK[r * KS + c4 * 4]) = kv;
+            *reinterpret_cast<f4v*>(&sV[r * HD + c4 * 4]) = vv;
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T (rows = keys, lanes = queries) ---------------------------------
+        f16v st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f4v k4 = *reinterpret_cast<const f4v*>(&sK[ql * KS + 8 * g + 4 * hh]);  // key = lane & 31
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[0], qreg[4 * g + 0], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[1], qreg[4 * g + 1], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[2], qreg[4 * g + 2], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[3], qreg[4 * g + 3], st, 0, 0, 0);
+        }
+        // ---- bias, scale, masks, online soft-max: register r of half hh is key (r&3) + 8*(r>>2) + 4*hh ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kj = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float sc = st[r];
+            if (SHAW) {
+                int rel = kj - qabs;
+                rel = max(-p.rel_left, min(p.rel_right, rel)) + p.rel_left;
+                sc += sQR[(wave * 32 + ql) * npos + rel];
+            }
+            sc *= scale;
+            const bool ok = (kj < kv_len) && (!p.causal || kj <= qabs);
+            sc = ok ? sc : -INFINITY;
+            st[r] = sc;
+            mx = fmaxf(mx, sc);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_i, mx);
+        const float alpha = expf(m_i - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = expf(st[r] - m_new);
+            st[r] = pv;
+            rs += pv;
+        }
+        rs += __shfl_xor(rs, 32);
+        l_i = l_i * alpha + rs;
+        m_i = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= alpha;
+            o1[r] *= alpha;
+        }
+        // ---- O^T += V^T . P^T: step s of half hh contracts key (s&3) + 8*(s>>2) + 4*hh = register s ----
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            const int key = (sidx & 3) + 8 * (sidx >> 2) + 4 * hh;
+            const float v0 = sV[key * HD + ql];
+            const float v1 = sV[key * HD + 32 + ql];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, st[sidx], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, st[sidx], o1, 0, 0, 0);
+        }
+    }
+
+    // ---- O^T (dims x queries) -> this wave's [32 queries][64 dims] tile in LDS -> 16-byte row stores ----
+    __syncthreads();  // every wave is done with the K/V tiles
+    float* ot = smem + wave * (32 * KS);
+    const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        ot[ql * KS + d] = o0[r] * inv;
+        ot[ql * KS + 32 + d] = o1[r] * inv;
+    }
+    // lanes 0..15 / 16..31 / ... take rows; 16 lanes x 16 bytes = one 256-byte row of this head
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const int c0 = (lane & 15) * 4;
+        const int qq = q0 + row;
+        const f4v of = *reinterpret_cast<const f4v*>(&ot[row * KS + c0]);
+        if (qq >= p.Sq) continue;
+        if (p.out_hi) {
+            typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+            const h4_t hi = __builtin_convertvector(of, h4_t);
+            const f4v back = __builtin_convertvector(hi, f4v);
+            const int64_t off = ((int64_t)n * p.Sq + qq) * p.ldoh + h * HD + c0;
+            *reinterpret_cast<h4_t*>(p.out_hi + off) = hi;
+            *reinterpret_cast<h4_t*>(p.out_lo + off) = __builtin_convertvector(of - back, h4_t);
+        } else {
+            *reinterpret_cast<f4v*>(p.out + ((int64_t)n * p.Sq + qq) * p.ldo + h * HD + c0) = of;
+        }
+    }
+}
+
 static bool g_attn_attr_set = false;
 
 void launch_attention(const AttnArgs& a, hipStream_t s) {
@@ -232,6 +426,27 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         g_attn_attr_set = true;
+    }
+    static const bool use_valu = getenv("SC_ATTN_VALU") && atoi(getenv("SC_ATTN_VALU")) != 0;
+    if (!use_valu) {
+        static bool mfma_attr = false;
+        if (!mfma_attr) {
+            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+            mfma_attr = true;
+        }
+        prof::Scope scope(a.rel_k ? "attention_shaw" : "attention", 4.0 * a.nb * a.heads * (double)a.Sq * a.Skv * HD,
+                          4.0 * a.nb * a.heads * HD * (2.0 * a.Sq + 2.0 * a.Skv), s);
+        size_t lds = (size_t)(4 * 32 * KS) * sizeof(float);  // K/V tiles, later the four output tiles
+        SC_CHECK(npos * KS <= 4 * 32 * KS, "attention: relative table too large");
+        if (a.rel_k) lds += (size_t)(MQ * npos) * sizeof(float);
+        dim3 grid(cdiv(a.Sq, MQ), a.heads, a.nb);
+        if (a.rel_k) hipLaunchKernelGGL((attn_mfma_kernel<true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((attn_mfma_kernel<false>), grid, dim3(256), lds, s, a);
+        SC_LAUNCH_CHECK();
+        return;
     }
     dim3 grid(cdiv(a.Sq, BQ), a.heads, a.nb);
     prof::Scope scope(a.rel_k ? "attention_shaw" : "attention", 4.0 * a.nb * a.heads * (double)a.Sq * a.Skv * HD,
