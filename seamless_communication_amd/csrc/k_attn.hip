@@ -279,19 +279,27 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs p) {
             *reinterpret_cast<f4v*>(&sR[r * KS + c4 * 4]) = *reinterpret_cast<const f4v*>(p.rel_k + r * HD + c4 * 4);
         }
         __syncthreads();
-        // qR[e] = sum_d q[d] R[e][d]: each half-lane holds 32 of the 64 dims of its query
-        for (int e = 0; e < npos; ++e) {
-            float acc = 0.f;
+        // (q.R)^T[e][query] = R . Q^T on the matrix cores: three 32-row fragments cover the npos <= 96 relative keys
+        // (rows >= npos read stale LDS and are not stored)
+#pragma unroll 1
+        for (int f = 0; f < 3; ++f) {
+            if (f * 32 >= npos) break;
+            f16v qr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qr[r] = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                const f4v r4 = *reinterpret_cast<const f4v*>(&sR[e * KS + 8 * g + 4 * hh]);
-                acc = fmaf(qreg[4 * g + 0], r4[0], acc);
-                acc = fmaf(qreg[4 * g + 1], r4[1], acc);
-                acc = fmaf(qreg[4 * g + 2], r4[2], acc);
-                acc = fmaf(qreg[4 * g + 3], r4[3], acc);
+                const f4v r4 = *reinterpret_cast<const f4v*>(&sR[(f * 32 + ql) * KS + 8 * g + 4 * hh]);
+                qr = __builtin_amdgcn_mfma_f32_32x32x2f32(r4[0], qreg[4 * g + 0], qr, 0, 0, 0);
+                qr = __builtin_amdgcn_mfma_f32_32x32x2f32(r4[1], qreg[4 * g + 1], qr, 0, 0, 0);
+                qr = __builtin_amdgcn_mfma_f32_32x32x2f32(r4[2], qreg[4 * g + 2], qr, 0, 0, 0);
+                qr = __builtin_amdgcn_mfma_f32_32x32x2f32(r4[3], qreg[4 * g + 3], qr, 0, 0, 0);
             }
-            acc += __shfl_xor(acc, 32);
-            if (hh == 0) sQR[(wave * 32 + ql) * npos + e] = acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (e < npos) sQR[(wave * 32 + ql) * npos + e] = qr[r];
+            }
         }
     }
 
@@ -440,7 +448,7 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         prof::Scope scope(a.rel_k ? "attention_shaw" : "attention", 4.0 * a.nb * a.heads * (double)a.Sq * a.Skv * HD,
                           4.0 * a.nb * a.heads * HD * (2.0 * a.Sq + 2.0 * a.Skv), s);
         size_t lds = (size_t)(4 * 32 * KS) * sizeof(float);  // K/V tiles, later the four output tiles
-        SC_CHECK(npos * KS <= 4 * 32 * KS, "attention: relative table too large");
+        SC_CHECK(npos <= 96, "attention: relative table too large");
         if (a.rel_k) lds += (size_t)(MQ * npos) * sizeof(float);
         dim3 grid(cdiv(a.Sq, MQ), a.heads, a.nb);
         if (a.rel_k) hipLaunchKernelGGL((attn_mfma_kernel<true>), grid, dim3(256), lds, s, a);
