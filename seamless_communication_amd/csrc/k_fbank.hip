@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ wa
     if (tid < NBINS) {
         float e = 0.f;
         for (int k = 0; k < 256; ++k) e = fmaf(melT[k * NBINS + tid], s_x[k], e);
-        orow[tid] = logf(fmaxf(e, 1.1920928955078125e-07f));
+        // std::max(e, FLT_EPS) of feature-fbank.cc:105 keeps a NaN energy (corrupted audio must stay visible to
+        // the caller's NaN filter, cli/m4t/evaluate/evaluate.py:278-289); fmaxf would replace it by the floor
+        orow[tid] = logf(e < 1.1920928955078125e-07f ? 1.1920928955078125e-07f : e);
     }
 }
 

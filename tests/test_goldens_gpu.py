@@ -43,3 +43,41 @@ def test_hip_vocoder_matches_reference_vocoder(hip):
     # weights are fp16 on both sides; the HIP path folds weight-norm in fp32 and re-rounds the
     # folded weight to fp16 for the MFMA operand: stated tolerance 2e-3 absolute on [-1, 1] audio
     assert err < 2e-3, err
+
+
+def test_evaluate_data_path_end_to_end(tmp_path):
+    """seamless_communication_amd.evaluate.run_eval with the real (tiny) Translator: GPU fbank per bucket, the NaN
+    filter, beam search defaults of the caller, and files on disk; hypotheses equal a direct predict() on the same bucket."""
+    from seamless_communication_amd import evaluate as ev
+    from seamless_communication_amd import synthetic as syn
+    from seamless_communication_amd.inference import SequenceGeneratorOptions, Translator
+    from seamless_communication_amd.inference.translator import DEFAULT_CARDS, Modality
+
+    card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch="tiny_v2")
+    tr = Translator(card, "vocoder_v2", device=torch.device("cuda", 0))
+    names = []
+    for i, secs in enumerate((1.0, 1.5, 0.8)):
+        w = syn.synthetic_waveform(i, secs).numpy()
+        if i == 1:
+            w[50] = np.nan
+        np.save(tmp_path / f"u{i}.npy", w)
+        names.append(f"u{i}.npy")
+    tsv = tmp_path / "dev.tsv"
+    tsv.write_text("audio\ttgt_text\n" + "".join(f"{n}\tref{i}\n" for i, n in enumerate(names)))
+    opts = SequenceGeneratorOptions(beam_size=3, soft_max_seq_len=(1, 200), hard_max_seq_len=10)
+    ctx = ev.EvalContext(task="S2ST", input_modality=Modality.SPEECH, output_modality=Modality.SPEECH, model_name="tiny",
+                         data_file=tsv, audio_root_dir=tmp_path, target_lang="fra", source_lang=None, batch_size=3,
+                         device=torch.device("cuda", 0), dtype=torch.float16, output_path=tmp_path / "out", ref_field="tgt_text",
+                         text_generation_opts=opts)
+    res = ev.run_eval(tr, ctx)
+    assert res["samples"] == 3
+    rows = [l.split("\t") for l in open(res["hypotheses"]).read().splitlines()[1:]]
+    assert [r[0] for r in rows] == ["ref0", "ref1", "ref2"] and rows[1][1] == ""
+    # the same bucket without the corrupted item, directly
+    fb = ev.gpu_fbank_fn(tr)([np.load(tmp_path / "u0.npy"), np.load(tmp_path / "u2.npy")])
+    texts, speech = tr.predict(ev.collate_fbank(fb), "S2ST", "fra", text_generation_opts=opts)
+    assert [rows[0][1], rows[2][1]] == [str(t) for t in texts]
+    units = open(res["units"]).read().split("\n")
+    assert units[0] == " ".join(map(str, speech.units[0])) and units[1] == "" and units[2] == " ".join(map(str, speech.units[1]))
+    w0, rate = ev.load_audio(Path(rows[0][2]))
+    assert rate == 16000 and len(w0) == speech.audio_wavs[0].shape[-1]
