@@ -73,9 +73,13 @@ def test_evaluate_data_path_end_to_end(tmp_path):
     assert res["samples"] == 3
     rows = [l.split("\t") for l in open(res["hypotheses"]).read().splitlines()[1:]]
     assert [r[0] for r in rows] == ["ref0", "ref1", "ref2"] and rows[1][1] == ""
-    # the same bucket without the corrupted item, directly
-    fb = ev.gpu_fbank_fn(tr)([np.load(tmp_path / "u0.npy"), np.load(tmp_path / "u2.npy")])
-    texts, speech = tr.predict(ev.collate_fbank(fb), "S2ST", "fra", text_generation_opts=opts)
+    # the same bucket directly: collated at the bucket's padded length, corrupted row dropped (evaluate.py:285-289
+    # filters rows but keeps the padding, and a padded item's result depends on its padding)
+    fb = ev.gpu_fbank_fn(tr)([np.load(tmp_path / f"u{i}.npy") for i in range(3)])
+    src = ev.collate_fbank(fb)
+    keep = torch.tensor([0, 2])
+    src = {"seqs": src["seqs"][keep.to(src["seqs"].device)], "seq_lens": src["seq_lens"][keep], "is_ragged": True}
+    texts, speech = tr.predict(src, "S2ST", "fra", text_generation_opts=opts)
     assert [rows[0][1], rows[2][1]] == [str(t) for t in texts]
     units = open(res["units"]).read().split("\n")
     assert units[0] == " ".join(map(str, speech.units[0])) and units[1] == "" and units[2] == " ".join(map(str, speech.units[1]))
