@@ -83,6 +83,54 @@ __device__ __forceinline__ void conv_from_lds(const _Float16* __restrict__ ah_pl
     }
 }
 
+// Same product with the weights ALSO in LDS: sW[col][ldb] holds, for every output channel, the K range
+// [chunk0*16, (chunk0 + nch)*16) of its packed weight row.  Per chunk and wave the global-path variant above pulls
+// NF KB through the CU's vector L1 for 2*NF MFMAs, i.e. up to 16 B/clk per wave with 12-20 waves per CU: the L1,
+// not HBM or the matrix pipe, was the limiter (profiles/r1_bench_b64.json: 0.9-1.8 TB/s, 90-190 TFLOP/s).
+template <int C, int NF>
+__device__ __forceinline__ void conv_from_lds_w(const _Float16* __restrict__ ah_plane, const _Float16* __restrict__ al_plane,
+                                                int a_row0, int tap_step, int tap0, int ntaps, const _Float16* __restrict__ sW,
+                                                int ldb, int lane, float16_t (&acc)[NF]) {
+    constexpr int CS = C + 8;
+    constexpr int CPT = C / 16;
+    const int koff = (lane >> 5) * 8;
+    const int a_base = (a_row0 + (lane & 31)) * CS + koff;
+    int w_base[NF];
+    bool wok[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        const int col = nf * 32 + (lane & 31);
+        wok[nf] = col < C;
+        w_base[nf] = (wok[nf] ? col : 0) * ldb + koff;
+    }
+    const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < ntaps; ++t) {
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) {
+            const int a_off = a_base + (tap0 + t) * tap_step * CS + cc * 16;
+            const half8_t ah = *reinterpret_cast<const half8_t*>(ah_plane + a_off);
+            const half8_t al = *reinterpret_cast<const half8_t*>(al_plane + a_off);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                const half8_t b = wok[nf] ? *reinterpret_cast<const half8_t*>(sW + w_base[nf] + (t * CPT + cc) * 16) : zero8;
+                acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b, acc[nf], 0, 0, 0);
+                acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[nf], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// sW[col][0 .. width) = W[col][k0 .. k0 + width) for col < C (width % 8 == 0), 16 bytes per thread and step
+template <int C>
+__device__ __forceinline__ void stage_weights(const __half* __restrict__ W, int64_t ldw, int k0, int width, _Float16* sW, int ldb,
+                                              int tid) {
+    const int vpr = width >> 3;
+    for (int i = tid; i < C * vpr; i += 256) {
+        const int col = i / vpr, v = i - col * vpr;
+        *reinterpret_cast<half8_t*>(sW + col * ldb + v * 8) = *reinterpret_cast<const half8_t*>(W + (int64_t)col * ldw + k0 + v * 8);
+    }
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int tiles) {
     constexpr int CS = C + 8;          // halfs per LDS row: 16-byte fragment reads of consecutive rows hit distinct banks
@@ -101,6 +149,10 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
     _Float16* xl = xh + R0 * CS;
     _Float16* th = xh;
     _Float16* tl = xl;
+    // weights: the whole packed row per output channel (C <= 32: <= 22.5 KB), or one tap at a time, double buffered (C = 64)
+    constexpr bool PER_TAP = C > 32;
+    _Float16* sW = xl + R0 * CS;
+    const int ldb = (PER_TAP ? C : k * C) + 8;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.x / tiles;
@@ -122,6 +174,8 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
         *reinterpret_cast<half4_t*>(xh + r * CS + c4 * 4) = hi;
         *reinterpret_cast<half4_t*>(xl + r * CS + c4 * 4) = lo;
     }
+    if (PER_TAP) stage_weights<C>(p.w1, p.ldw1, 0, C, sW, ldb, tid);
+    else stage_weights<C>(p.w1, p.ldw1, 0, k * C, sW, ldb, tid);
     __syncthreads();
 
     // ---- 2. conv1 (k taps, dilation d) for tmp rows [32*wave, 32*wave + 32) ---------------------
@@ -131,8 +185,18 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
         for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
-        conv_from_lds<C, NF>(xh, xl, 32 * wave, dil, k, p.w1, p.ldw1, lane, acc);
-        __syncthreads();  // every wave is done reading x before the tmp tile overwrites it
+        if (PER_TAP) {
+            for (int t = 0; t < k; ++t) {  // tap t from buffer t&1 while tap t+1 is staged into the other one
+                if (t + 1 < k) stage_weights<C>(p.w1, p.ldw1, (t + 1) * C, C, sW + ((t + 1) & 1) * C * ldb, ldb, tid);
+                conv_from_lds_w<C, NF>(xh, xl, 32 * wave, dil, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc);
+                __syncthreads();
+            }
+        } else {
+            conv_from_lds_w<C, NF>(xh, xl, 32 * wave, dil, 0, k, sW, ldb, lane, acc);
+            __syncthreads();  // every wave is done reading x (and W1) before the tmp tile / W2 overwrite them
+        }
+        if (PER_TAP) stage_weights<C>(p.w2, p.ldw2, 0, C, sW, ldb, tid);
+        else stage_weights<C>(p.w2, p.ldw2, 0, k * C, sW, ldb, tid);
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
             const int col = nf * 32 + (lane & 31);
@@ -159,7 +223,15 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
         for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
-        conv_from_lds<C, NF>(th, tl, 32 * wave, 1, k, p.w2, p.ldw2, lane, acc);
+        if (PER_TAP) {
+            for (int t = 0; t < k; ++t) {
+                if (t + 1 < k) stage_weights<C>(p.w2, p.ldw2, (t + 1) * C, C, sW + ((t + 1) & 1) * C * ldb, ldb, tid);
+                conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc);
+                if (t + 1 < k) __syncthreads();
+            }
+        } else {
+            conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, 0, k, sW, ldb, lane, acc);
+        }
         float* __restrict__ outn = p.out + (int64_t)n * T * C;
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
@@ -183,6 +255,12 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
     }
 }
 
+}  // namespace
+static size_t weights_lds_bytes(int C, int k) {
+    return C > 32 ? (size_t)2 * C * (C + 8) * sizeof(_Float16) : (size_t)C * (k * C + 8) * sizeof(_Float16);
+}
+namespace {
+
 template <int C>
 void launch_cfg(const ResPairArgs& a, hipStream_t s) {
     static bool attr_set = false;
@@ -194,7 +272,7 @@ void launch_cfg(const ResPairArgs& a, hipStream_t s) {
     const int H2 = (a.k - 1) / 2, H1 = a.dil * (a.k - 1) / 2;
     const int TT = RB_M1 - 2 * H2;
     const int tiles = cdiv(a.T, TT);
-    const size_t lds = (size_t)2 * (RB_M1 + 2 * H1) * (C + 8) * sizeof(_Float16);
+    const size_t lds = (size_t)2 * (RB_M1 + 2 * H1) * (C + 8) * sizeof(_Float16) + weights_lds_bytes(C, a.k);
     SC_CHECK(lds <= 120 * 1024, "resblock pair: %zu bytes of LDS (C=%d k=%d dil=%d)", lds, C, a.k, a.dil);
     char name[48];
     snprintf(name, sizeof(name), "resblock_pair_c%d", C);
@@ -209,7 +287,7 @@ void launch_cfg(const ResPairArgs& a, hipStream_t s) {
 bool resblock_pair_supported(int C, int k, int dil) {
     if (!(C == 16 || C == 32 || C == 64) || k < 1 || (k & 1) == 0 || dil < 1) return false;
     const int H1 = dil * (k - 1) / 2;
-    const size_t lds = (size_t)2 * (RB_M1 + 2 * H1) * (C + 8) * sizeof(_Float16);
+    const size_t lds = (size_t)2 * (RB_M1 + 2 * H1) * (C + 8) * sizeof(_Float16) + weights_lds_bytes(C, k);
     return RB_M1 - (k - 1) >= 32 && lds <= 120 * 1024;
 }
 
