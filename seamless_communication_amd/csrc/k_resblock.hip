@@ -232,7 +232,12 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
         } else {
             conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, 0, k, sW, ldb, lane, acc);
         }
-        float* __restrict__ outn = p.out + (int64_t)n * T * C;
+        // epilogue through LDS: (acc + bias) as a row-major fp32 tile over the (now dead) tmp planes, then 16 bytes per
+        // lane: residual read, optional 3-way average and store are 4x fewer (and fully coalesced) memory instructions
+        // than the column-per-lane accumulator layout allows
+        __syncthreads();  // every wave is done reading the tmp tile
+        constexpr int EPS = C + 4;  // floats per row
+        float* ep = reinterpret_cast<float*>(rb_smem);
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
             const int col = nf * 32 + (lane & 31);
@@ -241,16 +246,22 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int t = t0 + i;
-                if (i >= TT || t >= T) continue;
-                const int64_t idx = (int64_t)t * C + col;
-                float v = (acc[nf][r] + b) * 1.0f + xn[idx];
-                if (p.avg_a) {
-                    const int64_t g = (int64_t)n * T * C + idx;
-                    v = ((p.avg_a[g] + p.avg_b[g]) + v) / 3.0f;
-                }
-                outn[idx] = v;
+                ep[i * EPS + col] = (acc[nf][r] + b) * 1.0f;
             }
+        }
+        __syncthreads();
+        float* __restrict__ outn = p.out + (int64_t)n * T * C;
+        for (int idx = tid; idx < TT * VPR; idx += 256) {
+            const int i = idx / VPR, c4 = idx - i * VPR;
+            const int t = t0 + i;
+            if (t >= T) continue;
+            const int64_t off = (int64_t)t * C + c4 * 4;
+            f32x4_t v = *reinterpret_cast<const f32x4_t*>(ep + i * EPS + c4 * 4) + *reinterpret_cast<const f32x4_t*>(xn + off);
+            if (p.avg_a) {
+                const int64_t g = (int64_t)n * T * C + off;
+                v = ((*reinterpret_cast<const f32x4_t*>(p.avg_a + g) + *reinterpret_cast<const f32x4_t*>(p.avg_b + g)) + v) / 3.0f;
+            }
+            *reinterpret_cast<f32x4_t*>(outn + off) = v;
         }
     }
 }
