@@ -81,6 +81,71 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, float16_t (&acc)[TM]
     }
 }
 
+// The same epilogue through LDS: each 32-row fragment row of the wave is written to a row-major fp32 tile and read
+// back 16 bytes per lane (the four 16-lane groups of a ds_read_b128 take whole rows), so that bias / activation /
+// residual / store work on float4 and every global access is a run of 16-byte pieces of one output row instead of
+// 64 four-byte accesses per lane.  Same arithmetic per element.
+template <int TM, int TN, int WN, int EP_LD, int ACT, bool HAS_RES>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& p, float16_t (&acc)[TM][TN], float* ep, int m0w, int n0w, int lane,
+                                             int out_off, bool plain_rows) {
+    constexpr int LPR = WN / 4;    // lanes per row
+    constexpr int RPG = 16 / LPR;  // rows per 16-lane group
+    constexpr int RPI = 4 * RPG;   // rows per wave instruction
+    const int l5 = lane & 31;
+    const bool g1 = (l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28;
+    const int rank = g1 ? (l5 < 12 ? l5 - 4 : l5 < 20 ? l5 - 8 : l5 - 16) : (l5 < 4 ? l5 : l5 < 16 ? l5 - 8 : l5 - 12);
+    const int grp = (lane >> 5) * 2 + (g1 ? 1 : 0);
+    const int row_in = grp * RPG + rank / LPR;
+    const int c0 = (rank % LPR) * 4;
+    const int col = n0w + c0;
+    const bool vec_ok = (col + 3 < p.N) && (p.ldc % 4 == 0) && (!HAS_RES || p.ldr % 4 == 0) &&
+                        ((reinterpret_cast<uintptr_t>(p.C) | (HAS_RES ? reinterpret_cast<uintptr_t>(p.res) : 0)) & 15) == 0;
+    f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b4[e] = (col + e < p.N) ? p.bias[col + e] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int rr = it * RPI + row_in;
+            const int m = m0w + i * 32 + rr;
+            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ep + rr * EP_LD + c0);
+            if (m >= p.M || col >= p.N) continue;
+            int64_t row;
+            if (plain_rows) {
+                row = m;
+            } else {
+                const int n = m / p.rows_per_batch;
+                const int q = m - n * p.rows_per_batch;
+                const int dst_t = q * p.out_mul + out_off;
+                if (dst_t < 0 || dst_t >= p.t_out) continue;
+                row = (int64_t)n * p.t_out + dst_t;
+            }
+            f32x4_t v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fn<ACT>(a[e] + b4[e]) * p.alpha;
+            if (vec_ok) {
+                if (HAS_RES) v += *reinterpret_cast<const f32x4_t*>(p.res + row * p.ldr + col);
+                *reinterpret_cast<f32x4_t*>(p.C + row * p.ldc + col) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col + e >= p.N) continue;
+                    float x = v[e];
+                    if (HAS_RES) x += p.res[row * p.ldr + col + e];
+                    p.C[row * p.ldc + col + e] = x;
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WGM, int WGN, bool IN_ACT, bool CONV>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(GemmArgs p, int tiles_n, int tiles_mn, int tiles_total,
                                                         int tiles_per_xcd, float in_slope, int group_m) {
@@ -302,9 +367,14 @@ __global__ __launch_bounds__(256) void gemm_fast2_kernel(GemmArgs p, int tiles_n
     constexpr int B_IT = (BN * 4 + 255) / 256;
     constexpr uint32_t OOB = 0x80000000u;  // >= num_records of either buffer: the load returns zeros
 
-    __shared__ __attribute__((aligned(16))) _Float16 sAh[2][BM * FLD];
-    __shared__ __attribute__((aligned(16))) _Float16 sAl[2][BM * FLD];
-    __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * FLD];
+    // one LDS block: [2 stages of A_hi | 2 stages of A_lo | 2 stages of W]; reused by the epilogue as one fp32
+    // tile of 32 rows per wave
+    constexpr int EP_LD = WN + 4;
+    static_assert(4 * 32 * EP_LD * 4 <= (4 * BM + 2 * BN) * FLD * 2, "epilogue tiles must fit in the stage memory");
+    __shared__ __attribute__((aligned(16))) _Float16 smem_all[(4 * BM + 2 * BN) * FLD];
+    _Float16(*sAh)[BM * FLD] = reinterpret_cast<_Float16(*)[BM * FLD]>(smem_all);
+    _Float16(*sAl)[BM * FLD] = reinterpret_cast<_Float16(*)[BM * FLD]>(smem_all + 2 * BM * FLD);
+    _Float16(*sB)[BN * FLD] = reinterpret_cast<_Float16(*)[BN * FLD]>(smem_all + 4 * BM * FLD);
 
     const int bid = blockIdx.x;
     const int tile = (bid & 7) * tiles_per_xcd + (bid >> 3);
@@ -468,10 +538,12 @@ __global__ __launch_bounds__(256) void gemm_fast2_kernel(GemmArgs p, int tiles_n
 
     const bool plain_rows = (p.rows_per_batch == p.M) && p.out_mul == 1 && out_off == 0 && p.t_out == p.M;
     const int m0w = m0 + wm * WM, n0w = n0 + wn * WN;
-#define SC_EPI(ACT)                                                                               \
-    do {                                                                                          \
-        if (p.res) epilogue<TM, TN, WM, WN, ACT, true>(p, acc, m0w, n0w, lane, out_off, plain_rows); \
-        else epilogue<TM, TN, WM, WN, ACT, false>(p, acc, m0w, n0w, lane, out_off, plain_rows);    \
+    // epilogue through LDS (the last barrier of the K loop has retired every LDS read of the tile)
+    float* ep = reinterpret_cast<float*>(smem_all) + wave * (32 * EP_LD);
+#define SC_EPI(ACT)                                                                                             \
+    do {                                                                                                        \
+        if (p.res) epilogue_lds<TM, TN, WN, EP_LD, ACT, true>(p, acc, ep, m0w, n0w, lane, out_off, plain_rows);  \
+        else epilogue_lds<TM, TN, WN, EP_LD, ACT, false>(p, acc, ep, m0w, n0w, lane, out_off, plain_rows);       \
     } while (0)
     if (p.act == ACT_NONE) SC_EPI(ACT_NONE);
     else if (p.act == ACT_RELU) SC_EPI(ACT_RELU);
