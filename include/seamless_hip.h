@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 2
+#define SC_ABI_VERSION 3
 #define SC_MAX_UPSAMPLES 8
 #define SC_MAX_RESBLOCK_KERNELS 4
 #define SC_MAX_RESBLOCK_DILATIONS 4
@@ -85,7 +85,7 @@ typedef struct sc_config {
 } sc_config;
 
 /* Text generation options: the fields of SequenceGeneratorOptions
- * (inference/generator.py:59-84) that the greedy path honours. */
+ * (inference/generator.py:59-84) that the HIP path honours. */
 typedef struct sc_gen_opts {
     int32_t beam_size;        /* 1: greedy arg-max with a graph-captured step; 2..8: beam search (host-driven steps) */
     float soft_max_seq_len_a; /* max_len = min(hard, int(a*S_src) + b), prefix included */
@@ -96,6 +96,11 @@ typedef struct sc_gen_opts {
     int32_t use_graph; /* replay the decoder step from a captured hipGraph (greedy only) */
     float len_penalty;        /* beam search: hypothesis score / (len)^len_penalty (generator.py:81-84) */
     int32_t normalize_scores; /* beam search: apply the length normalisation (fairseq2 default: true) */
+    /* SequenceGeneratorOptions.step_processor = NGramRepeatBlockProcessor(ngram_size) (generator.py:75,
+     * cli/m4t/predict/predict.py:172-175): 0 = none; G > 0: a token that would complete a G-gram already
+     * present in the row's sequence (prompt included) gets log-probability -inf.  Runs the host-driven
+     * step loop for every beam_size (1 included). */
+    int32_t no_repeat_ngram_size;
 } sc_gen_opts;
 
 typedef struct sc_model sc_model;
@@ -179,6 +184,11 @@ int sc_vocode(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, c
 int sc_prof_enable(int on);
 int sc_prof_reset(void);
 int64_t sc_prof_report(char* buf, int64_t cap);
+
+/* Host logic of the n-gram step processor (no device work; callable without a GPU): the tokens
+ * NGramRepeatBlockProcessor(ngram_size) blocks after the `len` tokens of `h_seq`.  Writes at most `cap`
+ * of them to h_out (in window order, duplicates kept) and returns how many there are, or a negative status. */
+int32_t sc_ngram_blocked_tokens(const int32_t* h_seq, int32_t len, int32_t ngram_size, int32_t* h_out, int32_t cap);
 
 /* Kernel-level entry points used by the parity tests (tests/test_ops_gpu.py).
  * All pointers are device pointers; weights fp16, activations fp32. */

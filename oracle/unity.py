@@ -321,11 +321,31 @@ def greedy_generate(
     return (out, margins) if return_margins else out
 
 
+def ngram_repeat_block(seqs: Tensor, lprobs: Tensor, ngram_size: int) -> None:
+    """fairseq2 0.2 NGramRepeatBlockProcessor.__call__(seqs, probs, lprob=True), written as plain loops:
+    for every row, each window seqs[j:j+G] whose first G-1 tokens equal the row's last G-1 tokens blocks
+    its last token; G == 1 blocks every token seen; nothing happens while G >= S."""
+    rows, S = seqs.shape
+    G = ngram_size
+    if G >= S:
+        return
+    for r in range(rows):
+        row = seqs[r].tolist()
+        if G == 1:
+            for t in row:
+                lprobs[r, t] = -math.inf
+            continue
+        tail = row[S - G + 1 :]
+        for j in range(0, S - G + 1):
+            if row[j : j + G - 1] == tail:
+                lprobs[r, row[j + G - 1]] = -math.inf
+
+
 def beam_search_generate(
     P: Params, cfg, enc: Tensor, enc_lens: Tensor, prefix: Sequence[int], beam_size: int = 5,
     soft_max_seq_len: Tuple[float, int] = (1, 200), hard_max_seq_len: int = 1024, min_seq_len: int = 1,
     len_penalty: float = 1.0, unk_penalty: float = 0.0, normalize_scores: bool = True,
-    pos_table: Optional[Tensor] = None, return_all: bool = False,
+    pos_table: Optional[Tensor] = None, return_all: bool = False, no_repeat_ngram_size: int = 0,
 ):
     """BeamSearchSeq2SeqGenerator as the reference constructs it (inference/generator.py:147-156,
     beam_size=5 by default translator.py:311-313), restated from the in-tree C++ port of fairseq2's
@@ -338,6 +358,11 @@ def beam_search_generate(
         until `beam_size` beams are refilled; the search of an utterance ends when `beam_size`
         hypotheses are finished (:1546-1560); beams (sequences, scores, KV cache) are re-ordered;
       * hypotheses sorted by score, best first (:1597-1602).
+      * `no_repeat_ngram_size` = G > 0: SequenceGeneratorOptions.step_processor =
+        NGramRepeatBlockProcessor(G) (cli/m4t/predict/predict.py:172-175); the class is fairseq2 0.2's
+        (generation/step_processor.py, not under /root/reference — restated, parity unpinned): called on
+        seqs[:, :step+1] and the log-probabilities, it blocks every token that would complete a G-gram already in
+        the row (nothing while G >= the sequence length); not applied on the forced-EOS step.
     Uses log-probabilities throughout (the intent of the port; see tests/test_oracle_ggml_ref.py for what
     the compiled C++ actually does to them).  Ties between equal candidates: lower (beam, token) index.
     Returns the best hypothesis per utterance (and all finished ones with return_all)."""
@@ -378,6 +403,8 @@ def beam_search_generate(
             lprobs[:, cfg.pad_idx] = -math.inf
             if unk_penalty != 0:
                 lprobs[:, cfg.unk_idx] -= unk_penalty
+            if no_repeat_ngram_size > 0 and step_nr != max_len - 2:
+                ngram_repeat_block(seqs[:, : step_nr + 1], lprobs, no_repeat_ngram_size)
             if step_nr == start:
                 cand = lprobs[0:1] + (scores[0:1, step_nr : step_nr + 1] if step_nr > 0 else 0.0)
             else:

@@ -11,7 +11,7 @@ from typing import Optional
 
 LIB_PATH = Path(__file__).resolve().parent / "libseamless_hip.so"
 
-SC_ABI_VERSION = 2
+SC_ABI_VERSION = 3
 SC_MAX_UPSAMPLES = 8
 SC_MAX_RESBLOCK_KERNELS = 4
 SC_MAX_RESBLOCK_DILATIONS = 4
@@ -67,7 +67,7 @@ class sc_gen_opts(C.Structure):
     _fields_ = [
         ("beam_size", _i), ("soft_max_seq_len_a", C.c_float), ("soft_max_seq_len_b", _i),
         ("hard_max_seq_len", _i), ("min_seq_len", _i), ("unk_penalty", C.c_float), ("use_graph", _i),
-        ("len_penalty", C.c_float), ("normalize_scores", _i),
+        ("len_penalty", C.c_float), ("normalize_scores", _i), ("no_repeat_ngram_size", _i),
     ]
 
 
@@ -98,6 +98,7 @@ SIGNATURES = {
     "sc_prof_enable": (C.c_int, [C.c_int]),
     "sc_prof_reset": (C.c_int, []),
     "sc_prof_report": (C.c_int64, [C.c_char_p, C.c_int64]),
+    "sc_ngram_blocked_tokens": (C.c_int32, [_PI, C.c_int32, C.c_int32, _PI, C.c_int32]),
     "sc_op_force_general_gemm": (C.c_int, [C.c_int]),
     "sc_op_layernorm": (C.c_int, [_P, _P, _P, _P, _i, _i, _i]),
     "sc_op_linear": (C.c_int, [_P, _P, _P, _P, _P, _i, _i, _i, _i, C.c_float, _i, _i]),

@@ -213,6 +213,22 @@ int sc_prof_reset(void) {
 }
 int64_t sc_prof_report(char* buf, int64_t cap) { return (int64_t)sc::prof::report(buf, (size_t)(cap > 0 ? cap : 0)); }
 
+int32_t sc_ngram_blocked_tokens(const int32_t* h_seq, int32_t len, int32_t ngram_size, int32_t* h_out, int32_t cap) {
+    try {
+        SC_CHECK(len >= 0 && ngram_size >= 1 && cap >= 0 && (h_seq || len == 0) && (h_out || cap == 0),
+                 "sc_ngram_blocked_tokens: bad argument");
+        std::vector<int32_t> out;
+        sc::ngram_blocked_tokens(h_seq, len, ngram_size, out);
+        for (size_t i = 0; i < out.size() && i < (size_t)cap; ++i) h_out[i] = out[i];
+        return (int32_t)out.size();
+    } catch (const sc::Error& e) {
+        return e.code;
+    } catch (const std::exception& e) {
+        sc::set_error("unexpected C++ exception: %s", e.what());
+        return SC_ERR_INTERNAL;
+    }
+}
+
 // --------------------------------------------------------------------------- //
 // kernel-level entry points for the parity tests (default stream, synchronous)
 // --------------------------------------------------------------------------- //

@@ -8,6 +8,9 @@
 //   penalty), + the beam's cumulative score, then the best K = 2*beam candidates over the flattened
 //   (beam, token) space (first step: beam 0 only), best first, ties to the lower flattened index.
 //   HBM traffic: each logit row is read three times (max, sum, scan), L2 resident (1 MB per row).
+//   Step processor (NGramRepeatBlockProcessor): the host passes, per row, the tokens that would complete
+//   an n-gram already in the row's sequence (CSR: ban_off / ban_tok); they are overwritten with -inf in the
+//   logit row AFTER the row's log-sum-exp is known, i.e. the log-probability is blocked, not renormalised.
 // row_token_lprob_kernel: log-softmax value of ONE given token per row (scores of the echoed prompt).
 // gather_cache_kernel: K/V cache rows re-ordered by the surviving beams (all layers in one launch).
 #include "kernels.h"
@@ -38,11 +41,12 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
 
 __device__ __forceinline__ bool better(float v, int i, float w, int j) { return v > w || (v == w && i < j); }
 
-__global__ __launch_bounds__(256) void beam_candidates_kernel(const float* __restrict__ logits, int64_t ld, int beams, int V,
+__global__ __launch_bounds__(256) void beam_candidates_kernel(float* logits, int64_t ld, int beams, int V,
                                                               const float* __restrict__ cum, int first_step, int no_eos,
                                                               int force_eos, int pad_idx, int eos_idx, int unk_idx,
                                                               float unk_penalty, int K, float* __restrict__ cand_val,
-                                                              int* __restrict__ cand_idx) {
+                                                              int* __restrict__ cand_idx, const int* __restrict__ ban_off,
+                                                              const int* __restrict__ ban_tok) {
     __shared__ float red[4];
     __shared__ float lse[BEAM_MAX_K];
     __shared__ float s_val[256];
@@ -61,6 +65,14 @@ __global__ __launch_bounds__(256) void beam_candidates_kernel(const float* __res
         if (tid == 0) lse[b] = mx + logf(sm);
     }
     __syncthreads();
+    if (ban_off) {  // every thread is past its reads for the log-sum-exp (barrier above)
+        for (int b = 0; b < nb; ++b) {
+            float* row = logits + ((int64_t)n * beams + b) * ld;
+            const int r = n * beams + b;
+            for (int i = ban_off[r] + tid; i < ban_off[r + 1]; i += 256) row[ban_tok[i]] = -INFINITY;
+        }
+        __syncthreads();
+    }
     // per-thread best-K list, sorted best first
     float tv[BEAM_MAX_K];
     int ti[BEAM_MAX_K];
@@ -161,14 +173,14 @@ __global__ __launch_bounds__(256) void gather_cache_kernel(const float* __restri
 
 }  // namespace
 
-void launch_beam_candidates(const float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step,
+void launch_beam_candidates(float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step,
                             int no_eos, int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K,
-                            float* cand_val, int* cand_idx, hipStream_t s) {
+                            float* cand_val, int* cand_idx, const int* ban_off, const int* ban_tok, hipStream_t s) {
     SC_CHECK(K >= 1 && K <= BEAM_MAX_K && beams >= 1 && beams <= BEAM_MAX_K, "beam search: beam_size %d / K %d out of range (max %d candidates)",
              beams, K, BEAM_MAX_K);
     SC_CHECK((int64_t)beams * V < (1ll << 31) - 1, "beam search: beam * vocabulary overflows the candidate index");
     hipLaunchKernelGGL(beam_candidates_kernel, dim3(n_utt), dim3(256), 0, s, logits, ld, beams, V, cum, first_step, no_eos, force_eos,
-                       pad_idx, eos_idx, unk_idx, unk_penalty, K, cand_val, cand_idx);
+                       pad_idx, eos_idx, unk_idx, unk_penalty, K, cand_val, cand_idx, ban_off, ban_tok);
     SC_LAUNCH_CHECK();
 }
 

@@ -193,9 +193,10 @@ void launch_decode_attention(const float* q, int64_t ldq, const float* k_new, co
                              const float* bias_k = nullptr, const float* bias_v = nullptr);
 
 // beam search (k_beam.hip)
-void launch_beam_candidates(const float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step,
+// ban_off [n_utt*beams+1] / ban_tok: per-row tokens blocked by the step processor (null = none); logits is modified
+void launch_beam_candidates(float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step,
                             int no_eos, int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K,
-                            float* cand_val, int* cand_idx, hipStream_t s);
+                            float* cand_val, int* cand_idx, const int* ban_off, const int* ban_tok, hipStream_t s);
 void launch_row_token_lprob(const float* logits, int64_t ld, int rows, int V, int row_stride, int token, float* out, hipStream_t s);
 void launch_gather_cache(const float* src, float* dst, const int* src_row, int rows, int len, int cap, int M, int layers,
                          int64_t layer_stride, hipStream_t s);

@@ -196,6 +196,7 @@ int encoder_out_len(const Model& m, int t_frames);
 void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, const int32_t* h_lens, float* d_out,
                        int32_t* h_out_lens);
 int text_max_len(const Model& m, const sc_gen_opts& o, int s_enc);
+void ngram_blocked_tokens(const int32_t* seq, int S, int G, std::vector<int32_t>& out);
 void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens,
                        const sc_gen_opts& o, const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids,
                        int32_t* h_out_lens, float* h_scores, float* d_dec_hidden, const int32_t* h_forced_tokens,

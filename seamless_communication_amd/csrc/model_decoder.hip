@@ -206,7 +206,8 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
         max_len = forced_len + 1;  // hidden buffer has max_len-1 = forced_len rows
     } else {
         SC_CHECK(o.beam_size >= 1, "sc_generate_text: beam_size=%d", o.beam_size);
-        if (o.beam_size > 1) {
+        SC_CHECK(o.no_repeat_ngram_size >= 0, "sc_generate_text: no_repeat_ngram_size=%d", o.no_repeat_ngram_size);
+        if (o.beam_size > 1 || o.no_repeat_ngram_size > 0) {  // step processors run in the host-driven step loop
             run_generate_text_beam(m, d_enc, n, s_enc, h_enc_lens, o, h_prefix, prefix_len, h_out_ids, h_out_lens, h_scores,
                                    d_dec_hidden);
             return;
@@ -360,7 +361,23 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
 // best 2*beam candidates per utterance), then the host walks the candidates (finalise EOS hypotheses,
 // refill the beams), and the K/V caches are re-ordered on the device (double buffered, all layers in one
 // launch).  One host round trip per step; not graph-captured (the beam bookkeeping lives on the host).
+// Step processor: NGramRepeatBlockProcessor(G) (fairseq2 0.2 generation/step_processor.py, not under
+// /root/reference; call site cli/m4t/predict/predict.py:172-175) — see ngram_blocked_tokens below.
 // --------------------------------------------------------------------------------------------- //
+// Tokens the n-gram processor blocks for one row: seq = the row's sequence so far (prompt included, S tokens).
+// G >= S: nothing.  G == 1: every token of seq.  Otherwise every window seq[j..j+G) (j = 0..S-G) whose first
+// G-1 tokens equal the last G-1 tokens of seq contributes its last token.
+void ngram_blocked_tokens(const int32_t* seq, int S, int G, std::vector<int32_t>& out) {
+    if (G <= 0 || G >= S) return;
+    if (G == 1) {
+        out.insert(out.end(), seq, seq + S);
+        return;
+    }
+    const int32_t* tail = seq + S - (G - 1);
+    for (int j = 0; j + G <= S; ++j)
+        if (std::equal(seq + j, seq + j + G - 1, tail)) out.push_back(seq[j + G - 1]);
+}
+
 void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens, const sc_gen_opts& o,
                             const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids, int32_t* h_out_lens, float* h_scores,
                             float* d_dec_hidden) {
@@ -464,6 +481,9 @@ void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, cons
     std::vector<char> done(n, 0);
     std::vector<float> cand_val((size_t)n * K), pref(n);
     std::vector<int32_t> cand_idx((size_t)n * K);
+    const int G = o.no_repeat_ngram_size;
+    std::vector<int32_t> ban_off, ban_tok;
+    Buf<int> d_ban(&m.pool, G > 0 ? (size_t)(nb + 1) + (size_t)nb * max_len : 1);  // offsets, then tokens (<= S per row)
 
     // ---- prompt echo: feed prefix[:-1]; scores[i] = sum_{j<=i} lprob(prefix[j] | prefix[<j]) ---------
     for (int t = 0; t + 1 < prefix_len; ++t) {
@@ -488,8 +508,23 @@ void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, cons
         linear(m, c.hN, M, proj, nullptr, 0, c.logits, V, nb, ACT_NONE, 1.f);
         for (int r = 0; r < nb; ++r) cum[r] = scores[(size_t)r * max_len + step];
         SC_HIP(hipMemcpyAsync(d_cum.get(), cum.data(), (size_t)nb * 4, hipMemcpyHostToDevice, m.stream));
+        const int* d_ban_off = nullptr;
+        if (G > 0 && step != max_len - 2) {  // not on the forced-EOS step: blocking EOS there would leave no hypothesis
+            ban_off.assign(1, 0);
+            ban_tok.clear();
+            for (int r = 0; r < nb; ++r) {
+                if (!done[r / B]) ngram_blocked_tokens(&seqs[(size_t)r * max_len], step + 1, G, ban_tok);
+                ban_off.push_back((int32_t)ban_tok.size());
+            }
+            if (!ban_tok.empty()) {
+                d_ban_off = d_ban.get();
+                SC_HIP(hipMemcpyAsync(d_ban.get(), ban_off.data(), ban_off.size() * 4, hipMemcpyHostToDevice, m.stream));
+                SC_HIP(hipMemcpyAsync(d_ban.get() + nb + 1, ban_tok.data(), ban_tok.size() * 4, hipMemcpyHostToDevice, m.stream));
+            }
+        }
         launch_beam_candidates(c.logits, V, n, B, V, d_cum, step == start, step < o.min_seq_len, step == max_len - 2, cfg.pad_idx,
-                               cfg.eos_idx, cfg.unk_idx, o.unk_penalty, K, d_cand_val, d_cand_idx, m.stream);
+                               cfg.eos_idx, cfg.unk_idx, o.unk_penalty, K, d_cand_val, d_cand_idx, d_ban_off,
+                               d_ban.get() + nb + 1, m.stream);
         SC_HIP(hipMemcpyAsync(cand_val.data(), d_cand_val.get(), cand_val.size() * 4, hipMemcpyDeviceToHost, m.stream));
         SC_HIP(hipMemcpyAsync(cand_idx.data(), d_cand_idx.get(), cand_idx.size() * 4, hipMemcpyDeviceToHost, m.stream));
         SC_HIP(hipStreamSynchronize(m.stream));

@@ -1,4 +1,4 @@
-from .generator import SequenceGeneratorOptions
+from .generator import NGramRepeatBlockProcessor, SequenceGeneratorOptions
 from .translator import BatchedSpeechOutput, Modality, Task, Translator
 
-__all__ = ["BatchedSpeechOutput", "Modality", "SequenceGeneratorOptions", "Task", "Translator"]
+__all__ = ["BatchedSpeechOutput", "Modality", "NGramRepeatBlockProcessor", "SequenceGeneratorOptions", "Task", "Translator"]

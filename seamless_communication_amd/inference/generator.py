@@ -7,6 +7,40 @@ from dataclasses import dataclass
 from typing import Any, Optional, Tuple
 
 
+class NGramRepeatBlockProcessor:
+    """The step processor the reference's CLI installs for ``--text_generation_ngram_blocking``
+    (cli/m4t/predict/predict.py:172-175; class from fairseq2 0.2 ``fairseq2.generation`` — not under
+    /root/reference, restated from its published behaviour: parity unpinned).
+
+    Called with ``seqs`` (rows, S) = the sequences generated so far (prompt included) and ``probs``
+    (rows, V): every token that would complete an n-gram already present in its row is blocked
+    (``-inf`` for log-probabilities, ``0`` for probabilities).  On the HIP path only ``ngram_size`` is
+    read (``sc_gen_opts.no_repeat_ngram_size``); ``__call__`` is the host restatement for other callers.
+    """
+
+    def __init__(self, ngram_size: int) -> None:
+        if ngram_size <= 0:
+            raise ValueError("`ngram_size` must be greater than 0.")
+        self.ngram_size = int(ngram_size)
+
+    def __call__(self, seqs, probs, lprob: bool = False) -> None:
+        import torch
+
+        g = self.ngram_size
+        rows, seq_len = seqs.shape
+        if g >= seq_len:
+            return
+        fill = -torch.inf if lprob else 0.0
+        if g == 1:
+            probs.scatter_(1, seqs.to(torch.int64), fill)
+            return
+        windows = seqs.unfold(1, g, 1)  # (rows, S-g+1, g)
+        tail = seqs[:, seq_len - g + 1:]  # (rows, g-1)
+        for r in range(rows):
+            hit = (windows[r, :, :-1] == tail[r]).all(dim=1)
+            probs[r, windows[r, hit, -1].to(torch.int64)] = fill
+
+
 @dataclass
 class SequenceGeneratorOptions:
     """Holds the options to pass to a sequence generator."""

@@ -31,7 +31,7 @@ from .. import synthetic as _syn
 from ..config import S2STConfig, seamless_m4t_v2_large, tiny_config
 from ..runtime import HipS2STModel
 from ..tokenizer import CharTokenizer, NllbTextTokenizer, UnitTokenizer
-from .generator import SequenceGeneratorOptions
+from .generator import NGramRepeatBlockProcessor, SequenceGeneratorOptions
 
 logger = logging.getLogger(__name__)
 
@@ -249,8 +249,11 @@ class Translator:
             text_generation_opts = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(1, 200))
         if not 1 <= text_generation_opts.beam_size <= 8:
             raise ValueError("beam_size must be in [1, 8] on the HIP path")
+        ngram = 0
         if text_generation_opts.step_processor is not None:
-            raise NotImplementedError("step processors are not implemented on the HIP path")
+            if not isinstance(text_generation_opts.step_processor, NGramRepeatBlockProcessor):
+                raise NotImplementedError("the HIP path runs NGramRepeatBlockProcessor step processors only")
+            ngram = text_generation_opts.step_processor.ngram_size
 
         want_speech = output_modality == Modality.SPEECH
         # every sc_* stage call returns with its stream drained, so host timers are stage times
@@ -265,6 +268,7 @@ class Translator:
             soft_max_seq_len=text_generation_opts.soft_max_seq_len,
             hard_max_seq_len=text_generation_opts.hard_max_seq_len,
             unk_penalty=text_generation_opts.unk_penalty,
+            no_repeat_ngram_size=ngram,
             use_graph=self.use_graph,
             want_hidden=want_speech,
         )

@@ -45,3 +45,71 @@ def test_beam_score_is_sum_of_step_lprobs_normalised():
     total = sum(float(lp[i, seq[i + 1]]) for i in range(len(seq) - 1))
     # the last step is the forced EOS (all other tokens masked): its tweaked log-prob is the plain one
     assert abs(total / (len(seq) - 1) - every[0][0][0]) < 1e-4
+
+
+# --------------------------------------------------------------------------- #
+# step processor: NGramRepeatBlockProcessor (cli/m4t/predict/predict.py:172-175)
+# --------------------------------------------------------------------------- #
+def _has_repeated_ngram(seq, g):
+    grams = [tuple(seq[i : i + g]) for i in range(len(seq) - g + 1)]
+    return len(grams) != len(set(grams))
+
+
+def test_ngram_block_three_statements_agree():
+    """oracle loops == the vectorised processor shipped in the package == the C-ABI host logic."""
+    import ctypes as C
+
+    import numpy as np
+
+    from seamless_communication_amd import _lib
+    from seamless_communication_amd.inference import NGramRepeatBlockProcessor
+
+    lib = _lib.load_library()  # dlopen only: the entry point below does no device work
+    g = torch.Generator().manual_seed(11)
+    for G in (1, 2, 3, 4):
+        for S in (1, 2, 3, 4, 5, 9, 17):
+            seqs = torch.randint(0, 4, (6, S), generator=g)  # small alphabet: many repeats
+            a = torch.zeros(6, 7)
+            b = torch.zeros(6, 7)
+            ou.ngram_repeat_block(seqs, a, G)
+            NGramRepeatBlockProcessor(G)(seqs, b, lprob=True)
+            assert torch.equal(a, b), (G, S)
+            for r in range(6):
+                row = np.ascontiguousarray(seqs[r].numpy().astype(np.int32))
+                out = np.zeros(S + 1, dtype=np.int32)
+                cnt = lib.sc_ngram_blocked_tokens(row.ctypes.data_as(C.POINTER(C.c_int32)), S, G,
+                                                  out.ctypes.data_as(C.POINTER(C.c_int32)), S + 1)
+                assert cnt >= 0
+                want = sorted(set(torch.nonzero(a[r] == -math.inf).flatten().tolist()))
+                assert sorted(set(out[:cnt].tolist())) == want, (G, S, r)
+    c = torch.ones(2, 5)
+    NGramRepeatBlockProcessor(1)(torch.tensor([[1, 2], [3, 3]]), c)  # probabilities: blocked = 0
+    assert c.tolist() == [[1, 0, 0, 1, 1], [1, 1, 1, 0, 1]]
+
+
+def test_ngram_block_known_cases():
+    lp = torch.zeros(1, 10)
+    ou.ngram_repeat_block(torch.tensor([[5, 6, 7, 5, 6]]), lp, 3)  # "5 6" seen before, followed by 7
+    assert torch.nonzero(lp[0] == -math.inf).flatten().tolist() == [7]
+    lp = torch.zeros(1, 10)
+    ou.ngram_repeat_block(torch.tensor([[4, 4, 4]]), lp, 2)  # "4" followed by 4 (twice)
+    assert torch.nonzero(lp[0] == -math.inf).flatten().tolist() == [4]
+    lp = torch.zeros(1, 10)
+    ou.ngram_repeat_block(torch.tensor([[1, 2, 3]]), lp, 3)  # G >= S: untouched
+    assert not torch.isinf(lp).any()
+
+
+def test_beam_search_with_ngram_blocking_has_no_repeats():
+    cfg, P, enc, lens, pre = _setup(n=2)
+    for beam in (1, 4):
+        plain = ou.beam_search_generate(P, cfg, enc, lens, pre, beam, hard_max_seq_len=14)
+        for G in (1, 2, 3):
+            blocked, every = ou.beam_search_generate(P, cfg, enc, lens, pre, beam, hard_max_seq_len=14, no_repeat_ngram_size=G,
+                                                     return_all=True)
+            for p, b, hyps in zip(plain, blocked, every):
+                for _, seq in hyps:
+                    # the final token may be the forced EOS of the length limit (processor not applied there)
+                    body = seq[:-1] if len(seq) == 14 else seq
+                    assert not _has_repeated_ngram(body, G), (beam, G, seq)
+                if beam == 1 and not _has_repeated_ngram(p, G):
+                    assert b == p  # nothing to block on the path of a greedy search

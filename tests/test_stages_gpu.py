@@ -261,3 +261,59 @@ def test_beam_size_one_equals_greedy(env):
                            pos_table=orc.pos_table)
     ids, out_lens, _, _ = hip.generate_text(enc, enc_lens.tolist(), prefix, beam_size=1, hard_max_seq_len=11)
     assert a == b == [ids[0, : out_lens[0]].tolist()]
+
+
+@pytest.mark.parametrize("beam,ngram,hard_max", [(1, 2, 14), (1, 1, 9), (4, 2, 14), (5, 3, 16), (3, 1, 10)])
+def test_ngram_block_step_processor_matches_oracle(env, report_dir, beam, ngram, hard_max):
+    """SequenceGeneratorOptions.step_processor = NGramRepeatBlockProcessor(G) (cli/m4t/predict/predict.py:172-175):
+    ids exact against the oracle's beam search with the same processor, for greedy (beam 1, which leaves the
+    graph-captured step for the host-driven loop) and beam search; the unconstrained tiny model repeats itself,
+    so the processor changes the result."""
+    from oracle import unity as ou
+
+    cfg, tt, ct, orc, hip = env
+    fb, lens = orc.collate_fbank(common.waves((2.0, 1.37, 0.9)))
+    enc, enc_lens = hip.encode_speech(fb.cuda(), lens.tolist())
+    prefix = tt.target_prefix("fra")
+    el = torch.from_numpy(enc_lens.astype(np.int64))
+    want, every = ou.beam_search_generate(orc.P, cfg, enc.cpu(), el, prefix, beam, hard_max_seq_len=hard_max, pos_table=orc.pos_table,
+                                          return_all=True, no_repeat_ngram_size=ngram)
+    plain = ou.beam_search_generate(orc.P, cfg, enc.cpu(), el, prefix, beam, hard_max_seq_len=hard_max, pos_table=orc.pos_table)
+    ids, out_lens, scores, hidden = hip.generate_text(enc, enc_lens.tolist(), prefix, beam_size=beam, hard_max_seq_len=hard_max,
+                                                      no_repeat_ngram_size=ngram)
+    got = [ids[b, : out_lens[b]].tolist() for b in range(len(want))]
+    _log(report_dir, "ngram_block", beam=beam, ngram=ngram, got=got, want=want, unconstrained=plain)
+    assert got == want
+    for b in range(len(want)):
+        assert abs(float(scores[b]) - every[b][0][0]) < 2e-4
+    L = max(len(s) for s in want) - 1
+    toks = np.full((len(want), L), cfg.pad_idx, dtype=np.int32)
+    for b, s in enumerate(want):
+        toks[b, : len(s) - 1] = s[:-1]
+    forced = hip.decode_text(enc, enc_lens.tolist(), toks)
+    for b, s in enumerate(want):
+        assert float((hidden[b, : len(s) - 1] - forced[b, : len(s) - 1]).abs().max()) < 1e-5
+
+
+def test_translator_accepts_ngram_step_processor():
+    """Translator.predict with text_generation_opts.step_processor set (the reference CLI's
+    --text_generation_ngram_blocking): same text ids as the stage-level call; other processors are refused."""
+    from seamless_communication_amd.inference import NGramRepeatBlockProcessor, SequenceGeneratorOptions
+
+    from seamless_communication_amd.inference import Translator
+    from seamless_communication_amd.inference.translator import DEFAULT_CARDS
+
+    card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch="tiny_v2")
+    tr = Translator(card, None, device=torch.device("cuda", 0), output_modality=None)
+    wav = torch.from_numpy(common.waves((1.5,))[0])
+    opts = SequenceGeneratorOptions(beam_size=3, soft_max_seq_len=(0, 12), step_processor=NGramRepeatBlockProcessor(2))
+    tr.predict(wav, "S2TT", "fra", text_generation_opts=opts)
+    blocked = tr.last_text_ids[0]
+    tr.predict(wav, "S2TT", "fra", text_generation_opts=SequenceGeneratorOptions(beam_size=3, soft_max_seq_len=(0, 12)))
+    plain = tr.last_text_ids[0]
+    grams = [tuple(blocked[i : i + 2]) for i in range(len(blocked) - 1)]
+    body = grams[:-1] if len(blocked) == 12 else grams
+    assert len(body) == len(set(body)), blocked
+    assert blocked != plain or len(set(grams)) == len(grams)
+    with pytest.raises(NotImplementedError):
+        tr.predict(wav, "S2TT", "fra", text_generation_opts=SequenceGeneratorOptions(beam_size=1, step_processor=object()))
