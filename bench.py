@@ -214,12 +214,13 @@ def main():
     from seamless_communication_amd import cards, synthetic as syn
     from seamless_communication_amd.distributed import MicroBatcher, all_gather_ragged_ids
     from seamless_communication_amd.inference import SequenceGeneratorOptions, Translator
-    from seamless_communication_amd.inference.translator import DEFAULT_CARDS
+    from seamless_communication_amd.inference.translator import DEFAULT_CARDS, Modality
 
     log(f"rank {rank}/{world}: building weights + loading the model ...")
     t_load = time.perf_counter()
     card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch=args.arch)
-    translator = Translator(card, "vocoder_v2", device=device)
+    # speech input only: like the reference (translator.py:100-102) this skips the NLLB text encoder of T2TT/T2ST
+    translator = Translator(card, "vocoder_v2", device=device, input_modality=Modality.SPEECH)
     translator.use_graph = not args.no_graph
     model = translator.model
     cfg = translator.cfg

@@ -82,6 +82,8 @@ typedef struct sc_config {
     int32_t voc_num_embeddings, voc_embedding_dim, voc_lang_embedding_dim, voc_num_langs;
     int32_t voc_spkr_embedding_dim, voc_num_spkrs;
     int32_t has_t2u, has_vocoder;
+    /* NLLB text encoder of the text-input tasks (T2TT / T2ST; builder.py:169-173, :430-434): 0 layers = not loaded */
+    int32_t text_enc_layers, text_enc_ffn_dim;
 } sc_config;
 
 /* Text generation options: the fields of SequenceGeneratorOptions
@@ -150,6 +152,12 @@ int sc_encode_speech(sc_model* m, const float* d_fbank, int32_t n, int32_t t_fra
  * d_dec_hidden != NULL it receives the decoder output (after the final
  * LayerNorm) of every fed position: [n][max_len-1][model_dim] — the tensor the
  * reference recomputes with a second teacher-forced pass (generator.py:294-299). */
+/* Text input (T2TT / T2ST): UnitYModel.encode_text (models/unity/model.py:138-151) = the shared embedding
+ * frontend (embed * sqrt(model_dim) + sinusoidal positions from 0) and the pre-LN NLLB encoder stack + final
+ * LayerNorm.  h_tokens [n][s_text] (pad filled), h_lens the PaddingMask; d_enc_out [n][s_text][model_dim]
+ * feeds sc_generate_text with s_enc = s_text and h_enc_lens = h_lens. */
+int sc_encode_text(sc_model* m, const int32_t* h_tokens, int32_t n, int32_t s_text, const int32_t* h_lens, float* d_enc_out);
+
 int32_t sc_text_max_len(const sc_model* m, const sc_gen_opts* opts, int32_t s_enc);
 int sc_generate_text(sc_model* m, const float* d_enc, int32_t n, int32_t s_enc, const int32_t* h_enc_lens,
                      const sc_gen_opts* opts, const int32_t* h_prefix, int32_t prefix_len, int32_t* h_out_ids,

@@ -39,10 +39,33 @@ class OracleS2ST:
             out[i, : f.shape[0]] = f
         return out, lens
 
+    # translator.py:299-303: NLLB "source" tokens + Collater(pad_value=pad_idx, pad_to_multiple=2)
+    def collate_text(self, texts: Sequence[str], src_lang: str) -> Tuple[Tensor, Tensor]:
+        enc = self.text_tok.create_encoder(task="translation", lang=src_lang, mode="source")
+        ids = [enc(t) for t in texts]
+        lens = torch.tensor([len(i) for i in ids], dtype=torch.int64)
+        S = int(lens.max())
+        S += S % 2
+        out = torch.full((len(ids), S), self.cfg.pad_idx, dtype=torch.int64)
+        for b, i in enumerate(ids):
+            out[b, : len(i)] = i
+        return out, lens
+
     @torch.inference_mode()
     def s2tt(self, fbank: Tensor, lens: Tensor, tgt_lang: str, soft_max_seq_len=(1, 200),
              hard_max_seq_len: int = 1024, beam_size: int = 1):
         enc, enc_lens = ou.encode_speech(self.P, self.cfg, fbank, lens)
+        return self._text_from_encoder(enc, enc_lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size)
+
+    @torch.inference_mode()
+    def t2tt(self, tokens: Tensor, lens: Tensor, tgt_lang: str, soft_max_seq_len=(1, 200),
+             hard_max_seq_len: int = 1024, beam_size: int = 1):
+        """Text input (UnitYModel.encode_text, models/unity/model.py:138-151) -> the same generation."""
+        enc = ou.encode_text(self.P, self.cfg, tokens, lens, self.pos_table)
+        return self._text_from_encoder(enc, lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size)
+
+    def _text_from_encoder(self, enc: Tensor, enc_lens: Tensor, tgt_lang: str, soft_max_seq_len, hard_max_seq_len: int,
+                           beam_size: int):
         prefix = self.text_tok.target_prefix(tgt_lang)
         if beam_size > 1:
             seqs = ou.beam_search_generate(self.P, self.cfg, enc, enc_lens, prefix, beam_size, soft_max_seq_len,
@@ -58,8 +81,19 @@ class OracleS2ST:
     def s2st(self, fbank: Tensor, lens: Tensor, tgt_lang: str, soft_max_seq_len=(1, 200),
              hard_max_seq_len: int = 1024, duration_factor: float = 1.0, spkr: int = -1,
              vocode: bool = True, beam_size: int = 1):
-        cfg = self.cfg
         seqs, enc, enc_lens, margins = self.s2tt(fbank, lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size)
+        return self._speech_from_text(seqs, enc, enc_lens, margins, tgt_lang, duration_factor, spkr, vocode)
+
+    @torch.inference_mode()
+    def t2st(self, tokens: Tensor, lens: Tensor, tgt_lang: str, soft_max_seq_len=(1, 200),
+             hard_max_seq_len: int = 1024, duration_factor: float = 1.0, spkr: int = -1,
+             vocode: bool = True, beam_size: int = 1):
+        seqs, enc, enc_lens, margins = self.t2tt(tokens, lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size)
+        return self._speech_from_text(seqs, enc, enc_lens, margins, tgt_lang, duration_factor, spkr, vocode)
+
+    def _speech_from_text(self, seqs, enc: Tensor, enc_lens: Tensor, margins, tgt_lang: str, duration_factor: float,
+                          spkr: int, vocode: bool):
+        cfg = self.cfg
         # generator.py:281-291: pad_seqs + trim the final EOS column
         L = max(len(s) for s in seqs)
         text_seqs = torch.full((len(seqs), L), cfg.pad_idx, dtype=torch.int64)

@@ -206,6 +206,21 @@ def embed_text(P: Params, cfg, tokens: Tensor, start: int, pos_table: Tensor) ->
     return e + pos_table[start : start + tokens.shape[1]][None]
 
 
+def encode_text(P: Params, cfg, tokens: Tensor, lens: Optional[Tensor], pos_table: Tensor) -> Tensor:
+    """UnitYModel.encode_text (models/unity/model.py:138-151): `text_encoder_frontend` — the SAME module as the
+    decoder's frontend (builder.py:443-446; embedding shared by loader.py:150-153) — then the NLLB encoder:
+    pre-LN StandardTransformerEncoder layers + final LayerNorm (ggml/examples/unity/fairseq2.cpp:955-977, the
+    function tests/test_oracle_ggml_ref.py executes), key padding mask from `lens`."""
+    x = F.embedding(tokens, P["text_encoder_frontend.embed.weight"]) * math.sqrt(cfg.model_dim)
+    x = x + pos_table[: tokens.shape[1]][None]
+    for i in range(cfg.text_enc_layers):
+        p = f"text_encoder.layers.{i}"
+        h = P.layer_norm(x, p + ".self_attn_layer_norm")
+        x = x + mha(P, p + ".self_attn", h, h, cfg.num_heads, key_lens=lens)
+        x = x + ffn(P, p + ".ffn", P.layer_norm(x, p + ".ffn_layer_norm"), "relu")
+    return P.layer_norm(x, "text_encoder.layer_norm")
+
+
 def decoder_layer(
     P: Params, cfg, prefix: str, x: Tensor, enc: Tensor, enc_lens: Optional[Tensor],
     self_kv: Optional[Tensor] = None, self_lens: Optional[Tensor] = None,

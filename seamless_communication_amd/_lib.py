@@ -60,6 +60,7 @@ class sc_config(C.Structure):
         ("voc_num_embeddings", _i), ("voc_embedding_dim", _i), ("voc_lang_embedding_dim", _i), ("voc_num_langs", _i),
         ("voc_spkr_embedding_dim", _i), ("voc_num_spkrs", _i),
         ("has_t2u", _i), ("has_vocoder", _i),
+        ("text_enc_layers", _i), ("text_enc_ffn_dim", _i),
     ]
 
 
@@ -87,6 +88,7 @@ SIGNATURES = {
     "sc_fbank": (C.c_int, [_P, _P, _i, C.c_int64, _P, _i, _P, _i, _P]),
     "sc_encoder_out_len": (_i, [_P, _i]),
     "sc_encode_speech": (C.c_int, [_P, _P, _i, _i, _P, _P, _P]),
+    "sc_encode_text": (C.c_int, [_P, _PI, C.c_int32, C.c_int32, _PI, _P]),
     "sc_text_max_len": (_i, [_P, C.POINTER(sc_gen_opts), _i]),
     "sc_generate_text": (C.c_int, [_P, _P, _i, _i, _P, C.POINTER(sc_gen_opts), _P, _i, _P, _P, _P, _P]),
     "sc_decode_text": (C.c_int, [_P, _P, _i, _i, _P, _P, _i, _P]),
@@ -146,7 +148,7 @@ def check(status: int, what: str) -> None:
         raise SeamlessHipError(f"{what} failed with status {status}: {msg.decode() if msg else '?'}")
 
 
-def make_config(cfg, has_t2u: bool = True, has_vocoder: bool = True) -> sc_config:
+def make_config(cfg, has_t2u: bool = True, has_vocoder: bool = True, has_text_encoder: bool = False) -> sc_config:
     c = sc_config()
     c.abi_version = SC_ABI_VERSION
     for f in (
@@ -182,4 +184,6 @@ def make_config(cfg, has_t2u: bool = True, has_vocoder: bool = True) -> sc_confi
     c.voc_num_spkrs = v.num_spkrs
     c.has_t2u = int(has_t2u)
     c.has_vocoder = int(has_vocoder)
+    c.text_enc_layers = int(cfg.text_enc_layers) if has_text_encoder else 0
+    c.text_enc_ffn_dim = int(cfg.text_enc_ffn_dim)
     return c

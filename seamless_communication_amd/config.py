@@ -8,8 +8,8 @@ Field values of :func:`seamless_m4t_v2_large` restate the reference configs
 * ``base_nar`` T2U arch                  models/unity/t2u_builder.py:186-232
 * vocoder ``base`` arch                  models/vocoder/builder.py:42-64
 
-Only the S2ST path is described (speech in -> text -> units -> waveform); the
-text encoder that the reference builds for T2TT is not part of it.
+The S2ST path is speech in -> text -> units -> waveform; the NLLB text encoder
+(``text_enc_*``) serves the text-input tasks (T2TT / T2ST) of the same API.
 """
 from __future__ import annotations
 
@@ -68,6 +68,10 @@ class S2STConfig:
     adaptor_ffn_dim: int = 4096  # = w2v2 ffn_inner_dim (builder.py:508)
     adaptor_proj_dim: int = 4096  # model_dim * 4 (adaptor_block.py:79-87)
 
+    # NLLB dense_1b text encoder (text-input tasks; builder.py:169-173 use_text_encoder=True)
+    text_enc_layers: int = 24
+    text_enc_ffn_dim: int = 8192
+
     # NLLB dense_1b text decoder
     dec_layers: int = 24
     dec_ffn_dim: int = 8192
@@ -123,6 +127,8 @@ def tiny_config() -> S2STConfig:
         depthwise_conv_kernel_size=31,
         adaptor_ffn_dim=256,
         adaptor_proj_dim=512,
+        text_enc_layers=2,
+        text_enc_ffn_dim=256,
         dec_layers=2,
         dec_ffn_dim=256,
         text_vocab_size=1200,

@@ -130,6 +130,14 @@ int sc_encode_speech(sc_model* m, const float* d_fbank, int32_t n, int32_t t_fra
     SC_API_END
 }
 
+int sc_encode_text(sc_model* m, const int32_t* h_tokens, int32_t n, int32_t s_text, const int32_t* h_lens, float* d_enc_out) {
+    SC_API_BEGIN
+    SC_CHECK(m && h_tokens && h_lens && d_enc_out, "sc_encode_text: null argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    run_encode_text(m->m, h_tokens, n, s_text, h_lens, d_enc_out);
+    SC_API_END
+}
+
 int32_t sc_text_max_len(const sc_model* m, const sc_gen_opts* opts, int32_t s_enc) {
     return (m && opts) ? text_max_len(m->m, *opts, s_enc) : -1;
 }

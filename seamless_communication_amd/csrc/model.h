@@ -139,6 +139,9 @@ struct ModelData {
     const float* text_pos = nullptr;     // [max_len][M]
     std::vector<DecoderLayer> dec;
     LNorm dec_final_ln;
+    // text encoder (text-input tasks; shares the embedding frontend with the decoder)
+    std::vector<EncoderLayer> text_enc;
+    LNorm text_enc_ln;
     // t2u
     std::vector<EncoderLayer> t2u_enc;
     LNorm t2u_enc_ln;
@@ -195,6 +198,7 @@ void run_fbank(Model& m, const float* d_wav, int n, int64_t wav_stride, const in
 int encoder_out_len(const Model& m, int t_frames);
 void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, const int32_t* h_lens, float* d_out,
                        int32_t* h_out_lens);
+void run_encode_text(Model& m, const int32_t* h_tokens, int n, int s_text, const int32_t* h_lens, float* d_out);
 int text_max_len(const Model& m, const sc_gen_opts& o, int s_enc);
 void ngram_blocked_tokens(const int32_t* seq, int S, int G, std::vector<int32_t>& out);
 void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens,

@@ -351,6 +351,21 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
     }
     m.dec_final_ln = L.ln("text_decoder.layer_norm", M);
 
+    // ---- text encoder (text-input tasks) --------------------------------------------
+    SC_CHECK(c.text_enc_layers >= 0, "sc_load: text_enc_layers=%d", c.text_enc_layers);
+    m.text_enc.resize(c.text_enc_layers);
+    for (int i = 0; i < c.text_enc_layers; ++i) {
+        const std::string p = "text_encoder.layers." + std::to_string(i);
+        EncoderLayer& l = m.text_enc[i];
+        l.attn_ln = L.ln(p + ".self_attn_layer_norm", M);
+        l.qkv = L.fuse({p + ".self_attn.q_proj", p + ".self_attn.k_proj", p + ".self_attn.v_proj"}, M, M);
+        l.attn_out = L.lin(p + ".self_attn.output_proj", M, M);
+        l.ffn_ln = L.ln(p + ".ffn_layer_norm", M);
+        l.ffn_in = L.lin(p + ".ffn.inner_proj", c.text_enc_ffn_dim, M);
+        l.ffn_out = L.lin(p + ".ffn.output_proj", M, c.text_enc_ffn_dim);
+    }
+    if (c.text_enc_layers > 0) m.text_enc_ln = L.ln("text_encoder.layer_norm", M);
+
     // ---- NAR T2U -------------------------------------------------------------------
     if (c.has_t2u) {
         m.t2u_enc.resize(c.t2u_enc_layers);

@@ -76,6 +76,44 @@ void text_to_char_seqs(const Model& m, const int32_t* text_seqs, int n, int s_te
 
 }  // namespace
 
+// UnitYModel.encode_text (models/unity/model.py:138-151): the embedding frontend the decoder also uses
+// (builder.py:443-446: one shared module; fairseq2.cpp:917-953) and the NLLB encoder = pre-LN
+// StandardTransformerEncoder layers + final LayerNorm (fairseq2.cpp:955-977), key padding mask from h_lens.
+void run_encode_text(Model& m, const int32_t* h_tokens, int n, int s_text, const int32_t* h_lens, float* d_out) {
+    const sc_config& c = m.cfg;
+    const int M = c.model_dim;
+    SC_CHECK(!m.text_enc.empty(), "sc_encode_text: the model was loaded without a text encoder");
+    SC_CHECK(n > 0 && s_text > 0, "sc_encode_text: empty batch");
+    SC_CHECK(s_text <= c.text_max_seq_len, "sc_encode_text: %d tokens exceed text_max_seq_len=%d", s_text, c.text_max_seq_len);
+    prof::set_tag("tenc");
+    const int rows = n * s_text;
+    for (int b = 0; b < n; ++b) {
+        SC_CHECK(h_lens[b] > 0 && h_lens[b] <= s_text, "sc_encode_text: lens[%d]=%d out of range", b, h_lens[b]);
+        for (int t = 0; t < s_text; ++t) {
+            const int32_t tok = h_tokens[(size_t)b * s_text + t];
+            SC_CHECK(tok >= 0 && tok < c.text_vocab_size, "sc_encode_text: token %d at [%d][%d] outside the vocabulary", tok, b, t);
+        }
+    }
+    Buf<int> d_tok(&m.pool, rows), d_lens(&m.pool, n);
+    SC_HIP(hipMemcpyAsync(d_tok.get(), h_tokens, (size_t)rows * 4, hipMemcpyHostToDevice, m.stream));
+    SC_HIP(hipMemcpyAsync(d_lens.get(), h_lens, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+    const int wideN = std::max(3 * M, c.text_enc_ffn_dim);
+    Buf<float> h(&m.pool, (size_t)rows * M), wide(&m.pool, (size_t)rows * wideN), att(&m.pool, (size_t)rows * M);
+    float* x = d_out;
+    launch_embed_tokens(d_tok, rows, m.text_embed, M, sqrtf((float)M), m.text_pos, nullptr, s_text, x, M, m.stream);
+    for (const EncoderLayer& l : m.text_enc) {
+        layernorm(m, x, l.attn_ln, h, rows);
+        linear(m, h, M, l.qkv, nullptr, 0, wide, 3 * M, rows, ACT_NONE, 1.f);
+        attention_self(m, wide, M, att, n, s_text, d_lens);
+        linear(m, att, M, l.attn_out, x, M, x, M, rows, ACT_NONE, 1.f);
+        layernorm(m, x, l.ffn_ln, h, rows);
+        linear(m, h, M, l.ffn_in, nullptr, 0, wide, c.text_enc_ffn_dim, rows, ACT_RELU, 1.f);
+        linear(m, wide, c.text_enc_ffn_dim, l.ffn_out, x, M, x, M, rows, ACT_NONE, 1.f);
+    }
+    layernorm(m, x, m.text_enc_ln, x, rows);
+    SC_HIP(hipStreamSynchronize(m.stream));  // h_tokens / h_lens are the caller's; outputs complete on return
+}
+
 void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const int32_t* h_text_lens,
                  const int32_t* h_text_seqs, float duration_factor, int32_t* h_unit_lens, int32_t* out_su,
                  int32_t* out_sc) {

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import logging
 import time
+from pathlib import Path
 from dataclasses import dataclass
 from enum import Enum, auto
 from typing import Any, Dict, List, Optional, Tuple, Union
@@ -88,19 +89,22 @@ def _resolve_card(name_or_card: Union[str, Dict[str, Any]]) -> Dict[str, Any]:
 
 
 def _load_state_dict(card: Dict[str, Any], cfg: S2STConfig, kind: str, with_t2u: bool,
-                     char_pieces: Optional[List[str]] = None) -> Dict[str, Tensor]:
+                     char_pieces: Optional[List[str]] = None, with_text_encoder: bool = False) -> Dict[str, Tensor]:
     uri = card.get("checkpoint", "")
     if uri.startswith("synthetic://"):
         seed = int(uri[len("synthetic://"):] or _syn.DEFAULT_SEED)
         if kind == "unity":
-            return _syn.make_unity_state_dict(cfg, seed, with_t2u=with_t2u)
+            return _syn.make_unity_state_dict(cfg, seed, with_t2u=with_t2u, with_text_encoder=with_text_encoder)
         return _syn.make_vocoder_state_dict(cfg, seed)
     if uri.startswith("file://"):
         from ..checkpoint import load_converted_checkpoint
 
         # fairseq-keyed checkpoints (what the model cards publish) are converted like the reference's
         # convert_unity_checkpoint / convert_vocoder_checkpoint do
-        return load_converted_checkpoint(uri[len("file://"):], kind, char_spm_tokens=char_pieces)
+        sd = load_converted_checkpoint(uri[len("file://"):], kind, char_spm_tokens=char_pieces)
+        if kind == "unity" and not with_text_encoder:  # translator.py:100-102: skip loading the text encoder
+            sd = {k: v for k, v in sd.items() if not k.startswith("text_encoder")}
+        return sd
     raise ValueError(
         f"card '{card.get('name')}': checkpoint '{uri}' is not reachable offline; use file://<path> or synthetic://<seed>"
     )
@@ -131,11 +135,11 @@ class Translator:
         self.device = dev
         # reference: dtype of weights (fp16 on GPU).  Activations are fp32 in HBM.
         self.dtype = dtype
-        if input_modality is not None and input_modality != Modality.SPEECH:
-            raise NotImplementedError("text input is outside the MI355X S2ST hot path")
+        # translator.py:97-106: the text encoder is skipped for input_modality=SPEECH, the T2U model for output TEXT
+        with_text_encoder = input_modality != Modality.SPEECH
         with_t2u = output_modality is None or output_modality == Modality.SPEECH
         self.char_tokenizer = CharTokenizer(self.cfg.char_vocab_size, card.get("char_tokenizer_path"))
-        unity_sd = _load_state_dict(card, self.cfg, "unity", with_t2u, self.char_tokenizer.pieces())
+        unity_sd = _load_state_dict(card, self.cfg, "unity", with_t2u, self.char_tokenizer.pieces(), with_text_encoder)
         langs = card.get("langs", _cards.TEXT_LANGS)
         self.text_tokenizer = text_tokenizer or NllbTextTokenizer(
             self.cfg.text_vocab_size, langs, card.get("default_lang", "eng"), card.get("tokenizer_path")
@@ -213,21 +217,22 @@ class Translator:
         src_text: Optional[StringLike] = None,
     ) -> Tuple[List[StringLike], Optional[BatchedSpeechOutput]]:
         input_modality, output_modality = self.get_modalities_from_task_str(task_str)
-        if input_modality != Modality.SPEECH:
-            if src_lang is None:
-                raise ValueError("src_lang must be specified for T2ST, T2TT tasks.")
-            raise NotImplementedError("text input (T2ST/T2TT) is outside the MI355X S2ST hot path")
         if prosody_encoder_input is not None:
             raise NotImplementedError("expressive (prosody) models are outside the MI355X S2ST hot path")
 
         if isinstance(input, dict):
             src = input
-        else:
+        elif input_modality == Modality.SPEECH:
             audio = input
             if isinstance(audio, str):
-                raise NotImplementedError(
-                    "audio file decoding needs libsndfile (not in this image); pass a waveform tensor or SequenceData"
-                )
+                # translator.py:270-273 decodes the file with fairseq2's AudioDecoder (libsndfile); here RIFF/WAVE
+                # (PCM16/PCM32/float32) and .npy are read with the standard library, first channel, 16 kHz only
+                from ..evaluate import load_audio
+
+                samples, rate = load_audio(Path(audio))
+                if rate != 16000:
+                    raise ValueError(f"{audio}: sample rate {rate} Hz; the fbank kernel is built for 16 kHz input")
+                audio = torch.from_numpy(samples)
             assert audio.dim() <= 2, "The audio tensor can't be more than 2 dimensions."
             if audio.dim() == 1:
                 audio = audio.unsqueeze(1)
@@ -235,15 +240,29 @@ class Translator:
                 logger.warning("Transposing audio tensor from (bsz, seq_len) -> (seq_len, bsz).")
                 audio = audio.transpose(0, 1)
             src = self._collate_audio(audio)
+        else:
+            if src_lang is None:
+                raise ValueError("src_lang must be specified for T2ST, T2TT tasks.")
+            text = input
+            assert isinstance(text, str)
+            # translator.py:299-303: NLLB "source" mode tokens, Collater(pad_value=pad_idx, pad_to_multiple=2)
+            self.token_encoder = self.text_tokenizer.create_encoder(task="translation", lang=src_lang, mode="source")
+            ids = self.token_encoder(text)
+            padded = torch.full((1, len(ids) + len(ids) % 2), self.text_tokenizer.vocab_info.pad_idx, dtype=torch.int64)
+            padded[0, : len(ids)] = ids
+            src = {"seqs": padded, "seq_lens": torch.tensor([len(ids)]), "is_ragged": False}
 
         seqs: Tensor = src["seqs"]
         seq_lens = src["seq_lens"]
-        if seqs.dim() != 3:
-            raise ValueError("SequenceData['seqs'] must be (N, T, num_fbank_channels)")
-        if seqs.shape[1] % self.cfg.fbank_stride:  # Collater(pad_to_multiple=2)
-            seqs = torch.nn.functional.pad(seqs, (0, 0, 0, self.cfg.fbank_stride - seqs.shape[1] % self.cfg.fbank_stride))
-        seqs = seqs.to(self.device, torch.float32).contiguous()
-        frame_lens = [int(x) for x in (seq_lens.tolist() if isinstance(seq_lens, Tensor) else seq_lens)]
+        src_lens = [int(x) for x in (seq_lens.tolist() if isinstance(seq_lens, Tensor) else seq_lens)]
+        if input_modality == Modality.SPEECH:
+            if seqs.dim() != 3:
+                raise ValueError("SequenceData['seqs'] must be (N, T, num_fbank_channels)")
+            if seqs.shape[1] % self.cfg.fbank_stride:  # Collater(pad_to_multiple=2)
+                seqs = torch.nn.functional.pad(seqs, (0, 0, 0, self.cfg.fbank_stride - seqs.shape[1] % self.cfg.fbank_stride))
+            seqs = seqs.to(self.device, torch.float32).contiguous()
+        elif seqs.dim() != 2 or seqs.dtype.is_floating_point:
+            raise ValueError("SequenceData['seqs'] must be (N, S) token indices for text input")
 
         if text_generation_opts is None:
             text_generation_opts = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(1, 200))
@@ -258,7 +277,10 @@ class Translator:
         want_speech = output_modality == Modality.SPEECH
         # every sc_* stage call returns with its stream drained, so host timers are stage times
         t0 = time.perf_counter()
-        enc, enc_lens = self.model.encode_speech(seqs, frame_lens)
+        if input_modality == Modality.SPEECH:
+            enc, enc_lens = self.model.encode_speech(seqs, src_lens)
+        else:
+            enc, enc_lens = self.model.encode_text(seqs.cpu().numpy(), src_lens), np.asarray(src_lens, dtype=np.int32)
         t1 = time.perf_counter()
         prefix = self.text_tokenizer.target_prefix(tgt_lang)
         ids, out_lens, _scores, hidden = self.model.generate_text(

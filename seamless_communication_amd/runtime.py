@@ -63,12 +63,13 @@ class HipS2STModel:
         if not torch.cuda.is_available():
             raise SeamlessHipError("no HIP device is visible; the HIP path has no CPU fallback")
         has_t2u = any(k.startswith("t2u_model.") for k in unity_state_dict)
+        self.has_text_encoder = any(k.startswith("text_encoder.layers.") for k in unity_state_dict)
         tensors: Dict[str, torch.Tensor] = {}
         for k, v in unity_state_dict.items():
             if k in ("final_proj.weight", "t2u_model.final_proj.weight"):
                 continue  # TiedProjection: same storage as the embedding (builder.py:451)
-            if k.startswith("text_encoder"):
-                continue  # not on the speech-input path (translator.py:97-101)
+            if k.startswith("text_encoder_frontend."):
+                continue  # the decoder's frontend module (builder.py:443-446): same embedding storage
             tensors[k] = v
         tensors["text_decoder_frontend.pos_encoder.freqs"] = sinusoidal_freqs(cfg.text_max_seq_len, cfg.model_dim, 1)
         if has_t2u:
@@ -95,7 +96,8 @@ class HipS2STModel:
                 d.shape[j] = s
             d.data = v.data_ptr()
             d.on_device = 1 if v.is_cuda else 0
-        ccfg = _lib.make_config(cfg, has_t2u=has_t2u, has_vocoder=vocoder_state_dict is not None)
+        ccfg = _lib.make_config(cfg, has_t2u=has_t2u, has_vocoder=vocoder_state_dict is not None,
+                                has_text_encoder=self.has_text_encoder)
         self.handle = self.lib.sc_load(descs, len(tensors), C.byref(ccfg), self.device_index)
         if not self.handle:
             msg = self.lib.sc_last_error()
@@ -116,6 +118,7 @@ class HipS2STModel:
             raise SeamlessHipError(f"sc_fork failed: {msg.decode() if msg else '?'}")
         child.hop = self.hop
         child._has_nar_tables = self._has_nar_tables
+        child.has_text_encoder = self.has_text_encoder
         child._parent = self  # the parent owns the weights and must outlive the fork
         return child
 
@@ -177,6 +180,18 @@ class HipS2STModel:
         check(self.lib.sc_encode_speech(self.handle, _ptr(fbank), n, T, _ptr(lens), _ptr(out), _ptr(out_lens)),
               "sc_encode_speech")
         return out, out_lens
+
+    def encode_text(self, tokens, lens: Sequence[int]) -> torch.Tensor:
+        """UnitYModel.encode_text: tokens (n, s_text) int (pad filled), lens -> (n, s_text, M) fp32 on the device."""
+        if not self.has_text_encoder:
+            raise SeamlessHipError("the model was loaded without a text encoder (input_modality=SPEECH)")
+        tok = _i32(tokens)
+        n, s_text = tok.shape
+        out = torch.empty(n, s_text, self.cfg.model_dim, dtype=torch.float32, device=self.device)
+        ln = _i32(lens)
+        self._after_torch()
+        check(self.lib.sc_encode_text(self.handle, _ptr(tok), n, s_text, _ptr(ln), _ptr(out)), "sc_encode_text")
+        return out
 
     def _gen_opts(self, beam_size, soft_max_seq_len, hard_max_seq_len, min_seq_len, unk_penalty, use_graph,
                   len_penalty=1.0, normalize_scores=True, no_repeat_ngram_size=0):

@@ -77,9 +77,9 @@ class _Gen:
 
 def make_unity_state_dict(
     cfg: S2STConfig, seed: int = DEFAULT_SEED, dtype: torch.dtype = torch.float16,
-    with_t2u: bool = True,
+    with_t2u: bool = True, with_text_encoder: bool = False,
 ) -> Dict[str, torch.Tensor]:
-    """UnitY2 speech-encoder / text-decoder / NAR-T2U weights."""
+    """UnitY2 speech-encoder / text-decoder / NAR-T2U weights (+ the NLLB text encoder of the text-input tasks)."""
     g = _Gen(seed, dtype)
     M = cfg.model_dim
     feat = cfg.num_fbank_channels * cfg.fbank_stride
@@ -147,6 +147,17 @@ def make_unity_state_dict(
             gain = DEC_LAST_FFN_GAIN if (last and q.startswith("ffn")) else DEC_BRANCH_GAIN
             g.sd[f"{p}.{q}.weight"] = (g.sd[f"{p}.{q}.weight"].float() * gain).to(dtype)
     g.layer_norm("text_decoder.layer_norm", M)
+
+    if with_text_encoder:
+        # NLLB encoder; the embedding frontend is the decoder's (builder.py:443-446, loader.py:150-153)
+        g.sd["text_encoder_frontend.embed.weight"] = g.sd["text_decoder_frontend.embed.weight"]
+        for i in range(cfg.text_enc_layers):
+            p = f"text_encoder.layers.{i}"
+            g.layer_norm(f"{p}.self_attn_layer_norm", M)
+            g.mha(f"{p}.self_attn", M)
+            g.layer_norm(f"{p}.ffn_layer_norm", M)
+            g.ffn(f"{p}.ffn", M, cfg.text_enc_ffn_dim)
+        g.layer_norm("text_encoder.layer_norm", M)
 
     if not with_t2u:
         return g.sd

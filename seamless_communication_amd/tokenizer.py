@@ -247,6 +247,55 @@ class NllbTextTokenizer:
             )
         return self._lang_idx[lang]
 
+    # -- fairseq2 NllbTokenizer.create_encoder (call site translator.py:299-302) ---------- #
+    def create_encoder(self, *, task: Optional[str] = None, lang: Optional[str] = None, mode: Optional[str] = None,
+                       device=None, pin_memory: bool = False) -> "TextTokenEncoder":
+        """NLLB conventions (fairseq2 0.2 models/nllb/tokenizer.py, restated): ``source`` (default) =
+        ``[__lang__] pieces [</s>]``; ``target`` = ``[</s>, __lang__] pieces [</s>]``; ``source_mining`` /
+        ``source_mmt_bt`` / ``source_smt_bt`` insert the data-source tag after the language."""
+        if task is not None and task != "translation":
+            raise ValueError(f"`task` must be 'translation', but is '{task}' instead.")
+        lang = lang or self.default_lang
+        lang_idx = self.lang_token_idx(lang)
+        eos = self.vocab_info.eos_idx
+        tags = {"source_mining": "<MINED_DATA>", "source_mmt_bt": "<MMT_BT_DATA>", "source_smt_bt": "<SMT_BT_DATA>"}
+        if mode is None or mode == "source":
+            prefix = [lang_idx]
+        elif mode in tags:
+            prefix = [lang_idx, self.token_to_index(tags[mode])]
+        elif mode == "target":
+            prefix = [eos, lang_idx]
+        else:
+            raise ValueError(
+                f"`mode` must be 'source', 'source_mining', 'source_mmt_bt', 'source_smt_bt', or 'target', but is '{mode}' instead."
+            )
+        return TextTokenEncoder(self, prefix, [eos], device)
+
+    def encode_pieces(self, text: str) -> List[int]:
+        """text -> piece ids (no control symbols).  With a SentencePiece model: its own segmentation, ids shifted
+        by the ``<pad>@0`` slot.  Synthetic vocabulary: SentencePiece-style normalisation (dummy prefix, spaces ->
+        ``▁``) and greedy longest match; characters outside the vocabulary -> ``<unk>``."""
+        if self._spm is not None:
+            return [int(i) + 1 for i in self._spm.encode(text)]
+        norm = SPACE + SPACE.join(text.split())
+        if norm == SPACE:
+            return []
+        self.token_to_index(SPACE)  # builds the index
+        first_ctrl = self._first_lang
+        ids: List[int] = []
+        pos = 0
+        while pos < len(norm):
+            for n in range(min(8, len(norm) - pos), 0, -1):
+                i = self._index.get(norm[pos : pos + n])
+                if i is not None and 4 <= i < first_ctrl:
+                    ids.append(i)
+                    pos += n
+                    break
+            else:
+                ids.append(self.vocab_info.unk_idx)
+                pos += 1
+        return ids
+
     def target_prefix(self, lang: str) -> List[int]:
         """NLLB "target" mode prefix: ``[</s>, __lang__]``."""
         return [self.vocab_info.eos_idx, self.lang_token_idx(lang)]
@@ -285,6 +334,22 @@ class NllbTextTokenizer:
                 offs[i + 1] = len(ids)
             self._nar_tables = (tok_len, starts_sp, is_punc, offs, np.asarray(ids, dtype=np.int64))
         return self._nar_tables
+
+
+class TextTokenEncoder:
+    """Callable ``text -> 1-D int64 tensor`` (fairseq2 ``TextTokenEncoder``): prefix + pieces + suffix."""
+
+    def __init__(self, tokenizer: NllbTextTokenizer, prefix: Sequence[int], suffix: Sequence[int], device=None) -> None:
+        self.tokenizer = tokenizer
+        self.prefix_indices = list(prefix)
+        self.suffix_indices = list(suffix)
+        self.device = device
+
+    def __call__(self, text: str):
+        import torch
+
+        ids = self.prefix_indices + self.tokenizer.encode_pieces(text) + self.suffix_indices
+        return torch.tensor(ids, dtype=torch.int64, device=self.device)
 
 
 class CharTokenizer:

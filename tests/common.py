@@ -30,6 +30,31 @@ def make_oracle(seed: int = 20240901):
 
 
 @functools.lru_cache(maxsize=2)
+def tiny_bundle_text(seed: int = 20240901):
+    """tiny_bundle + the NLLB text encoder of the text-input tasks (every other tensor is identical: each is drawn
+    from its own (seed, key) generator)."""
+    cfg, _, vsd, tt, ct = tiny_bundle(seed)
+    return cfg, syn.make_unity_state_dict(cfg, seed, with_text_encoder=True), vsd, tt, ct
+
+
+def make_oracle_text(seed: int = 20240901):
+    from oracle.pipeline import OracleS2ST
+
+    cfg, sd, vsd, tt, ct = tiny_bundle_text(seed)
+    return OracleS2ST(cfg, sd, vsd, tt, ct, cards.vocoder_lang_spkr_idx_map())
+
+
+@functools.lru_cache(maxsize=1)
+def make_hip_text(seed: int = 20240901):
+    from seamless_communication_amd.runtime import HipS2STModel
+
+    cfg, sd, vsd, tt, ct = tiny_bundle_text(seed)
+    m = HipS2STModel(cfg, sd, vsd, device=0)
+    m.set_nar_tables(tt, ct)
+    return m
+
+
+@functools.lru_cache(maxsize=2)
 def make_hip(seed: int = 20240901):
     from seamless_communication_amd.runtime import HipS2STModel
 

@@ -205,3 +205,27 @@ def test_length_rule_matches_reference_source():
     assert ou.max_seq_len_rule(0.5, 4, 200, 6) == 7
     assert ou.max_seq_len_rule(0, 4, 200, 6) == 200
     assert ou.max_seq_len_rule(1, 200, 42, 63) == 42
+
+
+def test_text_encoder_frontend_and_stack():
+    """Text-input tasks (T2TT / T2ST): UnitYModel.encode_text = the shared embedding frontend + the NLLB pre-LN encoder
+    stack (models/unity/model.py:138-151) == oracle.encode_text, via the reference's TransformerEmbeddingFrontend_forward
+    and StandardTransformerEncoder_forward."""
+    cfg, sd, vsd, tt, ct = common.tiny_bundle_text()
+    P = ou.Params(sd)
+    ref = ggml_ref.GgmlRef(tensor_mem_mb=64)
+    try:
+        sub = {k: v for k, v in sd.items() if k.startswith("text_encoder.")}
+        assert len(sub) == cfg.text_enc_layers * 16 + 2
+        ref.add_state_dict(sub)
+        ref.configure(sub, num_heads=cfg.num_heads, norm_order=ggml_ref.NORM_ORDER_PRE)
+        pos = ou.sinusoidal_table(cfg.text_max_seq_len, cfg.model_dim, 1)
+        ref.add_tensor("text_encoder_frontend.embed.weight", P["text_encoder_frontend.embed.weight"] * math.sqrt(cfg.model_dim))
+        ref.add_tensor("text_encoder_frontend.pos_encoder", pos)
+        toks = tt.create_encoder(task="translation", lang="eng", mode="source")("hello there, my friend").tolist()
+        x = ref.embed("text_encoder_frontend", toks, cfg.model_dim)
+        got = ref.forward("StandardTransformerEncoder", "text_encoder", x[None])
+        want = ou.encode_text(P, cfg, torch.tensor([toks]), None, pos)
+        assert torch.allclose(got, want, atol=ATOL_TABLE), float((got - want).abs().max())
+    finally:
+        ref.close()
