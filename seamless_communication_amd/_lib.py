@@ -88,7 +88,7 @@ SIGNATURES = {
     "sc_fbank": (C.c_int, [_P, _P, _i, C.c_int64, _P, _i, _P, _i, _P]),
     "sc_encoder_out_len": (_i, [_P, _i]),
     "sc_encode_speech": (C.c_int, [_P, _P, _i, _i, _P, _P, _P]),
-    "sc_encode_text": (C.c_int, [_P, _PI, C.c_int32, C.c_int32, _PI, _P]),
+    "sc_encode_text": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     "sc_text_max_len": (_i, [_P, C.POINTER(sc_gen_opts), _i]),
     "sc_generate_text": (C.c_int, [_P, _P, _i, _i, _P, C.POINTER(sc_gen_opts), _P, _i, _P, _P, _P, _P]),
     "sc_decode_text": (C.c_int, [_P, _P, _i, _i, _P, _P, _i, _P]),

@@ -81,3 +81,23 @@ def test_product_path_fails_loudly_without_gpu():
     cfg = tiny_config()
     with pytest.raises(SeamlessHipError):
         HipS2STModel(cfg, syn.make_unity_state_dict(cfg), None, device=0)
+
+
+def test_host_array_arguments_convert_like_the_runtime_passes_them():
+    """The runtime hands numpy arrays / tensors over as c_void_p (runtime._ptr).  Calling the stage entry points with a
+    NULL handle exercises exactly that ctypes conversion and returns SC_ERR_INVALID before any device work."""
+    import numpy as np
+
+    from seamless_communication_amd import _lib
+    from seamless_communication_amd.runtime import _i32, _ptr
+
+    lib = _lib.load_library()
+    tok, lens = _i32(np.zeros((1, 4))), _i32([4])
+    buf = np.zeros(8, dtype=np.float32)
+    o = _lib.sc_gen_opts()
+    assert lib.sc_encode_text(None, _ptr(tok), 1, 4, _ptr(lens), _ptr(buf)) == -1
+    assert lib.sc_encode_speech(None, _ptr(buf), 1, 2, _ptr(lens), _ptr(buf), _ptr(lens)) == -1
+    assert lib.sc_generate_text(None, _ptr(buf), 1, 2, _ptr(lens), ctypes.byref(o), _ptr(tok), 2, _ptr(tok), _ptr(lens),
+                                _ptr(buf), _ptr(None)) == -1
+    assert lib.sc_decode_text(None, _ptr(buf), 1, 2, _ptr(lens), _ptr(tok), 4, _ptr(buf)) == -1
+    assert b"null" in lib.sc_last_error() or b"bad argument" in lib.sc_last_error()
