@@ -84,6 +84,10 @@ typedef struct sc_config {
     int32_t has_t2u, has_vocoder;
     /* NLLB text encoder of the text-input tasks (T2TT / T2ST; builder.py:169-173, :430-434): 0 layers = not loaded */
     int32_t text_enc_layers, text_enc_ffn_dim;
+    /* streaming monotonic text decoder (models/monotonic_decoder/builder.py:81-99 `dense_1b`): 0 layers = not loaded.
+     * Its tensors carry the fairseq2 names of convert_monotonic_checkpoint under the prefix "monotonic_decoder.". */
+    int32_t mma_layers, mma_ffn_dim, mma_energy_layers, mma_pre_decision_ratio;
+    float mma_temperature;
 } sc_config;
 
 /* Text generation options: the fields of SequenceGeneratorOptions
@@ -157,6 +161,21 @@ int sc_encode_speech(sc_model* m, const float* d_fbank, int32_t n, int32_t t_fra
  * LayerNorm.  h_tokens [n][s_text] (pad filled), h_lens the PaddingMask; d_enc_out [n][s_text][model_dim]
  * feeds sc_generate_text with s_enc = s_text and h_enc_lens = h_lens. */
 int sc_encode_text(sc_model* m, const int32_t* h_tokens, int32_t n, int32_t s_text, const int32_t* h_lens, float* d_enc_out);
+
+/* Streaming (cfg 5): the monotonic multihead attention decoder the simultaneous policy drives
+ * (MonotonicDecoderModel.decode / project, models/monotonic_decoder/model.py:41-66; caller
+ * streaming/agents/online_text_decoder.py:205-243, :303-387).
+ * sc_mma_begin = a fresh IncrementalStateBag over a (re-)encoded source (online_text_decoder.py:317): projects the
+ * encoder-decoder K/V of every layer and the key-side energies of the LAST average-pooled source position.
+ * d_enc [s_enc][model_dim] (one stream per handle); max_len = tokens that may be fed before the next begin.
+ * sc_mma_step feeds h_tokens[0..n_tokens) at the next positions (the first call of a round feeds prefix + all
+ * tokens written so far, later calls one token), and returns for the LAST fed token: *out_index = arg-max of the
+ * projected logits with the h_blocked entries (may be NULL) set to -inf (online_text_decoder.py:226-231),
+ * h_pchoose [mma_layers][num_heads] = p_choose[layer, head, -1, -1] (the policy reduces them: min / mean / median),
+ * and d_features [n_tokens][model_dim] = the decoder outputs of the fed tokens. */
+int sc_mma_begin(sc_model* m, const float* d_enc, int32_t s_enc, int32_t max_len);
+int sc_mma_step(sc_model* m, const int32_t* h_tokens, int32_t n_tokens, const int32_t* h_blocked, int32_t n_blocked,
+                int32_t* out_index, float* h_pchoose, float* d_features);
 
 int32_t sc_text_max_len(const sc_model* m, const sc_gen_opts* opts, int32_t s_enc);
 int sc_generate_text(sc_model* m, const float* d_enc, int32_t n, int32_t s_enc, const int32_t* h_enc_lens,

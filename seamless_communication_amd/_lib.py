@@ -61,6 +61,8 @@ class sc_config(C.Structure):
         ("voc_spkr_embedding_dim", _i), ("voc_num_spkrs", _i),
         ("has_t2u", _i), ("has_vocoder", _i),
         ("text_enc_layers", _i), ("text_enc_ffn_dim", _i),
+        ("mma_layers", _i), ("mma_ffn_dim", _i), ("mma_energy_layers", _i), ("mma_pre_decision_ratio", _i),
+        ("mma_temperature", C.c_float),
     ]
 
 
@@ -89,6 +91,8 @@ SIGNATURES = {
     "sc_encoder_out_len": (_i, [_P, _i]),
     "sc_encode_speech": (C.c_int, [_P, _P, _i, _i, _P, _P, _P]),
     "sc_encode_text": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "sc_mma_begin": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    "sc_mma_step": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     "sc_text_max_len": (_i, [_P, C.POINTER(sc_gen_opts), _i]),
     "sc_generate_text": (C.c_int, [_P, _P, _i, _i, _P, C.POINTER(sc_gen_opts), _P, _i, _P, _P, _P, _P]),
     "sc_decode_text": (C.c_int, [_P, _P, _i, _i, _P, _P, _i, _P]),
@@ -148,7 +152,8 @@ def check(status: int, what: str) -> None:
         raise SeamlessHipError(f"{what} failed with status {status}: {msg.decode() if msg else '?'}")
 
 
-def make_config(cfg, has_t2u: bool = True, has_vocoder: bool = True, has_text_encoder: bool = False) -> sc_config:
+def make_config(cfg, has_t2u: bool = True, has_vocoder: bool = True, has_text_encoder: bool = False,
+                has_monotonic_decoder: bool = False) -> sc_config:
     c = sc_config()
     c.abi_version = SC_ABI_VERSION
     for f in (
@@ -186,4 +191,9 @@ def make_config(cfg, has_t2u: bool = True, has_vocoder: bool = True, has_text_en
     c.has_vocoder = int(has_vocoder)
     c.text_enc_layers = int(cfg.text_enc_layers) if has_text_encoder else 0
     c.text_enc_ffn_dim = int(cfg.text_enc_ffn_dim)
+    c.mma_layers = int(cfg.mma_layers) if has_monotonic_decoder else 0
+    c.mma_ffn_dim = int(cfg.mma_ffn_dim)
+    c.mma_energy_layers = int(cfg.mma_energy_layers)
+    c.mma_pre_decision_ratio = int(cfg.mma_pre_decision_ratio)
+    c.mma_temperature = float(cfg.mma_temperature)
     return c

@@ -72,6 +72,14 @@ class S2STConfig:
     text_enc_layers: int = 24
     text_enc_ffn_dim: int = 8192
 
+    # streaming monotonic text decoder `dense_1b` (models/monotonic_decoder/builder.py:81-99); a separate checkpoint
+    mma_layers: int = 24
+    mma_ffn_dim: int = 8192
+    mma_energy_bias_value: float = -0.5
+    mma_temperature: float = 0.2
+    mma_energy_layers: int = 4
+    mma_pre_decision_ratio: int = 2
+
     # NLLB dense_1b text decoder
     dec_layers: int = 24
     dec_ffn_dim: int = 8192
@@ -129,6 +137,9 @@ def tiny_config() -> S2STConfig:
         adaptor_proj_dim=512,
         text_enc_layers=2,
         text_enc_ffn_dim=256,
+        mma_layers=2,
+        mma_ffn_dim=256,
+        mma_energy_layers=2,
         dec_layers=2,
         dec_ffn_dim=256,
         text_vocab_size=1200,

@@ -138,6 +138,23 @@ int sc_encode_text(sc_model* m, const int32_t* h_tokens, int32_t n, int32_t s_te
     SC_API_END
 }
 
+int sc_mma_begin(sc_model* m, const float* d_enc, int32_t s_enc, int32_t max_len) {
+    SC_API_BEGIN
+    SC_CHECK(m && d_enc, "sc_mma_begin: null argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    run_mma_begin(m->m, d_enc, s_enc, max_len);
+    SC_API_END
+}
+
+int sc_mma_step(sc_model* m, const int32_t* h_tokens, int32_t n_tokens, const int32_t* h_blocked, int32_t n_blocked,
+                int32_t* out_index, float* h_pchoose, float* d_features) {
+    SC_API_BEGIN
+    SC_CHECK(m && h_tokens && out_index && h_pchoose && d_features && (h_blocked || n_blocked == 0), "sc_mma_step: null argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    run_mma_step(m->m, h_tokens, n_tokens, h_blocked, n_blocked, out_index, h_pchoose, d_features);
+    SC_API_END
+}
+
 int32_t sc_text_max_len(const sc_model* m, const sc_gen_opts* opts, int32_t s_enc) {
     return (m && opts) ? text_max_len(m->m, *opts, s_enc) : -1;
 }

@@ -97,6 +97,20 @@ struct DecoderLayer {
     LNorm self_ln, cross_ln, ffn_ln;
     Linear qkv, self_out, cross_q, cross_kv, cross_out, ffn_in, ffn_out;
 };
+struct PChooseLayer {  // monotonic decoder: EnergyProjection MLPs of the query / pooled-key sides + energy bias
+    std::vector<Linear> q, k;
+    const float* energy_bias = nullptr;  // [1] or null
+};
+// One pre-LN transformer decoder (embedding frontend, layers, final LayerNorm): the UnitY text decoder or the
+// streaming monotonic decoder.  Views into ModelData.
+struct DecStack {
+    const __half* embed = nullptr;
+    const float* pos = nullptr;
+    const std::vector<DecoderLayer>* layers = nullptr;
+    const LNorm* final_ln = nullptr;
+    int ffn_dim = 0;
+    const std::vector<PChooseLayer>* pchoose = nullptr;
+};
 struct EncoderLayer {  // standard pre-LN transformer encoder layer (T2U encoder)
     LNorm attn_ln, ffn_ln;
     Linear qkv, attn_out, ffn_in, ffn_out;
@@ -139,6 +153,11 @@ struct ModelData {
     const float* text_pos = nullptr;     // [max_len][M]
     std::vector<DecoderLayer> dec;
     LNorm dec_final_ln;
+    // streaming monotonic text decoder (cfg 5; models/monotonic_decoder): own embedding, layers + p_choose
+    const __half* mma_embed = nullptr;
+    std::vector<DecoderLayer> mma_dec;
+    std::vector<PChooseLayer> mma_pc;
+    LNorm mma_final_ln;
     // text encoder (text-input tasks; shares the embedding frontend with the decoder)
     std::vector<EncoderLayer> text_enc;
     LNorm text_enc_ln;
@@ -170,6 +189,13 @@ struct ModelData {
     std::vector<ResBlock> voc_res;
 };
 
+// State bag of the streaming decoder between sc_mma_begin and the sc_mma_step calls of one policy round.
+struct MmaState {
+    int s_enc = 0, cap = 0, pos = 0;
+    Buf<float> kv, cross, kenergy, work, pchoose;
+    Buf<int> ints;
+};
+
 // One handle: the model description plus its own stream, scratch pool and per-call results.
 struct Model : ModelData {
     hipStream_t stream = nullptr;
@@ -180,6 +206,8 @@ struct Model : ModelData {
     // results of the last sc_t2u_nar call
     std::vector<int32_t> last_units, last_durations, last_char_ids, last_char_seq_lens;
     int last_n = 0, last_su = 0, last_sc = 0;
+
+    std::unique_ptr<MmaState> mma;  // buffers come from `pool`: released before it (see ~Model)
 
     // captured decoder step
     hipGraph_t step_graph = nullptr;
@@ -198,6 +226,9 @@ void run_fbank(Model& m, const float* d_wav, int n, int64_t wav_stride, const in
 int encoder_out_len(const Model& m, int t_frames);
 void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, const int32_t* h_lens, float* d_out,
                        int32_t* h_out_lens);
+void run_mma_begin(Model& m, const float* d_enc, int s_enc, int max_len);
+void run_mma_step(Model& m, const int32_t* h_tokens, int n_tokens, const int32_t* h_blocked, int n_blocked, int32_t* out_index,
+                  float* h_pchoose, float* d_features);
 void run_encode_text(Model& m, const int32_t* h_tokens, int n, int s_text, const int32_t* h_lens, float* d_out);
 int text_max_len(const Model& m, const sc_gen_opts& o, int s_enc);
 void ngram_blocked_tokens(const int32_t* seq, int S, int G, std::vector<int32_t>& out);

@@ -48,7 +48,57 @@ struct StepCtx {
     float* am_eos_logit = nullptr;       // [nb]
     int min_seq_len = 1, force_eos_step = -1;
     float unk_penalty = 0.f;
+    // which decoder stack runs (null = the UnitY text decoder) and the monotonic p_choose hook
+    const DecStack* stack = nullptr;
+    bool pchoose = false;           // compute p_choose[layer][head] of this step's (single) row
+    const float* d_kenergy = nullptr;  // [layers][M]: k_energy_proj of the last pooled encoder position
+    float* d_pchoose = nullptr;        // [layers][heads]
+    float* qe0 = nullptr;              // [M] scratch x2 for the query energy MLP
+    float* qe1 = nullptr;
 };
+
+DecStack unity_stack(const Model& m) {
+    DecStack w;
+    w.embed = m.text_embed;
+    w.pos = m.text_pos;
+    w.layers = &m.dec;
+    w.final_ln = &m.dec_final_ln;
+    w.ffn_dim = m.cfg.dec_ffn_dim;
+    w.pchoose = nullptr;
+    return w;
+}
+
+// p_choose[h] = sigmoid(((q_h . k_h) / sqrt(head_dim) + energy_bias) / temperature) for one query row and one
+// pooled key (PChooseLayer.forward, models/monotonic_decoder/p_choose.py:120-148, last query x last key only:
+// the streaming policy reads p_choose[..., -1, -1], streaming/agents/online_text_decoder.py:236-241).
+__global__ void pchoose_kernel(const float* __restrict__ q, const float* __restrict__ k, int head_dim,
+                               const float* __restrict__ energy_bias, float temperature, float* __restrict__ out) {
+    const int h = blockIdx.x, lane = threadIdx.x;
+    float acc = 0.f;
+    for (int c = lane; c < head_dim; c += 64) acc = fmaf(q[h * head_dim + c], k[h * head_dim + c], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        float e = acc * rsqrtf((float)head_dim);
+        if (energy_bias) e += energy_bias[0];
+        out[h] = 1.f / (1.f + expf(-(e / temperature)));
+    }
+}
+
+// EnergyProjection (p_choose.py:17-45): (Linear, ReLU) x n on `rows` rows; returns the buffer holding the result.
+float* energy_mlp(Model& m, const std::vector<Linear>& layers, const float* in, int64_t ld_in, float* a, float* b, int rows) {
+    const int M = m.cfg.model_dim;
+    const float* src = in;
+    int64_t ld = ld_in;
+    float* dst = a;
+    for (const Linear& L : layers) {
+        linear(m, src, ld, L, nullptr, 0, dst, M, rows, ACT_RELU, 1.f);
+        src = dst;
+        ld = M;
+        dst = (dst == a) ? b : a;
+    }
+    return const_cast<float*>(src);
+}
 
 __global__ void store_hidden_kernel(const float* __restrict__ hN, float* __restrict__ dst, int M, int hid_rows,
                                     const int* __restrict__ d_pos) {
@@ -108,11 +158,15 @@ bool proj_partials(Model& m, StepCtx& c, const float* in, int64_t ld_in, const L
 void decoder_step(Model& m, StepCtx& c, bool project) {
     const sc_config& cfg = m.cfg;
     const int M = cfg.model_dim, nb = c.nb;
-    launch_embed_tokens(c.d_tok, nb, m.text_embed, M, sqrtf((float)M), m.text_pos, c.d_pos, 0, c.x, M, m.stream);
-    layernorm(m, c.x, m.dec[0].self_ln, c.h, nb);
-    for (int li = 0; li < cfg.dec_layers; ++li) {
-        const DecoderLayer& l = m.dec[li];
-        const bool last = li + 1 == cfg.dec_layers;
+    const DecStack own = unity_stack(m);
+    const DecStack& W = c.stack ? *c.stack : own;
+    const std::vector<DecoderLayer>& layers = *W.layers;
+    const int n_layers = (int)layers.size();
+    launch_embed_tokens(c.d_tok, nb, W.embed, M, sqrtf((float)M), W.pos, c.d_pos, 0, c.x, M, m.stream);
+    layernorm(m, c.x, layers[0].self_ln, c.h, nb);
+    for (int li = 0; li < n_layers; ++li) {
+        const DecoderLayer& l = layers[li];
+        const bool last = li + 1 == n_layers;
         int sp = 1;
         // self attention: q/k/v partials are summed (+bias) by the attention kernel itself
         if (proj_partials(m, c, c.h, M, l.qkv, &sp)) {
@@ -126,6 +180,13 @@ void decoder_step(Model& m, StepCtx& c, bool project) {
                                     (int64_t)c.cap * M, c.cap, c.att, M, nb, cfg.num_heads, c.d_pos, nullptr, 0, m.stream);
         }
         out_proj_res_ln(m, c, c.att, M, l.self_out, l.cross_ln, c.h);
+        if (c.pchoose) {  // monotonic decoder: p_choose of the normed cross-attention input (monotonic_decoder_layer.py:170-172)
+            const PChooseLayer& pc = (*W.pchoose)[li];
+            const float* qe = energy_mlp(m, pc.q, c.h, M, c.qe0, c.qe1, 1);
+            hipLaunchKernelGGL(pchoose_kernel, dim3(cfg.num_heads), dim3(64), 0, m.stream, qe, c.d_kenergy + (int64_t)li * M,
+                               M / cfg.num_heads, pc.energy_bias, cfg.mma_temperature, c.d_pchoose + (int64_t)li * cfg.num_heads);
+            SC_LAUNCH_CHECK();
+        }
         // encoder-decoder attention over the K/V projected once per utterance
         if (proj_partials(m, c, c.h, M, l.cross_q, &sp)) {
             launch_decode_attention(c.partial, M, nullptr, nullptr, 0, c.cross_kv[li], c.cross_kv[li] + M, 2 * M,
@@ -138,9 +199,8 @@ void decoder_step(Model& m, StepCtx& c, bool project) {
                                     m.stream);
         }
         out_proj_res_ln(m, c, c.att, M, l.cross_out, l.ffn_ln, c.h);
-        linear(m, c.h, M, l.ffn_in, nullptr, 0, c.wide, cfg.dec_ffn_dim, nb, ACT_RELU, 1.f);
-        out_proj_res_ln(m, c, c.wide, cfg.dec_ffn_dim, l.ffn_out, last ? m.dec_final_ln : m.dec[li + 1].self_ln,
-                        last ? c.hN : c.h);
+        linear(m, c.h, M, l.ffn_in, nullptr, 0, c.wide, W.ffn_dim, nb, ACT_RELU, 1.f);
+        out_proj_res_ln(m, c, c.wide, W.ffn_dim, l.ffn_out, last ? *W.final_ln : layers[li + 1].self_ln, last ? c.hN : c.h);
     }
     if (c.dec_hidden) {
         hipLaunchKernelGGL(store_hidden_kernel, dim3(nb), dim3(256), 0, m.stream, c.hN, c.dec_hidden, M, c.cap - 1, c.d_pos);
@@ -152,7 +212,7 @@ void decoder_step(Model& m, StepCtx& c, bool project) {
             SkinnyArgs a;
             a.A = c.hN;
             a.lda = M;
-            a.W = m.text_embed;
+            a.W = W.embed;
             a.ldw = M;
             a.M = nb;
             a.N = cfg.text_vocab_size;
@@ -172,7 +232,7 @@ void decoder_step(Model& m, StepCtx& c, bool project) {
                                    cfg.eos_idx, c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len, c.d_score, m.stream);
         } else {
             Linear proj;
-            proj.w = m.text_embed;
+            proj.w = W.embed;
             proj.ldw = M;
             proj.kpad = M;
             proj.in = M;
@@ -189,6 +249,183 @@ void decoder_step(Model& m, StepCtx& c, bool project) {
 }
 
 }  // namespace
+
+// --------------------------------------------------------------------------------------------- //
+// Streaming monotonic decoder (cfg 5).  One row; the state lives in the handle between calls.
+// --------------------------------------------------------------------------------------------- //
+namespace {
+
+// out[c] = (sum_t rows[t][c]) / count — the last window of AvgPool1d(kernel = stride = ratio, ceil_mode=True)
+// (p_choose.py:114-118): a clipped window is divided by the number of positions it really covers.
+__global__ void mean_rows_kernel(const float* __restrict__ rows, int count, int M, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= M) return;
+    float acc = 0.f;
+    for (int t = 0; t < count; ++t) acc += rows[(int64_t)t * M + c];
+    out[c] = acc / (float)count;
+}
+
+__global__ void fill_indices_kernel(float* __restrict__ row, const int* __restrict__ idx, int n, int V, float value) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && idx[i] >= 0 && idx[i] < V) row[idx[i]] = value;
+}
+
+struct MmaWork {  // slices of MmaState::work
+    float *x, *h, *att, *hN, *wide, *partial, *logits, *qe0, *qe1, *pooled;
+};
+
+MmaWork mma_work(const Model& m, float* base, size_t* total) {
+    const sc_config& c = m.cfg;
+    const size_t M = c.model_dim;
+    const size_t wideN = std::max<size_t>(3 * M, c.mma_ffn_dim);
+    const size_t part = (size_t)std::max(1, std::max(c.model_dim, c.mma_ffn_dim) / 256) * 3 * M;
+    MmaWork w;
+    size_t o = 0;
+    auto take = [&](size_t n) {
+        float* p = base ? base + o : nullptr;
+        o += (n + 63) & ~(size_t)63;
+        return p;
+    };
+    w.x = take(M);
+    w.h = take(M);
+    w.att = take(M);
+    w.hN = take(M);
+    w.wide = take(wideN);
+    w.partial = take(part);
+    w.logits = take(c.text_vocab_size);
+    w.qe0 = take(M);
+    w.qe1 = take(M);
+    w.pooled = take(M);
+    if (total) *total = o;
+    return w;
+}
+
+DecStack mma_stack(const Model& m) {
+    DecStack w;
+    w.embed = m.mma_embed;
+    w.pos = m.text_pos;  // same sinusoidal table (builder.py:169-176: max_seq_len 4096, _legacy_pad_idx=1)
+    w.layers = &m.mma_dec;
+    w.final_ln = &m.mma_final_ln;
+    w.ffn_dim = m.cfg.mma_ffn_dim;
+    w.pchoose = &m.mma_pc;
+    return w;
+}
+
+}  // namespace
+
+void run_mma_begin(Model& m, const float* d_enc, int s_enc, int max_len) {
+    const sc_config& cfg = m.cfg;
+    const int M = cfg.model_dim, L = cfg.mma_layers, H = cfg.num_heads;
+    SC_CHECK(L > 0, "sc_mma_begin: the model was loaded without a monotonic decoder");
+    SC_CHECK(s_enc > 0 && s_enc <= 4096, "sc_mma_begin: encoder length %d out of range", s_enc);
+    SC_CHECK(max_len >= 2 && max_len <= cfg.text_max_seq_len && max_len <= 4096, "sc_mma_begin: max_len %d out of range", max_len);
+    prof::set_tag("mma");
+    m.mma.reset();  // the previous round's buffers go back to the pool first
+    std::unique_ptr<MmaState> st(new MmaState());
+    st->s_enc = s_enc;
+    st->cap = max_len;
+    st->pos = 0;
+    size_t work_n = 0;
+    mma_work(m, nullptr, &work_n);
+    st->kv = Buf<float>(&m.pool, (size_t)2 * L * max_len * M);
+    st->cross = Buf<float>(&m.pool, (size_t)L * s_enc * 2 * M);
+    st->kenergy = Buf<float>(&m.pool, (size_t)L * M);
+    st->pchoose = Buf<float>(&m.pool, (size_t)L * H);
+    st->work = Buf<float>(&m.pool, work_n);
+    st->ints = Buf<int>(&m.pool, 16 + 64);
+    const MmaWork w = mma_work(m, st->work.get(), nullptr);
+    // d_pos @0, d_tok @8, finished @9, out_len @10, enc_lens @11
+    const int32_t init[16] = {0, 0, 0, 0, 0, 0, 0, 0, cfg.pad_idx, 0, max_len, s_enc, 0, 0, 0, 0};
+    SC_HIP(hipMemcpyAsync(st->ints.get(), init, sizeof(init), hipMemcpyHostToDevice, m.stream));
+    // last pooled source position and its key-side energies, per layer
+    const int ratio = cfg.mma_pre_decision_ratio;
+    const int s_p = (s_enc + ratio - 1) / ratio;
+    const int start = (s_p - 1) * ratio, count = s_enc - start;
+    hipLaunchKernelGGL(mean_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, m.stream, d_enc + (int64_t)start * M, count, M, w.pooled);
+    SC_LAUNCH_CHECK();
+    for (int li = 0; li < L; ++li) {
+        const DecoderLayer& l = m.mma_dec[li];
+        linear(m, d_enc, M, l.cross_kv, nullptr, 0, st->cross.get() + (int64_t)li * s_enc * 2 * M, 2 * M, s_enc, ACT_NONE, 1.f);
+        const float* ke = energy_mlp(m, m.mma_pc[li].k, w.pooled, M, w.qe0, w.qe1, 1);
+        SC_HIP(hipMemcpyAsync(st->kenergy.get() + (int64_t)li * M, ke, (size_t)M * 4, hipMemcpyDeviceToDevice, m.stream));
+    }
+    SC_HIP(hipStreamSynchronize(m.stream));  // `init` is a host temporary; d_enc may be reused by the caller
+    m.mma = std::move(st);
+}
+
+void run_mma_step(Model& m, const int32_t* h_tokens, int n_tokens, const int32_t* h_blocked, int n_blocked, int32_t* out_index,
+                  float* h_pchoose, float* d_features) {
+    const sc_config& cfg = m.cfg;
+    const int M = cfg.model_dim, L = cfg.mma_layers, H = cfg.num_heads, V = cfg.text_vocab_size;
+    SC_CHECK(m.mma != nullptr, "sc_mma_step: call sc_mma_begin first");
+    MmaState& st = *m.mma;
+    SC_CHECK(n_tokens >= 1 && st.pos + n_tokens <= st.cap, "sc_mma_step: %d tokens at position %d exceed max_len %d", n_tokens,
+             st.pos, st.cap);
+    SC_CHECK(n_blocked >= 0 && n_blocked <= 32, "sc_mma_step: at most 32 blocked indices (got %d)", n_blocked);
+    for (int t = 0; t < n_tokens; ++t)
+        SC_CHECK(h_tokens[t] >= 0 && h_tokens[t] < V, "sc_mma_step: token %d outside the vocabulary", h_tokens[t]);
+    prof::set_tag("mma");
+    const MmaWork w = mma_work(m, st.work.get(), nullptr);
+    const DecStack W = mma_stack(m);
+    StepCtx c;
+    c.nb = 1;
+    c.cap = st.cap;
+    c.s_enc = st.s_enc;
+    c.d_pos = st.ints.get();
+    c.d_tok = st.ints.get() + 8;
+    c.d_finished = st.ints.get() + 9;
+    c.d_out_len = st.ints.get() + 10;
+    c.d_enc_lens = st.ints.get() + 11;
+    int* d_feed = st.ints.get() + 16;     // up to 32 tokens staged per chunk
+    int* d_blocked = st.ints.get() + 48;  // up to 32 blocked indices
+    c.x = w.x;
+    c.h = w.h;
+    c.att = w.att;
+    c.hN = w.hN;
+    c.wide = w.wide;
+    c.partial = w.partial;
+    c.logits = w.logits;
+    c.qe0 = w.qe0;
+    c.qe1 = w.qe1;
+    c.stack = &W;
+    c.d_kenergy = st.kenergy.get();
+    c.d_pchoose = st.pchoose.get();
+    const int64_t layer_stride = (int64_t)st.cap * M;
+    for (int li = 0; li < L; ++li) {
+        c.kcache.push_back(st.kv.get() + (int64_t)(2 * li) * layer_stride);
+        c.vcache.push_back(st.kv.get() + (int64_t)(2 * li + 1) * layer_stride);
+        c.cross_kv.push_back(st.cross.get() + (int64_t)li * st.s_enc * 2 * M);
+    }
+    for (int t0 = 0; t0 < n_tokens; t0 += 32) {
+        const int nt = std::min(32, n_tokens - t0);
+        SC_HIP(hipMemcpyAsync(d_feed, h_tokens + t0, (size_t)nt * 4, hipMemcpyHostToDevice, m.stream));
+        for (int t = 0; t < nt; ++t) {
+            SC_HIP(hipMemcpyAsync(c.d_tok, d_feed + t, 4, hipMemcpyDeviceToDevice, m.stream));
+            c.pchoose = (t0 + t == n_tokens - 1);
+            decoder_step(m, c, /*project=*/false);  // advances *d_pos
+            SC_HIP(hipMemcpyAsync(d_features + (int64_t)(t0 + t) * M, c.hN, (size_t)M * 4, hipMemcpyDeviceToDevice, m.stream));
+        }
+        SC_HIP(hipStreamSynchronize(m.stream));  // the pageable source of d_feed may be reused
+    }
+    // MonotonicDecoderModel.project (TiedProjection) on the last position + arg-max (online_text_decoder.py:225-231)
+    Linear proj;
+    proj.w = m.mma_embed;
+    proj.ldw = M;
+    proj.kpad = M;
+    proj.in = M;
+    proj.out = V;
+    linear(m, c.hN, M, proj, nullptr, 0, c.logits, V, 1, ACT_NONE, 1.f);
+    if (n_blocked > 0) {
+        SC_HIP(hipMemcpyAsync(d_blocked, h_blocked, (size_t)n_blocked * 4, hipMemcpyHostToDevice, m.stream));
+        hipLaunchKernelGGL(fill_indices_kernel, dim3(1), dim3(64), 0, m.stream, c.logits, d_blocked, n_blocked, V, -INFINITY);
+        SC_LAUNCH_CHECK();
+    }
+    launch_argmax_rows(c.logits, V, 1, V, nullptr, 0, -1, -1, -1, -1, 0.f, c.d_tok, nullptr, m.stream);
+    SC_HIP(hipMemcpyAsync(out_index, c.d_tok, 4, hipMemcpyDeviceToHost, m.stream));
+    SC_HIP(hipMemcpyAsync(h_pchoose, st.pchoose.get(), (size_t)L * H * 4, hipMemcpyDeviceToHost, m.stream));
+    SC_HIP(hipStreamSynchronize(m.stream));
+    st.pos += n_tokens;
+}
 
 // forced_tokens != null: teacher-forced pass over the given tokens (no arg-max
 // feedback, hidden states only).  Otherwise greedy generation.

@@ -36,6 +36,7 @@ void DevicePool::release_all() {
 }
 
 Model::~Model() {
+    mma.reset();
     if (step_exec) (void)hipGraphExecDestroy(step_exec);
     if (step_graph) (void)hipGraphDestroy(step_graph);
     if (stream) (void)hipStreamSynchronize(stream);
@@ -350,6 +351,40 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
         l.ffn_out = L.lin(p + ".ffn.output_proj", M, c.dec_ffn_dim);
     }
     m.dec_final_ln = L.ln("text_decoder.layer_norm", M);
+
+    // ---- streaming monotonic decoder (keys of convert_monotonic_checkpoint, models/monotonic_decoder/loader.py:30-46,
+    //      under the prefix "monotonic_decoder.") -----------------------------------------------------------
+    SC_CHECK(c.mma_layers >= 0 && c.mma_energy_layers >= 0, "sc_load: mma_layers=%d mma_energy_layers=%d", c.mma_layers,
+             c.mma_energy_layers);
+    if (c.mma_layers > 0) {
+        SC_CHECK(c.mma_energy_layers >= 1 && c.mma_pre_decision_ratio >= 1 && c.mma_temperature > 0.f,
+                 "sc_load: monotonic decoder needs energy layers / pre_decision_ratio / temperature");
+        const std::string root = "monotonic_decoder.";
+        m.mma_embed = L.f16(root + "text_decoder_frontend.embed.weight", {c.text_vocab_size, M});
+        m.mma_dec.resize(c.mma_layers);
+        m.mma_pc.resize(c.mma_layers);
+        for (int i = 0; i < c.mma_layers; ++i) {
+            const std::string p = root + "text_decoder.layers." + std::to_string(i);
+            DecoderLayer& l = m.mma_dec[i];
+            l.self_ln = L.ln(p + ".self_attn_layer_norm", M);
+            l.qkv = L.fuse({p + ".self_attn.q_proj", p + ".self_attn.k_proj", p + ".self_attn.v_proj"}, M, M);
+            l.self_out = L.lin(p + ".self_attn.output_proj", M, M);
+            l.cross_ln = L.ln(p + ".encoder_decoder_attn_layer_norm", M);
+            l.cross_q = L.lin(p + ".encoder_decoder_attn.q_proj", M, M);
+            l.cross_kv = L.fuse({p + ".encoder_decoder_attn.k_proj", p + ".encoder_decoder_attn.v_proj"}, M, M);
+            l.cross_out = L.lin(p + ".encoder_decoder_attn.output_proj", M, M);
+            l.ffn_ln = L.ln(p + ".ffn_layer_norm", M);
+            l.ffn_in = L.lin(p + ".ffn.inner_proj", c.mma_ffn_dim, M);
+            l.ffn_out = L.lin(p + ".ffn.output_proj", M, c.mma_ffn_dim);
+            PChooseLayer& pc = m.mma_pc[i];
+            for (int e = 0; e < c.mma_energy_layers; ++e) {  // ModuleList [Linear, ReLU] x n: Linears at even indices
+                pc.q.push_back(L.lin(p + ".p_choose_layer.q_energy_proj.layers." + std::to_string(2 * e), M, M));
+                pc.k.push_back(L.lin(p + ".p_choose_layer.k_energy_proj.layers." + std::to_string(2 * e), M, M));
+            }
+            pc.energy_bias = L.has(p + ".p_choose_layer.energy_bias") ? L.f32(p + ".p_choose_layer.energy_bias", {1}) : nullptr;
+        }
+        m.mma_final_ln = L.ln(root + "text_decoder.layer_norm", M);
+    }
 
     // ---- text encoder (text-input tasks) --------------------------------------------
     SC_CHECK(c.text_enc_layers >= 0, "sc_load: text_enc_layers=%d", c.text_enc_layers);

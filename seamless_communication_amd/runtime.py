@@ -55,6 +55,7 @@ class HipS2STModel:
         unity_state_dict: Dict[str, torch.Tensor],
         vocoder_state_dict: Optional[Dict[str, torch.Tensor]] = None,
         device: int = 0,
+        monotonic_state_dict: Optional[Dict[str, torch.Tensor]] = None,
     ) -> None:
         self.lib = _lib.load_library()
         self.cfg = cfg
@@ -76,6 +77,12 @@ class HipS2STModel:
             f = "t2u_model.decoder_frontend"
             tensors[f + ".char_pos_encoder.freqs"] = sinusoidal_freqs(cfg.char_max_seq_len, cfg.model_dim, cfg.unit_pad_idx)
             tensors[f + ".unit_pos_encoder.freqs"] = sinusoidal_freqs(cfg.unit_max_seq_len, cfg.model_dim, cfg.unit_pad_idx)
+        self.has_monotonic_decoder = monotonic_state_dict is not None
+        if monotonic_state_dict is not None:
+            # streaming text decoder (models/monotonic_decoder/loader.py): a second checkpoint, own tied embedding
+            for k, v in monotonic_state_dict.items():
+                if k != "final_proj.weight":
+                    tensors["monotonic_decoder." + k] = v
         if vocoder_state_dict is not None:
             for k, v in vocoder_state_dict.items():
                 if ".dur_predictor." in k:
@@ -97,7 +104,7 @@ class HipS2STModel:
             d.data = v.data_ptr()
             d.on_device = 1 if v.is_cuda else 0
         ccfg = _lib.make_config(cfg, has_t2u=has_t2u, has_vocoder=vocoder_state_dict is not None,
-                                has_text_encoder=self.has_text_encoder)
+                                has_text_encoder=self.has_text_encoder, has_monotonic_decoder=self.has_monotonic_decoder)
         self.handle = self.lib.sc_load(descs, len(tensors), C.byref(ccfg), self.device_index)
         if not self.handle:
             msg = self.lib.sc_last_error()
@@ -119,6 +126,7 @@ class HipS2STModel:
         child.hop = self.hop
         child._has_nar_tables = self._has_nar_tables
         child.has_text_encoder = self.has_text_encoder
+        child.has_monotonic_decoder = self.has_monotonic_decoder
         child._parent = self  # the parent owns the weights and must outlive the fork
         return child
 
@@ -192,6 +200,32 @@ class HipS2STModel:
         self._after_torch()
         check(self.lib.sc_encode_text(self.handle, _ptr(tok), n, s_text, _ptr(ln), _ptr(out)), "sc_encode_text")
         return out
+
+    # ---- streaming monotonic decoder (cfg 5) ------------------------------------------------------ #
+    def mma_begin(self, enc: torch.Tensor, max_len: int) -> None:
+        """A fresh incremental state over the (re-)encoded source: enc (S, M) or (1, S, M) fp32 on the device."""
+        if not self.has_monotonic_decoder:
+            raise SeamlessHipError("the model was loaded without a monotonic decoder")
+        if enc.dim() == 3:
+            if enc.shape[0] != 1:
+                raise ValueError("the streaming decoder handles one stream per handle")
+            enc = enc[0]
+        enc = enc.to(self.device, torch.float32).contiguous()
+        self._after_torch()
+        check(self.lib.sc_mma_begin(self.handle, _ptr(enc), enc.shape[0], int(max_len)), "sc_mma_begin")
+
+    def mma_step(self, tokens: Sequence[int], blocked: Sequence[int] = ()):
+        """Feeds `tokens`; -> (arg-max index after the last one, p_choose (layers, heads) of the last one,
+        decoder outputs (len(tokens), M) on the device)."""
+        tok = _i32(tokens).reshape(-1)
+        blk = _i32(list(blocked)).reshape(-1)
+        feats = torch.empty(len(tok), self.cfg.model_dim, dtype=torch.float32, device=self.device)
+        index = np.zeros(1, dtype=np.int32)
+        pch = np.zeros((self.cfg.mma_layers, self.cfg.num_heads), dtype=np.float32)
+        self._after_torch()
+        check(self.lib.sc_mma_step(self.handle, _ptr(tok), len(tok), _ptr(blk) if len(blk) else _ptr(None), len(blk), _ptr(index),
+                                   _ptr(pch), _ptr(feats)), "sc_mma_step")
+        return int(index[0]), pch, feats
 
     def _gen_opts(self, beam_size, soft_max_seq_len, hard_max_seq_len, min_seq_len, unk_penalty, use_graph,
                   len_penalty=1.0, normalize_scores=True, no_repeat_ngram_size=0):

@@ -205,6 +205,54 @@ def make_unity_state_dict(
     return g.sd
 
 
+def make_monotonic_decoder_state_dict(cfg: S2STConfig, seed: int = DEFAULT_SEED, dtype: torch.dtype = torch.float16) -> Dict[str, torch.Tensor]:
+    """Streaming monotonic decoder weights with the fairseq2 key names convert_monotonic_checkpoint produces
+    (models/monotonic_decoder/loader.py:30-46): a pre-LN NLLB decoder with its own tied embedding + one PChooseLayer per
+    layer (q/k EnergyProjection MLPs = ModuleList [Linear, ReLU] x n, energy_bias).  Keys are generated under their own
+    seeds ("mma/" + key), so the values differ from the UnitY text decoder's."""
+    g = _Gen(seed, dtype)
+    M = cfg.model_dim
+    out: Dict[str, torch.Tensor] = {}
+
+    def put(key: str, make) -> None:
+        make("mma/" + key)
+        out[key] = g.sd.pop("mma/" + key)
+
+    put("text_decoder_frontend.embed.weight", lambda k: g.normal(k, (cfg.text_vocab_size, M), 0.5 * M ** -0.5))
+    out["text_decoder_frontend.embed.weight"][cfg.pad_idx].zero_()
+    out["text_decoder_frontend.embed.weight"][cfg.text_vocab_size - len(TEXT_CONTROL_TAIL):].mul_(0.1)
+    out["final_proj.weight"] = out["text_decoder_frontend.embed.weight"]
+
+    def linear(prefix: str, o: int, i: int, gain: float = 1.0) -> None:
+        bound = gain * math.sqrt(6.0 / (i + o))
+        put(prefix + ".weight", lambda k: g.uniform(k, (o, i), bound))
+        put(prefix + ".bias", lambda k: g.uniform(k, (o,), 0.02))
+
+    def layer_norm(prefix: str) -> None:
+        put(prefix + ".weight", lambda k: g.uniform(k, (M,), 0.1, center=1.0))
+        put(prefix + ".bias", lambda k: g.uniform(k, (M,), 0.05))
+
+    for i in range(cfg.mma_layers):
+        p = f"text_decoder.layers.{i}"
+        last = i == cfg.mma_layers - 1
+        for ln in ("self_attn_layer_norm", "encoder_decoder_attn_layer_norm", "ffn_layer_norm"):
+            layer_norm(f"{p}.{ln}")
+        for att in ("self_attn", "encoder_decoder_attn"):
+            for q in ("q_proj", "k_proj", "v_proj"):
+                linear(f"{p}.{att}.{q}", M, M)
+            linear(f"{p}.{att}.output_proj", M, M, DEC_BRANCH_GAIN)
+        linear(f"{p}.ffn.inner_proj", cfg.mma_ffn_dim, M)
+        linear(f"{p}.ffn.output_proj", M, cfg.mma_ffn_dim, DEC_LAST_FFN_GAIN if last else DEC_BRANCH_GAIN)
+        for side in ("q_energy_proj", "k_energy_proj"):
+            for e in range(cfg.mma_energy_layers):
+                # gains chosen so that q.k / sqrt(d) of the non-negative (post-ReLU) energy vectors lands around the
+                # -energy_bias: p_choose spreads over (0.1, 0.99) instead of saturating (see test_oracle_monotonic.py)
+                linear(f"{p}.p_choose_layer.{side}.layers.{2 * e}", M, M, 0.8 if e == cfg.mma_energy_layers - 1 else 1.4)
+        out[f"{p}.p_choose_layer.energy_bias"] = torch.full((1,), cfg.mma_energy_bias_value, dtype=dtype)
+    layer_norm("text_decoder.layer_norm")
+    return out
+
+
 def make_vocoder_state_dict(
     cfg: S2STConfig, seed: int = DEFAULT_SEED, dtype: torch.dtype = torch.float16
 ) -> Dict[str, torch.Tensor]:
