@@ -1,0 +1,481 @@
+"""Streaming S2ST / S2TT agents (BASELINE cfg 5): the reference's five-agent chain
+(src/seamless_communication/streaming/agents/seamless_streaming_s2st.py:28-35) with its arithmetic behind a backend
+object — ``HipStreamingBackend`` (this package, HIP kernels through the C ABI) in production; the CPU oracle supplies
+its own backend to the tests.  Policies, state handling and defaults follow the reference files cited per class; the
+model calls they make are:
+
+    fbank(samples)                                    WaveformToFbankConverter(standardize=False)
+    encode_speech(frames)                             UnitYModel.encode_speech on everything heard so far
+    mma_begin(enc, max_len) / mma_step(tokens, blocked)  MonotonicDecoderModel.decode + project with a fresh state bag
+    t2u(features, token_ids, duration_factor)         UnitYNART2UModel.forward + arg-max
+    vocode(units, lang, spkr)                         Vocoder(dur_prediction=False)
+"""
+from __future__ import annotations
+
+import math
+from argparse import Namespace
+from dataclasses import dataclass
+from typing import Any, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .simul import (Action, AgentPipeline, AgentStates, GenericAgent, ReadAction, Segment, SpeechSegment, TextSegment,
+                    WriteAction)
+
+SHIFT_SIZE = 10
+WINDOW_SIZE = 25
+SAMPLE_RATE = 16000
+FEATURE_DIM = 80
+
+
+def default_args(**overrides: Any) -> Namespace:
+    """The argparse defaults of the reference agents (add_args of each class; cli/streaming/evaluate.py:56-69 for the
+    values its evaluation sets)."""
+    args = Namespace(
+        # online_feature_extractor.py:76-101
+        shift_size=SHIFT_SIZE, window_size=WINDOW_SIZE, sample_rate=SAMPLE_RATE, feature_dim=FEATURE_DIM, denormalize=False,
+        # offline_w2v_bert_encoder.py:57-64, fbank_stride of the w2v2 config
+        min_starting_wait_w2vbert=None, fbank_stride=2,
+        # online_text_decoder.py:98-130, :163-187
+        max_len_a=1, max_len_b=200, max_consecutive_write=50, min_starting_wait=1, no_early_stop=False, tgt_lang="eng",
+        decision_threshold=0.5, decision_method="min", p_choose_start_layer=0, block_ngrams=False,
+        # online_unit_decoder.py:79-92
+        min_unit_chunk_size=50, d_factor=1.0,
+        # online_vocoder.py:72-86
+        vocoder_speaker_id=-1,
+    )
+    for k, v in overrides.items():
+        if not hasattr(args, k):
+            raise ValueError(f"unknown streaming option '{k}'")
+        setattr(args, k, v)
+    return args
+
+
+# --------------------------------------------------------------------------------------------------------- #
+# 1. OnlineFeatureExtractorAgent (online_feature_extractor.py:29-152)
+# --------------------------------------------------------------------------------------------------------- #
+class FeatureStates(AgentStates):
+    def reset(self) -> None:
+        super().reset()
+        self.previous_residual_samples: List[float] = []
+        self.tgt_lang = None
+
+    def update_source(self, segment: Segment) -> None:
+        self.source_finished = segment.finished
+        if self.tgt_lang is None and segment.tgt_lang is not None:
+            self.tgt_lang = segment.tgt_lang
+        if not segment.is_empty:
+            self.source.append(segment.content)
+
+
+class OnlineFeatureExtractorAgent(GenericAgent):
+    """fbank on the fly: every new segment contributes the frames whose 25 ms window is complete, the tail
+    (15 ms + remainder) is carried over; features are NOT standardised (online_feature_extractor.py:65-71)."""
+
+    source_type = "speech"
+    target_type = "speech"
+
+    def __init__(self, backend, args: Namespace) -> None:
+        self.backend = backend
+        self.shift_size = args.shift_size
+        self.window_size = args.window_size
+        assert self.window_size >= self.shift_size
+        self.sample_rate = args.sample_rate
+        self.feature_dim = args.feature_dim
+        self.num_samples_per_shift = int(self.shift_size * self.sample_rate / 1000)
+        self.num_samples_per_window = int(self.window_size * self.sample_rate / 1000)
+        self.waveform_scale = 2.0 ** 15 if args.denormalize else 1.0
+        super().__init__(args)
+
+    def len_ms_to_samples(self, x: float) -> float:
+        return x * self.sample_rate / 1000
+
+    def build_states(self) -> FeatureStates:
+        return FeatureStates()
+
+    def policy(self, states: FeatureStates) -> Action:
+        if len(states.source) == 0:
+            if states.source_finished:
+                return WriteAction({}, finished=states.source_finished)
+            return ReadAction()
+        samples = states.previous_residual_samples + list(states.source[-1])
+        if len(samples) < self.num_samples_per_window:
+            states.previous_residual_samples = samples
+            return ReadAction()
+        # frames that the new segment completes, and the samples they span (including the carried-over tail)
+        num_frames = math.floor((len(samples) - self.len_ms_to_samples(self.window_size - self.shift_size)) / self.num_samples_per_shift)
+        effective_num_samples = int(num_frames * self.len_ms_to_samples(self.shift_size)
+                                    + self.len_ms_to_samples(self.window_size - self.shift_size))
+        input_samples = samples[:effective_num_samples]
+        states.previous_residual_samples = samples[num_frames * self.num_samples_per_shift:]
+        output = self.backend.fbank(input_samples, self.waveform_scale)
+        return WriteAction(SpeechSegment(content=output, tgt_lang=states.tgt_lang, finished=states.source_finished),
+                           finished=states.source_finished)
+
+
+# --------------------------------------------------------------------------------------------------------- #
+# 2. OfflineWav2VecBertEncoderAgent (offline_w2v_bert_encoder.py:27-110)
+# --------------------------------------------------------------------------------------------------------- #
+class OfflineWav2VecBertEncoderAgent(GenericAgent):
+    """Re-encodes everything heard so far whenever new frames arrive (offline_w2v_bert_encoder.py:66-100)."""
+
+    source_type = "speech"
+    target_type = "speech"
+
+    def __init__(self, backend, args: Namespace) -> None:
+        self.backend = backend
+        self.min_starting_wait = args.min_starting_wait_w2vbert
+        self.min_input_length = args.fbank_stride
+        super().__init__(args)
+
+    def policy(self, states: AgentStates) -> Action:
+        if self.min_starting_wait is not None and len(states.source) < self.min_starting_wait and not states.source_finished:
+            return ReadAction()
+        if len(states.source) < self.min_input_length:
+            if states.source_finished:
+                return WriteAction({}, finished=states.source_finished)
+            return ReadAction()
+        inputs = torch.stack(list(states.source))
+        encoder_output = self.backend.encode_speech(inputs)
+        return WriteAction(SpeechSegment(content=encoder_output, tgt_lang=states.tgt_lang, finished=states.source_finished),
+                           finished=states.source_finished)
+
+
+# --------------------------------------------------------------------------------------------------------- #
+# 3. UnitYMMATextDecoderAgent (online_text_decoder.py:25-444)
+# --------------------------------------------------------------------------------------------------------- #
+class DecoderAgentStates(AgentStates):
+    def reset(self) -> None:
+        self.source_len = 0
+        self.target_indices: List[int] = []
+        self.ngram_block_count = 0
+        super().reset()
+
+    def update_source(self, segment: Segment) -> None:
+        self.source_finished = segment.finished
+        if self.tgt_lang is None and segment.tgt_lang is not None:
+            self.tgt_lang = segment.tgt_lang
+        if not segment.is_empty:
+            self.source = segment.content
+            if len(self.source) == 0 and segment.finished:
+                self.target_finished = True
+                return
+            self.source_len = self.source.size(1)
+
+
+@dataclass
+class UnitYTextDecoderOutput:
+    decoder_features: Tensor
+    tokens: List[str]
+    target_indices: Optional[Tensor] = None
+
+
+class MMATextDecoderAgent(GenericAgent):
+    """Simultaneous greedy decoding under the monotonic-attention read/write policy: keep writing while the
+    decision statistic of p_choose[..., -1, -1] over (layers >= start, heads) stays above the threshold
+    (online_text_decoder.py:205-243, :303-387).  Emits the written pieces as text (S2TT)."""
+
+    source_type = "speech"
+    target_type = "text"
+
+    def __init__(self, backend, text_tokenizer, args: Namespace) -> None:
+        self.backend = backend
+        self.text_tokenizer = text_tokenizer
+        self.max_len_a: int = args.max_len_a
+        self.max_len_b: int = args.max_len_b
+        self.max_consecutive_writes = args.max_consecutive_write
+        self.min_starting_wait = args.min_starting_wait
+        self.no_early_stop = args.no_early_stop
+        self.eos_idx = text_tokenizer.vocab_info.eos_idx
+        assert args.tgt_lang is not None
+        self.prefix_indices: List[int] = list(text_tokenizer.create_encoder(lang=args.tgt_lang, mode="target").prefix_indices)
+        self.decision_threshold = args.decision_threshold
+        self.decision_method = args.decision_method
+        self.block_ngrams = args.block_ngrams
+        self.p_choose_start_layer = args.p_choose_start_layer
+        self.step_nr = 0  # IncrementalStateBag.step_nr of the current policy round
+        super().__init__(args)
+
+    def build_states(self) -> DecoderAgentStates:
+        return DecoderAgentStates()
+
+    def max_len(self, states: DecoderAgentStates) -> int:
+        return self.max_len_a * int(states.source.size(1)) + self.max_len_b
+
+    def enforce_tgt_lang_in_prefix(self, states: DecoderAgentStates) -> None:
+        if states.tgt_lang:
+            self.prefix_indices[-1] = self.text_tokenizer.token_to_index(f"__{states.tgt_lang}__")
+
+    def run_decoder(self, states: DecoderAgentStates, pred_indices: List[int]) -> Tuple[int, float, Tensor]:
+        if len(pred_indices) == 0:
+            self.enforce_tgt_lang_in_prefix(states)
+            target_input = self.prefix_indices + states.target_indices
+        else:
+            target_input = pred_indices[-1:]
+        blocked: Sequence[int] = ()
+        if self.block_ngrams and states.source_finished:
+            blocked = (states.target_indices + pred_indices)[-4:]
+        index, p_choose, decoder_output = self.backend.mma_step(target_input, blocked)
+        p = np.asarray(p_choose, dtype=np.float32)[self.p_choose_start_layer:]
+        if self.decision_method == "min":
+            prob = float(p.min())
+        elif self.decision_method == "mean":
+            prob = float(p.mean())
+        else:
+            prob = float(torch.from_numpy(p.reshape(-1).copy()).median())  # torch.median: the lower middle value
+        return index, prob, decoder_output.unsqueeze(0)
+
+    def postprocess(self, states: DecoderAgentStates, pred_indices: List[int], finished: bool,
+                    decoder_features_out: Optional[Tensor] = None) -> TextSegment:
+        return TextSegment(content=" ".join(self.text_tokenizer.index_to_token(idx) for idx in pred_indices), finished=finished,
+                           tgt_lang=states.tgt_lang)
+
+    def get_blocked_ngrams(self, target_indices: List[int]) -> Optional[Set[str]]:
+        if not self.block_ngrams:
+            return None
+        blocked_ngrams = set()
+        if len(target_indices) >= 4:
+            blocked_ngrams.add(str(target_indices[-4:]))
+            blocked_ngrams.add(str(target_indices[-4:-2]))
+            blocked_ngrams.add(str(target_indices[-4:-1]))
+        if len(target_indices) >= 3:
+            blocked_ngrams.add(str(target_indices[-3:]))
+            blocked_ngrams.add(str(target_indices[-3:-1]))
+        if len(target_indices) >= 2:
+            blocked_ngrams.add(str(target_indices[-2:]))
+        return blocked_ngrams
+
+    def maybe_block_ngrams(self, states: DecoderAgentStates, pred_indices: List[int], decoder_features_out: Tensor,
+                           blocked_ngrams: Optional[Set[str]], index: int) -> Tuple[bool, Tensor]:
+        """Forces a READ when an n-gram repeats before the source is finished (online_text_decoder.py:276-301)."""
+        if not self.block_ngrams or states.source_finished:
+            return False, decoder_features_out
+        assert blocked_ngrams is not None
+        all_indices = states.target_indices + pred_indices + [index]
+        for n in [3, 2]:
+            if len(all_indices) >= n and states.ngram_block_count <= 4:
+                if str(all_indices[-n:]) in blocked_ngrams:
+                    states.ngram_block_count += 1
+                    pred_indices[:] = pred_indices[: -(n - 1)]
+                    decoder_features_out = decoder_features_out[:, : -(n - 1)]
+                    return True, decoder_features_out
+                blocked_ngrams.add(str(all_indices[-n:]))
+        return False, decoder_features_out
+
+    @torch.inference_mode()
+    def policy(self, states: DecoderAgentStates) -> Action:
+        if len(states.source) == 0:
+            return ReadAction()
+        if states.source_len < self.min_starting_wait and not states.source_finished:
+            return ReadAction()
+        if states.target_finished:
+            return WriteAction("", finished=True)
+
+        # a fresh incremental state per policy call (online_text_decoder.py:317): the prefix and everything written so
+        # far are fed again over the re-encoded source
+        self.step_nr = 0
+        budget = len(self.prefix_indices) + len(states.target_indices) + self.max_consecutive_writes + 4
+        self.backend.mma_begin(states.source, budget)
+        states.source_len = states.source.size(1)
+
+        pred_indices: List[int] = []
+        finished = False
+        blocked_ngrams = self.get_blocked_ngrams(states.target_indices)
+        decoder_features_out = None
+        while True:
+            index, prob, decoder_features = self.run_decoder(states, pred_indices)
+            if decoder_features_out is None:
+                decoder_features_out = decoder_features.new_zeros((1, 0, decoder_features.shape[-1]))
+            decoder_features_out = torch.cat([decoder_features_out, decoder_features], dim=1)
+
+            if self.no_early_stop and not states.source_finished and (prob < self.decision_threshold or index == self.eos_idx):
+                if prob == 1.0:
+                    pred_indices = []
+                break
+            block_ngram, decoder_features_out = self.maybe_block_ngrams(states, pred_indices, decoder_features_out, blocked_ngrams, index)
+            if block_ngram:
+                break
+            if finished or index == self.eos_idx or len(states.target_indices + pred_indices) > self.max_len(states):
+                finished = True
+                break
+            if prob < self.decision_threshold and not states.source_finished:
+                break
+            if (len(states.target_indices + pred_indices) >= self.max_len(states)
+                    or len(pred_indices) >= self.max_consecutive_writes):
+                break
+            pred_indices.append(index)
+            if self.step_nr == 0:
+                self.step_nr += len(self.prefix_indices + states.target_indices)
+            else:
+                self.step_nr += 1
+
+        states.target_indices += pred_indices
+        if len(pred_indices) > 0 or finished:
+            finished = finished or len(states.target_indices + pred_indices) > self.max_len(states)
+            states.ngram_block_count = 0
+            return WriteAction(self.postprocess(states, pred_indices, finished, decoder_features_out), finished=finished)
+        return ReadAction()
+
+
+class UnitYMMATextDecoderAgent(MMATextDecoderAgent):
+    """The text decoder of the S2ST chain: hands decoder features + token ids to the unit decoder
+    (online_text_decoder.py:402-444)."""
+
+    def postprocess(self, states: DecoderAgentStates, pred_indices: List[int], finished: bool,
+                    decoder_features_out: Optional[Tensor] = None) -> TextSegment:
+        tokens = [self.text_tokenizer.index_to_token(idx) for idx in pred_indices]
+        assert decoder_features_out is not None
+        token_list = self.prefix_indices + states.target_indices
+        if len(pred_indices) > 0 and pred_indices[-1] != self.eos_idx:
+            # a "," is appended so that the partial phrase is synthesised with a natural ending (:423-435)
+            ending_token_index = self.text_tokenizer.token_to_index(",")
+            token_list = token_list + [ending_token_index]
+            self.step_nr += 1
+            _, _, decoder_features = self.run_decoder(states, [ending_token_index])
+            decoder_features_out = torch.cat([decoder_features_out, decoder_features], dim=1)
+        target_input = torch.tensor(token_list, dtype=torch.int64).unsqueeze(0)
+        return TextSegment(content=UnitYTextDecoderOutput(decoder_features_out, tokens, target_input), finished=finished,
+                           tgt_lang=states.tgt_lang)
+
+
+# --------------------------------------------------------------------------------------------------------- #
+# 4. NARUnitYUnitDecoderAgent (online_unit_decoder.py:24-156)
+# --------------------------------------------------------------------------------------------------------- #
+class NARUnitDecoderAgentStates(AgentStates):
+    def reset(self) -> None:
+        self.source_token_list: List[str] = []
+        self.source_indices: Optional[Tensor] = None
+        self.duration_start_index: int = 0
+        super().reset()
+
+    def update_source(self, segment: Segment) -> None:
+        self.source_finished = segment.finished
+        if self.tgt_lang is None and segment.tgt_lang is not None:
+            self.tgt_lang = segment.tgt_lang
+        if segment.is_empty:
+            if segment.finished:
+                self.target_finished = True
+            return
+        out: UnitYTextDecoderOutput = segment.content
+        self.source_indices = out.target_indices
+        self.source_token_list += out.tokens
+        self.source = out.decoder_features
+
+
+class NARUnitYUnitDecoderAgent(GenericAgent):
+    """Runs the NAR T2U model over all decoder features so far and emits the units of the part not yet spoken, once
+    at least `min_unit_chunk_size` of them have accumulated (online_unit_decoder.py:94-147)."""
+
+    source_type = "text"
+    target_type = "text"
+
+    def __init__(self, backend, args: Namespace) -> None:
+        self.backend = backend
+        self.min_unit_chunk_size = args.min_unit_chunk_size
+        self.d_factor = args.d_factor
+        super().__init__(args)
+
+    def build_states(self) -> NARUnitDecoderAgentStates:
+        return NARUnitDecoderAgentStates()
+
+    @torch.inference_mode()
+    def policy(self, states: NARUnitDecoderAgentStates) -> Action:
+        if states.target_finished:
+            return WriteAction("", finished=True)
+        if len(states.source_token_list) < 2:
+            if not states.source_finished:
+                return ReadAction()
+            return WriteAction("", finished=True)
+        units, durations = self.backend.t2u(states.source, states.source_indices, self.d_factor)
+        durations = [int(d) for d in durations]
+        if states.source_finished and states.duration_start_index > 0:
+            # one more word is considered for the EOS that closes the utterance (:112-121)
+            if sum(durations[states.duration_start_index:]) == 0:
+                return WriteAction("", finished=True)
+            states.duration_start_index = max(states.duration_start_index - 1, 0)
+        current_duration = sum(durations[states.duration_start_index:])
+        if current_duration < self.min_unit_chunk_size:
+            if not states.source_finished:
+                return ReadAction()
+            if current_duration == 0:
+                return WriteAction("", finished=True)
+        index_start_offset = sum(durations[: states.duration_start_index])
+        new_units = torch.as_tensor(np.asarray(units)[index_start_offset:], dtype=torch.int64).unsqueeze(0)
+        states.duration_start_index = len(durations) - 1  # minus one: every phrase ends with the added ","
+        return WriteAction(TextSegment(content=new_units, finished=states.source_finished, tgt_lang=states.tgt_lang),
+                           finished=states.source_finished)
+
+
+# --------------------------------------------------------------------------------------------------------- #
+# 5. VocoderAgent (online_vocoder.py:26-70)
+# --------------------------------------------------------------------------------------------------------- #
+class VocoderAgent(GenericAgent):
+    source_type = "text"
+    target_type = "speech"
+
+    def __init__(self, backend, args: Namespace) -> None:
+        self.backend = backend
+        self.sample_rate = args.sample_rate
+        self.tgt_lang = args.tgt_lang
+        self.speaker_id = args.vocoder_speaker_id
+        super().__init__(args)
+
+    @torch.inference_mode()
+    def policy(self, states: AgentStates) -> Action:
+        units = states.source
+        if len(units) == 0 or len(units[0]) == 0:
+            if states.source_finished:
+                return WriteAction([], finished=True)
+            return ReadAction()
+        tgt_lang = states.tgt_lang if states.tgt_lang else self.tgt_lang
+        u = units[0][0]
+        wav = self.backend.vocode([int(x) for x in u.tolist()], tgt_lang, self.speaker_id)
+        states.source = []
+        return WriteAction(SpeechSegment(content=wav.reshape(-1).tolist(), finished=states.source_finished,
+                                         sample_rate=self.sample_rate, tgt_lang=tgt_lang), finished=states.source_finished)
+
+
+# --------------------------------------------------------------------------------------------------------- #
+# pipelines (seamless_streaming_s2st.py:28-35, seamless_streaming_s2t.py; unity_pipeline.py:160-183)
+# --------------------------------------------------------------------------------------------------------- #
+class UnitYAgentPipeline(AgentPipeline):
+    def pop(self, states: Optional[List[Optional[AgentStates]]] = None) -> Segment:
+        output_segment = super().pop(states)
+        first_states = self.module_list[0].states if states is None else states[0]
+        if not first_states.source_finished and output_segment.finished:
+            # an early stop: start over (unity_pipeline.py:171-179)
+            if states is not None:
+                for s in states:
+                    if s is not None:
+                        s.reset()
+            else:
+                self.reset()
+            output_segment.finished = False
+        return output_segment
+
+
+class SeamlessStreamingS2STAgent(UnitYAgentPipeline):
+    def __init__(self, backend, text_tokenizer, args: Optional[Namespace] = None) -> None:
+        args = args if args is not None else default_args()
+        super().__init__([
+            OnlineFeatureExtractorAgent(backend, args),
+            OfflineWav2VecBertEncoderAgent(backend, args),
+            UnitYMMATextDecoderAgent(backend, text_tokenizer, args),
+            NARUnitYUnitDecoderAgent(backend, args),
+            VocoderAgent(backend, args),
+        ])
+
+
+class SeamlessStreamingS2TAgent(UnitYAgentPipeline):
+    """Speech-to-text: the chain without the unit decoder and the vocoder; pieces are joined with spaces like the
+    reference's text decoder agent writes them (the detokenizer agent is not part of this path)."""
+
+    def __init__(self, backend, text_tokenizer, args: Optional[Namespace] = None) -> None:
+        args = args if args is not None else default_args()
+        super().__init__([
+            OnlineFeatureExtractorAgent(backend, args),
+            OfflineWav2VecBertEncoderAgent(backend, args),
+            MMATextDecoderAgent(backend, text_tokenizer, args),
+        ])

@@ -64,6 +64,49 @@ def make_hip(seed: int = 20240901):
     return m
 
 
+@functools.lru_cache(maxsize=1)
+def monotonic_sd(seed: int = 20240901):
+    return syn.make_monotonic_decoder_state_dict(tiny_config(), seed)
+
+
+@functools.lru_cache(maxsize=1)
+def make_hip_streaming(seed: int = 20240901):
+    """tiny UnitY + vocoder + the streaming monotonic decoder in one handle."""
+    from seamless_communication_amd.runtime import HipS2STModel
+
+    cfg, sd, vsd, tt, ct = tiny_bundle(seed)
+    m = HipS2STModel(cfg, sd, vsd, device=0, monotonic_state_dict=monotonic_sd(seed))
+    m.set_nar_tables(tt, ct)
+    return m
+
+
+def make_oracle_streaming_backend(seed: int = 20240901):
+    from oracle.streaming_backend import OracleStreamingBackend
+
+    cfg, sd, vsd, tt, ct = tiny_bundle(seed)
+    return OracleStreamingBackend(cfg, sd, vsd, monotonic_sd(seed), tt, ct, cards.vocoder_lang_spkr_idx_map())
+
+
+def run_stream(agent, wav, segment_samples: int = 5120, tgt_lang: str = "fra"):
+    """Feeds `wav` to a streaming pipeline in fixed-size source segments (320 ms = cli/streaming/evaluate.py:57) and
+    returns the list of non-empty output segments."""
+    from seamless_communication_amd.streaming import SpeechSegment
+
+    outs = []
+    n = len(wav)
+    pos = 0
+    while pos < n:
+        chunk = wav[pos : pos + segment_samples]
+        pos += segment_samples
+        seg = SpeechSegment(content=[float(x) for x in chunk], sample_rate=16000, finished=pos >= n, tgt_lang=tgt_lang)
+        out = agent.pushpop(seg)
+        if not out.is_empty:
+            outs.append(out)
+        if out.finished:
+            break
+    return outs
+
+
 def waves(seconds=(2.0, 1.37), start: int = 0):
     return [syn.synthetic_waveform(start + i, s).numpy() for i, s in enumerate(seconds)]
 

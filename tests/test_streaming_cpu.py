@@ -1,0 +1,153 @@
+"""CPU: host logic of the streaming agents (seamless_communication_amd/streaming, reference
+src/seamless_communication/streaming/agents/*.py) driven by the oracle backend: online feature extraction equals
+offline feature extraction, the read/write loop, the unit-chunk policy, early-stop restarts, and the SimulEval contract
+restated in streaming/simul.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fbank as ofb
+from seamless_communication_amd.streaming import (EmptySegment, OnlineFeatureExtractorAgent, SeamlessStreamingS2STAgent,
+                                                  SeamlessStreamingS2TAgent, SpeechSegment, TextSegment, default_args)
+from seamless_communication_amd.streaming import agents as A
+from seamless_communication_amd.streaming.simul import AgentPipeline, AgentStates, GenericAgent, ReadAction, WriteAction
+from tests import common
+
+
+@pytest.fixture(scope="module")
+def backend():
+    return common.make_oracle_streaming_backend()
+
+
+@pytest.mark.parametrize("segment_samples", [5120, 1600, 233, 16000])
+def test_online_features_equal_offline_features(backend, segment_samples):
+    """Frames are emitted as soon as their 25 ms window is complete, the tail is carried over: the concatenation is the
+    offline fbank of the whole waveform (online_feature_extractor.py:102-148), here with waveform_scale 1 (no --denormalize)."""
+    wav = common.waves((1.3,))[0]
+    ag = OnlineFeatureExtractorAgent(backend, default_args())
+    feats, pos, n_out = [], 0, 0
+    while pos < len(wav):
+        chunk = wav[pos : pos + segment_samples]
+        pos += segment_samples
+        out = ag.pushpop(SpeechSegment(content=chunk.tolist(), sample_rate=16000, finished=pos >= len(wav)))
+        if not out.is_empty:
+            feats.append(out.content)
+            n_out += 1
+    got = torch.cat(feats)
+    want = torch.from_numpy(ofb.fbank_raw(wav, 1.0))
+    assert got.shape == want.shape
+    assert torch.equal(got, want)
+    if segment_samples == 233:
+        assert n_out < len(wav) // segment_samples  # short segments are buffered until a window is complete
+
+
+def test_denormalize_scales_the_waveform(backend):
+    wav = common.waves((0.5,))[0]
+    out = OnlineFeatureExtractorAgent(backend, default_args(denormalize=True)).pushpop(
+        SpeechSegment(content=wav.tolist(), sample_rate=16000, finished=True))
+    n = out.content.shape[0]
+    assert torch.equal(out.content, torch.from_numpy(ofb.fbank_raw(wav))[:n])  # fbank_raw default scale = 2**15
+
+
+def _args(**kw):
+    base = dict(tgt_lang="fra", decision_threshold=0.35, min_unit_chunk_size=20, min_starting_wait_w2vbert=48, max_len_a=0,
+                max_len_b=30)
+    base.update(kw)
+    return default_args(**base)
+
+
+def test_s2t_stream_reads_then_writes_incrementally(backend):
+    cfg, sd, vsd, tt, ct = common.tiny_bundle()
+    wav = common.waves((2.6,))[0]
+    ag = SeamlessStreamingS2TAgent(backend, tt, _args())
+    outs = common.run_stream(ag, wav)
+    assert len(outs) >= 2 and outs[-1].finished and not any(o.finished for o in outs[:-1])
+    pieces = [p for o in outs for p in o.content.split()]
+    dec_states = ag.module_list[2].states
+    assert pieces == [tt.index_to_token(i) for i in dec_states.target_indices]
+    assert len(pieces) <= 30 + 1
+    again = common.run_stream(SeamlessStreamingS2TAgent(backend, tt, _args()), wav)
+    assert [o.content for o in again] == [o.content for o in outs]
+    # a high threshold keeps reading until the source is finished, then writes everything at once
+    late = common.run_stream(SeamlessStreamingS2TAgent(backend, tt, _args(decision_threshold=0.99)), wav)
+    assert len(late) == 1 and late[0].finished
+
+
+def test_first_encoder_call_waits_for_min_frames(backend):
+    cfg, sd, vsd, tt, ct = common.tiny_bundle()
+    calls = []
+    orig = backend.encode_speech
+    backend.encode_speech = lambda frames: (calls.append(frames.shape[0]), orig(frames))[1]
+    try:
+        common.run_stream(SeamlessStreamingS2TAgent(backend, tt, _args(min_starting_wait_w2vbert=100, decision_threshold=0.99)),
+                          common.waves((2.0,))[0])
+    finally:
+        backend.encode_speech = orig
+    assert calls[0] >= 100 and calls == sorted(calls) and len(set(calls)) == len(calls)  # everything heard so far, each time
+
+
+def test_s2st_stream_units_and_waveform_chunks(backend):
+    cfg, sd, vsd, tt, ct = common.tiny_bundle()
+    wav = common.waves((2.6,))[0]
+    seen_units = []
+    orig = backend.vocode
+    backend.vocode = lambda units, lang, spkr: (seen_units.append(list(units)), orig(units, lang, spkr))[1]
+    try:
+        ag = SeamlessStreamingS2STAgent(backend, tt, _args())
+        outs = common.run_stream(ag, wav)
+    finally:
+        backend.vocode = orig
+    assert outs and outs[-1].finished and all(isinstance(o, SpeechSegment) and o.sample_rate == 16000 for o in outs)
+    assert len(outs) == len(seen_units)
+    for o, u in zip(outs, seen_units):
+        assert len(o.content) == len(u) * cfg.vocoder.hop and len(u) >= 1
+    assert all(len(u) >= 20 for u in seen_units[:-1])  # min_unit_chunk_size, except for the closing chunk
+
+
+def test_block_ngrams_forces_reads_and_blocks_repeats(backend):
+    cfg, sd, vsd, tt, ct = common.tiny_bundle()
+    wav = common.waves((2.6,))[0]
+    plain = common.run_stream(SeamlessStreamingS2TAgent(backend, tt, _args(decision_threshold=0.2)), wav)
+    blocked = common.run_stream(SeamlessStreamingS2TAgent(backend, tt, _args(decision_threshold=0.2, block_ngrams=True)), wav)
+    assert [o.content for o in plain] != [o.content for o in blocked]  # the unconstrained tiny model repeats itself
+
+
+def test_early_stop_restarts_the_pipeline(backend):
+    """The decoder reaching its length limit before the source ends is an early stop: the pipeline resets itself and
+    reports the segment as unfinished (unity_pipeline.py:171-179)."""
+    cfg, sd, vsd, tt, ct = common.tiny_bundle()
+    wav = common.waves((2.6,))[0]
+    ag = SeamlessStreamingS2TAgent(backend, tt, _args(decision_threshold=0.0, max_len_b=6))
+    outs = common.run_stream(ag, wav)
+    assert len(outs) >= 2 and not any(o.finished for o in outs[:-1]) and outs[-1].finished
+    assert all(len(o.content.split()) <= 7 for o in outs)
+
+
+def test_simul_contract():
+    class Echo(GenericAgent):
+        source_type = target_type = "text"
+
+        def policy(self, states):
+            if not states.source:
+                return ReadAction()
+            return WriteAction(states.source.pop(0).upper(), finished=states.source_finished)
+
+    class Twice(Echo):
+        def policy(self, states):
+            if not states.source:
+                return ReadAction()
+            return WriteAction(TextSegment(content=states.source.pop(0) * 2, finished=states.source_finished),
+                               finished=states.source_finished)
+
+    pipe = AgentPipeline([Echo(), Twice()])
+    assert pipe.pushpop(TextSegment(content="ab")).content == "ABAB"
+    assert pipe.pushpop(EmptySegment()).is_empty
+    last = pipe.pushpop(TextSegment(content="c", finished=True))
+    assert last.content == "CC" and last.finished
+    assert pipe.module_list[0].states.target_finished and pipe.module_list[0].pop().finished  # wrapped content updates the target state
+    st = AgentStates()
+    st.update_source(SpeechSegment(content=torch.zeros(3, 2), sample_rate=16000))
+    st.update_source(SpeechSegment(content=[1.0, 2.0], sample_rate=16000))
+    assert len(st.source) == 5  # speech extends, text appends
+    with pytest.raises(ValueError):
+        default_args(not_an_option=1)
