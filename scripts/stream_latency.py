@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--arch", default="base_v2", choices=["base_v2", "tiny_v2"])
     ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--max-len-b", type=int, default=100, help="cli/streaming/evaluate.py:64; lower it for tiny_v2 (unit_max_seq_len)")
     a = ap.parse_args()
     from seamless_communication_amd import cards, synthetic as syn
     from seamless_communication_amd.config import seamless_m4t_v2_large, tiny_config
@@ -55,7 +56,7 @@ def main():
     seg = 5120
     for method in ("min", "mean"):
         args = default_args(tgt_lang="fra", min_starting_wait_w2vbert=192, decision_threshold=0.5, no_early_stop=True, max_len_a=0,
-                            max_len_b=100, min_unit_chunk_size=50, decision_method=method)
+                            max_len_b=a.max_len_b, min_unit_chunk_size=50, decision_method=method)
         for rep in range(2):  # first pass warms allocations up
             agent = SeamlessStreamingS2STAgent(be, tt, args)
             stage.clear()
