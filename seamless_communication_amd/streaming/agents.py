@@ -45,6 +45,8 @@ def default_args(**overrides: Any) -> Namespace:
         min_unit_chunk_size=50, d_factor=1.0,
         # online_vocoder.py:72-86
         vocoder_speaker_id=-1,
+        # detokenizer.py:35-41
+        detokenize_only=True,
     )
     for k, v in overrides.items():
         if not hasattr(args, k):
@@ -438,6 +440,37 @@ class VocoderAgent(GenericAgent):
 
 
 # --------------------------------------------------------------------------------------------------------- #
+# DetokenizerAgent (detokenizer.py:21-62): sentence pieces -> text for the speech-to-text chain
+# --------------------------------------------------------------------------------------------------------- #
+class DetokenizerAgent(GenericAgent):
+    source_type = "text"
+    target_type = "text"
+
+    def __init__(self, args: Namespace) -> None:
+        self.detokenize_only = args.detokenize_only
+        super().__init__(args)
+
+    def policy(self, states: AgentStates) -> Action:
+        possible_full_words = self.decode(" ".join([x for x in states.source]))
+        if self.detokenize_only and len(states.source) > 0:
+            states.source = []
+            if len(possible_full_words) == 0 and not states.source_finished:
+                return ReadAction()
+            return WriteAction(possible_full_words, states.source_finished)
+        if states.source_finished:
+            return WriteAction(possible_full_words, True)
+        if len(possible_full_words.split()) > 1:
+            full_word = possible_full_words.split()[0]
+            states.source = states.source[-1:]
+            return WriteAction(full_word, finished=False)
+        return ReadAction()
+
+    @staticmethod
+    def decode(x: str) -> str:
+        return x.replace(" ", "").replace("\u2581", " ").strip()
+
+
+# --------------------------------------------------------------------------------------------------------- #
 # pipelines (seamless_streaming_s2st.py:28-35, seamless_streaming_s2t.py; unity_pipeline.py:160-183)
 # --------------------------------------------------------------------------------------------------------- #
 class UnitYAgentPipeline(AgentPipeline):
@@ -468,9 +501,22 @@ class SeamlessStreamingS2STAgent(UnitYAgentPipeline):
         ])
 
 
+class SeamlessStreamingS2TDetokAgent(UnitYAgentPipeline):
+    """Speech-to-text with detokenised output (seamless_streaming_s2t.py:20-26)."""
+
+    def __init__(self, backend, text_tokenizer, args: Optional[Namespace] = None) -> None:
+        args = args if args is not None else default_args()
+        super().__init__([
+            OnlineFeatureExtractorAgent(backend, args),
+            OfflineWav2VecBertEncoderAgent(backend, args),
+            MMATextDecoderAgent(backend, text_tokenizer, args),
+            DetokenizerAgent(args),
+        ])
+
+
 class SeamlessStreamingS2TAgent(UnitYAgentPipeline):
-    """Speech-to-text: the chain without the unit decoder and the vocoder; pieces are joined with spaces like the
-    reference's text decoder agent writes them (the detokenizer agent is not part of this path)."""
+    """Speech-to-text (seamless_streaming_s2t.py:29-34): sentence pieces joined with spaces, as the text decoder agent
+    writes them."""
 
     def __init__(self, backend, text_tokenizer, args: Optional[Namespace] = None) -> None:
         args = args if args is not None else default_args()

@@ -151,3 +151,24 @@ def test_simul_contract():
     assert len(st.source) == 5  # speech extends, text appends
     with pytest.raises(ValueError):
         default_args(not_an_option=1)
+
+
+def test_detokenizer_agent(backend):
+    from seamless_communication_amd.streaming import DetokenizerAgent, SeamlessStreamingS2TDetokAgent
+
+    ag = DetokenizerAgent(default_args())
+    out = ag.pushpop(TextSegment(content="▁hel lo ▁wor"))
+    assert out.content == "hello wor" and not out.finished
+    assert ag.pushpop(EmptySegment()).is_empty
+    out = ag.pushpop(TextSegment(content="ld", finished=True))
+    assert out.content == "ld" and out.finished
+    word = DetokenizerAgent(default_args(detokenize_only=False))  # waits for a complete word
+    assert word.pushpop(TextSegment(content="▁hel")).is_empty
+    assert word.pushpop(TextSegment(content="lo")).is_empty
+    assert word.pushpop(TextSegment(content="▁wor")).content == "hello"
+    assert word.pushpop(TextSegment(content="ld", finished=True)).content == "world"
+    cfg, sd, vsd, tt, ct = common.tiny_bundle()
+    wav = common.waves((2.6,))[0]
+    pieces = common.run_stream(SeamlessStreamingS2TAgent(backend, tt, _args()), wav)
+    text = common.run_stream(SeamlessStreamingS2TDetokAgent(backend, tt, _args()), wav)
+    assert [DetokenizerAgent.decode(o.content) for o in pieces] == [o.content for o in text]
