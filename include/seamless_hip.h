@@ -222,6 +222,9 @@ int32_t sc_ngram_blocked_tokens(const int32_t* h_seq, int32_t len, int32_t ngram
 /* 1: route every dense product to the general MFMA kernel instead of the double-buffered fast path
  * (the two produce identical bits; used by the parity tests and for A/B timing). */
 int sc_op_force_general_gemm(int on);
+/* Decoder-step product kernel: 0 = skinny_kernel (default), 1 = the software-pipelined skinny2_kernel (experimental;
+ * also selected by SC_SKINNY2=1 in the environment).  The two are meant to produce identical bits. */
+int sc_op_set_skinny_variant(int variant);
 int sc_op_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float* d_y, int32_t rows, int32_t C,
                     int32_t act);
 int sc_op_linear(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y,

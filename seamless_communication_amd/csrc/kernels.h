@@ -134,6 +134,10 @@ struct SkinnyArgs {
     int am_pad_idx = -1, am_eos_idx = -1, am_unk_idx = -1;
     float am_unk_penalty = 0.f;
 };
+// experimental software-pipelined variant (k_skinny2.hip): 0 = skinny_kernel (default), 1 = skinny2_kernel
+extern std::atomic<int> g_skinny_variant;
+int skinny_variant();
+bool launch_skinny2(const SkinnyArgs& a, dim3 grid, int nt, hipStream_t s);
 // number of am_part tiles launch_skinny will write for N output features and M rows
 int skinny_argmax_tiles(int M, int N);
 void launch_argmax_finalize(const float4* part, int tiles, int nb, const float* eos_logit, const int* d_pos,

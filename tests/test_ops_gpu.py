@@ -576,3 +576,82 @@ def test_skinny_fused_argmax(lib, report_dir, M, N, K, mode):
     err = float((lp.cpu().double() - ref_lp).abs().max()) if mode != "unk_pen" else 0.0
     _log(report_dir, "skinny_argmax", M=M, N=N, K=K, mode=mode, err=err)
     assert err < 1e-4
+
+
+# --------------------------------------------------------------------------------------------------------- #
+# Experimental software-pipelined decoder-step product (k_skinny2.hip).  Written without GPU time left in round 1:
+# the tests below are the first thing to run on hardware (SC_TEST_EXPERIMENTAL=1) before SC_SKINNY2 is made the default.
+# --------------------------------------------------------------------------------------------------------- #
+import os  # noqa: E402
+
+_EXPERIMENTAL = pytest.mark.skipif(os.environ.get("SC_TEST_EXPERIMENTAL") != "1",
+                                   reason="skinny2_kernel has not run on hardware yet: set SC_TEST_EXPERIMENTAL=1")
+
+
+@pytest.fixture
+def skinny_variants(lib):
+    def run(fn):
+        outs = []
+        try:
+            for v in (0, 1):
+                check(lib, lib.sc_op_set_skinny_variant(v))
+                outs.append(fn())
+        finally:
+            lib.sc_op_set_skinny_variant(0)
+        return outs
+    return run
+
+
+@_EXPERIMENTAL
+@pytest.mark.parametrize("M,N,K", SKINNY_SHAPES + [(64, 8192, 1024), (64, 1024, 8192), (32, 256102, 1024), (64, 256102, 1024)])
+def test_skinny2_linear_bit_identical(lib, skinny_variants, M, N, K):
+    g = torch.Generator().manual_seed(M * 11 + N * 5 + K)
+    x = dev(torch.randn(M, K, generator=g) * 2.0)
+    w = dev((torch.randn(N, K, generator=g) / math.sqrt(K)).half())
+    b = dev(torch.randn(N, generator=g) * 0.1)
+    r = dev(torch.randn(M, N, generator=g))
+
+    def one():
+        y = torch.full((M, N), float("nan"), device="cuda")
+        check(lib, lib.sc_op_skinny_linear(P(x), P(w), P(b), P(r), P(y), M, N, K, 1, 0.5))
+        return y.cpu()
+
+    a, b2 = skinny_variants(one)
+    assert torch.equal(a, b2), float((a - b2).abs().max())
+
+
+@_EXPERIMENTAL
+@pytest.mark.parametrize("M,N,K,splits", [(16, 1024, 1024, 0), (16, 1024, 8192, 0), (64, 1024, 8192, 4), (3, 128, 256, 0),
+                                          (64, 1024, 1024, 2), (32, 3072, 1024, 0), (1, 1024, 1024, 0)])
+def test_skinny2_split_k_bit_identical(lib, skinny_variants, M, N, K, splits):
+    g = torch.Generator().manual_seed(M + N + K + splits)
+    inp = dev(torch.randn(M, K, generator=g))
+    w = dev((torch.randn(N, K, generator=g) / math.sqrt(K)).half())
+    b = dev(torch.randn(N, generator=g) * 0.1)
+    x0 = torch.randn(M, N, generator=g)
+    gam, bet = dev(torch.rand(N, generator=g) + 0.5), dev(torch.randn(N, generator=g) * 0.1)
+
+    def one():
+        x, h = dev(x0.clone()), torch.empty(M, N, device="cuda")
+        check(lib, lib.sc_op_skinny_res_ln(P(inp), P(w), P(b), P(x), P(gam), P(bet), P(h), M, N, K, splits))
+        return x.cpu(), h.cpu()
+
+    (xa, ha), (xb, hb) = skinny_variants(one)
+    assert torch.equal(xa, xb) and torch.equal(ha, hb)
+
+
+@_EXPERIMENTAL
+@pytest.mark.parametrize("M,N,K", [(16, 256102, 1024), (1, 256102, 1024), (5, 1200, 128), (40, 10082, 1024), (64, 256102, 1024)])
+def test_skinny2_fused_argmax_bit_identical(lib, skinny_variants, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = dev(torch.randn(M, K, generator=g))
+    w = dev((torch.randn(N, K, generator=g) / math.sqrt(K)).half())
+
+    def one():
+        idx = torch.empty(M, dtype=torch.int32, device="cuda")
+        lp = torch.empty(M, device="cuda")
+        check(lib, lib.sc_op_skinny_argmax(P(x), P(w), M, N, K, 5, 0, -1, 0, 3, 1, 0.0, P(idx), P(lp)))
+        return idx.cpu(), lp.cpu()
+
+    (ia, la), (ib, lb) = skinny_variants(one)
+    assert torch.equal(ia, ib) and torch.equal(la, lb)
