@@ -15,8 +15,7 @@ fairseq2 names convert_monotonic_checkpoint produces (models/monotonic_decoder/l
 """
 from __future__ import annotations
 
-import math
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.nn.functional as F

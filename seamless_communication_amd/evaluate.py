@@ -18,7 +18,6 @@ from __future__ import annotations
 import json
 import logging
 import struct
-import wave
 from dataclasses import dataclass
 from pathlib import Path
 from typing import Any, Callable, Dict, Iterator, List, Optional, Sequence, Tuple

@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import math
 import zlib
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 
