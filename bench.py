@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--cpu-baseline-timeout", type=int, default=240)
     ap.add_argument("--no-profile-step", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement")
+    ap.add_argument("--profile-slices", action="store_true",
+                    help="run the HIP-event profiled pass on the timed micro-batch slicing (concurrent slices) instead of one "
+                         "64-row slice on one stream, so that its kernel shapes are those of the timed passes")
     ap.add_argument("--no-graph", action="store_true", help="launch decoder steps eagerly instead of hipGraph replay")
     ap.add_argument("--free-run", action="store_true",
                     help="let the micro-batch slices free-run over the K steps (joined once) instead of joining them after "
@@ -336,13 +339,15 @@ def main():
         lib = model.lib
         lib.sc_prof_reset()
         lib.sc_prof_enable(1)
-        translator.use_graph = False  # launches inside a captured graph cannot carry events
-        step(single_stream=True)
+        for v in batcher.views:
+            v.use_graph = False  # launches inside a captured graph cannot carry events
+        step(single_stream=not (args.profile_slices and batcher.groups > 1))
         torch.cuda.synchronize()
         lib.sc_prof_enable(0)
         fams = prof_report(lib)
         log("profiled step done")
-        translator.use_graph = not args.no_graph
+        for v in batcher.views:
+            v.use_graph = not args.no_graph
         if rank == 0:
             roof, shares = roofline_of(fams)
             result["roofline"] = roof

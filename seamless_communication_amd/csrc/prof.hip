@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -20,7 +21,8 @@ struct Agg {
     double ms = 0, flops = 0, bytes = 0;
 };
 bool g_on = false;
-std::string g_tag;
+thread_local std::string g_tag;  // the stage tag belongs to the host thread that drives a handle
+std::mutex g_mu;                 // several handles (host threads) may record while profiling is on
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_free;
 std::map<std::string, Agg> g_agg;
@@ -57,6 +59,7 @@ bool enabled() { return g_on; }
 void enable(bool on) { g_on = on; }
 void set_tag(const char* tag) { g_tag = tag ? tag : ""; }
 void reset() {
+    std::lock_guard<std::mutex> lock(g_mu);
     drain();
     g_agg.clear();
 }
@@ -65,6 +68,7 @@ int begin(const char* name, double flops, double bytes, hipStream_t s) {
     if (!g_on) return -1;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return -1;
+    std::lock_guard<std::mutex> lock(g_mu);
     if (g_recs.size() > 200000) drain();
     Rec r;
     r.name = g_tag.empty() ? std::string(name) : g_tag + ":" + name;
@@ -78,11 +82,14 @@ int begin(const char* name, double flops, double bytes, hipStream_t s) {
 }
 
 void end(int token, hipStream_t s) {
-    if (token < 0 || token >= (int)g_recs.size()) return;
+    if (token < 0) return;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (token >= (int)g_recs.size()) return;
     (void)hipEventRecord(g_recs[token].b, s);
 }
 
 size_t report(char* buf, size_t cap) {
+    std::lock_guard<std::mutex> lock(g_mu);
     drain();
     std::string out;
     char line[512];
