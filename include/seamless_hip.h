@@ -212,6 +212,16 @@ int sc_prof_enable(int on);
 int sc_prof_reset(void);
 int64_t sc_prof_report(char* buf, int64_t cap);
 
+/* Host logic of NARDecoderFrontend's string rules (models/unity/nar_decoder_frontend.py:31-49, :158-259) exactly as
+ * sc_t2u_nar runs it, on caller-supplied tables (the arguments of sc_set_nar_tables) — no device work, callable without a
+ * GPU.  h_text_seqs [n][s_text] is text_seqs[:, :-1]; writes the per-subword character counts [n][s_text] (zero at the
+ * language slot and on padding), the character ids [n][cap] and their number per item; returns the longest sequence or a
+ * negative status. */
+int32_t sc_text_to_char_seqs(int32_t vocab, const int32_t* h_tok_len, const uint8_t* h_starts_space, const uint8_t* h_is_punct,
+                             const int64_t* h_char_offsets, const int32_t* h_char_ids, int32_t pad_idx, int32_t unk_idx,
+                             int32_t eos_idx, const int32_t* h_text_seqs, int32_t n, int32_t s_text, int32_t* h_char_lens,
+                             int32_t* h_out_char_ids, int32_t cap, int32_t* h_char_seq_lens);
+
 /* Host logic of the n-gram step processor (no device work; callable without a GPU): the tokens
  * NGramRepeatBlockProcessor(ngram_size) blocks after the `len` tokens of `h_seq`.  Writes at most `cap`
  * of them to h_out (in window order, duplicates kept) and returns how many there are, or a negative status. */

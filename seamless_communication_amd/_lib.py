@@ -104,6 +104,8 @@ SIGNATURES = {
     "sc_prof_enable": (C.c_int, [C.c_int]),
     "sc_prof_reset": (C.c_int, []),
     "sc_prof_report": (C.c_int64, [C.c_char_p, C.c_int64]),
+    "sc_text_to_char_seqs": (C.c_int32, [C.c_int32, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32,
+                                         _P, _P, C.c_int32, _P]),
     "sc_ngram_blocked_tokens": (C.c_int32, [_PI, C.c_int32, C.c_int32, _PI, C.c_int32]),
     "sc_op_force_general_gemm": (C.c_int, [C.c_int]),
     "sc_op_set_skinny_variant": (C.c_int, [C.c_int]),

@@ -238,6 +238,24 @@ int sc_prof_reset(void) {
 }
 int64_t sc_prof_report(char* buf, int64_t cap) { return (int64_t)sc::prof::report(buf, (size_t)(cap > 0 ? cap : 0)); }
 
+int32_t sc_text_to_char_seqs(int32_t vocab, const int32_t* h_tok_len, const uint8_t* h_starts_space, const uint8_t* h_is_punct,
+                             const int64_t* h_char_offsets, const int32_t* h_char_ids, int32_t pad_idx, int32_t unk_idx,
+                             int32_t eos_idx, const int32_t* h_text_seqs, int32_t n, int32_t s_text, int32_t* h_char_lens,
+                             int32_t* h_out_char_ids, int32_t cap, int32_t* h_char_seq_lens) {
+    try {
+        SC_CHECK(h_tok_len && h_starts_space && h_is_punct && h_char_offsets && h_char_ids && h_text_seqs && h_char_lens &&
+                     h_out_char_ids && h_char_seq_lens && cap >= 0,
+                 "sc_text_to_char_seqs: null argument");
+        return text_to_char_seqs_host(vocab, h_tok_len, h_starts_space, h_is_punct, h_char_offsets, h_char_ids, pad_idx, unk_idx,
+                                      eos_idx, h_text_seqs, n, s_text, h_char_lens, h_out_char_ids, cap, h_char_seq_lens);
+    } catch (const sc::Error& e) {
+        return e.code;
+    } catch (const std::exception& e) {
+        sc::set_error("unexpected C++ exception: %s", e.what());
+        return SC_ERR_INTERNAL;
+    }
+}
+
 int32_t sc_ngram_blocked_tokens(const int32_t* h_seq, int32_t len, int32_t ngram_size, int32_t* h_out, int32_t cap) {
     try {
         SC_CHECK(len >= 0 && ngram_size >= 1 && cap >= 0 && (h_seq || len == 0) && (h_out || cap == 0),

@@ -229,6 +229,9 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
 void run_mma_begin(Model& m, const float* d_enc, int s_enc, int max_len);
 void run_mma_step(Model& m, const int32_t* h_tokens, int n_tokens, const int32_t* h_blocked, int n_blocked, int32_t* out_index,
                   float* h_pchoose, float* d_features);
+int text_to_char_seqs_host(int vocab, const int32_t* tok_len, const uint8_t* starts_space, const uint8_t* is_punct,
+                           const int64_t* offs, const int32_t* ids, int pad_idx, int unk_idx, int eos_idx, const int32_t* text_seqs,
+                           int n, int s_text, int32_t* out_char_lens, int32_t* out_char_ids, int cap, int32_t* out_seq_lens);
 void run_encode_text(Model& m, const int32_t* h_tokens, int n, int s_text, const int32_t* h_lens, float* d_out);
 int text_max_len(const Model& m, const sc_gen_opts& o, int s_enc);
 void ngram_blocked_tokens(const int32_t* seq, int S, int G, std::vector<int32_t>& out);

@@ -76,6 +76,36 @@ void text_to_char_seqs(const Model& m, const int32_t* text_seqs, int n, int s_te
 
 }  // namespace
 
+// The same host logic without a handle (parity tests on machines without a GPU): a scratch model that only carries
+// the tables and the three special ids.  Returns the longest char sequence.
+int text_to_char_seqs_host(int vocab, const int32_t* tok_len, const uint8_t* starts_space, const uint8_t* is_punct,
+                           const int64_t* offs, const int32_t* ids, int pad_idx, int unk_idx, int eos_idx, const int32_t* text_seqs,
+                           int n, int s_text, int32_t* out_char_lens, int32_t* out_char_ids, int cap, int32_t* out_seq_lens) {
+    SC_CHECK(vocab > 0 && n > 0 && s_text >= 2, "sc_text_to_char_seqs: bad geometry");
+    Model m;  // no device work happens in its constructor / destructor while nothing is loaded
+    m.cfg.pad_idx = pad_idx;
+    m.cfg.unk_idx = unk_idx;
+    m.cfg.eos_idx = eos_idx;
+    m.tok_len.assign(tok_len, tok_len + vocab);
+    m.starts_space.assign(starts_space, starts_space + vocab);
+    m.is_punct.assign(is_punct, is_punct + vocab);
+    m.char_offsets.assign(offs, offs + vocab + 1);
+    m.char_ids.assign(ids, ids + offs[vocab]);
+    std::vector<int32_t> char_lens;
+    std::vector<std::vector<int32_t>> cids;
+    text_to_char_seqs(m, text_seqs, n, s_text, char_lens, cids);
+    std::copy(char_lens.begin(), char_lens.end(), out_char_lens);
+    int longest = 0;
+    for (int b = 0; b < n; ++b) {
+        const int len = (int)cids[b].size();
+        SC_CHECK(len <= cap, "sc_text_to_char_seqs: item %d has %d characters, capacity %d", b, len, cap);
+        std::copy(cids[b].begin(), cids[b].end(), out_char_ids + (size_t)b * cap);
+        out_seq_lens[b] = len;
+        longest = std::max(longest, len);
+    }
+    return longest;
+}
+
 // UnitYModel.encode_text (models/unity/model.py:138-151): the embedding frontend the decoder also uses
 // (builder.py:443-446: one shared module; fairseq2.cpp:917-953) and the NLLB encoder = pre-LN
 // StandardTransformerEncoder layers + final LayerNorm (fairseq2.cpp:955-977), key padding mask from h_lens.

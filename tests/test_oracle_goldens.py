@@ -135,3 +135,37 @@ def test_fft_layer_matches_reference_layer(bundle):
     ref = torch.from_numpy(g["layer_out"])
     for b, n in enumerate(g["lens"].tolist()):
         assert float((y[b, :n] - ref[b, :n]).abs().max()) < FTOL
+
+
+def test_cxx_char_rules_match_reference_frontend(bundle):
+    """The C++ restatement of the string rules that sc_t2u_nar runs (csrc/model_t2u.hip: text_to_char_seqs) — called on the
+    CPU through its host-only C-ABI entry — against the characters the reference's own nar_decoder_frontend.py produced."""
+    import ctypes as C
+
+    from seamless_communication_amd import _lib
+
+    cfg, sd, vsd, tt, ct = bundle
+    g = np.load(G / "nar_frontend_ref.npz")
+    lib = _lib.load_library()
+    tok_len, starts_sp, is_punc, offs, ids = tt.nar_tables(ct)
+    arr = [np.ascontiguousarray(tok_len.astype(np.int32)), np.ascontiguousarray(starts_sp.astype(np.uint8)),
+           np.ascontiguousarray(is_punc.astype(np.uint8)), np.ascontiguousarray(offs.astype(np.int64)),
+           np.ascontiguousarray(ids.astype(np.int32))]
+    text = np.ascontiguousarray(g["text_seqs"].astype(np.int32))
+    n, s_text = text.shape
+    cap = 64
+    char_lens = np.zeros((n, s_text), dtype=np.int32)
+    char_ids = np.full((n, cap), -1, dtype=np.int32)
+    seq_lens = np.zeros(n, dtype=np.int32)
+    P = lambda a: C.c_void_p(a.ctypes.data)
+    longest = lib.sc_text_to_char_seqs(len(tok_len), *[P(a) for a in arr], cfg.pad_idx, cfg.unk_idx, cfg.eos_idx, P(text), n, s_text,
+                                       P(char_lens), P(char_ids), cap, P(seq_lens))
+    assert longest == int(g["char_seq_lens"].max()), lib.sc_last_error()
+    assert np.array_equal(char_lens, g["char_lens"])
+    assert np.array_equal(seq_lens, g["char_seq_lens"])
+    for b in range(n):
+        assert char_ids[b, : seq_lens[b]].tolist() == g["char_seqs"][b, : seq_lens[b]].tolist()
+    # capacity and geometry errors are reported, not written past
+    assert lib.sc_text_to_char_seqs(len(tok_len), *[P(a) for a in arr], cfg.pad_idx, cfg.unk_idx, cfg.eos_idx, P(text), n, s_text,
+                                    P(char_lens), P(char_ids), 3, P(seq_lens)) < 0
+    assert b"capacity" in lib.sc_last_error()
