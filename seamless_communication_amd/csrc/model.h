@@ -21,10 +21,12 @@ class DevicePool {
     void* get(size_t bytes);
     void put(void* p);
     void release_all();
+    void trim();  // hipFree every cached (not handed out) block
 
    private:
     std::multimap<size_t, void*> free_;
     std::unordered_map<void*, size_t> size_;
+    size_t cached_bytes_ = 0;  // bytes sitting in free_
 };
 
 template <typename T>

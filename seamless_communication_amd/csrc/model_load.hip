@@ -10,29 +10,50 @@ namespace sc {
 // --------------------------------------------------------------------------- //
 DevicePool::~DevicePool() { release_all(); }
 
+// Blocks are never split or merged; a request takes the smallest cached block that is not more than twice (+1 MB) too
+// large.  Workloads whose shapes keep growing (a streaming session re-encodes an ever longer source) leave a trail of
+// too-small blocks behind: when the device runs out of memory the cache is dropped and the allocation retried.  (No
+// proactive limit: a steady-state batch keeps tens of GB cached on purpose, and trimming that would re-malloc every pass.)
 void* DevicePool::get(size_t bytes) {
     bytes = (size_t)align_up((int64_t)std::max<size_t>(bytes, 256), 256);
     auto it = free_.lower_bound(bytes);
     if (it != free_.end() && it->first <= bytes * 2 + (1 << 20)) {
         void* p = it->second;
+        cached_bytes_ -= it->first;
         free_.erase(it);
         return p;
     }
     void* p = nullptr;
-    SC_HIP(hipMalloc(&p, bytes));
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        trim();
+        SC_HIP(hipMalloc(&p, bytes));
+    }
     size_[p] = bytes;
     return p;
 }
 
 void DevicePool::put(void* p) {
     if (!p) return;
-    free_.emplace(size_[p], p);
+    const size_t n = size_[p];
+    free_.emplace(n, p);
+    cached_bytes_ += n;
+}
+
+void DevicePool::trim() {
+    for (auto& kv : free_) {
+        (void)hipFree(kv.second);
+        size_.erase(kv.second);
+    }
+    free_.clear();
+    cached_bytes_ = 0;
 }
 
 void DevicePool::release_all() {
     for (auto& kv : size_) (void)hipFree(kv.first);
     size_.clear();
     free_.clear();
+    cached_bytes_ = 0;
 }
 
 Model::~Model() {
