@@ -172,3 +172,60 @@ def test_detokenizer_agent(backend):
     pieces = common.run_stream(SeamlessStreamingS2TAgent(backend, tt, _args()), wav)
     text = common.run_stream(SeamlessStreamingS2TDetokAgent(backend, tt, _args()), wav)
     assert [DetokenizerAgent.decode(o.content) for o in pieces] == [o.content for o in text]
+
+
+class _ScriptedBackend:
+    """Backend whose T2U output is scripted: lets the unit-decoder policy be followed step by step."""
+
+    def __init__(self, durations_per_call):
+        self.script = list(durations_per_call)
+        self.calls = 0
+
+    def t2u(self, features, token_ids, d_factor):
+        dur = self.script[self.calls]
+        self.calls += 1
+        return np.arange(sum(dur), dtype=np.int64) + 1000 * self.calls, np.asarray(dur)
+
+
+def _text_out(tokens, n_feats, finished=False):
+    out = A.UnitYTextDecoderOutput(torch.zeros(1, n_feats, 4), tokens, torch.zeros(1, n_feats, dtype=torch.int64))
+    return TextSegment(content=out, finished=finished, tgt_lang="fra")
+
+
+def test_unit_decoder_chunk_policy_step_by_step():
+    """online_unit_decoder.py:94-147: wait for >= 2 tokens, emit only once min_unit_chunk_size new units exist, restart
+    one word early after the ',' that closes every phrase, and flush (or stop on silence) when the source is finished."""
+    be = _ScriptedBackend([[0, 3, 4, 0], [0, 3, 4, 2, 9, 0], [0, 3, 4, 2, 9, 5, 0], [0, 3, 4, 2, 9, 5, 0, 0]])
+    ag = A.NARUnitYUnitDecoderAgent(be, default_args(min_unit_chunk_size=8))
+    assert ag.pushpop(_text_out(["a"], 3)).is_empty and be.calls == 0           # fewer than two tokens so far
+    assert ag.pushpop(_text_out(["b"], 4)).is_empty and be.calls == 1           # 7 units < 8: keep reading
+    out = ag.pushpop(_text_out(["c", ","], 6))
+    assert be.calls == 2 and out.content.tolist() == [list(range(2000, 2018))]  # everything so far (18 units)
+    assert ag.states.duration_start_index == 5                                  # len(durations) - 1: the "," slot is redone
+    out = ag.pushpop(_text_out(["d"], 7))
+    assert out.is_empty and be.calls == 3                                       # only 5 new units after index 5
+    last = ag.pushpop(_text_out([], 8, finished=True))
+    # source finished: one word earlier (index 4), units from offset sum(dur[:4]) = 9
+    assert be.calls == 4 and last.finished and last.content.tolist() == [list(range(4009, 4023))]
+
+
+def test_unit_decoder_stops_on_trailing_silence_and_empty_input():
+    be = _ScriptedBackend([[0, 5, 6, 0], [0, 5, 6, 0, 0]])
+    ag = A.NARUnitYUnitDecoderAgent(be, default_args(min_unit_chunk_size=4))
+    assert ag.pushpop(_text_out(["a", ","], 4)).content.shape[1] == 11
+    out = ag.pushpop(_text_out(["."], 5, finished=True))  # nothing but silence after the start index
+    assert out.finished and out.content == ""
+    fresh = A.NARUnitYUnitDecoderAgent(_ScriptedBackend([]), default_args())
+    from seamless_communication_amd.streaming import EmptySegment as E
+
+    assert fresh.pushpop(E(finished=True)).finished  # finished before anything arrived
+
+
+def test_text_decoder_respects_max_consecutive_writes_and_no_early_stop(backend):
+    cfg, sd, vsd, tt, ct = common.tiny_bundle()
+    wav = common.waves((2.6,))[0]
+    outs = common.run_stream(SeamlessStreamingS2TAgent(backend, tt, _args(decision_threshold=0.0, max_consecutive_write=3, max_len_b=30)), wav)
+    assert all(len(o.content.split()) <= 3 for o in outs)
+    # no_early_stop: before the source ends an EOS / low-probability step only stops the round, it never finishes the stream
+    outs = common.run_stream(SeamlessStreamingS2TAgent(backend, tt, _args(no_early_stop=True, decision_threshold=0.35)), wav)
+    assert outs[-1].finished and not any(o.finished for o in outs[:-1])
