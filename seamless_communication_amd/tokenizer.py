@@ -301,14 +301,18 @@ class NllbTextTokenizer:
         return [self.vocab_info.eos_idx, self.lang_token_idx(lang)]
 
     def decode(self, ids: Sequence[int]) -> str:
-        """ids -> text; control symbols are skipped (SentencePiece decode)."""
+        """ids -> text; control symbols are skipped (SentencePiece decode).  With a SentencePiece model the pieces go
+        through its own decoder (normalisation rules, byte pieces); the synthetic vocabulary joins pieces directly."""
         first, last = self._first_lang, self._first_lang + len(self.langs) + 3
-        toks = []
+        keep = []
         for i in ids:
             i = int(i)
             if i in (0, 2, 3) or first <= i < last or i >= last:
                 continue
-            toks.append(" ⁇ " if i == 1 else self._pieces[i])
+            keep.append(i)
+        if self._spm is not None:
+            return self._spm.decode([i - 1 for i in keep])  # ids are shifted by the <pad>@0 slot
+        toks = [" ⁇ " if i == 1 else self._pieces[i] for i in keep]
         return "".join(toks).replace(SPACE, " ").strip()
 
     # -- per-vocabulary tables for the NAR frontend (built once) ------------ #

@@ -64,3 +64,5 @@ def test_sentencepiece_backed_vocabulary(tmp_path):
     ids = tt.create_encoder(lang="eng", mode="source")(text).tolist()
     assert ids == [tt.lang_token_idx("eng")] + [i + 1 for i in sp.encode(text)] + [3]
     assert tt.decode(ids) == text
+    body = [i + 1 for i in sp.encode("foggy rivers near zebras")]
+    assert tt.decode([3, tt.lang_token_idx("fra")] + body + [1, 3]) == sp.decode([i - 1 for i in body] + [0])  # prompt skipped, <unk> kept
