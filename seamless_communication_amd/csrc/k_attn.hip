@@ -237,7 +237,10 @@ static constexpr int MQ = 128;   // queries per workgroup
 static constexpr int MKV = 32;   // keys per iteration
 static constexpr int KS = 68;    // padded row stride of the K tile / R staging / output tile (floats)
 
-template <bool SHAW>
+// PF (experimental, decoder-kernel variant switch): the K/V rows of tile t+1 are requested into registers — unconditionally,
+// on row indices clamped into the valid range — before tile t is multiplied, instead of load -> LDS -> barrier -> multiply
+// in sequence for every 32 keys.  Same values reach LDS (rows beyond kv_len are still stored as zeros), same arithmetic.
+template <bool SHAW, bool PF = false>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs p) {
     typedef float f16v __attribute__((ext_vector_type(16)));
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -315,18 +318,46 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs p) {
     int k_end = kv_len;
     if (p.causal) k_end = min(k_end, (int)(blockIdx.x * MQ) + MQ - 1 + shift + 1);
 
+    // PF: every thread owns items tid and tid + 256 of a 32 x 16 tile of float4s
+    static_assert(MKV * (HD / 4) == 512, "two items per thread");
+    f4v pfk[2], pfv[2];
+    const int last_row = max(kv_len - 1, 0);
+#define ATT_PREFETCH(K0)                                                                                      \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                       \
+            const int idx = tid + 256 * u;                                                                    \
+            const int64_t row = (int64_t)n * p.Skv + min((K0) + (idx >> 4), last_row);                        \
+            pfk[u] = *reinterpret_cast<const f4v*>(p.k + row * p.ldk + h * HD + (idx & 15) * 4);               \
+            pfv[u] = *reinterpret_cast<const f4v*>(p.v + row * p.ldv + h * HD + (idx & 15) * 4);               \
+        }                                                                                                     \
+    } while (0)
+    if (PF) ATT_PREFETCH(0);
+
     for (int k0 = 0; k0 < k_end; k0 += MKV) {
         __syncthreads();  // previous tile fully consumed (also orders the sQR writes before their first use)
-        for (int idx = tid; idx < MKV * (HD / 4); idx += 256) {
-            const int r = idx >> 4, c4 = idx & 15;
-            f4v kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
-            if (k0 + r < kv_len) {
-                const int64_t row = (int64_t)n * p.Skv + k0 + r;
-                kv = *reinterpret_cast<const f4v*>(p.k + row * p.ldk + h * HD + c4 * 4);
-                vv = *reinterpret_cast<const f4v*>(p.v + row * p.ldv + h * HD + c4 * 4);
+        if (PF) {
+            const f4v zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int idx = tid + 256 * u;
+                const int r = idx >> 4, c4 = idx & 15;
+                const bool ok = k0 + r < kv_len;
+                *reinterpret_cast<f4v*>(&sK[r * KS + c4 * 4]) = ok ? pfk[u] : zero;
+                *reinterpret_cast<f4v*>(&sV[r * HD + c4 * 4]) = ok ? pfv[u] : zero;
             }
-            *reinterpret_cast<f4v*>(&sK[r * KS + c4 * 4]) = kv;
-            *reinterpret_cast<f4v*>(&sV[r * HD + c4 * 4]) = vv;
+            ATT_PREFETCH(k0 + MKV);  // lands while this tile is multiplied (clamped rows past the end are never stored)
+        } else {
+            for (int idx = tid; idx < MKV * (HD / 4); idx += 256) {
+                const int r = idx >> 4, c4 = idx & 15;
+                f4v kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+                if (k0 + r < kv_len) {
+                    const int64_t row = (int64_t)n * p.Skv + k0 + r;
+                    kv = *reinterpret_cast<const f4v*>(p.k + row * p.ldk + h * HD + c4 * 4);
+                    vv = *reinterpret_cast<const f4v*>(p.v + row * p.ldv + h * HD + c4 * 4);
+                }
+                *reinterpret_cast<f4v*>(&sK[r * KS + c4 * 4]) = kv;
+                *reinterpret_cast<f4v*>(&sV[r * HD + c4 * 4]) = vv;
+            }
         }
         __syncthreads();
 
@@ -388,6 +419,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs p) {
         }
     }
 
+#undef ATT_PREFETCH
+
     // ---- O^T (dims x queries) -> this wave's [32 queries][64 dims] tile in LDS -> 16-byte row stores ----
     __syncthreads();  // every wave is done with the K/V tiles
     float* ot = smem + wave * (32 * KS);
@@ -443,6 +476,10 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
             SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
             mfma_attr = true;
         }
         prof::Scope scope(a.rel_k ? "attention_shaw" : "attention", 4.0 * a.nb * a.heads * (double)a.Sq * a.Skv * HD,
@@ -451,8 +488,14 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         SC_CHECK(npos <= 96, "attention: relative table too large");
         if (a.rel_k) lds += (size_t)(MQ * npos) * sizeof(float);
         dim3 grid(cdiv(a.Sq, MQ), a.heads, a.nb);
-        if (a.rel_k) hipLaunchKernelGGL((attn_mfma_kernel<true>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((attn_mfma_kernel<false>), grid, dim3(256), lds, s, a);
+        if (skinny_variant() == 1) {  // experimental: K/V tiles prefetched into registers (same bits)
+            if (a.rel_k) hipLaunchKernelGGL((attn_mfma_kernel<true, true>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((attn_mfma_kernel<false, true>), grid, dim3(256), lds, s, a);
+        } else if (a.rel_k) {
+            hipLaunchKernelGGL((attn_mfma_kernel<true>), grid, dim3(256), lds, s, a);
+        } else {
+            hipLaunchKernelGGL((attn_mfma_kernel<false>), grid, dim3(256), lds, s, a);
+        }
         SC_LAUNCH_CHECK();
         return;
     }

@@ -655,3 +655,24 @@ def test_skinny2_fused_argmax_bit_identical(lib, skinny_variants, M, N, K):
 
     (ia, la), (ib, lb) = skinny_variants(one)
     assert torch.equal(ia, ib) and torch.equal(la, lb)
+
+
+@_EXPERIMENTAL
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_register_prefetch_bit_identical(lib, skinny_variants, case):
+    """attn_mfma_kernel<SHAW, PF=true> (K/V tiles prefetched into registers) against the shipped instantiation."""
+    nb, H, Sq, Skv, lens, causal, shaw = case
+    g = torch.Generator().manual_seed(Sq * 13 + Skv)
+    M = H * 64
+    q, k, v = (dev(torch.randn(nb, S, M, generator=g)) for S in (Sq, Skv, Skv))
+    rel = dev(torch.randn(73, 64, generator=g) * 0.3) if shaw else None
+    d_lens = dev(torch.tensor(lens, dtype=torch.int32)) if lens is not None else None
+
+    def one():
+        out = torch.full((nb, Sq, M), float("nan"), device="cuda")
+        check(lib, lib.sc_op_attention(P(q), P(k), P(v), P(out), nb, H, Sq, Skv, M, M, M, M, P(d_lens), int(causal),
+                                       P(rel) if shaw else None, 64 if shaw else 0, 8 if shaw else 0))
+        return out.cpu()
+
+    a, b = skinny_variants(one)
+    assert torch.equal(a, b), float((a - b).abs().max())
