@@ -403,10 +403,14 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs p) {
         rs += __shfl_xor(rs, 32);
         l_i = l_i * alpha + rs;
         m_i = m_new;
+        // PF variant: once the running maxima of all 64 lanes have settled alpha is exactly 1 and the rescale of the 32
+        // accumulator registers (which live in AGPRs: a read, a multiply and a write each) is skipped — same bits
+        if (!PF || __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o0[r] *= alpha;
-            o1[r] *= alpha;
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= alpha;
+                o1[r] *= alpha;
+            }
         }
         // ---- O^T += V^T . P^T: step s of half hh contracts key (s&3) + 8*(s>>2) + 4*hh = register s ----
 #pragma unroll
