@@ -234,37 +234,50 @@ class MMATextDecoderAgent(GenericAgent):
         return TextSegment(content=" ".join(self.text_tokenizer.index_to_token(idx) for idx in pred_indices), finished=finished,
                            tgt_lang=states.tgt_lang)
 
-    def get_blocked_ngrams(self, target_indices: List[int]) -> Optional[Set[str]]:
+    # ---- n-gram guard (online_text_decoder.py:260-301) --------------------------------------------------- #
+    # Before the source ends, writing a token that completes an n-gram (n = 3, 2) already seen at the end of the
+    # previous output forces a READ instead.  The guard set starts from the last 2..4 written tokens: for each of the
+    # tails of length 4, 3, 2 every prefix of at least two tokens; n-grams met during the round are added as they pass.
+    def get_blocked_ngrams(self, target_indices: List[int]) -> Optional[Set[Tuple[int, ...]]]:
         if not self.block_ngrams:
             return None
-        blocked_ngrams = set()
-        if len(target_indices) >= 4:
-            blocked_ngrams.add(str(target_indices[-4:]))
-            blocked_ngrams.add(str(target_indices[-4:-2]))
-            blocked_ngrams.add(str(target_indices[-4:-1]))
-        if len(target_indices) >= 3:
-            blocked_ngrams.add(str(target_indices[-3:]))
-            blocked_ngrams.add(str(target_indices[-3:-1]))
-        if len(target_indices) >= 2:
-            blocked_ngrams.add(str(target_indices[-2:]))
-        return blocked_ngrams
+        guard: Set[Tuple[int, ...]] = set()
+        for n in (4, 3, 2):
+            if len(target_indices) >= n:
+                tail = tuple(target_indices[-n:])
+                guard.update(tail[:k] for k in range(2, n + 1))
+        return guard
 
     def maybe_block_ngrams(self, states: DecoderAgentStates, pred_indices: List[int], decoder_features_out: Tensor,
-                           blocked_ngrams: Optional[Set[str]], index: int) -> Tuple[bool, Tensor]:
-        """Forces a READ when an n-gram repeats before the source is finished (online_text_decoder.py:276-301)."""
+                           blocked_ngrams: Optional[Set[Tuple[int, ...]]], index: int) -> Tuple[bool, Tensor]:
         if not self.block_ngrams or states.source_finished:
             return False, decoder_features_out
         assert blocked_ngrams is not None
-        all_indices = states.target_indices + pred_indices + [index]
-        for n in [3, 2]:
-            if len(all_indices) >= n and states.ngram_block_count <= 4:
-                if str(all_indices[-n:]) in blocked_ngrams:
-                    states.ngram_block_count += 1
-                    pred_indices[:] = pred_indices[: -(n - 1)]
-                    decoder_features_out = decoder_features_out[:, : -(n - 1)]
-                    return True, decoder_features_out
-                blocked_ngrams.add(str(all_indices[-n:]))
+        history = states.target_indices + pred_indices + [index]
+        for n in (3, 2):
+            if len(history) < n or states.ngram_block_count > 4:
+                continue
+            gram = tuple(history[-n:])
+            if gram in blocked_ngrams:
+                # give up the n-1 tokens that led into the repeat (and their decoder outputs) and read more source
+                states.ngram_block_count += 1
+                del pred_indices[len(pred_indices) - (n - 1):]
+                return True, decoder_features_out[:, : -(n - 1)]
+            blocked_ngrams.add(gram)
         return False, decoder_features_out
+
+    # ---- one policy round (online_text_decoder.py:303-387) ------------------------------------------------ #
+    def _verdict(self, states: DecoderAgentStates, written: List[int], index: int, prob: float) -> str:
+        """What to do with the candidate `index` after `written`: "continue" appends it; everything else ends the round.
+        The order of the tests is the reference's (the n-gram guard runs between "hold" and "finish")."""
+        total = len(states.target_indices) + len(written)
+        if index == self.eos_idx or total > self.max_len(states):
+            return "finish"
+        if prob < self.decision_threshold and not states.source_finished:
+            return "read"
+        if total >= self.max_len(states) or len(written) >= self.max_consecutive_writes:
+            return "pause"
+        return "continue"
 
     @torch.inference_mode()
     def policy(self, states: DecoderAgentStates) -> Action:
@@ -282,43 +295,34 @@ class MMATextDecoderAgent(GenericAgent):
         self.backend.mma_begin(states.source, budget)
         states.source_len = states.source.size(1)
 
-        pred_indices: List[int] = []
+        written: List[int] = []
         finished = False
-        blocked_ngrams = self.get_blocked_ngrams(states.target_indices)
-        decoder_features_out = None
+        guard = self.get_blocked_ngrams(states.target_indices)
+        features: Optional[Tensor] = None
         while True:
-            index, prob, decoder_features = self.run_decoder(states, pred_indices)
-            if decoder_features_out is None:
-                decoder_features_out = decoder_features.new_zeros((1, 0, decoder_features.shape[-1]))
-            decoder_features_out = torch.cat([decoder_features_out, decoder_features], dim=1)
-
+            index, prob, step_features = self.run_decoder(states, written)
+            features = step_features if features is None else torch.cat([features, step_features], dim=1)
             if self.no_early_stop and not states.source_finished and (prob < self.decision_threshold or index == self.eos_idx):
+                # "hold": before the source ends neither an EOS nor an uncertain step may finish the stream
                 if prob == 1.0:
-                    pred_indices = []
+                    written = []
                 break
-            block_ngram, decoder_features_out = self.maybe_block_ngrams(states, pred_indices, decoder_features_out, blocked_ngrams, index)
-            if block_ngram:
+            blocked, features = self.maybe_block_ngrams(states, written, features, guard, index)
+            if blocked:
                 break
-            if finished or index == self.eos_idx or len(states.target_indices + pred_indices) > self.max_len(states):
-                finished = True
+            verdict = self._verdict(states, written, index, prob)
+            if verdict != "continue":
+                finished = verdict == "finish"
                 break
-            if prob < self.decision_threshold and not states.source_finished:
-                break
-            if (len(states.target_indices + pred_indices) >= self.max_len(states)
-                    or len(pred_indices) >= self.max_consecutive_writes):
-                break
-            pred_indices.append(index)
-            if self.step_nr == 0:
-                self.step_nr += len(self.prefix_indices + states.target_indices)
-            else:
-                self.step_nr += 1
+            written.append(index)
+            self.step_nr += len(self.prefix_indices) + len(states.target_indices) if self.step_nr == 0 else 1
 
-        states.target_indices += pred_indices
-        if len(pred_indices) > 0 or finished:
-            finished = finished or len(states.target_indices + pred_indices) > self.max_len(states)
-            states.ngram_block_count = 0
-            return WriteAction(self.postprocess(states, pred_indices, finished, decoder_features_out), finished=finished)
-        return ReadAction()
+        states.target_indices += written
+        if not written and not finished:
+            return ReadAction()
+        finished = finished or len(states.target_indices) + len(written) > self.max_len(states)
+        states.ngram_block_count = 0
+        return WriteAction(self.postprocess(states, written, finished, features), finished=finished)
 
 
 class UnitYMMATextDecoderAgent(MMATextDecoderAgent):
