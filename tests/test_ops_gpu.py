@@ -676,3 +676,30 @@ def test_attention_register_prefetch_bit_identical(lib, skinny_variants, case):
 
     a, b = skinny_variants(one)
     assert torch.equal(a, b), float((a - b).abs().max())
+
+
+@_EXPERIMENTAL
+@pytest.mark.parametrize("nb,T,C_,k,dil,avg", RESPAIR_CASES)
+def test_resblock_pair_batched_loads_bit_identical(lib, skinny_variants, nb, T, C_, k, dil, avg):
+    """resblock_pair_kernel<C, FL=true> (batched unconditional loads, per-tap weights prefetched into registers) against
+    the shipped instantiation."""
+    g = torch.Generator().manual_seed(T * 13 + C_ * 5 + k + dil)
+    x = dev(torch.randn(nb, T, C_, generator=g))
+    w1 = (torch.randn(C_, C_, k, generator=g) / math.sqrt(C_ * k)).half()
+    w2 = (torch.randn(C_, C_, k, generator=g) / math.sqrt(C_ * k)).half()
+    b1, b2 = dev(torch.randn(C_, generator=g) * 0.1), dev(torch.randn(C_, generator=g) * 0.1)
+    ra, rb = dev(torch.randn(nb, T, C_, generator=g)), dev(torch.randn(nb, T, C_, generator=g))
+    kpad = (C_ * k + 31) // 32 * 32
+    wp1 = torch.zeros(C_, kpad, dtype=torch.float16, device="cuda")
+    wp2 = torch.zeros(C_, kpad, dtype=torch.float16, device="cuda")
+    check(lib, lib.sc_op_pack_conv_weight(P(dev(w1)), P(wp1), C_, C_, k))
+    check(lib, lib.sc_op_pack_conv_weight(P(dev(w2)), P(wp2), C_, C_, k))
+
+    def one():
+        got = torch.full((nb, T, C_), float("nan"), device="cuda")
+        check(lib, lib.sc_op_resblock_pair(P(x), P(wp1), P(b1), P(wp2), P(b2), P(got), nb, T, C_, k, dil, 0.1,
+                                           P(ra) if avg else None, P(rb) if avg else None))
+        return got.cpu()
+
+    a, b = skinny_variants(one)
+    assert not torch.isnan(a).any() and torch.equal(a, b), float((a - b).abs().max())
