@@ -238,7 +238,9 @@ __global__ __launch_bounds__(256) void skinny2_kernel(SkinnyArgs p, uint32_t a_b
 int skinny_variant() {
     int v = g_skinny_variant.load(std::memory_order_relaxed);
     if (v < 0) {
-        const char* e = getenv("SC_SKINNY2");
+        // SC_KERNEL_VARIANT=1 (alias SC_SKINNY2=1, the first kernel that sat behind the switch)
+        const char* e = getenv("SC_KERNEL_VARIANT");
+        if (!e) e = getenv("SC_SKINNY2");
         v = (e && e[0] == '1') ? 1 : 0;
         g_skinny_variant.store(v, std::memory_order_relaxed);
     }
