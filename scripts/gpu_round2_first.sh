@@ -8,7 +8,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-( SC_TEST_EXPERIMENTAL=1 timeout 150 python -m pytest tests/test_ops_gpu.py tests/test_stages_gpu.py -k "skinny2 or experimental or register_prefetch or batched_loads" -m gpu -q > gpurun_out/r2_experimental_tests.log 2>&1; echo "pytest exit $?" >> gpurun_out/r2_experimental_tests.log )
+( SC_TEST_EXPERIMENTAL=1 timeout 150 python -m pytest tests/test_ops_gpu.py tests/test_stages_gpu.py -k "skinny2 or experimental or register_prefetch or batched_loads or loads_up_front" -m gpu -q > gpurun_out/r2_experimental_tests.log 2>&1; echo "pytest exit $?" >> gpurun_out/r2_experimental_tests.log )
 tail -4 gpurun_out/r2_experimental_tests.log
 ( timeout 120 python scripts/skinny_bench.py --variant both > gpurun_out/r2_skinny_ab.txt 2>&1 ); grep -v amdgpu gpurun_out/r2_skinny_ab.txt | head -70
 for v in 0 1; do

@@ -703,3 +703,20 @@ def test_resblock_pair_batched_loads_bit_identical(lib, skinny_variants, nb, T, 
 
     a, b = skinny_variants(one)
     assert not torch.isnan(a).any() and torch.equal(a, b), float((a - b).abs().max())
+
+
+@_EXPERIMENTAL
+@pytest.mark.parametrize("rows,C_,act", [(37, 1024, 0), (5, 128, 2), (1000, 1024, 0), (3, 256, 1), (64, 160, 0)])
+def test_layernorm_loads_up_front_bit_identical(lib, skinny_variants, rows, C_, act):
+    """layernorm_kernel<MAXV, FL=true> against the shipped instantiation."""
+    g = torch.Generator().manual_seed(rows + C_)
+    x = dev(torch.randn(rows, C_, generator=g) * 3 + 0.5)
+    gam, bet = dev(torch.rand(C_, generator=g) + 0.5), dev(torch.randn(C_, generator=g) * 0.1)
+
+    def one():
+        y = torch.full((rows, C_), float("nan"), device="cuda")
+        check(lib, lib.sc_op_layernorm(P(x), P(gam), P(bet), P(y), rows, C_, act))
+        return y.cpu()
+
+    a, b = skinny_variants(one)
+    assert not torch.isnan(a).any() and torch.equal(a, b)
