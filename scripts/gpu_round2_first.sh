@@ -11,8 +11,9 @@ R=$GRAFT_REPO_ROOT
 ( SC_TEST_EXPERIMENTAL=1 timeout 150 python -m pytest tests/test_ops_gpu.py tests/test_stages_gpu.py -k "skinny2 or experimental or register_prefetch or batched_loads or loads_up_front" -m gpu -q > gpurun_out/r2_experimental_tests.log 2>&1; echo "pytest exit $?" >> gpurun_out/r2_experimental_tests.log )
 tail -4 gpurun_out/r2_experimental_tests.log
 ( timeout 120 python scripts/skinny_bench.py --variant both > gpurun_out/r2_skinny_ab.txt 2>&1 ); grep -v amdgpu gpurun_out/r2_skinny_ab.txt | head -70
-for v in 0 1; do
-  ( SC_SKINNY2=$v timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r2_bench_variant$v.json 2> gpurun_out/r2_bench_variant$v.err; echo "exit $?" >> gpurun_out/r2_bench_variant$v.err )
+# masks: 0 shipped, 7 decoder-step kernels only, 63 everything (KernelVariantBits in csrc/kernels.h)
+for v in 0 7 63; do
+  ( SC_KERNEL_VARIANT=$v timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r2_bench_variant$v.json 2> gpurun_out/r2_bench_variant$v.err; echo "exit $?" >> gpurun_out/r2_bench_variant$v.err )
   python - <<PY
 import json
 try:
@@ -23,6 +24,6 @@ except Exception as e:
 PY
 done
 rm -rf gpurun_out/prof_r2
-( cd /tmp && SC_SKINNY2=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r2 -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile-step --no-latency > $R/gpurun_out/r2_rocprof.log 2>&1; echo "exit $?" >> $R/gpurun_out/r2_rocprof.log )
+( cd /tmp && SC_KERNEL_VARIANT=63 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r2 -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile-step --no-latency > $R/gpurun_out/r2_rocprof.log 2>&1; echo "exit $?" >> $R/gpurun_out/r2_rocprof.log )
 find gpurun_out/prof_r2 -name "*kernel_trace*" -delete 2>/dev/null
 head -12 gpurun_out/prof_r2/bench_kernel_stats.csv | cut -c1-170

@@ -11,7 +11,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from seamless_communication_amd import _lib  # noqa: E402
 
 lib = _lib.load_library()
-VARIANTS = {"0": (0,), "1": (1,), "both": (0, 1)}[sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else "0"]
+VARIANTS = {"0": (0,), "1": (3,), "both": (0, 3)}  # 3 = KV_SKINNY | KV_REDUCE[sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else "0"]
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 

@@ -281,8 +281,8 @@ int sc_op_force_general_gemm(int on) {
 }
 
 int sc_op_set_skinny_variant(int variant) {
-    if (variant != 0 && variant != 1) {
-        sc::set_error("sc_op_set_skinny_variant: variant %d (0 or 1)", variant);
+    if (variant < 0 || variant > sc::KV_ALL) {
+        sc::set_error("sc_op_set_skinny_variant: mask %d outside 0..%d", variant, (int)sc::KV_ALL);
         return SC_ERR_INVALID;
     }
     sc::g_skinny_variant.store(variant);

@@ -492,7 +492,7 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         SC_CHECK(npos <= 96, "attention: relative table too large");
         if (a.rel_k) lds += (size_t)(MQ * npos) * sizeof(float);
         dim3 grid(cdiv(a.Sq, MQ), a.heads, a.nb);
-        if (skinny_variant() == 1) {  // experimental: K/V tiles prefetched into registers (same bits)
+        if (skinny_variant() & KV_ATTN_PREFETCH) {  // experimental: K/V tiles prefetched into registers (same bits)
             if (a.rel_k) hipLaunchKernelGGL((attn_mfma_kernel<true, true>), grid, dim3(256), lds, s, a);
             else hipLaunchKernelGGL((attn_mfma_kernel<false, true>), grid, dim3(256), lds, s, a);
         } else if (a.rel_k) {
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     }
 }
 
-// EXPERIMENTAL (SC_SKINNY2=1 / sc_op_set_skinny_variant(1), see k_skinny2.hip): decode_attn_kernel with its global loads
+// EXPERIMENTAL (SC_KERNEL_VARIANT / sc_op_set_skinny_variant, see k_skinny2.hip): decode_attn_kernel with its global loads
 // hoisted.  Same lanes handle the same keys and every sum runs in the same order, so the bits are the same; what changes
 // is that the loads of a phase are issued together and unconditionally (row index clamped into the valid range, the
 // value discarded by a select) instead of one predicated load per dependent step: the shipped kernel exposes one
@@ -727,7 +727,7 @@ void launch_decode_attention(const float* q, int64_t ldq, const float* k_new, co
                              const float* bias_v) {
     SC_CHECK(cap <= MAX_CACHE, "decode attention: cache capacity %d > %d", cap, MAX_CACHE);
     SC_CHECK(nb > 0 && heads > 0, "decode attention: empty problem");
-    if (skinny_variant() == 1) {  // experimental: hoisted loads (same bits)
+    if (skinny_variant() & KV_DECODE_ATTN) {  // experimental: hoisted loads (same bits)
         hipLaunchKernelGGL(decode_attn2_kernel, dim3(heads, nb), dim3(256), 0, s, q, ldq, k_new, v_new, ldkv,
                            kcache, vcache, cache_ld, cache_bs, cap, out, ldo, heads, d_pos, kv_lens, use_lens,
                            in_splits < 1 ? 1 : in_splits, in_split_stride, bias_q, bias_k, bias_v);

@@ -127,7 +127,7 @@ void launch_layernorm_split(const float* x, int64_t ldx, const float* gamma, con
     if (rows <= 0) return;
     dim3 grid(cdiv(rows, 4));
     float* none = nullptr;
-    const bool fl = skinny_variant() == 1;  // experimental: loads up front (same bits)
+    const bool fl = (skinny_variant() & KV_LAYERNORM) != 0;  // experimental: loads up front (same bits)
     if (C <= 256 && fl) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
     else if (C <= 1024 && fl) hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
     else if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
@@ -144,7 +144,7 @@ void launch_layernorm(const float* x, int64_t ldx, const float* gamma, const flo
     SC_CHECK(C <= 4096, "layernorm: C=%d > 4096 unsupported", C);
     if (rows <= 0) return;
     dim3 grid(cdiv(rows, 4));
-    const bool fl = skinny_variant() == 1;  // experimental: loads up front (same bits)
+    const bool fl = (skinny_variant() & KV_LAYERNORM) != 0;  // experimental: loads up front (same bits)
     if (C <= 256 && fl) {
         hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch, (__half*)nullptr, (__half*)nullptr, (int64_t)0);
     } else if (C <= 1024 && fl) {

@@ -429,7 +429,7 @@ void launch_cfg(const ResPairArgs& a, hipStream_t s) {
     const double rows = (double)a.nb * a.T;
     prof::Scope scope(name, 2.0 * 2.0 * rows * C * (double)C * a.k,
                       4.0 * rows * C * (a.avg_a ? 4.0 : 2.0) + 2.0 * 2.0 * C * (double)C * a.k, s);
-    if (skinny_variant() == 1)  // experimental: batched unconditional loads (same bits)
+    if (skinny_variant() & KV_RESBLOCK)  // experimental: batched unconditional loads (same bits)
         hipLaunchKernelGGL((resblock_pair_kernel<C, true>), dim3((unsigned)(a.nb * tiles)), dim3(256), lds, s, a, tiles);
     else
         hipLaunchKernelGGL((resblock_pair_kernel<C>), dim3((unsigned)(a.nb * tiles)), dim3(256), lds, s, a, tiles);

@@ -276,7 +276,7 @@ void launch_skinny(const SkinnyArgs& a0, hipStream_t s) {
                       2.0 * a.N * (double)a.K + 4.0 * a.M * ((double)a.K + (double)a.N * a.splits), s);
     SC_CHECK(!a.am_part || a.splits == 1, "skinny gemm: arg-max epilogue cannot be combined with split-K");
     if (a.am_part) a.am_tiles = (int)grid.x;
-    if (skinny_variant() == 1 && launch_skinny2(a, grid, nt, s)) return;  // experimental pipelined variant (k_skinny2.hip)
+    if ((skinny_variant() & KV_SKINNY) && launch_skinny2(a, grid, nt, s)) return;  // experimental pipelined variant (k_skinny2.hip)
     if (a.M <= 32) {
         if (nt == 4) hipLaunchKernelGGL((skinny_kernel<1, 4, 2>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((skinny_kernel<1, 1, 4>), grid, dim3(256), 0, s, a);
@@ -540,7 +540,7 @@ void launch_reduce_res_ln(const float* partial, int splits, const float* bias, f
     SC_CHECK(splits >= 1 && partial, "reduce_res_ln: need at least one partial");
     if (rows <= 0) return;
     if (C <= 1024) {
-        if (skinny_variant() == 1)
+        if (skinny_variant() & KV_REDUCE)
             hipLaunchKernelGGL(reduce_res_ln_row2_kernel, dim3(rows), dim3(256), 0, s, partial, splits, bias, x, gamma, beta, h, rows, C);
         else
             hipLaunchKernelGGL(reduce_res_ln_row_kernel, dim3(rows), dim3(256), 0, s, partial, splits, bias, x, gamma, beta, h, rows, C);

@@ -1,4 +1,4 @@
-// EXPERIMENTAL (off by default; SC_SKINNY2=1 or sc_op_set_skinny_variant(1)): software-pipelined variant of
+// EXPERIMENTAL (off by default; SC_KERNEL_VARIANT or sc_op_set_skinny_variant): software-pipelined variant of
 // skinny_kernel (k_skinny.hip) for the decoder-step products.  Same tiling, same K order, same hi/lo split and the
 // same cross-wave reduction, hence the same bits; what changes is how operands arrive:
 //
@@ -13,6 +13,9 @@
 //
 // Not yet run on hardware: tests/test_ops_gpu.py::test_skinny2_* (bit identity against skinny_kernel for every shape
 // of the decoder step) and scripts/skinny_bench.py --variant 1 are the first things to run before it is enabled.
+#include <cstdlib>
+#include <cstring>
+
 #include "kernels.h"
 
 namespace sc {
@@ -238,10 +241,10 @@ __global__ __launch_bounds__(256) void skinny2_kernel(SkinnyArgs p, uint32_t a_b
 int skinny_variant() {
     int v = g_skinny_variant.load(std::memory_order_relaxed);
     if (v < 0) {
-        // SC_KERNEL_VARIANT=1 (alias SC_SKINNY2=1, the first kernel that sat behind the switch)
+        // SC_KERNEL_VARIANT=<bit mask of KernelVariantBits> or "all"
         const char* e = getenv("SC_KERNEL_VARIANT");
-        if (!e) e = getenv("SC_SKINNY2");
-        v = (e && e[0] == '1') ? 1 : 0;
+        v = 0;
+        if (e && *e) v = (strcmp(e, "all") == 0) ? KV_ALL : (atoi(e) & KV_ALL);
         g_skinny_variant.store(v, std::memory_order_relaxed);
     }
     return v;

@@ -580,7 +580,7 @@ def test_skinny_fused_argmax(lib, report_dir, M, N, K, mode):
 
 # --------------------------------------------------------------------------------------------------------- #
 # Experimental software-pipelined decoder-step product (k_skinny2.hip).  Written without GPU time left in round 1:
-# the tests below are the first thing to run on hardware (SC_TEST_EXPERIMENTAL=1) before SC_SKINNY2 is made the default.
+# the tests below are the first thing to run on hardware (SC_TEST_EXPERIMENTAL=1) before any of them is made the default (SC_KERNEL_VARIANT bit mask).
 # --------------------------------------------------------------------------------------------------------- #
 import os  # noqa: E402
 
@@ -593,7 +593,7 @@ def skinny_variants(lib):
     def run(fn):
         outs = []
         try:
-            for v in (0, 1):
+            for v in (0, 63):  # 0 = shipped kernels, 63 = every experimental variant (KernelVariantBits)
                 check(lib, lib.sc_op_set_skinny_variant(v))
                 outs.append(fn())
         finally:
