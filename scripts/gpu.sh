@@ -1,0 +1,87 @@
+#!/bin/bash
+# One parameterised GPU-box script (replaces the numbered one-off scripts of round 1):
+#     gpurun --timeout 900 -- 'bash scripts/gpu.sh TAG task [task ...]'
+# TAG names the output files (gpurun_out/<TAG>_*).  Tasks run in the order given; every task is wrapped in its own
+# `timeout` so that a hung kernel cannot hold the box.  Tasks:
+#   tests        the whole `-m gpu` suite                       fullsize   tests/test_fullsize_gpu.py only
+#   quick        op + stage tests (tiny model)                  smoke      __graft_entry__.smoke()
+#   exp          experimental-variant bit-identity tests (SC_TEST_EXPERIMENTAL=1) + per-shape A/B
+#   bench        python bench.py $BENCH_ARGS                    benchfast  bench without cpu baseline / latency
+#   masks        bench with SC_KERNEL_VARIANT in $MASKS (default "0 7 63"), stage times only
+#   rocprof      rocprofv3 --kernel-trace --stats of `bench.py $PROF_ARGS` (the driver's command line by default)
+#   pmc          FETCH_SIZE / WRITE_SIZE passes (separate runs) + scripts/pmc_summary.py
+#   dstep        scripts/dstep_bench.py (decoder step timing per batch size)
+#   micro        every scripts/micro/*.hip compiled with hipcc and run
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=$1; shift
+O=gpurun_out/$TAG
+BENCH_ARGS=${BENCH_ARGS:---steps 5 --warmup 2}
+PROF_ARGS=${PROF_ARGS:---steps 3 --warmup 1 --no-cpu-baseline --no-latency}
+MASKS=${MASKS:-0 7 63}
+
+line() { python - "$1" <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
+    r = d.get("roofline") or {}
+    print("  value", round(d["value"], 2), d["unit"], "| ms/step", round(d["ms_per_step"], 1), "|", d.get("stage_ms_last_step_slice0"))
+    print("  roofline", r.get("kernel"), r.get("bound"), round(r.get("achieved") or 0, 1), r.get("unit"), "frac", round(r.get("frac") or 0, 4),
+          "| batch-1", (d.get("latency_batch1") or {}).get("stage_ms"), "| parity", d.get("parity"))
+except Exception as e:
+    print("  no bench line:", e)
+PY
+}
+
+for task in "$@"; do
+  echo "=== $task"
+  case $task in
+    tests)
+      ( timeout 1500 python -m pytest tests -m gpu -q -x > ${O}_pytest_gpu.log 2>&1; echo "pytest exit $?" >> ${O}_pytest_gpu.log )
+      grep -E "^FAILED|^ERROR|passed|failed|^E  |exit" ${O}_pytest_gpu.log | head -20 ;;
+    fullsize)
+      ( timeout 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x > ${O}_pytest_fullsize.log 2>&1; echo "pytest exit $?" >> ${O}_pytest_fullsize.log )
+      grep -E "^FAILED|^ERROR|passed|failed|^E  |exit" ${O}_pytest_fullsize.log | head -20; tail -12 gpurun_out/fullsize_report.txt 2>/dev/null | cut -c1-300 ;;
+    quick)
+      ( timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_stages_gpu.py -m gpu -q -x > ${O}_pytest_quick.log 2>&1; echo "pytest exit $?" >> ${O}_pytest_quick.log )
+      grep -E "^FAILED|^ERROR|passed|failed|^E  |exit" ${O}_pytest_quick.log | head -20 ;;
+    smoke)
+      ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > ${O}_smoke.log 2>&1; echo "smoke exit $?" >> ${O}_smoke.log ); tail -2 ${O}_smoke.log | cut -c1-300 ;;
+    exp)
+      ( SC_TEST_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_ops_gpu.py tests/test_stages_gpu.py -k "skinny2 or experimental or register_prefetch or batched_loads or loads_up_front" -m gpu -q > ${O}_exp_tests.log 2>&1; echo "pytest exit $?" >> ${O}_exp_tests.log )
+      tail -4 ${O}_exp_tests.log
+      ( timeout 150 python scripts/skinny_bench.py --variant both > ${O}_skinny_ab.txt 2>&1 ); grep -v amdgpu ${O}_skinny_ab.txt | head -80 ;;
+    bench)
+      ( timeout 900 python bench.py $BENCH_ARGS > ${O}_bench.json 2> ${O}_bench.err; echo "exit $?" >> ${O}_bench.err ); tail -3 ${O}_bench.err | cut -c1-300; line ${O}_bench.json ;;
+    benchfast)
+      ( timeout 600 python bench.py $BENCH_ARGS --no-cpu-baseline --no-latency > ${O}_benchfast.json 2> ${O}_benchfast.err; echo "exit $?" >> ${O}_benchfast.err ); tail -2 ${O}_benchfast.err | cut -c1-300; line ${O}_benchfast.json ;;
+    masks)
+      for v in $MASKS; do
+        ( SC_KERNEL_VARIANT=$v timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline $MASK_ARGS > ${O}_bench_mask$v.json 2> ${O}_bench_mask$v.err; echo "exit $?" >> ${O}_bench_mask$v.err )
+        echo "mask $v:"; line ${O}_bench_mask$v.json
+      done ;;
+    rocprof)
+      rm -rf gpurun_out/${TAG}_prof
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -o bench -- python $R/bench.py $PROF_ARGS > $R/${O}_rocprof.log 2>&1; echo "exit $?" >> $R/${O}_rocprof.log )
+      find gpurun_out/${TAG}_prof -name "*kernel_trace*" -delete 2>/dev/null
+      f=$(find gpurun_out/${TAG}_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f ${O}_kernel_stats.csv && head -14 ${O}_kernel_stats.csv | cut -c1-180
+      grep -E "^\{" ${O}_rocprof.log | tail -1 > ${O}_rocprof_bench.json; line ${O}_rocprof_bench.json ;;
+    pmc)
+      rm -rf gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write
+      PMC_ARGS=${PMC_ARGS:---steps 1 --warmup 0 --no-cpu-baseline --no-profile-step --no-latency --no-graph}
+      ( cd /tmp && timeout 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -o bench -- python $R/bench.py $PMC_ARGS > $R/${O}_pmc_fetch.log 2>&1; echo "exit $?" >> $R/${O}_pmc_fetch.log )
+      ( cd /tmp && timeout 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -o bench -- python $R/bench.py $PMC_ARGS > $R/${O}_pmc_write.log 2>&1; echo "exit $?" >> $R/${O}_pmc_write.log )
+      python scripts/pmc_summary.py gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write > ${O}_pmc_hbm_traffic.csv 2> ${O}_pmc_summary.err
+      find gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write -name "*.csv" -size +2M -delete 2>/dev/null
+      head -8 ${O}_pmc_hbm_traffic.csv | cut -c1-200 ;;
+    dstep)
+      ( timeout 300 python scripts/dstep_bench.py $DSTEP_ARGS > ${O}_dstep.txt 2>&1; echo "exit $?" >> ${O}_dstep.txt ); grep -v amdgpu ${O}_dstep.txt | tail -40 | cut -c1-200 ;;
+    micro)
+      for src in scripts/micro/*.hip; do
+        b=/tmp/$(basename $src .hip)
+        ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $src -o $b && timeout 120 $b > ${O}_micro_$(basename $src .hip).txt 2>&1 ); head -40 ${O}_micro_$(basename $src .hip).txt
+      done ;;
+    *) echo "unknown task $task" ;;
+  esac
+done

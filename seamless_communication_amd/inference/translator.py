@@ -1,13 +1,13 @@
-"""Drop-in ``Translator`` for the speech-input tasks (S2ST / S2TT / ASR) whose
-arithmetic runs in libseamless_hip on one MI355X.
+"""Drop-in ``Translator`` (S2ST / S2TT / ASR / T2TT / T2ST) whose arithmetic runs
+in libseamless_hip on one MI355X.
 
 Mirrors src/seamless_communication/inference/translator.py of the reference:
 ``Task`` / ``Modality`` (:53-63), ``BatchedSpeechOutput`` (:66-75),
-``Translator.__init__`` (:79-154), ``get_modalities_from_task_str`` (:199-213),
-``predict`` (:216-428) — same argument names, defaults, return types and
-error behaviour for the path it covers.  Text-input tasks (T2ST/T2TT) and
-mintox are outside the S2ST hot path and raise
-``NotImplementedError``.
+``Translator.__init__`` (:79-154), ``get_prediction`` (:155-196),
+``get_modalities_from_task_str`` (:199-213), ``predict`` (:216-428) — same
+argument names, defaults, return types and error behaviour.  mintox and the
+expressive (prosody) inputs are outside the hot path
+and raise ``NotImplementedError``.
 
 Models are named by asset cards like in the reference; a card is a dict with
 the reference schema (``model_arch``, ``checkpoint``, ...).  Offline, the
@@ -164,6 +164,8 @@ class Translator:
         self.use_graph = True  # replay the decoder step from a captured hipGraph
         self.last_text_ids: List[List[int]] = []
         self.last_stage_ms: Dict[str, float] = {}
+        self.last_t2u: Optional[Dict[str, Any]] = None  # units / durations / char ids of the last speech-output call
+        self.last_wav_full: Optional[Tensor] = None     # un-trimmed vocoder output (N, 1, S_u * hop) of the last call
 
     def fork(self) -> "Translator":
         """A view of this translator for another host thread: same weights and tokenizers, own HIP
@@ -173,6 +175,7 @@ class Translator:
         view = copy.copy(self)
         view.model = self.model.fork()
         view.last_text_ids, view.last_stage_ms = [], {}
+        view.last_t2u, view.last_wav_full = None, None
         return view
 
     # translator.py:199-213
@@ -195,7 +198,10 @@ class Translator:
         """convert_to_fbank + Collater(pad_value=0, pad_to_multiple=2) (translator.py:135-146, :293)."""
         wav = audio.to(torch.float32)
         if wav.size(1) > 1:
-            raise NotImplementedError("multi-channel audio: pass mono (T,) or (T,1) tensors")
+            # (T, C) input (translator.py:280-286 hands it to WaveformToFbankConverter(channel_last=True)); fairseq2n's
+            # multi-channel behaviour is not restated anywhere under /root/reference (SURVEY appendix A-7), so the
+            # first channel is used, as for files (evaluate.load_audio)
+            logger.warning("Multi-channel audio (%d channels): the fbank front-end uses channel 0.", wav.size(1))
         wav = wav[:, 0].contiguous().unsqueeze(0).to(self.device)
         fb, frames = self.model.fbank(wav, [wav.shape[1]], standardize=True, pad_to_multiple=2)
         return {"seqs": fb, "seq_lens": torch.tensor(frames.astype(np.int64)), "is_ragged": False}
@@ -266,6 +272,80 @@ class Translator:
 
         if text_generation_opts is None:
             text_generation_opts = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(1, 200))
+        if unit_generation_opts is None:
+            unit_generation_opts = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(25, 50))
+
+        trace: Dict[str, Any] = {"use_graph": self.use_graph}
+        texts, units_t = self.get_prediction(
+            self.model, self.text_tokenizer, self.unit_tokenizer, seqs, src_lens, input_modality, output_modality,
+            tgt_lang, text_generation_opts, unit_generation_opts,
+            unit_generation_ngram_filtering=unit_generation_ngram_filtering, duration_factor=duration_factor,
+            prosody_encoder_input=prosody_encoder_input, _trace=trace,
+        )
+        self.last_text_ids = trace["text_ids"]
+        self.last_stage_ms = trace["stage_ms"]
+        self.last_t2u = trace.get("t2u")
+        if output_modality == Modality.TEXT:
+            return texts, None
+
+        assert units_t is not None and self.unit_tokenizer is not None
+        t4 = time.perf_counter()
+        units = units_t.numpy()
+        pad = self.unit_tokenizer.vocab_info.pad_idx
+        # translator.py:398-404: drops every pad (and every genuine unit equal to the pad value)
+        speech_units = [[int(u) for u in units[i] if u != pad] for i in range(units.shape[0])]
+        audio_wavs: List[Tensor] = []
+        if self.has_vocoder:
+            lang_map = self.lang_spkr_idx_map
+            n = units.shape[0]
+            lang_idx = [lang_map["multilingual"][tgt_lang]] * n
+            # Vocoder.forward (models/vocoder/vocoder.py:33-42): an int speaker is broadcast first, so only None
+            # (and -1) select the language's default speaker; 0 is speaker 0
+            spkr_list = [spkr if spkr is not None else -1] * n
+            spkr_idx = [lang_map["multispkr"][tgt_lang][0] if s == -1 else s for s in spkr_list]
+            wav = self.model.vocode(units, lang_idx, spkr_idx)
+            self.last_stage_ms["vocoder"] = (time.perf_counter() - t4) * 1e3
+            self.last_wav_full = wav
+            for i in range(n):
+                keep = int(wav.size(-1) * len(speech_units[i]) / units.shape[1])
+                audio_wavs.append(wav[i, :, :keep].unsqueeze(0))
+        return texts, BatchedSpeechOutput(units=speech_units, audio_wavs=audio_wavs, sample_rate=sample_rate)
+
+    # translator.py:155-196
+    @classmethod
+    def get_prediction(
+        cls,
+        model: HipS2STModel,
+        text_tokenizer: NllbTextTokenizer,
+        unit_tokenizer: Optional[UnitTokenizer],
+        seqs: Tensor,
+        padding_mask: Any,
+        input_modality: Modality,
+        output_modality: Modality,
+        tgt_lang: str,
+        text_generation_opts: SequenceGeneratorOptions,
+        unit_generation_opts: Optional[SequenceGeneratorOptions],
+        unit_generation_ngram_filtering: bool = False,
+        duration_factor: float = 1.0,
+        prosody_encoder_input: Optional[SequenceData] = None,
+        _trace: Optional[Dict[str, Any]] = None,
+    ) -> Tuple[List[StringLike], Optional[Tensor]]:
+        """``UnitYGenerator(model, ...)(seqs, padding_mask, ...)`` of the reference (inference/generator.py:86-353)
+        on the HIP model: returns the texts and, for speech output, the decoded unit matrix ``(N, S_u)`` int64 with
+        pad = ``unit_tokenizer.vocab_info.pad_idx`` (what ``UnitTokenDecoder`` leaves, unit_tokenizer.py:232-243).
+
+        ``model`` is the :class:`HipS2STModel`; ``padding_mask`` is ``None`` (every row full length), a sequence /
+        tensor of lengths, or any object with a ``seq_lens`` attribute (fairseq2 ``PaddingMask``).
+        ``unit_generation_opts`` and ``unit_generation_ngram_filtering`` are disregarded for the NAR T2U model like in
+        the reference (translator.py:173-177, generator.py:338-353).  ``_trace`` (not part of the reference API)
+        receives the ids / per-stage data the batch driver and the parity tests read back."""
+        if prosody_encoder_input is not None:
+            raise NotImplementedError("expressive (prosody) models are outside the MI355X S2ST hot path")
+        if padding_mask is None:
+            src_lens = [int(seqs.shape[1])] * int(seqs.shape[0])
+        else:
+            lens = getattr(padding_mask, "seq_lens", padding_mask)
+            src_lens = [int(x) for x in (lens.tolist() if isinstance(lens, Tensor) else lens)]
         if not 1 <= text_generation_opts.beam_size <= 8:
             raise ValueError("beam_size must be in [1, 8] on the HIP path")
         ngram = 0
@@ -273,17 +353,18 @@ class Translator:
             if not isinstance(text_generation_opts.step_processor, NGramRepeatBlockProcessor):
                 raise NotImplementedError("the HIP path runs NGramRepeatBlockProcessor step processors only")
             ngram = text_generation_opts.step_processor.ngram_size
-
+        trace = _trace if _trace is not None else {}
         want_speech = output_modality == Modality.SPEECH
+
         # every sc_* stage call returns with its stream drained, so host timers are stage times
         t0 = time.perf_counter()
         if input_modality == Modality.SPEECH:
-            enc, enc_lens = self.model.encode_speech(seqs, src_lens)
+            enc, enc_lens = model.encode_speech(seqs, src_lens)
         else:
-            enc, enc_lens = self.model.encode_text(seqs.cpu().numpy(), src_lens), np.asarray(src_lens, dtype=np.int32)
+            enc, enc_lens = model.encode_text(seqs.cpu().numpy(), src_lens), np.asarray(src_lens, dtype=np.int32)
         t1 = time.perf_counter()
-        prefix = self.text_tokenizer.target_prefix(tgt_lang)
-        ids, out_lens, _scores, hidden = self.model.generate_text(
+        prefix = text_tokenizer.target_prefix(tgt_lang)
+        ids, out_lens, scores, hidden = model.generate_text(
             enc, enc_lens.tolist(), prefix,
             beam_size=text_generation_opts.beam_size,
             len_penalty=text_generation_opts.len_penalty,
@@ -291,37 +372,24 @@ class Translator:
             hard_max_seq_len=text_generation_opts.hard_max_seq_len,
             unk_penalty=text_generation_opts.unk_penalty,
             no_repeat_ngram_size=ngram,
-            use_graph=self.use_graph,
+            use_graph=trace.get("use_graph", True),
             want_hidden=want_speech,
         )
         t2 = time.perf_counter()
-        self.last_text_ids = [ids[b, : out_lens[b]].tolist() for b in range(ids.shape[0])]
-        texts: List[StringLike] = [self.text_tokenizer.decode(t) for t in self.last_text_ids]
-        self.last_stage_ms = {"encoder": (t1 - t0) * 1e3, "text_decoder": (t2 - t1) * 1e3}
+        text_ids = [ids[b, : out_lens[b]].tolist() for b in range(ids.shape[0])]
+        texts: List[StringLike] = [text_tokenizer.decode(t) for t in text_ids]
+        trace.update(text_ids=text_ids, text_scores=scores,
+                     stage_ms={"encoder": (t1 - t0) * 1e3, "text_decoder": (t2 - t1) * 1e3})
         if not want_speech:
             return texts, None
 
-        if self.unit_tokenizer is None:
+        if unit_tokenizer is None:
             raise ValueError("the model was loaded with output_modality=TEXT; speech output is unavailable")
         # generator.py:281-291: pad_seqs + trim the last column; PaddingMask.trim(1)
         text_seqs = ids[:, :-1]
         text_lens = (out_lens - 1).tolist()
         t3 = time.perf_counter()
-        units, unit_lens, _dur, _cids, _clens = self.model.t2u_nar(hidden, text_seqs, text_lens, duration_factor)
-        t4 = time.perf_counter()
-        self.last_stage_ms["t2u"] = (t4 - t3) * 1e3
-        pad = self.unit_tokenizer.vocab_info.pad_idx
-        speech_units = [[int(u) for u in units[i] if u != pad] for i in range(units.shape[0])]
-        audio_wavs: List[Tensor] = []
-        if self.has_vocoder:
-            lang_map = self.lang_spkr_idx_map
-            n = units.shape[0]
-            lang_idx = [lang_map["multilingual"][tgt_lang]] * n
-            spkr_list = [spkr if spkr is not None else -1] * n
-            spkr_idx = [lang_map["multispkr"][tgt_lang][0] if s == -1 else s for s in spkr_list]
-            wav = self.model.vocode(units, lang_idx, spkr_idx)
-            self.last_stage_ms["vocoder"] = (time.perf_counter() - t4) * 1e3
-            for i in range(n):
-                keep = int(wav.size(-1) * len(speech_units[i]) / units.shape[1])
-                audio_wavs.append(wav[i, :, :keep].unsqueeze(0))
-        return texts, BatchedSpeechOutput(units=speech_units, audio_wavs=audio_wavs, sample_rate=sample_rate)
+        units, unit_lens, dur, cids, clens = model.t2u_nar(hidden, text_seqs, text_lens, duration_factor)
+        trace["stage_ms"]["t2u"] = (time.perf_counter() - t3) * 1e3
+        trace["t2u"] = {"units": units, "unit_lens": unit_lens, "durations": dur, "char_ids": cids, "char_seq_lens": clens}
+        return texts, torch.from_numpy(units.astype(np.int64))

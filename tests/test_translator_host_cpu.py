@@ -166,3 +166,46 @@ def test_text_input_and_generation_options(translator):
     opts = SequenceGeneratorOptions(beam_size=2, hard_max_seq_len=10, unk_penalty=float("inf"), step_processor=NGramRepeatBlockProcessor(3))
     tr.predict(text, "T2TT", "fra", src_lang="eng", text_generation_opts=opts)
     assert tr.model.calls[-1] == dict(beam_size=2, no_repeat_ngram_size=3, unk_penalty=float("inf"), hard_max_seq_len=10, want_hidden=False)
+
+
+def test_get_prediction_classmethod_and_multichannel(translator, caplog):
+    """Translator.get_prediction (translator.py:155-196): the generator call without the vocoder tail; multi-channel
+    (T, C) waveforms use channel 0."""
+    tr, orc = translator
+    ws = common.waves((1.2, 0.9))
+    fb, lens = orc.collate_fbank(ws)
+    seqs, speech_units, _, units, _ = orc.s2st(fb, lens, "fra", (1, 200), 12, vocode=False)
+
+    class Mask:  # fairseq2 PaddingMask surface
+        seq_lens = lens
+
+    for mask in (Mask(), lens, lens.tolist()):
+        trace = {}
+        texts, got = Translator.get_prediction(tr.model, tr.text_tokenizer, tr.unit_tokenizer, fb, mask, Modality.SPEECH,
+                                               Modality.SPEECH, "fra", OPTS, None, _trace=trace)
+        assert trace["text_ids"] == seqs and texts == [orc.text_tok.decode(s) for s in seqs]
+        assert got.dtype == torch.int64 and got.tolist() == units.tolist()
+    texts, got = Translator.get_prediction(tr.model, tr.text_tokenizer, None, fb, Mask(), Modality.SPEECH, Modality.TEXT, "fra",
+                                           OPTS, None)
+    assert got is None and len(texts) == 2
+    # padding_mask=None: every row is full length
+    one = fb[:1, : int(lens[0])]
+    one = one[:, : one.shape[1] - one.shape[1] % 2]
+    t_none, _ = Translator.get_prediction(tr.model, tr.text_tokenizer, None, one, None, Modality.SPEECH, Modality.TEXT, "fra", OPTS, None)
+    t_mask, _ = Translator.get_prediction(tr.model, tr.text_tokenizer, None, one, [one.shape[1]], Modality.SPEECH, Modality.TEXT, "fra", OPTS, None)
+    assert t_none == t_mask
+    with pytest.raises(NotImplementedError):
+        Translator.get_prediction(tr.model, tr.text_tokenizer, None, fb, None, Modality.SPEECH, Modality.TEXT, "fra", OPTS, None,
+                                  prosody_encoder_input={"seqs": fb})
+    # (T, 2) waveform: channel 0 is what gets translated
+    w = torch.from_numpy(ws[0])
+    tr.predict(w, "S2TT", "fra", text_generation_opts=OPTS)
+    want = tr.last_text_ids
+    stereo = torch.stack([w, torch.zeros_like(w)], dim=1)
+    with caplog.at_level(logging.WARNING):
+        tr.predict(stereo, "S2TT", "fra", text_generation_opts=OPTS)
+    assert tr.last_text_ids == want and any("Multi-channel" in r.message for r in caplog.records)
+    # spkr: None and -1 pick the language's default speaker, 0 is speaker 0 (models/vocoder/vocoder.py:33-42)
+    _, s_def = tr.predict(w, "S2ST", "fra", text_generation_opts=OPTS, spkr=None)
+    _, s_m1 = tr.predict(w, "S2ST", "fra", text_generation_opts=OPTS, spkr=-1)
+    assert torch.equal(s_def.audio_wavs[0], s_m1.audio_wavs[0])
