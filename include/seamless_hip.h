@@ -255,6 +255,22 @@ int sc_op_skinny_res_ln(const float* d_in, const void* d_w_f16, const float* d_b
 int sc_op_skinny_argmax(const float* d_x, const void* d_w_f16, int32_t M, int32_t N, int32_t K, int32_t step,
                         int32_t min_step_for_eos, int32_t force_eos_step, int32_t pad_idx, int32_t eos_idx,
                         int32_t unk_idx, float unk_penalty, int32_t* d_idx, float* d_lprob);
+
+/* Second-generation decoder-step kernels (k_dstep.hip): weights packed into MFMA fragment order, activations as split
+ * fp16 planes; same near-fp32 products, own summation order (results agree with the k_skinny.hip kernels to fp32
+ * re-association).  sc_op_dstep_res_ln mirrors sc_op_skinny_res_ln (splits: wanted K ranges, 0 = 4);
+ * sc_op_dstep_linear_planes: y = act(x.W^T + b) through the split-plane epilogue (K <= 1024);
+ * sc_op_dstep_argmax mirrors sc_op_skinny_argmax (ntl: 32-feature tiles per workgroup, 0 = 4);
+ * sc_op_dstep_attention: the single-query attention of the step (see api.hip for the operand layout). */
+int sc_op_dstep_res_ln(const float* d_in, const void* d_w_f16, const float* d_bias, float* d_x_inout, const float* d_gamma,
+                       const float* d_beta, float* d_h, int32_t M, int32_t N, int32_t K, int32_t splits);
+int sc_op_dstep_linear_planes(const float* d_x, const void* d_w_f16, const float* d_bias, float* d_y, int32_t M, int32_t N, int32_t K,
+                              int32_t act);
+int sc_op_dstep_argmax(const float* d_x, const void* d_w_f16, int32_t M, int32_t N, int32_t K, int32_t step,
+                       int32_t min_step_for_eos, int32_t force_eos_step, int32_t pad_idx, int32_t eos_idx, int32_t unk_idx,
+                       float unk_penalty, int32_t ntl, int32_t* d_idx, float* d_lprob);
+int sc_op_dstep_attention(const float* d_proj, int32_t S, const float* d_bias, float* d_kcache, float* d_vcache, int32_t cap,
+                          int32_t pos, const int32_t* d_lens, int32_t cross, int32_t nb, int32_t heads, float* d_out);
 int sc_op_conv1d(const float* d_x, const void* d_w_f16_packed, const float* d_bias, const float* d_res, float* d_y,
                  int32_t nb, int32_t t_in, int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t pad,
                  int32_t dil, const int32_t* d_in_lens, int32_t in_act, int32_t act);

@@ -21,6 +21,22 @@ struct sc_model {
 
 static hipStream_t g_op_stream = nullptr;  // ops use the default stream
 
+namespace {
+struct OpScratch {  // hipMalloc'ed scratch of one op call
+    std::vector<void*> ptrs;
+    template <typename T>
+    T* get(size_t n) {
+        void* p = nullptr;
+        SC_HIP(hipMalloc(&p, std::max<size_t>(n * sizeof(T), 256)));
+        ptrs.push_back(p);
+        return static_cast<T*>(p);
+    }
+    ~OpScratch() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+};
+}  // namespace
+
 extern "C" {
 
 const char* sc_last_error(void) { return sc::get_error(); }
@@ -430,6 +446,149 @@ int sc_op_skinny_argmax(const float* d_x, const void* d_w_f16, int32_t M, int32_
         throw;
     }
     (void)hipFree(buf);
+    SC_API_END
+}
+
+// ---- second-generation decoder-step kernels (k_dstep.hip), op level ------------------------------------------------
+
+int sc_op_dstep_res_ln(const float* d_in, const void* d_w_f16, const float* d_bias, float* d_x_inout, const float* d_gamma,
+                       const float* d_beta, float* d_h, int32_t M, int32_t N, int32_t K, int32_t splits) {
+    SC_API_BEGIN
+    SC_CHECK(gemvp_supported(M, N, K), "sc_op_dstep_res_ln: M=%d N=%d K=%d unsupported", M, N, K);
+    OpScratch scratch;
+    const int RB = M <= 32 ? 32 : 64;
+    __half* wp = scratch.get<__half>((size_t)packed_weight_halfs(N, K));
+    __half* ah = scratch.get<__half>((size_t)K * RB);
+    __half* al = scratch.get<__half>((size_t)K * RB);
+    const int S = gemvp_splits(K, splits > 0 ? splits : 4);
+    float* partial = scratch.get<float>((size_t)S * M * N);
+    launch_pack_weight(static_cast<const __half*>(d_w_f16), K, N, K, wp, g_op_stream);
+    SC_HIP(hipMemsetAsync(ah, 0xff, (size_t)K * RB * 2, g_op_stream));  // NaN in the unused row slots: must not leak
+    SC_HIP(hipMemsetAsync(al, 0xff, (size_t)K * RB * 2, g_op_stream));
+    launch_rows_to_planes(d_in, K, M, K, RB, ah, al, g_op_stream);
+    GemvPArgs a;
+    a.Wp = wp, a.Ah = ah, a.Al = al, a.RB = RB, a.M = M, a.N = N, a.K = K;
+    a.splits = splits > 0 ? splits : 4;
+    a.epi = EPI_PARTIAL;
+    a.partial = partial;
+    launch_gemvp(a, g_op_stream);
+    launch_reduce_ln(partial, S, d_bias, d_x_inout, d_gamma, d_beta, nullptr, nullptr, RB, nullptr, 0, 0, nullptr, M, N, g_op_stream, d_h);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+int sc_op_dstep_linear_planes(const float* d_x, const void* d_w_f16, const float* d_bias, float* d_y, int32_t M, int32_t N, int32_t K,
+                              int32_t act) {
+    SC_API_BEGIN
+    SC_CHECK(gemvp_supported(M, N, K) && N % 8 == 0, "sc_op_dstep_linear_planes: M=%d N=%d K=%d unsupported", M, N, K);
+    OpScratch scratch;
+    const int RB = M <= 32 ? 32 : 64;
+    __half* wp = scratch.get<__half>((size_t)packed_weight_halfs(N, K));
+    __half* ah = scratch.get<__half>((size_t)K * RB);
+    __half* al = scratch.get<__half>((size_t)K * RB);
+    __half* oh = scratch.get<__half>((size_t)N * RB);
+    __half* ol = scratch.get<__half>((size_t)N * RB);
+    launch_pack_weight(static_cast<const __half*>(d_w_f16), K, N, K, wp, g_op_stream);
+    SC_HIP(hipMemsetAsync(ah, 0xff, (size_t)K * RB * 2, g_op_stream));
+    SC_HIP(hipMemsetAsync(al, 0xff, (size_t)K * RB * 2, g_op_stream));
+    launch_rows_to_planes(d_x, K, M, K, RB, ah, al, g_op_stream);
+    GemvPArgs a;
+    a.Wp = wp, a.Ah = ah, a.Al = al, a.RB = RB, a.M = M, a.N = N, a.K = K;
+    a.splits = 1;
+    a.epi = EPI_PLANES;
+    a.bias = d_bias;
+    a.act = act;
+    a.Oh = oh, a.Ol = ol, a.ORB = RB;
+    launch_gemvp(a, g_op_stream);
+    launch_planes_to_rows(oh, ol, RB, d_y, N, M, N, g_op_stream);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+int sc_op_dstep_argmax(const float* d_x, const void* d_w_f16, int32_t M, int32_t N, int32_t K, int32_t step,
+                       int32_t min_step_for_eos, int32_t force_eos_step, int32_t pad_idx, int32_t eos_idx, int32_t unk_idx,
+                       float unk_penalty, int32_t ntl, int32_t* d_idx, float* d_lprob) {
+    SC_API_BEGIN
+    SC_CHECK(gemvp_supported(M, N, K), "sc_op_dstep_argmax: M=%d N=%d K=%d unsupported", M, N, K);
+    OpScratch scratch;
+    const int RB = M <= 32 ? 32 : 64;
+    if (ntl < 1) ntl = 4;
+    const int tiles = gemvp_argmax_tiles(N, ntl);
+    const int hist_ld = step + 2;
+    __half* wp = scratch.get<__half>((size_t)packed_weight_halfs(N, K));
+    __half* ah = scratch.get<__half>((size_t)K * RB);
+    __half* al = scratch.get<__half>((size_t)K * RB);
+    float4* part = scratch.get<float4>((size_t)tiles * M);
+    float* eos_logit = scratch.get<float>(M);
+    int* ints = scratch.get<int>((size_t)4 + (size_t)M * hist_ld + 2 * M);
+    int* d_pos = ints;
+    int* hist = ints + 4;
+    int* finished = hist + (size_t)M * hist_ld;
+    int* out_len = finished + M;
+    SC_HIP(hipMemsetAsync(ints, 0, ((size_t)4 + (size_t)M * hist_ld + 2 * M) * 4, g_op_stream));
+    SC_HIP(hipMemsetAsync(eos_logit, 0, (size_t)M * 4, g_op_stream));
+    SC_HIP(hipMemcpyAsync(d_pos, &step, 4, hipMemcpyHostToDevice, g_op_stream));
+    SC_HIP(hipMemsetAsync(d_lprob, 0, (size_t)M * 4, g_op_stream));
+    launch_pack_weight(static_cast<const __half*>(d_w_f16), K, N, K, wp, g_op_stream);
+    SC_HIP(hipMemsetAsync(ah, 0xff, (size_t)K * RB * 2, g_op_stream));
+    SC_HIP(hipMemsetAsync(al, 0xff, (size_t)K * RB * 2, g_op_stream));
+    launch_rows_to_planes(d_x, K, M, K, RB, ah, al, g_op_stream);
+    GemvPArgs a;
+    a.Wp = wp, a.Ah = ah, a.Al = al, a.RB = RB, a.M = M, a.N = N, a.K = K;
+    a.splits = 1;
+    a.ntl = ntl;
+    a.epi = EPI_ARGMAX;
+    a.am_part = part;
+    a.am_tiles_cap = tiles;
+    a.am_eos_logit = eos_logit;
+    a.am_pos = d_pos;
+    a.am_min_step_for_eos = min_step_for_eos;
+    a.am_force_eos_step = force_eos_step;
+    a.am_pad_idx = pad_idx, a.am_eos_idx = eos_idx, a.am_unk_idx = unk_idx;
+    a.am_unk_penalty = unk_penalty;
+    launch_gemvp(a, g_op_stream);
+    launch_argmax_finalize(part, tiles, M, eos_logit, d_pos, force_eos_step, pad_idx, eos_idx, d_idx, hist, hist_ld, finished, out_len,
+                           d_lprob, g_op_stream);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+/* Single-query attention of the decoder step.  d_proj: [S][nb][ld] partial sums of the fused projection (self: q | k | v at
+ * columns 0 / M / 2M, M = heads * 64; cross: q only, ld = M).  self (cross == 0): the new key / value row is appended to the
+ * caches [nb][cap][M] at position `pos`, keys 0..pos take part.  cross: d_kcache = [nb][cap][2M] with keys at column 0 and
+ * values at column M, d_vcache ignored, d_lens [nb] valid keys.  d_out [nb][M]. */
+int sc_op_dstep_attention(const float* d_proj, int32_t S, const float* d_bias, float* d_kcache, float* d_vcache, int32_t cap,
+                          int32_t pos, const int32_t* d_lens, int32_t cross, int32_t nb, int32_t heads, float* d_out) {
+    SC_API_BEGIN
+    SC_CHECK(nb >= 1 && nb <= 64 && heads >= 1 && S >= 1, "sc_op_dstep_attention: bad shape");
+    OpScratch scratch;
+    const int M = heads * 64, RB = nb <= 32 ? 32 : 64;
+    __half* oh = scratch.get<__half>((size_t)M * RB);
+    __half* ol = scratch.get<__half>((size_t)M * RB);
+    int* d_pos = scratch.get<int>(4);
+    SC_HIP(hipMemcpyAsync(d_pos, &pos, 4, hipMemcpyHostToDevice, g_op_stream));
+    DAttnArgs a;
+    a.q = d_proj;
+    a.S = S;
+    a.bias = d_bias;
+    a.cap = cap;
+    a.Oh = oh, a.Ol = ol, a.ORB = RB;
+    a.nb = nb, a.heads = heads;
+    if (cross) {
+        a.ldq = M, a.sstride = (int64_t)nb * M;
+        a.kcache = d_kcache, a.vcache = d_kcache + M;
+        a.cache_ld = 2 * M, a.cache_bs = (int64_t)cap * 2 * M;
+        a.kv_lens = d_lens;
+    } else {
+        a.ldq = 3 * M, a.sstride = (int64_t)nb * 3 * M;
+        a.koff = M, a.voff = 2 * M;
+        a.kcache = d_kcache, a.vcache = d_vcache;
+        a.cache_ld = M, a.cache_bs = (int64_t)cap * M;
+        a.d_pos = d_pos;
+    }
+    launch_dattn(a, cross != 0, g_op_stream);
+    launch_planes_to_rows(oh, ol, RB, d_out, M, nb, M, g_op_stream);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
     SC_API_END
 }
 

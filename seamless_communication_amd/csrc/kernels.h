@@ -160,6 +160,77 @@ int skinny_splits(int M, int N, int K, int want_split);
 void launch_reduce_res_ln(const float* partial, int splits, const float* bias, float* x, const float* gamma,
                           const float* beta, float* h, int rows, int C, hipStream_t s);
 
+// ---- decoder step, second generation (k_dstep.hip) ---------------------------------------------------------------
+// Weights packed at load into MFMA fragment order Wp[ceil(N/32)][K/16][64 lanes][8] (rows >= N zero); activations as
+// two fp16 planes (hi, lo) in k-group-major order P[K/8][RB][8], RB = 32 or 64 row slots.
+int64_t packed_weight_halfs(int N, int K);
+void launch_pack_weight(const __half* w, int64_t ldw, int N, int K, __half* dst, hipStream_t s);
+enum GemvEpilogue {
+    EPI_PARTIAL = 0,  // raw K-range partial sums -> partial[split][M][N] (no bias)
+    EPI_PLANES = 1,   // act(sum + bias) as split planes Oh / Ol [N/8][ORB][8] (whole K in one workgroup)
+    EPI_ARGMAX = 2,   // vocabulary projection: per (workgroup, row) arg-max / log-sum-exp record, no logits in HBM
+};
+struct GemvPArgs {
+    const __half* Wp = nullptr;
+    const __half* Ah = nullptr;  // activation planes [K/8][RB][8]
+    const __half* Al = nullptr;
+    int RB = 32;
+    int M = 0, N = 0, K = 0;
+    int splits = 1;  // in: wanted K ranges; the launcher rounds it to what the tiling allows (gemvp_splits)
+    int ntl = 1;     // consecutive 32-feature tiles per workgroup (EPI_ARGMAX: records per row = ceil(N/32/ntl))
+    int epi = EPI_PARTIAL;
+    float* partial = nullptr;
+    const float* bias = nullptr;
+    int act = ACT_NONE;
+    __half* Oh = nullptr;
+    __half* Ol = nullptr;
+    int ORB = 32;
+    // arg-max epilogue (same record format and rules as SkinnyArgs)
+    float4* am_part = nullptr;
+    int am_tiles_cap = 0;
+    float* am_eos_logit = nullptr;
+    const int* am_pos = nullptr;
+    int am_min_step_for_eos = 0, am_force_eos_step = -1;
+    int am_pad_idx = -1, am_eos_idx = -1, am_unk_idx = -1;
+    float am_unk_penalty = 0.f;
+    // filled by the launcher
+    int KS = 0, NT = 0, ks_per_wg = 0;
+    uint32_t w_bytes = 0, a_bytes = 0;
+};
+bool gemvp_supported(int M, int N, int K);
+int gemvp_splits(int K, int want_splits);  // K ranges launch_gemvp will really use
+int gemvp_argmax_tiles(int N, int ntl);
+void launch_gemvp(const GemvPArgs& a, hipStream_t s);
+// x[row] += bias + sum_s partial[s][row]; h = LayerNorm(x[row]) -> planes Hh / Hl (nullable) and / or the fp32 row
+// hrow + row * hrow_bs + *d_pos * C when *d_pos < hrow_rows (nullable): the captured decoder output; hfix (nullable):
+// h as plain fp32 rows [rows][C]
+void launch_reduce_ln(const float* partial, int S, const float* bias, float* x, const float* gamma, const float* beta, __half* Hh,
+                      __half* Hl, int RB, float* hrow, int64_t hrow_bs, int hrow_rows, const int* d_pos, int rows, int C,
+                      hipStream_t s, float* hfix = nullptr);
+// x[row] = embed[tok[row]] * scale + pos_table[*d_pos]; h = LayerNorm(x[row]) -> planes
+void launch_embed_ln(const int* tok, const __half* embed, float scale, const float* pos_table, const int* d_pos, float* x,
+                     const float* gamma, const float* beta, __half* Hh, __half* Hl, int RB, int rows, int C, hipStream_t s);
+struct DAttnArgs {
+    const float* q = nullptr;  // projection partials: element (s, b, col) at q[s * sstride + b * ldq + col]
+    int64_t ldq = 0, sstride = 0;
+    int S = 1;
+    int koff = 0, voff = 0;      // self-attention: columns of the new key / value row inside the fused projection
+    const float* bias = nullptr; // bias of the fused projection (same column layout), nullable
+    float* kcache = nullptr;     // key row j of (b, head) at kcache + b * cache_bs + j * cache_ld + head * 64
+    float* vcache = nullptr;
+    int64_t cache_ld = 0, cache_bs = 0;
+    int cap = 0;
+    const int* d_pos = nullptr;    // self: position of the new row, kv_len = *d_pos + 1
+    const int* kv_lens = nullptr;  // cross: valid keys per batch row
+    __half* Oh = nullptr;          // output planes [heads*8][ORB][8]
+    __half* Ol = nullptr;
+    int ORB = 32;
+    int nb = 0, heads = 0;
+};
+void launch_dattn(const DAttnArgs& a, bool cross, hipStream_t s);
+void launch_planes_to_rows(const __half* Hh, const __half* Hl, int RB, float* out, int64_t ldo, int rows, int C, hipStream_t s);
+void launch_rows_to_planes(const float* x, int64_t ldx, int rows, int C, int RB, __half* Hh, __half* Hl, hipStream_t s);
+
 // y = act(LayerNorm(x) * gamma + beta); rows masked to zero when t >= lens[n] (optional).
 void launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
                       int64_t ldy, int rows, int C, int act, const int* lens, int t_per_batch,

@@ -64,6 +64,7 @@ class Buf {
 
 struct Linear {
     const __half* w = nullptr;  // [out][ldw]
+    const __half* wp = nullptr;  // the same values packed into MFMA fragment order (k_dstep.hip); decoder-step products only
     int64_t ldw = 0;
     const float* b = nullptr;
     int out = 0, in = 0, kpad = 0;
@@ -107,6 +108,7 @@ struct PChooseLayer {  // monotonic decoder: EnergyProjection MLPs of the query 
 // streaming monotonic decoder.  Views into ModelData.
 struct DecStack {
     const __half* embed = nullptr;
+    const __half* embed_p = nullptr;  // packed copy (vocabulary projection of the second-generation step)
     const float* pos = nullptr;
     const std::vector<DecoderLayer>* layers = nullptr;
     const LNorm* final_ln = nullptr;
@@ -152,11 +154,13 @@ struct ModelData {
     AdaptorLayer adaptor;
     // text decoder
     const __half* text_embed = nullptr;  // [V][M]
+    const __half* text_embed_p = nullptr;  // packed copy for the vocabulary projection of the decoder step
     const float* text_pos = nullptr;     // [max_len][M]
     std::vector<DecoderLayer> dec;
     LNorm dec_final_ln;
     // streaming monotonic text decoder (cfg 5; models/monotonic_decoder): own embedding, layers + p_choose
     const __half* mma_embed = nullptr;
+    const __half* mma_embed_p = nullptr;
     std::vector<DecoderLayer> mma_dec;
     std::vector<PChooseLayer> mma_pc;
     LNorm mma_final_ln;
@@ -191,6 +195,9 @@ struct ModelData {
     std::vector<ResBlock> voc_res;
 };
 
+struct DecodeSession;
+void delete_decode_session(DecodeSession* s);
+
 // State bag of the streaming decoder between sc_mma_begin and the sc_mma_step calls of one policy round.
 struct MmaState {
     int s_enc = 0, cap = 0, pos = 0;
@@ -211,9 +218,8 @@ struct Model : ModelData {
 
     std::unique_ptr<MmaState> mma;  // buffers come from `pool`: released before it (see ~Model)
 
-    // captured decoder step
-    hipGraph_t step_graph = nullptr;
-    hipGraphExec_t step_exec = nullptr;
+    // buffers + captured step graph of the greedy text generation, kept across calls (model_decoder.hip)
+    std::unique_ptr<DecodeSession, void (*)(DecodeSession*)> dec_session{nullptr, delete_decode_session};
 
     Model() = default;
     Model(const Model&) = delete;

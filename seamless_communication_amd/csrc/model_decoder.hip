@@ -55,11 +55,19 @@ struct StepCtx {
     float* d_pchoose = nullptr;        // [layers][heads]
     float* qe0 = nullptr;              // [M] scratch x2 for the query energy MLP
     float* qe1 = nullptr;
+    // second-generation step (k_dstep.hip): activations between the launches as split fp16 planes [K/8][rb][8]
+    int rb = 0;  // row slots of the planes (32 or 64); 0 = first-generation step
+    int am_ntl = 4;  // 32-feature tiles per workgroup of the fused vocabulary projection
+    __half *hH = nullptr, *hL = nullptr;      // LayerNorm output       [M/8][rb][8]
+    __half *attH = nullptr, *attL = nullptr;  // attention output       [M/8][rb][8]
+    __half *wideH = nullptr, *wideL = nullptr;  // FFN inner activation [ffn/8][rb][8]
+    Buf<__half> planes;                       // backing store of the six planes
 };
 
 DecStack unity_stack(const Model& m) {
     DecStack w;
     w.embed = m.text_embed;
+    w.embed_p = m.text_embed_p;
     w.pos = m.text_pos;
     w.layers = &m.dec;
     w.final_ln = &m.dec_final_ln;
@@ -154,12 +162,175 @@ bool proj_partials(Model& m, StepCtx& c, const float* in, int64_t ld_in, const L
     return true;
 }
 
+// ---- second-generation step (k_dstep.hip) --------------------------------------------------------------------
+bool step2_eligible(const Model& m, const DecStack& W, int nb) {
+    const int M = m.cfg.model_dim;
+    static const bool off = getenv("SC_DECODER_GEN1") != nullptr;  // A/B switch: the first-generation kernels
+    if (off || nb < 1 || nb > 64 || M % 64 != 0 || M > 1024 || W.ffn_dim % 64 != 0 || M != m.cfg.num_heads * 64) return false;
+    for (const DecoderLayer& l : *W.layers)
+        if (!l.qkv.wp || !l.self_out.wp || !l.cross_q.wp || !l.cross_out.wp || !l.ffn_in.wp || !l.ffn_out.wp) return false;
+    return true;
+}
+
+// plane buffers of one decoder-step context (rows beyond nb are never read: their lanes load out of range)
+void alloc_step2(Model& m, StepCtx& c, int ffn_dim) {
+    const int M = m.cfg.model_dim;
+    c.rb = c.nb <= 32 ? 32 : 64;
+    const size_t pm = (size_t)M * c.rb, pf = (size_t)ffn_dim * c.rb;
+    c.planes = Buf<__half>(&m.pool, 4 * pm + 2 * pf);
+    c.hH = c.planes.get();
+    c.hL = c.hH + pm;
+    c.attH = c.hL + pm;
+    c.attL = c.attH + pm;
+    c.wideH = c.attL + pm;
+    c.wideL = c.wideH + pf;
+}
+
+static void gemv2(Model& m, StepCtx& c, const __half* Ah, const __half* Al, const Linear& L, int want_splits, int* splits) {
+    GemvPArgs a;
+    a.Wp = L.wp;
+    a.Ah = Ah;
+    a.Al = Al;
+    a.RB = c.rb;
+    a.M = c.nb;
+    a.N = L.out;
+    a.K = L.in;
+    a.splits = want_splits;
+    a.epi = EPI_PARTIAL;
+    a.partial = c.partial;
+    launch_gemvp(a, m.stream);
+    *splits = gemvp_splits(L.in, want_splits);
+}
+
+// One decoder step for all batch rows on the second-generation kernels: 11 launches per layer
+// (QKV | self-attention | out-proj | +res+LN | q | cross-attention | out-proj | +res+LN | FFN-in | FFN-out | +res+LN).
+void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
+    const sc_config& cfg = m.cfg;
+    const int M = cfg.model_dim, nb = c.nb, H = cfg.num_heads;
+    const std::vector<DecoderLayer>& layers = *W.layers;
+    const int n_layers = (int)layers.size();
+    launch_embed_ln(c.d_tok, W.embed, sqrtf((float)M), W.pos, c.d_pos, c.x, layers[0].self_ln.g, layers[0].self_ln.b, c.hH, c.hL,
+                    c.rb, nb, M, m.stream);
+    for (int li = 0; li < n_layers; ++li) {
+        const DecoderLayer& l = layers[li];
+        const bool last = li + 1 == n_layers;
+        int sp = 1;
+        // self attention
+        gemv2(m, c, c.hH, c.hL, l.qkv, 2, &sp);
+        DAttnArgs a;
+        a.q = c.partial;
+        a.ldq = 3 * M;
+        a.sstride = (int64_t)nb * 3 * M;
+        a.S = sp;
+        a.koff = M;
+        a.voff = 2 * M;
+        a.bias = l.qkv.b;
+        a.kcache = c.kcache[li];
+        a.vcache = c.vcache[li];
+        a.cache_ld = M;
+        a.cache_bs = (int64_t)c.cap * M;
+        a.cap = c.cap;
+        a.d_pos = c.d_pos;
+        a.Oh = c.attH;
+        a.Ol = c.attL;
+        a.ORB = c.rb;
+        a.nb = nb;
+        a.heads = H;
+        launch_dattn(a, /*cross=*/false, m.stream);
+        gemv2(m, c, c.attH, c.attL, l.self_out, 4, &sp);
+        launch_reduce_ln(c.partial, sp, l.self_out.b, c.x, l.cross_ln.g, l.cross_ln.b, c.hH, c.hL, c.rb, nullptr, 0, 0, nullptr, nb, M,
+                         m.stream);
+        // encoder-decoder attention over the K/V projected once per utterance
+        gemv2(m, c, c.hH, c.hL, l.cross_q, 4, &sp);
+        DAttnArgs x;
+        x.q = c.partial;
+        x.ldq = M;
+        x.sstride = (int64_t)nb * M;
+        x.S = sp;
+        x.bias = l.cross_q.b;
+        x.kcache = c.cross_kv[li];
+        x.vcache = c.cross_kv[li] + M;
+        x.cache_ld = 2 * M;
+        x.cache_bs = (int64_t)c.s_enc * 2 * M;
+        x.cap = c.s_enc;
+        x.kv_lens = c.d_enc_lens;
+        x.Oh = c.attH;
+        x.Ol = c.attL;
+        x.ORB = c.rb;
+        x.nb = nb;
+        x.heads = H;
+        launch_dattn(x, /*cross=*/true, m.stream);
+        gemv2(m, c, c.attH, c.attL, l.cross_out, 4, &sp);
+        launch_reduce_ln(c.partial, sp, l.cross_out.b, c.x, l.ffn_ln.g, l.ffn_ln.b, c.hH, c.hL, c.rb, nullptr, 0, 0, nullptr, nb, M,
+                         m.stream);
+        // feed-forward network: the inner activation stays in split planes
+        GemvPArgs f;
+        f.Wp = l.ffn_in.wp;
+        f.Ah = c.hH;
+        f.Al = c.hL;
+        f.RB = c.rb;
+        f.M = nb;
+        f.N = W.ffn_dim;
+        f.K = M;
+        f.splits = 1;
+        f.epi = EPI_PLANES;
+        f.bias = l.ffn_in.b;
+        f.act = ACT_RELU;
+        f.Oh = c.wideH;
+        f.Ol = c.wideL;
+        f.ORB = c.rb;
+        launch_gemvp(f, m.stream);
+        gemv2(m, c, c.wideH, c.wideL, l.ffn_out, 8, &sp);
+        const LNorm& next = last ? *W.final_ln : layers[li + 1].self_ln;
+        // the last layer's LayerNorm is the decoder output: also kept as fp32 rows (c.hN) and, when asked for, captured
+        // per position (the teacher-forced pass of the reference, generator.py:294-299)
+        if (last) {
+            launch_reduce_ln(c.partial, sp, l.ffn_out.b, c.x, next.g, next.b, c.hH, c.hL, c.rb, c.dec_hidden,
+                             (int64_t)(c.cap - 1) * M, c.dec_hidden ? c.cap - 1 : 0, c.d_pos, nb, M, m.stream, c.hN);
+        } else {
+            launch_reduce_ln(c.partial, sp, l.ffn_out.b, c.x, next.g, next.b, c.hH, c.hL, c.rb, nullptr, 0, 0, nullptr, nb, M, m.stream);
+        }
+    }
+    if (project) {
+        GemvPArgs v;
+        v.Wp = W.embed_p;
+        v.Ah = c.hH;
+        v.Al = c.hL;
+        v.RB = c.rb;
+        v.M = nb;
+        v.N = cfg.text_vocab_size;
+        v.K = M;
+        v.splits = 1;
+        v.ntl = c.am_ntl;
+        v.epi = EPI_ARGMAX;
+        v.am_part = c.am_part;
+        v.am_tiles_cap = c.am_tiles;
+        v.am_eos_logit = c.am_eos_logit;
+        v.am_pos = c.d_pos;
+        v.am_min_step_for_eos = c.min_seq_len;
+        v.am_force_eos_step = c.force_eos_step;
+        v.am_pad_idx = cfg.pad_idx;
+        v.am_eos_idx = cfg.eos_idx;
+        v.am_unk_idx = cfg.unk_idx;
+        v.am_unk_penalty = c.unk_penalty;
+        launch_gemvp(v, m.stream);
+        launch_argmax_finalize(c.am_part, gemvp_argmax_tiles(cfg.text_vocab_size, c.am_ntl), nb, c.am_eos_logit, c.d_pos,
+                               c.force_eos_step, cfg.pad_idx, cfg.eos_idx, c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len,
+                               c.d_score, m.stream);
+    }
+    launch_add_i32(c.d_pos, 1, m.stream);
+}
+
 // One decoder step for all batch rows: feeds d_tok at position *d_pos.
 void decoder_step(Model& m, StepCtx& c, bool project) {
     const sc_config& cfg = m.cfg;
     const int M = cfg.model_dim, nb = c.nb;
     const DecStack own = unity_stack(m);
     const DecStack& W = c.stack ? *c.stack : own;
+    if (c.rb > 0 && !c.pchoose) {
+        decoder_step2(m, c, project, W);
+        return;
+    }
     const std::vector<DecoderLayer>& layers = *W.layers;
     const int n_layers = (int)layers.size();
     launch_embed_tokens(c.d_tok, nb, W.embed, M, sqrtf((float)M), W.pos, c.d_pos, 0, c.x, M, m.stream);
@@ -303,6 +474,7 @@ MmaWork mma_work(const Model& m, float* base, size_t* total) {
 DecStack mma_stack(const Model& m) {
     DecStack w;
     w.embed = m.mma_embed;
+    w.embed_p = m.mma_embed_p;
     w.pos = m.text_pos;  // same sinusoidal table (builder.py:169-176: max_seq_len 4096, _legacy_pad_idx=1)
     w.layers = &m.mma_dec;
     w.final_ln = &m.mma_final_ln;
@@ -427,6 +599,102 @@ void run_mma_step(Model& m, const int32_t* h_tokens, int n_tokens, const int32_t
     st.pos += n_tokens;
 }
 
+// Buffers of one generation / teacher-forcing run and the step context that points into them.  Greedy generation keeps
+// one of these per handle ACROSS sc_generate_text calls (Model::dec_session): the captured hipGraph of the step bakes
+// the buffer addresses and the scalar step rules in, so a call with the same key replays the cached executable graph
+// instead of capturing and instantiating a new one (round 1 did that on every call).
+struct DecodeSession {
+    // key
+    int n = 0, max_len = 0, s_enc = 0, min_seq_len = 0, has_hidden = 0, fused_argmax = 0;
+    float unk_penalty = 0.f;
+    StepCtx c;
+    Buf<int> ints;
+    Buf<float> fl, x, h, wide, att, hN, logits, partial, am_eos, hidden;
+    Buf<float4> am_part;
+    std::vector<Buf<float>> caches;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    ~DecodeSession() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+    }
+};
+
+void delete_decode_session(DecodeSession* s) { delete s; }
+
+namespace {
+
+// allocates every buffer of a run and fills the step context (no device work besides the allocations)
+void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bool forced, bool want_hidden, const sc_gen_opts& o) {
+    const sc_config& cfg = m.cfg;
+    const int M = cfg.model_dim;
+    StepCtx& c = S.c;
+    S.n = n, S.max_len = max_len, S.s_enc = s_enc, S.min_seq_len = o.min_seq_len, S.unk_penalty = o.unk_penalty;
+    S.has_hidden = want_hidden;
+    c.nb = n;
+    c.cap = max_len;
+    c.s_enc = s_enc;
+    c.min_seq_len = o.min_seq_len;
+    c.force_eos_step = max_len - 2;
+    c.unk_penalty = o.unk_penalty;
+    S.ints = Buf<int>(&m.pool, (size_t)8 + 4 * n + (size_t)n * max_len);
+    c.d_pos = S.ints;
+    c.d_tok = S.ints.get() + 8;
+    c.d_finished = c.d_tok + n;
+    c.d_out_len = c.d_finished + n;
+    c.d_enc_lens = c.d_out_len + n;
+    c.d_hist = c.d_enc_lens + n;
+    S.fl = Buf<float>(&m.pool, (size_t)2 * n);
+    c.d_lprob = S.fl;
+    c.d_score = S.fl.get() + n;
+    const DecStack W = unity_stack(m);
+    const bool gen2 = step2_eligible(m, W, n);
+    const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
+    const bool fused_argmax = !forced && n <= 64 && M % 64 == 0;
+    S.fused_argmax = fused_argmax;
+    S.x = Buf<float>(&m.pool, (size_t)n * M);
+    S.h = Buf<float>(&m.pool, (size_t)n * M);
+    S.wide = Buf<float>(&m.pool, gen2 ? 4 : (size_t)n * wideN);
+    S.att = Buf<float>(&m.pool, (size_t)n * M);
+    S.hN = Buf<float>(&m.pool, (size_t)n * M);
+    S.logits = Buf<float>(&m.pool, (forced || fused_argmax) ? 4 : (size_t)n * cfg.text_vocab_size);
+    // worst case: K/256 ranges of an [n][M] out-projection, or M/256 ranges of the [n][3M] q/k/v projection
+    S.partial = Buf<float>(&m.pool, (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * n * 3 * M);
+    c.partial = S.partial;
+    if (gen2) {
+        alloc_step2(m, c, cfg.dec_ffn_dim);
+        c.am_ntl = 4;
+        c.am_tiles = fused_argmax ? gemvp_argmax_tiles(cfg.text_vocab_size, c.am_ntl) : 0;
+    } else {
+        c.am_tiles = fused_argmax ? skinny_argmax_tiles(n, cfg.text_vocab_size) : 0;
+    }
+    S.am_part = Buf<float4>(&m.pool, (size_t)std::max(1, c.am_tiles) * n);
+    S.am_eos = Buf<float>(&m.pool, (size_t)n);
+    c.am_part = S.am_part;
+    c.am_eos_logit = S.am_eos;
+    c.x = S.x;
+    c.h = S.h;
+    c.wide = S.wide;
+    c.att = S.att;
+    c.hN = S.hN;
+    c.logits = S.logits;
+    if (want_hidden) {
+        S.hidden = Buf<float>(&m.pool, (size_t)n * (max_len - 1) * M);
+        c.dec_hidden = S.hidden;
+    }
+    S.caches.reserve(3 * cfg.dec_layers);
+    for (int li = 0; li < cfg.dec_layers; ++li) {
+        S.caches.emplace_back(&m.pool, (size_t)n * max_len * M);
+        c.kcache.push_back(S.caches.back());
+        S.caches.emplace_back(&m.pool, (size_t)n * max_len * M);
+        c.vcache.push_back(S.caches.back());
+        S.caches.emplace_back(&m.pool, (size_t)n * s_enc * 2 * M);
+        c.cross_kv.push_back(S.caches.back());
+    }
+}
+
+}  // namespace
+
 // forced_tokens != null: teacher-forced pass over the given tokens (no arg-max
 // feedback, hidden states only).  Otherwise greedy generation.
 void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens,
@@ -459,55 +727,30 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     for (int i = 0; i < n; ++i)
         SC_CHECK(h_enc_lens[i] > 0 && h_enc_lens[i] <= s_enc, "sc_generate_text: enc_lens[%d]=%d out of range", i, h_enc_lens[i]);
 
-    StepCtx c;
-    c.nb = n;
-    c.cap = max_len;
-    c.s_enc = s_enc;
-    c.min_seq_len = o.min_seq_len;
-    c.force_eos_step = max_len - 2;
-    c.unk_penalty = o.unk_penalty;
-    c.dec_hidden = d_dec_hidden;
-
-    Buf<int> ints(&m.pool, (size_t)8 + 4 * n + (size_t)n * max_len);
-    c.d_pos = ints;
-    c.d_tok = ints.get() + 8;
-    c.d_finished = c.d_tok + n;
-    c.d_out_len = c.d_finished + n;
-    c.d_enc_lens = c.d_out_len + n;
-    c.d_hist = c.d_enc_lens + n;
-    Buf<float> fl(&m.pool, (size_t)2 * n);
-    c.d_lprob = fl;
-    c.d_score = fl.get() + n;
-    const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
-    const bool fused_argmax = !forced && n <= 64 && M % 64 == 0;
-    Buf<float> x(&m.pool, (size_t)n * M), h(&m.pool, (size_t)n * M), wide(&m.pool, (size_t)n * wideN), att(&m.pool, (size_t)n * M),
-        hN(&m.pool, (size_t)n * M), logits(&m.pool, (forced || fused_argmax) ? 4 : (size_t)n * cfg.text_vocab_size);
-    // worst case: K/256 ranges of an [n][M] out-projection, or M/256 ranges of the [n][3M] q/k/v projection
-    Buf<float> partial(&m.pool, (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * n * 3 * M);
-    c.partial = partial;
-    c.am_tiles = fused_argmax ? skinny_argmax_tiles(n, cfg.text_vocab_size) : 0;
-    Buf<float4> am_part(&m.pool, (size_t)std::max(1, c.am_tiles) * n);
-    Buf<float> am_eos(&m.pool, (size_t)n);
-    c.am_part = am_part;
-    c.am_eos_logit = am_eos;
-    c.x = x;
-    c.h = h;
-    c.wide = wide;
-    c.att = att;
-    c.hN = hN;
-    c.logits = logits;
-    std::vector<Buf<float>> caches;
-    caches.reserve(3 * cfg.dec_layers);
-    for (int li = 0; li < cfg.dec_layers; ++li) {
-        caches.emplace_back(&m.pool, (size_t)n * max_len * M);
-        c.kcache.push_back(caches.back());
-        caches.emplace_back(&m.pool, (size_t)n * max_len * M);
-        c.vcache.push_back(caches.back());
-        caches.emplace_back(&m.pool, (size_t)n * s_enc * 2 * M);
-        c.cross_kv.push_back(caches.back());
-        // encoder-decoder K/V once per utterance (fairseq2 caches them in the state bag at step 0)
-        linear(m, d_enc, M, m.dec[li].cross_kv, nullptr, 0, c.cross_kv.back(), 2 * M, n * s_enc, ACT_NONE, 1.f);
+    // ---- the run's buffers: a fresh set for teacher forcing, the handle's cached session for generation -------------
+    const bool want_hidden = d_dec_hidden != nullptr;
+    std::unique_ptr<DecodeSession> local;
+    DecodeSession* S = nullptr;
+    if (forced) {
+        local.reset(new DecodeSession());
+        S = local.get();
+        setup_session(m, *S, n, max_len, s_enc, forced, want_hidden, o);
+    } else {
+        DecodeSession* cur = m.dec_session.get();
+        const bool hit = cur && cur->n == n && cur->max_len == max_len && cur->s_enc == s_enc && cur->min_seq_len == o.min_seq_len &&
+                         cur->unk_penalty == o.unk_penalty && cur->has_hidden == (int)want_hidden;
+        if (!hit) {
+            m.dec_session.reset();  // the old buffers go back to the pool first
+            m.dec_session = std::unique_ptr<DecodeSession, void (*)(DecodeSession*)>(new DecodeSession(), delete_decode_session);
+            setup_session(m, *m.dec_session, n, max_len, s_enc, forced, want_hidden, o);
+        }
+        S = m.dec_session.get();
     }
+    StepCtx& c = S->c;
+
+    // encoder-decoder K/V once per utterance (fairseq2 caches them in the state bag at step 0)
+    for (int li = 0; li < cfg.dec_layers; ++li)
+        linear(m, d_enc, M, m.dec[li].cross_kv, nullptr, 0, c.cross_kv[li], 2 * M, n * s_enc, ACT_NONE, 1.f);
 
     // ---- initial state ------------------------------------------------------------
     std::vector<int32_t> hist((size_t)n * max_len, cfg.pad_idx), init(8 + 4 * n, 0);
@@ -520,10 +763,10 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
         init[8 + 2 * n + b] = max_len;            // out_len default (forced EOS at the end)
         init[8 + 3 * n + b] = h_enc_lens[b];
     }
-    SC_HIP(hipMemcpyAsync(ints.get(), init.data(), init.size() * 4, hipMemcpyHostToDevice, m.stream));
+    SC_HIP(hipMemcpyAsync(S->ints.get(), init.data(), init.size() * 4, hipMemcpyHostToDevice, m.stream));
     SC_HIP(hipMemcpyAsync(c.d_hist, hist.data(), hist.size() * 4, hipMemcpyHostToDevice, m.stream));
-    SC_HIP(hipMemsetAsync(fl.get(), 0, (size_t)2 * n * 4, m.stream));
-    if (d_dec_hidden) SC_HIP(hipMemsetAsync(d_dec_hidden, 0, (size_t)n * (max_len - 1) * M * 4, m.stream));
+    SC_HIP(hipMemsetAsync(S->fl.get(), 0, (size_t)2 * n * 4, m.stream));
+    if (c.dec_hidden) SC_HIP(hipMemsetAsync(c.dec_hidden, 0, (size_t)n * (max_len - 1) * M * 4, m.stream));
 
     // ---- feed the known tokens (prompt echo / teacher forcing) ---------------------
     // positions 0 .. feed_len-2 are fed without projection; the next input is read from hist.
@@ -533,19 +776,19 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     }
     if (forced) {
         decoder_step(m, c, false);  // last forced position
+        if (want_hidden)
+            SC_HIP(hipMemcpyAsync(d_dec_hidden, c.dec_hidden, (size_t)n * (max_len - 1) * M * 4, hipMemcpyDeviceToDevice, m.stream));
         SC_HIP(hipStreamSynchronize(m.stream));
         return;
     }
 
     // ---- generation loop: step_nr = prefix_len-1 .. max_len-2 -----------------------
     const int first = prefix_len - 1;
-    bool use_graph = o.use_graph != 0;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    const bool use_graph = o.use_graph != 0;
     std::vector<int32_t> fin(n);
     for (int step = first; step <= max_len - 2; ++step) {
         if (use_graph) {
-            if (!exec) {
+            if (!S->exec) {
                 // Thread-local capture: another handle's host thread may allocate scratch (hipMalloc) while
                 // this one records; captures and instantiations are serialised process-wide.
                 std::lock_guard<std::mutex> lock(g_capture_mutex);
@@ -558,10 +801,10 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
                     if (dead) (void)hipGraphDestroy(dead);
                     throw;
                 }
-                SC_HIP(hipStreamEndCapture(m.stream, &graph));
-                SC_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                SC_HIP(hipStreamEndCapture(m.stream, &S->graph));
+                SC_HIP(hipGraphInstantiate(&S->exec, S->graph, nullptr, nullptr, 0));
             }
-            SC_HIP(hipGraphLaunch(exec, m.stream));
+            SC_HIP(hipGraphLaunch(S->exec, m.stream));
         } else {
             decoder_step(m, c, true);
         }
@@ -578,9 +821,9 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     SC_HIP(hipMemcpyAsync(hist.data(), c.d_hist, hist.size() * 4, hipMemcpyDeviceToHost, m.stream));
     SC_HIP(hipMemcpyAsync(lens.data(), c.d_out_len, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
     SC_HIP(hipMemcpyAsync(scores.data(), c.d_score, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
+    if (want_hidden)
+        SC_HIP(hipMemcpyAsync(d_dec_hidden, c.dec_hidden, (size_t)n * (max_len - 1) * M * 4, hipMemcpyDeviceToDevice, m.stream));
     SC_HIP(hipStreamSynchronize(m.stream));
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
     for (int b = 0; b < n; ++b) {
         const int len = lens[b];
         for (int t = 0; t < max_len; ++t) h_out_ids[(size_t)b * max_len + t] = t < len ? hist[(size_t)b * max_len + t] : cfg.pad_idx;
@@ -673,6 +916,10 @@ void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, cons
     c.att = att;
     c.hN = hN;
     c.logits = logits;
+    {
+        const DecStack W = unity_stack(m);
+        if (step2_eligible(m, W, nb)) alloc_step2(m, c, cfg.dec_ffn_dim);  // second-generation step kernels (<= 64 live rows)
+    }
     // self-attention K/V caches of all layers in one allocation, twice (re-ordered from one into the other)
     const int64_t layer_stride = (int64_t)nb * max_len * M;
     Buf<float> kv_a(&m.pool, (size_t)2 * L * layer_stride), kv_b(&m.pool, (size_t)2 * L * layer_stride);

@@ -57,10 +57,9 @@ void DevicePool::release_all() {
 }
 
 Model::~Model() {
-    mma.reset();
-    if (step_exec) (void)hipGraphExecDestroy(step_exec);
-    if (step_graph) (void)hipGraphDestroy(step_graph);
     if (stream) (void)hipStreamSynchronize(stream);
+    mma.reset();
+    dec_session.reset();
     if (order_event) (void)hipEventDestroy(order_event);
     pool.release_all();
     for (void* p : owned) (void)hipFree(p);
@@ -157,6 +156,18 @@ struct Loader {
         l.out = out;
         l.in = in;
         return l;
+    }
+    // second copy of a decoder-step weight in MFMA fragment order (k_dstep.hip); the row-major one stays for the
+    // many-row products of the same layer (encoder K/V projection, teacher-forced pass)
+    const __half* packed(const __half* w, int64_t ldw, int out, int in) {
+        if (in % 64 != 0 || packed_weight_halfs(out, in) * 2 >= (1ll << 32)) return nullptr;
+        __half* d = static_cast<__half*>(dalloc((size_t)packed_weight_halfs(out, in) * 2));
+        launch_pack_weight(w, ldw, out, in, d, m.stream);
+        return d;
+    }
+    void pack(Linear& l) { l.wp = packed(l.w, l.ldw, l.out, l.in); }
+    void pack_decoder_layer(DecoderLayer& l) {
+        pack(l.qkv), pack(l.self_out), pack(l.cross_q), pack(l.cross_out), pack(l.ffn_in), pack(l.ffn_out);
     }
     // concatenate several (out_i, in) projections into one [sum out_i][in] weight
     Linear fuse(const std::vector<std::string>& ps, int out_each, int in) {
@@ -370,7 +381,9 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
         l.ffn_ln = L.ln(p + ".ffn_layer_norm", M);
         l.ffn_in = L.lin(p + ".ffn.inner_proj", c.dec_ffn_dim, M);
         l.ffn_out = L.lin(p + ".ffn.output_proj", M, c.dec_ffn_dim);
+        L.pack_decoder_layer(l);
     }
+    m.text_embed_p = L.packed(m.text_embed, M, c.text_vocab_size, M);
     m.dec_final_ln = L.ln("text_decoder.layer_norm", M);
 
     // ---- streaming monotonic decoder (keys of convert_monotonic_checkpoint, models/monotonic_decoder/loader.py:30-46,
@@ -397,6 +410,7 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
             l.ffn_ln = L.ln(p + ".ffn_layer_norm", M);
             l.ffn_in = L.lin(p + ".ffn.inner_proj", c.mma_ffn_dim, M);
             l.ffn_out = L.lin(p + ".ffn.output_proj", M, c.mma_ffn_dim);
+            L.pack_decoder_layer(l);
             PChooseLayer& pc = m.mma_pc[i];
             for (int e = 0; e < c.mma_energy_layers; ++e) {  // ModuleList [Linear, ReLU] x n: Linears at even indices
                 pc.q.push_back(L.lin(p + ".p_choose_layer.q_energy_proj.layers." + std::to_string(2 * e), M, M));
@@ -404,6 +418,7 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
             }
             pc.energy_bias = L.has(p + ".p_choose_layer.energy_bias") ? L.f32(p + ".p_choose_layer.energy_bias", {1}) : nullptr;
         }
+        m.mma_embed_p = L.packed(m.mma_embed, M, c.text_vocab_size, M);
         m.mma_final_ln = L.ln(root + "text_decoder.layer_norm", M);
     }
 
