@@ -271,6 +271,9 @@ int sc_op_dstep_argmax(const float* d_x, const void* d_w_f16, int32_t M, int32_t
                        float unk_penalty, int32_t ntl, int32_t* d_idx, float* d_lprob);
 int sc_op_dstep_attention(const float* d_proj, int32_t S, const float* d_bias, float* d_kcache, float* d_vcache, int32_t cap,
                           int32_t pos, const int32_t* d_lens, int32_t cross, int32_t nb, int32_t heads, float* d_out);
+/* Diagnostic: n launches of one decoder-step kernel as a dependent chain in a replayed hipGraph; wall time per launch
+ * (kinds: see api.hip). */
+int sc_op_chain_bench(int32_t kind, int32_t rows, int32_t n, int32_t reps, float* us_per_kernel);
 int sc_op_conv1d(const float* d_x, const void* d_w_f16_packed, const float* d_bias, const float* d_res, float* d_y,
                  int32_t nb, int32_t t_in, int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t pad,
                  int32_t dil, const int32_t* d_in_lens, int32_t in_act, int32_t act);

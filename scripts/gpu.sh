@@ -38,7 +38,7 @@ for task in "$@"; do
   echo "=== $task"
   case $task in
     tests)
-      ( timeout 1500 python -m pytest tests -m gpu -q -x > ${O}_pytest_gpu.log 2>&1; echo "pytest exit $?" >> ${O}_pytest_gpu.log )
+      ( timeout 1500 python -m pytest tests -m gpu -q --maxfail=20 > ${O}_pytest_gpu.log 2>&1; echo "pytest exit $?" >> ${O}_pytest_gpu.log )
       grep -E "^FAILED|^ERROR|passed|failed|^E  |exit" ${O}_pytest_gpu.log | head -20 ;;
     fullsize)
       ( timeout 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x > ${O}_pytest_fullsize.log 2>&1; echo "pytest exit $?" >> ${O}_pytest_fullsize.log )
@@ -77,6 +77,13 @@ for task in "$@"; do
       head -8 ${O}_pmc_hbm_traffic.csv | cut -c1-200 ;;
     dstep)
       ( timeout 300 python scripts/dstep_bench.py $DSTEP_ARGS > ${O}_dstep.txt 2>&1; echo "exit $?" >> ${O}_dstep.txt ); grep -v amdgpu ${O}_dstep.txt | tail -40 | cut -c1-200 ;;
+    dtrace)
+      # kernel trace of the decoder-step bench: durations + gaps between consecutive launches (scripts/trace_gaps.py)
+      rm -rf gpurun_out/${TAG}_dtrace
+      ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_dtrace -o d -- python $R/scripts/dstep_bench.py ${DTRACE_ARGS:---rows 1 --reps 2} > $R/${O}_dtrace.log 2>&1; echo "exit $?" >> $R/${O}_dtrace.log )
+      f=$(find gpurun_out/${TAG}_dtrace -name "*kernel_trace.csv" | head -1)
+      [ -n "$f" ] && python scripts/trace_gaps.py $f --last ${DTRACE_LAST:-10000} > ${O}_dtrace_summary.txt 2>&1; cat ${O}_dtrace_summary.txt | cut -c1-130
+      find gpurun_out/${TAG}_dtrace -name "*.csv" -size +20M -delete 2>/dev/null ;;
     micro)
       for src in scripts/micro/*.hip; do
         b=/tmp/$(basename $src .hip)

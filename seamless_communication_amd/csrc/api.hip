@@ -592,6 +592,98 @@ int sc_op_dstep_attention(const float* d_proj, int32_t S, const float* d_bias, f
     SC_API_END
 }
 
+/* Diagnostic: `n` launches of ONE decoder-step kernel (kind) as a dependent chain in a captured hipGraph, replayed
+ * `reps` times; *us_per_kernel = wall time per launch.  Shapes are those of the full-size model with `rows` batch rows.
+ * kind 0 add_i32 | 1 reduce_ln (4 partials) | 2 gemvp 1024x1024 (4 K ranges) | 3 gemvp 1024x8192 (8 ranges) |
+ * 4 gemvp 8192x1024 planes epilogue | 5 self-attention (position 20) | 6 cross-attention (63 keys) | 7 = 2 + 1 alternating */
+int sc_op_chain_bench(int32_t kind, int32_t rows, int32_t n, int32_t reps, float* us_per_kernel) {
+    SC_API_BEGIN
+    SC_CHECK(kind >= 0 && kind <= 7 && rows >= 1 && rows <= 64 && n >= 1 && reps >= 1 && us_per_kernel, "sc_op_chain_bench: bad argument");
+    OpScratch scratch;
+    const int M = 1024, F = 8192, H = 16, RB = rows <= 32 ? 32 : 64, cap = 42, s_enc = 63;
+    __half* wp = scratch.get<__half>((size_t)packed_weight_halfs(F, M));
+    __half* planes = scratch.get<__half>((size_t)4 * F * RB);
+    float* partial = scratch.get<float>((size_t)8 * rows * 3 * M);
+    float* x = scratch.get<float>((size_t)rows * M);
+    float* gb = scratch.get<float>((size_t)3 * M);
+    float* kv = scratch.get<float>((size_t)rows * s_enc * 2 * M);
+    int* ints = scratch.get<int>(64 + rows);
+    SC_HIP(hipMemset(wp, 0, (size_t)packed_weight_halfs(F, M) * 2));
+    SC_HIP(hipMemset(planes, 0, (size_t)4 * F * RB * 2));
+    SC_HIP(hipMemset(partial, 0, (size_t)8 * rows * 3 * M * 4));
+    SC_HIP(hipMemset(x, 0, (size_t)rows * M * 4));
+    SC_HIP(hipMemset(gb, 0, (size_t)3 * M * 4));
+    SC_HIP(hipMemset(kv, 0, (size_t)rows * s_enc * 2 * M * 4));
+    std::vector<int> hi(64 + rows, s_enc);
+    hi[0] = 20;
+    SC_HIP(hipMemcpy(ints, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
+    __half *ah = planes, *al = planes + (size_t)F * RB, *oh = al + (size_t)F * RB, *ol = oh + (size_t)F * RB;
+    hipStream_t st = nullptr;
+    SC_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    auto one = [&](int k) {
+        if (k == 0) {
+            launch_add_i32(ints + 1, 1, st);
+        } else if (k == 1) {
+            launch_reduce_ln(partial, 4, gb, x, gb + M, gb + 2 * M, ah, al, RB, nullptr, 0, 0, nullptr, rows, M, st);
+        } else if (k == 2 || k == 3 || k == 4) {
+            GemvPArgs a;
+            a.Wp = wp, a.Ah = ah, a.Al = al, a.RB = RB, a.M = rows;
+            a.N = k == 4 ? F : M;
+            a.K = k == 3 ? F : M;
+            a.splits = k == 2 ? 4 : (k == 3 ? 8 : 1);
+            a.epi = k == 4 ? EPI_PLANES : EPI_PARTIAL;
+            a.partial = partial;
+            a.bias = k == 4 ? gb : nullptr;
+            a.act = ACT_RELU;
+            a.Oh = oh, a.Ol = ol, a.ORB = RB;
+            launch_gemvp(a, st);
+        } else {
+            DAttnArgs a;
+            a.q = partial;
+            a.bias = gb;
+            a.Oh = oh, a.Ol = ol, a.ORB = RB;
+            a.nb = rows, a.heads = H;
+            if (k == 5) {
+                a.S = 2, a.ldq = 3 * M, a.sstride = (int64_t)rows * 3 * M, a.koff = M, a.voff = 2 * M;
+                a.kcache = kv, a.vcache = kv + (size_t)rows * cap * M, a.cache_ld = M, a.cache_bs = (int64_t)cap * M, a.cap = cap;
+                a.d_pos = ints;
+            } else {
+                a.S = 4, a.ldq = M, a.sstride = (int64_t)rows * M;
+                a.kcache = kv, a.vcache = kv + M, a.cache_ld = 2 * M, a.cache_bs = (int64_t)s_enc * 2 * M, a.cap = s_enc;
+                a.kv_lens = ints + 64;
+            }
+            launch_dattn(a, k == 6, st);
+        }
+    };
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    SC_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < n; ++i) {
+        if (kind == 7) one(i & 1 ? 1 : 2);
+        else one(kind);
+    }
+    SC_HIP(hipStreamEndCapture(st, &g));
+    SC_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    for (int r = 0; r < 2; ++r) SC_HIP(hipGraphLaunch(ge, st));
+    SC_HIP(hipStreamSynchronize(st));
+    hipEvent_t e0, e1;
+    SC_HIP(hipEventCreate(&e0));
+    SC_HIP(hipEventCreate(&e1));
+    SC_HIP(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) SC_HIP(hipGraphLaunch(ge, st));
+    SC_HIP(hipEventRecord(e1, st));
+    SC_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    SC_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *us_per_kernel = 1e3f * ms / (float)(reps * n);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipGraphExecDestroy(ge);
+    (void)hipGraphDestroy(g);
+    (void)hipStreamDestroy(st);
+    SC_API_END
+}
+
 int sc_op_pack_conv_weight(const void* d_w_f16, void* d_dst_f16, int32_t cout, int32_t cin, int32_t k) {
     SC_API_BEGIN
     const int kpad = (int)align_up((int64_t)cin * k, 32);
