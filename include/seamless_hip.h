@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 3
+#define SC_ABI_VERSION 4
 #define SC_MAX_UPSAMPLES 8
 #define SC_MAX_RESBLOCK_KERNELS 4
 #define SC_MAX_RESBLOCK_DILATIONS 4
@@ -205,6 +205,15 @@ int sc_get_durations(sc_model* m, int32_t* h_durations /* [n][s_char_max] */, in
 int32_t sc_vocoder_hop(const sc_model* m);
 int sc_vocode(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, const int32_t* h_lang_idx,
               const int32_t* h_spkr_idx, float* d_wav);
+/* The same for a padded batch of which only the first h_unit_lens[i] * hop samples of row i will be kept (the
+ * proportional trim of Translator.predict, inference/translator.py:411-419, never keeps more): rows are vocoded in length
+ * buckets, each on min(s_units, unit_lens[i] + receptive field) frames of the padded row, so the kept samples are those of
+ * the padded batch while the padding itself is not synthesised.  Samples behind that window read as zero. */
+int sc_vocode_ragged(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, const int32_t* h_unit_lens,
+                     const int32_t* h_lang_idx, const int32_t* h_spkr_idx, float* d_wav);
+/* Unit rows the last sc_t2u_nar call computed in its length buckets / would have computed padded to the batch maximum,
+ * and the unit frames the last sc_vocode* call computed (measurement: padding is not useful work). */
+int sc_last_padding(sc_model* m, int64_t* t2u_rows_computed, int64_t* t2u_rows_padded, int64_t* vocoder_rows_computed);
 
 /* Per-kernel HIP-event timing on the handle's stream (bench.py roofline).  The report is text:
  * one "name launches total_ms algorithmic_flops algorithmic_bytes" line per kernel family. */

@@ -11,7 +11,7 @@ from typing import Optional
 
 LIB_PATH = Path(__file__).resolve().parent / "libseamless_hip.so"
 
-SC_ABI_VERSION = 3
+SC_ABI_VERSION = 4
 SC_MAX_UPSAMPLES = 8
 SC_MAX_RESBLOCK_KERNELS = 4
 SC_MAX_RESBLOCK_DILATIONS = 4
@@ -101,6 +101,8 @@ SIGNATURES = {
     "sc_get_durations": (C.c_int, [_P, _P, _P, _P]),
     "sc_vocoder_hop": (_i, [_P]),
     "sc_vocode": (C.c_int, [_P, _P, _i, _i, _P, _P, _P]),
+    "sc_vocode_ragged": (C.c_int, [_P, _P, _i, _i, _P, _P, _P, _P]),
+    "sc_last_padding": (C.c_int, [_P, _P, _P, _P]),
     "sc_prof_enable": (C.c_int, [C.c_int]),
     "sc_prof_reset": (C.c_int, []),
     "sc_prof_report": (C.c_int64, [C.c_char_p, C.c_int64]),

@@ -244,6 +244,24 @@ int sc_vocode(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, c
     SC_API_END
 }
 
+int sc_vocode_ragged(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, const int32_t* h_unit_lens,
+                     const int32_t* h_lang_idx, const int32_t* h_spkr_idx, float* d_wav) {
+    SC_API_BEGIN
+    SC_CHECK(m && h_units && h_unit_lens && h_lang_idx && h_spkr_idx && d_wav, "sc_vocode_ragged: null argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    run_vocode(m->m, h_units, n, s_units, h_lang_idx, h_spkr_idx, d_wav, h_unit_lens);
+    SC_API_END
+}
+
+int sc_last_padding(sc_model* m, int64_t* t2u_rows_computed, int64_t* t2u_rows_padded, int64_t* vocoder_rows_computed) {
+    SC_API_BEGIN
+    SC_CHECK(m, "sc_last_padding: null handle");
+    if (t2u_rows_computed) *t2u_rows_computed = m->m.last_padded_unit_rows;
+    if (t2u_rows_padded) *t2u_rows_padded = (int64_t)m->m.last_n * m->m.last_su;
+    if (vocoder_rows_computed) *vocoder_rows_computed = m->m.last_vocoder_unit_rows;
+    SC_API_END
+}
+
 int sc_prof_enable(int on) {
     sc::prof::enable(on != 0);
     return SC_OK;

@@ -215,6 +215,8 @@ struct Model : ModelData {
     // results of the last sc_t2u_nar call
     std::vector<int32_t> last_units, last_durations, last_char_ids, last_char_seq_lens;
     int last_n = 0, last_su = 0, last_sc = 0;
+    int64_t last_padded_unit_rows = 0;  // unit rows the NAR decoder really computed (length buckets), vs last_n * last_su
+    int64_t last_vocoder_unit_rows = 0; // unit frames the vocoder really computed in the last sc_vocode* call
 
     std::unique_ptr<MmaState> mma;  // buffers come from `pool`: released before it (see ~Model)
 
@@ -250,8 +252,11 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
 void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const int32_t* h_text_lens,
                  const int32_t* h_text_seqs, float duration_factor, int32_t* h_unit_lens, int32_t* out_su,
                  int32_t* out_sc);
+// h_unit_lens == null: the whole padded batch.  Otherwise only the first h_unit_lens[i] * hop samples of row i are
+// guaranteed (computed exactly as in the padded batch), the rest of the row is zero.
 void run_vocode(Model& m, const int32_t* h_units, int n, int s_units, const int32_t* h_lang, const int32_t* h_spkr,
-                float* d_wav);
+                float* d_wav, const int32_t* h_unit_lens = nullptr);
+std::vector<std::vector<int>> plan_length_groups(const std::vector<int>& lens, int overhead_rows, int max_groups);
 
 // helpers shared by the stages
 void linear(Model& m, const float* x, int64_t ldx, const Linear& L, const float* res, int64_t ldr, float* y,

@@ -76,6 +76,44 @@ void text_to_char_seqs(const Model& m, const int32_t* text_seqs, int n, int s_te
 
 }  // namespace
 
+// Length buckets for ragged execution.  The NAR decoder and the vocoder are exact per item under their padding masks /
+// finite receptive fields, so a batch whose items differ widely in length (synthetic weights: 230..1100 units around a
+// mean of 460) need not be computed at the batch maximum: items are sorted by length and cut into contiguous groups, each
+// run at its own maximum.  Dynamic programme over the sorted order: cost = sum over groups of count * longest +
+// `overhead_rows` per group (the launch chain of one more pass, in row equivalents), at most `max_groups` groups.
+std::vector<std::vector<int>> plan_length_groups(const std::vector<int>& lens, int overhead_rows, int max_groups) {
+    const int n = (int)lens.size();
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+    max_groups = std::max(1, std::min(max_groups, n));
+    const int64_t INF = (int64_t)1 << 60;
+    // best[g][i]: cost of covering sorted items i.. with exactly g groups
+    std::vector<std::vector<int64_t>> best(max_groups + 1, std::vector<int64_t>(n + 1, INF));
+    std::vector<std::vector<int>> cut(max_groups + 1, std::vector<int>(n + 1, n));
+    for (int g = 0; g <= max_groups; ++g) best[g][n] = 0;
+    for (int g = 1; g <= max_groups; ++g)
+        for (int i = n - 1; i >= 0; --i)
+            for (int j = i + 1; j <= n; ++j) {  // group = sorted items i..j-1, longest = lens[order[i]]
+                if (best[g - 1][j] >= INF) continue;
+                const int64_t c = (int64_t)(j - i) * lens[order[i]] + overhead_rows + best[g - 1][j];
+                if (c < best[g][i]) {
+                    best[g][i] = c;
+                    cut[g][i] = j;
+                }
+            }
+    int g_best = 1;
+    for (int g = 2; g <= max_groups; ++g)
+        if (best[g][0] < best[g_best][0]) g_best = g;
+    std::vector<std::vector<int>> groups;
+    for (int i = 0, g = g_best; i < n && g >= 1; --g) {
+        const int j = cut[g][i];
+        groups.emplace_back(order.begin() + i, order.begin() + j);
+        i = j;
+    }
+    return groups;
+}
+
 // The same host logic without a handle (parity tests on machines without a GPU): a scratch model that only carries
 // the tables and the three special ids.  Returns the longest char sequence.
 int text_to_char_seqs_host(int vocab, const int32_t* tok_len, const uint8_t* starts_space, const uint8_t* is_punct,
@@ -232,48 +270,80 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
     }
     SC_CHECK(Su > 0, "sc_t2u_nar: zero units predicted");
     const int urows = n * Su;
-    std::vector<int32_t> uidx((size_t)urows, -1);
-    for (int b = 0; b < n; ++b) {
-        int pos = 0;
-        for (int k = 0; k < Sc; ++k)
-            for (int r = 0; r < dur[(size_t)b * Sc + k]; ++r) uidx[(size_t)b * Su + pos++] = b * Sc + k;
-    }
-    Buf<int> d_uidx(&m.pool, urows), d_ulens(&m.pool, n), d_ids(&m.pool, urows);
-    SC_HIP(hipMemcpyAsync(d_uidx.get(), uidx.data(), (size_t)urows * 4, hipMemcpyHostToDevice, m.stream));
+    Buf<int> d_ulens(&m.pool, n);
     SC_HIP(hipMemcpyAsync(d_ulens.get(), ulens.data(), (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
 
-    // ---- FFT decoder ---------------------------------------------------------------------
-    std::vector<int32_t> ids((size_t)urows);
-    {
-        Buf<float> u(&m.pool, (size_t)urows * M), y(&m.pool, (size_t)urows * M), att(&m.pool, (size_t)urows * M),
-            wide(&m.pool, (size_t)urows * wideN);
-        launch_gather_rows(cs, M, d_uidx, u, M, urows, M, m.stream);
-        launch_pos_add(u, M, m.unit_pos, Su, m.pos_alpha, urows, M, m.stream);
+    // ---- FFT decoder, one pass per length bucket -----------------------------------------------------------
+    // Exact per item: the attention is key-masked, both convolutions see zeros behind an item's end (fft_decoder_layer.py:
+    // 74-101: mask before each conv) and LayerNorm / the projection act on single rows, so an item's units do not
+    // depend on what it is batched with.  SC_T2U_GROUPS=1 restores the single padded pass.
+    std::vector<int32_t> ids((size_t)urows, c.unit_pad_idx);
+    static const int max_groups = getenv("SC_T2U_GROUPS") ? std::max(1, atoi(getenv("SC_T2U_GROUPS"))) : 8;
+    const std::vector<std::vector<int>> groups = plan_length_groups(std::vector<int>(ulens.begin(), ulens.end()), 400, max_groups);
+    int64_t rows_done = 0;
+    std::vector<std::vector<int32_t>> keep_alive;  // host staging of every group until the final synchronisation
+    std::vector<Buf<int>> id_bufs;
+    keep_alive.reserve(3 * groups.size());
+    for (const std::vector<int>& grp : groups) {
+        const int ng = (int)grp.size();
+        int Lg = 0;
+        for (int b : grp) Lg = std::max(Lg, ulens[b]);
+        const int grows = ng * Lg;
+        rows_done += grows;
+        keep_alive.emplace_back((size_t)grows, -1);
+        std::vector<int32_t>& uidx = keep_alive.back();
+        keep_alive.emplace_back((size_t)ng);
+        std::vector<int32_t>& glens = keep_alive.back();
+        for (int gi = 0; gi < ng; ++gi) {
+            const int b = grp[gi];
+            glens[gi] = ulens[b];
+            int pos = 0;
+            for (int k = 0; k < Sc; ++k)
+                for (int r = 0; r < dur[(size_t)b * Sc + k]; ++r) uidx[(size_t)gi * Lg + pos++] = b * Sc + k;
+        }
+        Buf<int> d_uidx(&m.pool, grows), d_glens(&m.pool, ng);
+        id_bufs.emplace_back(&m.pool, grows);
+        int* d_ids = id_bufs.back();
+        SC_HIP(hipMemcpyAsync(d_uidx.get(), uidx.data(), (size_t)grows * 4, hipMemcpyHostToDevice, m.stream));
+        SC_HIP(hipMemcpyAsync(d_glens.get(), glens.data(), (size_t)ng * 4, hipMemcpyHostToDevice, m.stream));
+        Buf<float> u(&m.pool, (size_t)grows * M), y(&m.pool, (size_t)grows * M), att(&m.pool, (size_t)grows * M),
+            wide(&m.pool, (size_t)grows * wideN);
+        launch_gather_rows(cs, M, d_uidx, u, M, grows, M, m.stream);
+        launch_pos_add(u, M, m.unit_pos, Lg, m.pos_alpha, grows, M, m.stream);
         const int K = c.t2u_conv_kernel;
         for (const FFTLayer& l : m.t2u_dec) {
-            linear(m, u, M, l.qkv, nullptr, 0, wide, 3 * M, urows, ACT_NONE, 1.f);
-            attention_self(m, wide, M, att, n, Su, d_ulens);
-            linear(m, att, M, l.attn_out, u, M, y, M, urows, ACT_NONE, 1.f);
-            layernorm(m, y, l.attn_ln, y, urows);
-            conv1d(m, y, l.conv1, nullptr, wide, n, Su, 1, K / 2, 1, d_ulens, IN_NONE, ACT_RELU);
-            conv1d(m, wide, l.conv2, y, u, n, Su, 1, K / 2, 1, d_ulens, IN_NONE, ACT_NONE);
-            layernorm(m, u, l.conv_ln, u, urows);
+            linear(m, u, M, l.qkv, nullptr, 0, wide, 3 * M, grows, ACT_NONE, 1.f);
+            attention_self(m, wide, M, att, ng, Lg, d_glens);
+            linear(m, att, M, l.attn_out, u, M, y, M, grows, ACT_NONE, 1.f);
+            layernorm(m, y, l.attn_ln, y, grows);
+            conv1d(m, y, l.conv1, nullptr, wide, ng, Lg, 1, K / 2, 1, d_glens, IN_NONE, ACT_RELU);
+            conv1d(m, wide, l.conv2, y, u, ng, Lg, 1, K / 2, 1, d_glens, IN_NONE, ACT_NONE);
+            layernorm(m, u, l.conv_ln, u, grows);
         }
-        layernorm(m, u, m.t2u_dec_ln, u, urows);
+        layernorm(m, u, m.t2u_dec_ln, u, grows);
         // project + argmax (model.py:438-441, generator.py:346)
-        Buf<float> logits(&m.pool, (size_t)urows * c.unit_vocab_size);
+        Buf<float> logits(&m.pool, (size_t)grows * c.unit_vocab_size);
         Linear proj;
         proj.w = m.unit_embed;
         proj.ldw = M;
         proj.kpad = M;
         proj.in = M;
         proj.out = c.unit_vocab_size;
-        linear(m, u, M, proj, nullptr, 0, logits, c.unit_vocab_size, urows, ACT_NONE, 1.f);
-        launch_argmax_rows(logits, c.unit_vocab_size, urows, c.unit_vocab_size, nullptr, -1, -1, -1, -1, -1, 0.f, d_ids,
-                           nullptr, m.stream);
-        SC_HIP(hipMemcpyAsync(ids.data(), d_ids.get(), (size_t)urows * 4, hipMemcpyDeviceToHost, m.stream));
-        SC_HIP(hipStreamSynchronize(m.stream));
+        linear(m, u, M, proj, nullptr, 0, logits, c.unit_vocab_size, grows, ACT_NONE, 1.f);
+        launch_argmax_rows(logits, c.unit_vocab_size, grows, c.unit_vocab_size, nullptr, -1, -1, -1, -1, -1, 0.f, d_ids, nullptr,
+                           m.stream);
+        keep_alive.emplace_back((size_t)grows);
+        SC_HIP(hipMemcpyAsync(keep_alive.back().data(), d_ids, (size_t)grows * 4, hipMemcpyDeviceToHost, m.stream));
     }
+    SC_HIP(hipStreamSynchronize(m.stream));
+    for (size_t g = 0; g < groups.size(); ++g) {
+        const std::vector<int>& grp = groups[g];
+        const std::vector<int32_t>& gids = keep_alive[3 * g + 2];
+        const int Lg = (int)(gids.size() / grp.size());
+        for (size_t gi = 0; gi < grp.size(); ++gi)
+            for (int t = 0; t < ulens[grp[gi]]; ++t) ids[(size_t)grp[gi] * Su + t] = gids[gi * Lg + t];
+    }
+    m.last_padded_unit_rows = rows_done;
     // apply_padding_mask(pad) + UnitTokenDecoder NAR branch (unit_tokenizer.py:232-243)
     m.last_units.assign((size_t)urows, 0);
     for (int b = 0; b < n; ++b)
@@ -293,31 +363,18 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
     if (out_sc) *out_sc = Sc;
 }
 
-void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h_lang, const int32_t* h_spkr,
-                float* d_wav) {
-    const sc_config& c = m.cfg;
-    SC_CHECK(c.has_vocoder, "sc_vocode: the model was loaded without a vocoder");
-    prof::set_tag("voc");
-    SC_CHECK(n > 0 && T > 0, "sc_vocode: empty batch");
-    for (int i = 0; i < n; ++i) {
-        SC_CHECK(h_lang[i] >= 0 && h_lang[i] < c.voc_num_langs, "sc_vocode: lang index %d out of range", h_lang[i]);
-        SC_CHECK(h_spkr[i] >= 0 && h_spkr[i] < c.voc_num_spkrs, "sc_vocode: speaker index %d out of range", h_spkr[i]);
-    }
-    for (int64_t i = 0; i < (int64_t)n * T; ++i)
-        SC_CHECK(h_units[i] >= 0 && h_units[i] < c.voc_num_embeddings, "sc_vocode: unit %d out of range [0,%d)", h_units[i],
-                 c.voc_num_embeddings);
-    const int E = c.voc_embedding_dim, Lg = c.voc_lang_embedding_dim, Sp = c.voc_spkr_embedding_dim;
-    Buf<int> d_units(&m.pool, (size_t)n * T), d_ls(&m.pool, 2 * n);
-    SC_HIP(hipMemcpyAsync(d_units.get(), h_units, (size_t)n * T * 4, hipMemcpyHostToDevice, m.stream));
-    SC_HIP(hipMemcpyAsync(d_ls.get(), h_lang, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
-    SC_HIP(hipMemcpyAsync(d_ls.get() + n, h_spkr, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+namespace {
 
+// Generator.forward on one padded batch [n][T] of unit ids already on the device -> d_wav [n][T * hop]
+void vocode_batch(Model& m, const int* d_units, const int* d_lang, const int* d_spkr, int n, int T, float* d_wav) {
+    const sc_config& c = m.cfg;
+    const int E = c.voc_embedding_dim, Lg = c.voc_lang_embedding_dim, Sp = c.voc_spkr_embedding_dim;
     int ch = c.voc_upsample_initial_channel;
     int t = T;
     Buf<float> x;
     {
         Buf<float> in(&m.pool, (size_t)n * T * (E + Lg + Sp));
-        launch_vocoder_embed(d_units, n, T, m.voc_dict, E, m.voc_lang, Lg, d_ls, m.voc_spkr, Sp, d_ls.get() + n, in, m.stream);
+        launch_vocoder_embed(d_units, n, T, m.voc_dict, E, m.voc_lang, Lg, d_lang, m.voc_spkr, Sp, d_spkr, in, m.stream);
         x = Buf<float>(&m.pool, (size_t)n * T * ch);
         conv1d(m, in, m.voc_pre, nullptr, x, n, T, 1, 3, 1, nullptr, IN_NONE, ACT_NONE);
     }
@@ -381,6 +438,100 @@ void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h
     }
     // F.leaky_relu default slope 0.01, conv_post, tanh (hifigan.py:192-194)
     conv1d(m, x, m.voc_post, nullptr, d_wav, n, t, 1, 3, 1, nullptr, IN_LRELU_001, ACT_TANH);
+}
+
+// Unit frames of context a kept output sample can depend on, per side: conv_pre (3) + per stage the transposed
+// convolution's taps and the widest ResBlock ((k - 1) * (1 + 3 + 5 + 3) / 2 = 60 samples at k = 11) at that stage's rate:
+// 3 + 3 + 60/5 + 1 + 60/20 + 1 + 60/80 + ... < 25 for the reference configuration (vocoder/builder.py:44-63).  Computed
+// from the loaded geometry, rounded up, plus a margin.
+int vocoder_halo_units(const Model& m) {
+    const sc_config& c = m.cfg;
+    double halo = 3.0, rate = 1.0;
+    for (int i = 0; i < c.voc_num_upsamples; ++i) {
+        const ConvT& up = m.voc_ups[i];
+        halo += (double)up.taps / rate;  // input frames of the previous stage
+        rate *= up.stride;
+        int widest = 0;
+        for (int j = 0; j < c.voc_num_resblock_kernels; ++j) {
+            const ResBlock& r = m.voc_res[i * c.voc_num_resblock_kernels + j];
+            int reach = 0;
+            for (size_t d = 0; d < r.dil.size(); ++d) reach += (r.convs1[d].k - 1) * r.dil[d] / 2 + (r.convs2[d].k - 1) / 2;
+            widest = std::max(widest, reach);
+        }
+        halo += (double)widest / rate;
+    }
+    halo += 3.0 / rate;
+    return (int)halo + 8;
+}
+
+}  // namespace
+
+void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h_lang, const int32_t* h_spkr, float* d_wav,
+                const int32_t* h_unit_lens) {
+    const sc_config& c = m.cfg;
+    SC_CHECK(c.has_vocoder, "sc_vocode: the model was loaded without a vocoder");
+    prof::set_tag("voc");
+    SC_CHECK(n > 0 && T > 0, "sc_vocode: empty batch");
+    for (int i = 0; i < n; ++i) {
+        SC_CHECK(h_lang[i] >= 0 && h_lang[i] < c.voc_num_langs, "sc_vocode: lang index %d out of range", h_lang[i]);
+        SC_CHECK(h_spkr[i] >= 0 && h_spkr[i] < c.voc_num_spkrs, "sc_vocode: speaker index %d out of range", h_spkr[i]);
+        SC_CHECK(!h_unit_lens || (h_unit_lens[i] >= 0 && h_unit_lens[i] <= T), "sc_vocode: unit_lens[%d]=%d outside [0,%d]", i,
+                 h_unit_lens ? h_unit_lens[i] : 0, T);
+    }
+    for (int64_t i = 0; i < (int64_t)n * T; ++i)
+        SC_CHECK(h_units[i] >= 0 && h_units[i] < c.voc_num_embeddings, "sc_vocode: unit %d out of range [0,%d)", h_units[i],
+                 c.voc_num_embeddings);
+    int hop = 1;
+    for (const ConvT& up : m.voc_ups) hop *= up.stride;
+    static const int max_groups = getenv("SC_VOC_GROUPS") ? std::max(1, atoi(getenv("SC_VOC_GROUPS"))) : 8;
+    if (!h_unit_lens || max_groups == 1) {
+        Buf<int> d_units(&m.pool, (size_t)n * T), d_ls(&m.pool, 2 * n);
+        SC_HIP(hipMemcpyAsync(d_units.get(), h_units, (size_t)n * T * 4, hipMemcpyHostToDevice, m.stream));
+        SC_HIP(hipMemcpyAsync(d_ls.get(), h_lang, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+        SC_HIP(hipMemcpyAsync(d_ls.get() + n, h_spkr, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+        vocode_batch(m, d_units, d_ls, d_ls.get() + n, n, T, d_wav);
+        m.last_vocoder_unit_rows = (int64_t)n * T;
+        SC_HIP(hipStreamSynchronize(m.stream));
+        return;
+    }
+    // ---- ragged: one pass per length bucket --------------------------------------------------------------------
+    // The reference vocodes the padded batch (pads are unit id 1, translator.py:407) and keeps the first
+    // int(T_wav * len(speech_units) / T) samples of each row (:411-419).  A kept sample depends on a bounded window of
+    // unit frames, so row i is computed on min(T, len_i + halo) frames: either the padded row itself, or a row whose
+    // artificial end lies further from every kept sample than anything the network can see.
+    const int halo = vocoder_halo_units(m);
+    std::vector<int> need(n);
+    for (int i = 0; i < n; ++i) need[i] = std::min(T, h_unit_lens[i] + halo);
+    const std::vector<std::vector<int>> groups = plan_length_groups(need, 250, max_groups);
+    SC_HIP(hipMemsetAsync(d_wav, 0, (size_t)n * T * hop * sizeof(float), m.stream));
+    std::vector<std::vector<int32_t>> staging;
+    staging.reserve(2 * groups.size());
+    int64_t rows_done = 0;
+    for (const std::vector<int>& grp : groups) {
+        const int ng = (int)grp.size();
+        int Lg = 0;
+        for (int b : grp) Lg = std::max(Lg, need[b]);
+        rows_done += (int64_t)ng * Lg;
+        staging.emplace_back((size_t)ng * Lg);
+        std::vector<int32_t>& gu = staging.back();
+        staging.emplace_back((size_t)2 * ng);
+        std::vector<int32_t>& gls = staging.back();
+        for (int gi = 0; gi < ng; ++gi) {
+            const int b = grp[gi];
+            std::copy(h_units + (size_t)b * T, h_units + (size_t)b * T + Lg, gu.begin() + (size_t)gi * Lg);
+            gls[gi] = h_lang[b];
+            gls[ng + gi] = h_spkr[b];
+        }
+        Buf<int> d_units(&m.pool, (size_t)ng * Lg), d_ls(&m.pool, 2 * ng);
+        SC_HIP(hipMemcpyAsync(d_units.get(), gu.data(), (size_t)ng * Lg * 4, hipMemcpyHostToDevice, m.stream));
+        SC_HIP(hipMemcpyAsync(d_ls.get(), gls.data(), (size_t)2 * ng * 4, hipMemcpyHostToDevice, m.stream));
+        Buf<float> gw(&m.pool, (size_t)ng * Lg * hop);
+        vocode_batch(m, d_units, d_ls, d_ls.get() + ng, ng, Lg, gw);
+        for (int gi = 0; gi < ng; ++gi)
+            SC_HIP(hipMemcpyAsync(d_wav + (size_t)grp[gi] * T * hop, gw.get() + (size_t)gi * Lg * hop, (size_t)Lg * hop * sizeof(float),
+                                  hipMemcpyDeviceToDevice, m.stream));
+    }
+    m.last_vocoder_unit_rows = rows_done;
     SC_HIP(hipStreamSynchronize(m.stream));
 }
 

@@ -303,7 +303,10 @@ class Translator:
             # (and -1) select the language's default speaker; 0 is speaker 0
             spkr_list = [spkr if spkr is not None else -1] * n
             spkr_idx = [lang_map["multispkr"][tgt_lang][0] if s == -1 else s for s in spkr_list]
-            wav = self.model.vocode(units, lang_idx, spkr_idx)
+            # only the first len(speech_units[i]) * hop samples of a row are kept below: the unit lengths let the library
+            # vocode in length buckets instead of synthesising the padding (sc_vocode_ragged)
+            unit_lens = self.last_t2u["unit_lens"] if self.last_t2u is not None else None
+            wav = self.model.vocode(units, lang_idx, spkr_idx, unit_lens)
             self.last_stage_ms["vocoder"] = (time.perf_counter() - t4) * 1e3
             self.last_wav_full = wav
             for i in range(n):

@@ -298,10 +298,25 @@ class HipS2STModel:
         check(self.lib.sc_get_durations(self.handle, _ptr(dur), _ptr(cids), _ptr(clens)), "sc_get_durations")
         return units, ulens, dur, cids, clens
 
-    def vocode(self, units: np.ndarray, lang_idx: Sequence[int], spkr_idx: Sequence[int]) -> torch.Tensor:
+    def vocode(self, units: np.ndarray, lang_idx: Sequence[int], spkr_idx: Sequence[int],
+               unit_lens: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """units (n, S_u) padded batch -> waveform (n, 1, S_u * hop).  With ``unit_lens`` only the first
+        ``unit_lens[i] * hop`` samples of row i are guaranteed (``sc_vocode_ragged``: length buckets, the padding is not
+        synthesised); the rest of the row reads as zero."""
         u = _i32(units)
         n, s_u = u.shape
         wav = torch.empty(n, 1, s_u * self.hop, dtype=torch.float32, device=self.device)
         li, si = _i32(lang_idx), _i32(spkr_idx)
-        check(self.lib.sc_vocode(self.handle, _ptr(u), n, s_u, _ptr(li), _ptr(si), _ptr(wav)), "sc_vocode")
+        if unit_lens is None:
+            check(self.lib.sc_vocode(self.handle, _ptr(u), n, s_u, _ptr(li), _ptr(si), _ptr(wav)), "sc_vocode")
+        else:
+            ul = _i32(unit_lens)
+            assert ul.shape == (n,)
+            check(self.lib.sc_vocode_ragged(self.handle, _ptr(u), n, s_u, _ptr(ul), _ptr(li), _ptr(si), _ptr(wav)), "sc_vocode_ragged")
         return wav
+
+    def last_padding(self) -> Dict[str, int]:
+        """Unit rows computed by the last t2u_nar / vocode calls (length buckets) vs the padded batch."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self.lib.sc_last_padding(self.handle, C.byref(a), C.byref(b), C.byref(c)), "sc_last_padding")
+        return {"t2u_rows_computed": a.value, "t2u_rows_padded": b.value, "vocoder_rows_computed": c.value}

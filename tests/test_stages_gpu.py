@@ -345,3 +345,38 @@ def test_experimental_decoder_kernels_bit_identical(env):
     for a, b in zip(*results):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         assert torch.equal(a[3], b[3])
+
+
+def test_ragged_vocoder_and_bucketed_t2u_match_the_padded_batch(env, report_dir):
+    """Length buckets (sc_vocode_ragged; the bucketed NAR decoder inside sc_t2u_nar): every kept sample / unit equals the
+    padded batch's.  Items of very different lengths, so that several buckets form; the padded batch is the reference
+    semantics (translator.py:407-419: the vocoder runs on the padded unit matrix, the trim is proportional)."""
+    from oracle import vocoder as ov
+
+    cfg, tt, ct, orc, hip = env
+    rng = np.random.RandomState(5)
+    lens = [230, 40, 7, 228, 100, 1, 64, 229]
+    T = max(lens)
+    units = np.full((len(lens), T), cfg.unit_pad_idx, dtype=np.int32)
+    for i, l in enumerate(lens):
+        units[i, :l] = rng.randint(2, cfg.vocoder.num_embeddings, size=l)
+    lang_idx, spkr_idx = ov.resolve_lang_spkr(orc.lang_spkr_idx_map, ["fra"] * len(lens), [-1] * len(lens))
+    full = hip.vocode(units, lang_idx, spkr_idx)
+    rag = hip.vocode(units, lang_idx, spkr_idx, lens)
+    pad = hip.last_padding()
+    hop = full.shape[-1] // T
+    errs = [float((full[i, :, : l * hop] - rag[i, :, : l * hop]).abs().max()) for i, l in enumerate(lens)]
+    _log(report_dir, "ragged_vocoder", errs=errs, rows_computed=pad["vocoder_rows_computed"], rows_padded=len(lens) * T)
+    assert max(errs) == 0.0  # the same kernels on the same window: bit-identical where it is kept
+    assert pad["vocoder_rows_computed"] < 0.75 * len(lens) * T
+    # NAR decoder: ids of a ragged batch equal the ids of each item run alone (one bucket each)
+    ws = common.waves((2.0, 0.6, 1.3, 0.4))
+    fb, flens = orc.collate_fbank(ws)
+    seqs, enc, enc_lens, _ = orc.s2tt(fb, flens, "fra", (1, 200), 14)
+    ids, out_lens, _, hidden = hip.generate_text(enc.cuda().contiguous(), enc_lens.tolist(), tt.target_prefix("fra"), hard_max_seq_len=14)
+    u_all, ul_all, _, _, _ = hip.t2u_nar(hidden, ids[:, :-1].copy(), (out_lens - 1).tolist(), 1.0)
+    pad = hip.last_padding()
+    for b in range(len(ws)):
+        u1, ul1, _, _, _ = hip.t2u_nar(hidden[b : b + 1].contiguous(), ids[b : b + 1, :-1].copy(), [int(out_lens[b]) - 1], 1.0)
+        assert int(ul1[0]) == int(ul_all[b]) and u1[0, : ul1[0]].tolist() == u_all[b, : ul_all[b]].tolist()
+    assert pad["t2u_rows_computed"] <= pad["t2u_rows_padded"]

@@ -61,7 +61,7 @@ class OracleModel:
                                 self.orc.text_tok, self.orc.char_tok, duration_factor)
         return units.numpy().astype(np.int32), aux["unit_lens"].numpy(), aux["durations"].numpy(), None, None
 
-    def vocode(self, units, lang_idx, spkr_idx):
+    def vocode(self, units, lang_idx, spkr_idx, unit_lens=None):  # unit_lens: what the caller keeps (the padded batch is a superset)
         from oracle import vocoder as ov
 
         return ov.vocode(self.orc.vocoder_sd, self.cfg.vocoder, torch.as_tensor(units.astype(np.int64)), torch.tensor(lang_idx),
