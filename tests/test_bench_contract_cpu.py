@@ -23,12 +23,25 @@ def test_argument_contract(monkeypatch):
 
 
 def test_cpu_baseline_worker_reports_the_oracle_on_one_utterance():
+    """1 warm-up + 3 timed passes (median), per-stage split, and the ids / arg-max margins of the checked utterances."""
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-worker", "--arch", "tiny_v2", "--text-len", "10",
                         "--cpu-threads", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-500:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["kind"] == "port" and d["unit"] == "utterances/s" and d["cores"] == 2 and d["value"] > 0
-    assert len(d["text_ids"]) == 10 and d["text_ids"][0] == 3 and len(d["units"]) > 0 and "1 utterance" in d["sample"]
+    assert len(d["seconds_all"]) == 3 and sorted(d["seconds_all"])[1] == d["seconds"] and "median" in d["sample"]
+    assert set(d["stage_ms"]) == {"fbank", "encoder", "text_decoder", "t2u_and_vocoder"}
+    assert [c["index"] for c in d["checked"]] == [37, 0]
+    for c in d["checked"]:
+        assert len(c["text_ids"]) == 10 and c["text_ids"][0] == 3 and len(c["units"]) > 0
+        assert c["min_text_margin"] >= 0 and c["min_unit_margin"] >= 0
+        assert sum(c["text_margin_hist"].values()) == 8 and sum(c["unit_margin_hist"].values()) >= len(c["units"])
+
+
+def test_margin_histogram_and_parity_block_without_oracle_output():
+    assert bench._margin_hist([5e-6, 2e-4, 0.5, 3e-3, 1e-5]) == {"<1e-5": 1, "<1e-4": 1, "<1e-3": 1, "<1e-2": 1, ">=1e-2": 1}
+    p = bench.parity_block({"error": "boom"}, None, None, None, None, None, None, None)
+    assert p["n_checked"] == 0 and p["error"] == "boom"
 
 
 def test_roofline_bookkeeping_and_pmc_lookup():
@@ -38,17 +51,20 @@ def test_roofline_bookkeeping_and_pmc_lookup():
     assert roof["kernel"] == "dec:skinny_m64" and roof["bound"] == "hbm" and roof["unit"] == "GB/s"
     assert abs(roof["achieved"] - 800.0) < 1e-6 and abs(roof["frac"] - 0.1) < 1e-9 and roof["peak"] == 8000.0
     assert abs(roof["avg_launch_us"] - 20.0) < 1e-9 and roof["algorithmic_bytes_per_launch"] == 1.6e7
-    assert roof["traffic"] is None or roof["traffic"] > 0  # from the newest committed PMC summary, when there is one
+    # traffic is never measured inside bench.py: either null or the value of a committed round-2 PMC summary, named
+    assert (roof["traffic"] is None) == (roof["traffic_from"] is None)
     assert list(shares)[0] == "dec:skinny_m64" and shares["_profiled_total_ms"] == 3.0
     fams["enc:gemm_128x128_presplit"]["ms"] = 5.0
     roof, _ = bench.roofline_of(fams)
     assert roof["bound"] == "mfma" and abs(roof["achieved"] - 80.0) < 1e-9 and abs(roof["mfma_issue_tflops"] - 160.0) < 1e-9
     assert bench.roofline_of({}) == (None, {})
-    # the lookup reads the newest committed PMC summary (not the "early" ones) and matches the kernel by its template arguments
+    assert bench.pmc_traffic("enc:no_such_family") == (None, None)
     import csv
     import glob
 
-    newest = sorted(f for f in glob.glob(str(ROOT / "profiles" / "*pmc_hbm_traffic*.csv")) if "early" not in f)[-1]
-    rows = [r for r in csv.DictReader(open(newest, newline="")) if "skinny_kernel<2, 1" in r["kernel"]]
-    assert rows and bench.pmc_traffic("dec:skinny_m64") == float(rows[0]["hbm_bytes_per_launch_corrected"]) > 1e6
-    assert bench.pmc_traffic("enc:no_such_family") is None
+    files = sorted(glob.glob(str(ROOT / "profiles" / "r2*pmc_hbm_traffic*.csv")))
+    if files:  # the lookup matches the kernel by its template arguments in the newest round-2 summary
+        rows = [r for r in csv.DictReader(open(files[-1], newline="")) if "gemm_ps_kernel<128, 128>" in r["kernel"]]
+        if rows:
+            val, src = bench.pmc_traffic("enc:gemm_128x128_presplit")
+            assert val == float(rows[0]["hbm_bytes_per_launch_corrected"]) and src.startswith("profiles/r2")
