@@ -241,11 +241,6 @@ int32_t sc_ngram_blocked_tokens(const int32_t* h_seq, int32_t len, int32_t ngram
 /* 1: route every dense product to the general MFMA kernel instead of the double-buffered fast path
  * (the two produce identical bits; used by the parity tests and for A/B timing). */
 int sc_op_force_general_gemm(int on);
-/* Experimental kernel variants, a bit mask (0 = the kernels measured in round 1; also SC_KERNEL_VARIANT=<mask>|all in the
- * environment): 1 decoder-step products (skinny2_kernel), 2 reduce+residual+LayerNorm, 4 decoder-step attention,
- * 8 K/V register prefetch of the MFMA attention, 16 fused ResBlock pair loads, 32 LayerNorm loads.  Every variant is
- * meant to produce the bits of the kernel it replaces (tests/test_ops_gpu.py, SC_TEST_EXPERIMENTAL=1). */
-int sc_op_set_skinny_variant(int variant);
 int sc_op_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float* d_y, int32_t rows, int32_t C,
                     int32_t act);
 int sc_op_linear(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y,

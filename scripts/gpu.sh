@@ -5,12 +5,11 @@
 # `timeout` so that a hung kernel cannot hold the box.  Tasks:
 #   tests        the whole `-m gpu` suite                       fullsize   tests/test_fullsize_gpu.py only
 #   quick        op + stage tests (tiny model)                  smoke      __graft_entry__.smoke()
-#   exp          experimental-variant bit-identity tests (SC_TEST_EXPERIMENTAL=1) + per-shape A/B
 #   bench        python bench.py $BENCH_ARGS                    benchfast  bench without cpu baseline / latency
-#   masks        bench with SC_KERNEL_VARIANT in $MASKS (default "0 7 63"), stage times only
 #   rocprof      rocprofv3 --kernel-trace --stats of `bench.py $PROF_ARGS` (the driver's command line by default)
 #   pmc          FETCH_SIZE / WRITE_SIZE passes (separate runs) + scripts/pmc_summary.py
-#   dstep        scripts/dstep_bench.py (decoder step timing per batch size)
+#   dstep        scripts/dstep_bench.py (decoder step timing per batch size)         dtrace   kernel trace of it + gap analysis
+#   chain        scripts/chain_bench.py (each decoder-step kernel as a dependent chain in a replayed graph)
 #   micro        every scripts/micro/*.hip compiled with hipcc and run
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -19,7 +18,6 @@ TAG=$1; shift
 O=gpurun_out/$TAG
 BENCH_ARGS=${BENCH_ARGS:---steps 5 --warmup 2}
 PROF_ARGS=${PROF_ARGS:---steps 3 --warmup 1 --no-cpu-baseline --no-latency}
-MASKS=${MASKS:-0 7 63}
 
 line() { python - "$1" <<'PY'
 import json, sys
@@ -48,19 +46,10 @@ for task in "$@"; do
       grep -E "^FAILED|^ERROR|passed|failed|^E  |exit" ${O}_pytest_quick.log | head -20 ;;
     smoke)
       ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > ${O}_smoke.log 2>&1; echo "smoke exit $?" >> ${O}_smoke.log ); tail -2 ${O}_smoke.log | cut -c1-300 ;;
-    exp)
-      ( SC_TEST_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_ops_gpu.py tests/test_stages_gpu.py -k "skinny2 or experimental or register_prefetch or batched_loads or loads_up_front" -m gpu -q > ${O}_exp_tests.log 2>&1; echo "pytest exit $?" >> ${O}_exp_tests.log )
-      tail -4 ${O}_exp_tests.log
-      ( timeout 150 python scripts/skinny_bench.py --variant both > ${O}_skinny_ab.txt 2>&1 ); grep -v amdgpu ${O}_skinny_ab.txt | head -80 ;;
     bench)
       ( timeout 900 python bench.py $BENCH_ARGS > ${O}_bench.json 2> ${O}_bench.err; echo "exit $?" >> ${O}_bench.err ); tail -3 ${O}_bench.err | cut -c1-300; line ${O}_bench.json ;;
     benchfast)
       ( timeout 600 python bench.py $BENCH_ARGS --no-cpu-baseline --no-latency > ${O}_benchfast.json 2> ${O}_benchfast.err; echo "exit $?" >> ${O}_benchfast.err ); tail -2 ${O}_benchfast.err | cut -c1-300; line ${O}_benchfast.json ;;
-    masks)
-      for v in $MASKS; do
-        ( SC_KERNEL_VARIANT=$v timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline $MASK_ARGS > ${O}_bench_mask$v.json 2> ${O}_bench_mask$v.err; echo "exit $?" >> ${O}_bench_mask$v.err )
-        echo "mask $v:"; line ${O}_bench_mask$v.json
-      done ;;
     rocprof)
       rm -rf gpurun_out/${TAG}_prof
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -o bench -- python $R/bench.py $PROF_ARGS > $R/${O}_rocprof.log 2>&1; echo "exit $?" >> $R/${O}_rocprof.log )
@@ -84,6 +73,8 @@ for task in "$@"; do
       f=$(find gpurun_out/${TAG}_dtrace -name "*kernel_trace.csv" | head -1)
       [ -n "$f" ] && python scripts/trace_gaps.py $f --last ${DTRACE_LAST:-10000} > ${O}_dtrace_summary.txt 2>&1; cat ${O}_dtrace_summary.txt | cut -c1-130
       find gpurun_out/${TAG}_dtrace -name "*.csv" -size +20M -delete 2>/dev/null ;;
+    chain)
+      ( timeout 200 python scripts/chain_bench.py > ${O}_chain.txt 2>&1 ); grep -v amdgpu ${O}_chain.txt | head -40 ;;
     micro)
       for src in scripts/micro/*.hip; do
         b=/tmp/$(basename $src .hip)

@@ -314,15 +314,6 @@ int sc_op_force_general_gemm(int on) {
     return SC_OK;
 }
 
-int sc_op_set_skinny_variant(int variant) {
-    if (variant < 0 || variant > sc::KV_ALL) {
-        sc::set_error("sc_op_set_skinny_variant: mask %d outside 0..%d", variant, (int)sc::KV_ALL);
-        return SC_ERR_INVALID;
-    }
-    sc::g_skinny_variant.store(variant);
-    return SC_OK;
-}
-
 int sc_op_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float* d_y, int32_t rows, int32_t C,
                     int32_t act) {
     SC_API_BEGIN

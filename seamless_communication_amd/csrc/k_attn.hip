@@ -237,10 +237,7 @@ static constexpr int MQ = 128;   // queries per workgroup
 static constexpr int MKV = 32;   // keys per iteration
 static constexpr int KS = 68;    // padded row stride of the K tile / R staging / output tile (floats)
 
-// PF (experimental, decoder-kernel variant switch): the K/V rows of tile t+1 are requested into registers — unconditionally,
-// on row indices clamped into the valid range — before tile t is multiplied, instead of load -> LDS -> barrier -> multiply
-// in sequence for every 32 keys.  Same values reach LDS (rows beyond kv_len are still stored as zeros), same arithmetic.
-template <bool SHAW, bool PF = false>
+template <bool SHAW>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs p) {
     typedef float f16v __attribute__((ext_vector_type(16)));
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -318,46 +315,18 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs p) {
     int k_end = kv_len;
     if (p.causal) k_end = min(k_end, (int)(blockIdx.x * MQ) + MQ - 1 + shift + 1);
 
-    // PF: every thread owns items tid and tid + 256 of a 32 x 16 tile of float4s
-    static_assert(MKV * (HD / 4) == 512, "two items per thread");
-    f4v pfk[2], pfv[2];
-    const int last_row = max(kv_len - 1, 0);
-#define ATT_PREFETCH(K0)                                                                                      \
-    do {                                                                                                      \
-        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                       \
-            const int idx = tid + 256 * u;                                                                    \
-            const int64_t row = (int64_t)n * p.Skv + min((K0) + (idx >> 4), last_row);                        \
-            pfk[u] = *reinterpret_cast<const f4v*>(p.k + row * p.ldk + h * HD + (idx & 15) * 4);               \
-            pfv[u] = *reinterpret_cast<const f4v*>(p.v + row * p.ldv + h * HD + (idx & 15) * 4);               \
-        }                                                                                                     \
-    } while (0)
-    if (PF) ATT_PREFETCH(0);
-
     for (int k0 = 0; k0 < k_end; k0 += MKV) {
         __syncthreads();  // previous tile fully consumed (also orders the sQR writes before their first use)
-        if (PF) {
-            const f4v zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int idx = tid + 256 * u;
-                const int r = idx >> 4, c4 = idx & 15;
-                const bool ok = k0 + r < kv_len;
-                *reinterpret_cast<f4v*>(&sK[r * KS + c4 * 4]) = ok ? pfk[u] : zero;
-                *reinterpret_cast<f4v*>(&sV[r * HD + c4 * 4]) = ok ? pfv[u] : zero;
+        for (int idx = tid; idx < MKV * (HD / 4); idx += 256) {
+            const int r = idx >> 4, c4 = idx & 15;
+            f4v kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+            if (k0 + r < kv_len) {
+                const int64_t row = (int64_t)n * p.Skv + k0 + r;
+                kv = *reinterpret_cast<const f4v*>(p.k + row * p.ldk + h * HD + c4 * 4);
+                vv = *reinterpret_cast<const f4v*>(p.v + row * p.ldv + h * HD + c4 * 4);
             }
-            ATT_PREFETCH(k0 + MKV);  // lands while this tile is multiplied (clamped rows past the end are never stored)
-        } else {
-            for (int idx = tid; idx < MKV * (HD / 4); idx += 256) {
-                const int r = idx >> 4, c4 = idx & 15;
-                f4v kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
-                if (k0 + r < kv_len) {
-                    const int64_t row = (int64_t)n * p.Skv + k0 + r;
-                    kv = *reinterpret_cast<const f4v*>(p.k + row * p.ldk + h * HD + c4 * 4);
-                    vv = *reinterpret_cast<const f4v*>(p.v + row * p.ldv + h * HD + c4 * 4);
-                }
-                *reinterpret_cast<f4v*>(&sK[r * KS + c4 * 4]) = kv;
-                *reinterpret_cast<f4v*>(&sV[r * HD + c4 * 4]) = vv;
-            }
+            *reinterpret_cast<f4v*>(&sK[r * KS + c4 * 4]) = kv;
+            *reinterpret_cast<f4v*>(&sV[r * HD + c4 * 4]) = vv;
         }
         __syncthreads();
 
@@ -403,14 +372,10 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs p) {
         rs += __shfl_xor(rs, 32);
         l_i = l_i * alpha + rs;
         m_i = m_new;
-        // PF variant: once the running maxima of all 64 lanes have settled alpha is exactly 1 and the rescale of the 32
-        // accumulator registers (which live in AGPRs: a read, a multiply and a write each) is skipped — same bits
-        if (!PF || __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o0[r] *= alpha;
-                o1[r] *= alpha;
-            }
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= alpha;
+            o1[r] *= alpha;
         }
         // ---- O^T += V^T . P^T: step s of half hh contracts key (s&3) + 8*(s>>2) + 4*hh = register s ----
 #pragma unroll
@@ -422,8 +387,6 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs p) {
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, st[sidx], o1, 0, 0, 0);
         }
     }
-
-#undef ATT_PREFETCH
 
     // ---- O^T (dims x queries) -> this wave's [32 queries][64 dims] tile in LDS -> 16-byte row stores ----
     __syncthreads();  // every wave is done with the K/V tiles
@@ -480,10 +443,6 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
             SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<true, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
             mfma_attr = true;
         }
         prof::Scope scope(a.rel_k ? "attention_shaw" : "attention", 4.0 * a.nb * a.heads * (double)a.Sq * a.Skv * HD,
@@ -492,14 +451,8 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         SC_CHECK(npos <= 96, "attention: relative table too large");
         if (a.rel_k) lds += (size_t)(MQ * npos) * sizeof(float);
         dim3 grid(cdiv(a.Sq, MQ), a.heads, a.nb);
-        if (skinny_variant() & KV_ATTN_PREFETCH) {  // experimental: K/V tiles prefetched into registers (same bits)
-            if (a.rel_k) hipLaunchKernelGGL((attn_mfma_kernel<true, true>), grid, dim3(256), lds, s, a);
-            else hipLaunchKernelGGL((attn_mfma_kernel<false, true>), grid, dim3(256), lds, s, a);
-        } else if (a.rel_k) {
-            hipLaunchKernelGGL((attn_mfma_kernel<true>), grid, dim3(256), lds, s, a);
-        } else {
-            hipLaunchKernelGGL((attn_mfma_kernel<false>), grid, dim3(256), lds, s, a);
-        }
+        if (a.rel_k) hipLaunchKernelGGL((attn_mfma_kernel<true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((attn_mfma_kernel<false>), grid, dim3(256), lds, s, a);
         SC_LAUNCH_CHECK();
         return;
     }
@@ -608,117 +561,6 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
     }
 }
 
-// EXPERIMENTAL (SC_KERNEL_VARIANT / sc_op_set_skinny_variant, see k_skinny2.hip): decode_attn_kernel with its global loads
-// hoisted.  Same lanes handle the same keys and every sum runs in the same order, so the bits are the same; what changes
-// is that the loads of a phase are issued together and unconditionally (row index clamped into the valid range, the
-// value discarded by a select) instead of one predicated load per dependent step: the shipped kernel exposes one
-// L2 / HBM round trip per 16 keys, per value row and per input partial (~15 us per launch in profiles/r1_bench_b64_kernel_stats.csv
-// for a few KB of traffic).  Not yet run on hardware.
-__global__ __launch_bounds__(256) void decode_attn2_kernel(
-    const float* __restrict__ q, int64_t ldq, const float* __restrict__ k_new,
-    const float* __restrict__ v_new, int64_t ldkv, float* __restrict__ kcache,
-    float* __restrict__ vcache, int64_t cache_ld, int64_t cache_bs, int cap, float* __restrict__ out,
-    int64_t ldo, int heads, const int* __restrict__ d_pos, const int* __restrict__ kv_lens, int use_lens,
-    int in_splits, int64_t in_split_stride, const float* __restrict__ bias_q,
-    const float* __restrict__ bias_k, const float* __restrict__ bias_v) {
-    __shared__ float s_q[HD];
-    __shared__ float s_sc[MAX_CACHE];
-    __shared__ float s_red[8];
-    __shared__ float s_part[4][HD];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int pos = d_pos ? *d_pos : 0;
-    const int kv_len = use_lens ? min(kv_lens[b], cap) : pos + 1;
-    float* kc = kcache + (int64_t)b * cache_bs + h * HD;
-    float* vc = vcache + (int64_t)b * cache_bs + h * HD;
-    if (tid < 3 * HD) {
-        const int which = tid >> 6, d = tid & 63;  // 0: q, 1: k_new, 2: v_new (wave-uniform)
-        if (which == 0 || k_new) {
-            const float* src = which == 0 ? q : (which == 1 ? k_new : v_new);
-            const int64_t ld = which == 0 ? ldq : ldkv;
-            const float* bias = which == 0 ? bias_q : (which == 1 ? bias_k : bias_v);
-            const float* base = src + (int64_t)b * ld + h * HD + d;
-            float v = 0.f;
-            for (int sp0 = 0; sp0 < in_splits; sp0 += 8) {
-                float pv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) pv[u] = base[(int64_t)min(sp0 + u, in_splits - 1) * in_split_stride];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v += (sp0 + u < in_splits) ? pv[u] : 0.f;
-            }
-            if (bias) v += bias[h * HD + d];
-            if (which == 0) s_q[d] = v;
-            else if (which == 1) kc[(int64_t)pos * cache_ld + d] = v;
-            else vc[(int64_t)pos * cache_ld + d] = v;
-        }
-    }
-    __syncthreads();
-    // scores: 16 lanes per key row, key j on (wave, grp) = ((j % 16) / 4, j % 4) as in decode_attn_kernel; 64 keys per trip
-    const int sub = lane & 15, grp = lane >> 4;
-    const float4 q4 = *reinterpret_cast<const float4*>(&s_q[sub * 4]);
-    const int last = kv_len - 1;
-    float lmax = -INFINITY;
-    for (int j0 = 0; j0 < kv_len; j0 += 64) {
-        float4 kv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + 16 * u + wave * 4 + grp;
-            kv[u] = *reinterpret_cast<const float4*>(kc + (int64_t)min(j, last) * cache_ld + sub * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + 16 * u + wave * 4 + grp;
-            float d = 0.f;
-            d = fmaf(q4.x, kv[u].x, d);
-            d = fmaf(q4.y, kv[u].y, d);
-            d = fmaf(q4.z, kv[u].z, d);
-            d = fmaf(q4.w, kv[u].w, d);
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) d += __shfl_xor(d, off);
-            if (j < kv_len) {
-                d *= 0.125f;
-                if (sub == 0) s_sc[j] = d;
-                lmax = fmaxf(lmax, d);
-            }
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-    if (lane == 0) s_red[wave] = lmax;
-    __syncthreads();
-    const float mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    float lsum = 0.f;
-    for (int j = tid; j < kv_len; j += 256) {
-        const float e = expf(s_sc[j] - mx);
-        s_sc[j] = e;
-        lsum += e;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off);
-    if (lane == 0) s_red[4 + wave] = lsum;
-    __syncthreads();
-    const float denom = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-    // PV: lane = dim, wave = key partition (keys wave, wave+4, ...), 8 value rows per trip
-    float acc = 0.f;
-    for (int j = wave; j < kv_len; j += 32) {
-        float vv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) vv[u] = vc[(int64_t)min(j + 4 * u, last) * cache_ld + lane];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int jj = j + 4 * u;
-            if (jj < kv_len) acc = fmaf(s_sc[jj], vv[u], acc);
-        }
-    }
-    s_part[wave][lane] = acc;
-    __syncthreads();
-    if (tid < HD) {
-        const float v = (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
-        out[(int64_t)b * ldo + h * HD + tid] = v / denom;
-    }
-}
-
 void launch_decode_attention(const float* q, int64_t ldq, const float* k_new, const float* v_new,
                              int64_t ldkv, float* kcache, float* vcache, int64_t cache_ld, int64_t cache_bs,
                              int cap, float* out, int64_t ldo, int nb, int heads, const int* d_pos,
@@ -727,13 +569,6 @@ void launch_decode_attention(const float* q, int64_t ldq, const float* k_new, co
                              const float* bias_v) {
     SC_CHECK(cap <= MAX_CACHE, "decode attention: cache capacity %d > %d", cap, MAX_CACHE);
     SC_CHECK(nb > 0 && heads > 0, "decode attention: empty problem");
-    if (skinny_variant() & KV_DECODE_ATTN) {  // experimental: hoisted loads (same bits)
-        hipLaunchKernelGGL(decode_attn2_kernel, dim3(heads, nb), dim3(256), 0, s, q, ldq, k_new, v_new, ldkv,
-                           kcache, vcache, cache_ld, cache_bs, cap, out, ldo, heads, d_pos, kv_lens, use_lens,
-                           in_splits < 1 ? 1 : in_splits, in_split_stride, bias_q, bias_k, bias_v);
-        SC_LAUNCH_CHECK();
-        return;
-    }
     hipLaunchKernelGGL(decode_attn_kernel, dim3(heads, nb), dim3(256), 0, s, q, ldq, k_new, v_new, ldkv,
                        kcache, vcache, cache_ld, cache_bs, cap, out, ldo, heads, d_pos, kv_lens, use_lens,
                        in_splits < 1 ? 1 : in_splits, in_split_stride, bias_q, bias_k, bias_v);

@@ -412,7 +412,10 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     const int c = lane & 15, g = lane >> 4;
     const int pos = CROSS ? 0 : *p.d_pos;
     const int kv_len = CROSS ? min(p.kv_lens[b], p.cap) : pos + 1;
-    const int last = kv_len - 1;
+    // row index clamp of the loads.  Cross-attention clamps to the capacity, not to the row's own length: every row of
+    // the projected encoder K/V is initialised (finite), so the addresses do not have to wait for kv_lens[b]; keys behind
+    // the length are masked below.  Self-attention rows behind `pos` are uninitialised memory and are never touched.
+    const int last = CROSS ? p.cap - 1 : kv_len - 1;
     const float* kc = p.kcache + (int64_t)b * p.cache_bs + hd * 64 + 4 * c;
     const float* vc = p.vcache + (int64_t)b * p.cache_bs + hd * 64 + 4 * c;
 
@@ -443,6 +446,7 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const float4*>(kc + (int64_t)min(4 * i + g, last) * p.cache_ld);
 #pragma unroll
     for (int i = 0; i < 16; ++i) vreg[i] = *reinterpret_cast<const float4*>(vc + (int64_t)min(4 * i + g, last) * p.cache_ld);
+    __builtin_amdgcn_sched_barrier(0);  // every load above is issued before the first of them is waited for
 
     float4 q4 = zero, kn = zero, vn = zero;
 #pragma unroll
@@ -467,7 +471,8 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
 
     float m_run = -INFINITY, l_run = 0.f;
     float4 acc = zero;
-    for (int j0 = 0; j0 < kv_len; j0 += 64) {
+    int j0 = 0;
+    do {  // at least one key: the first trip's loads above are unconditional
         if (j0 > 0) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const float4*>(kc + (int64_t)min(j0 + 4 * i + g, last) * p.cache_ld);
@@ -503,6 +508,7 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
             const int j = j0 + 4 * i + g;
             float4 vv = vreg[i];
             if (!CROSS && j == pos) vv = vn;
+            if (CROSS && j >= kv_len) vv = zero;  // a masked row may hold anything finite or not: keep it out of the sum
             const float e = expf(sc[i] - m_new);  // exp(-inf) = 0 for masked keys
             ls += e;
             a4.x = fmaf(e, vv.x, a4.x);
@@ -516,7 +522,8 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
         acc.z = acc.z * alpha + a4.z;
         acc.w = acc.w * alpha + a4.w;
         m_run = m_new;
-    }
+        j0 += 64;
+    } while (j0 < kv_len);
     // the four key groups: sum their partial soft-max sums and value sums
 #pragma unroll
     for (int off = 16; off <= 32; off <<= 1) {

@@ -18,10 +18,7 @@ __device__ __forceinline__ float act_f(float v, int act) {
 }
 
 // One wave per row, row cached in registers (C <= 64*4*MAXV).
-// FL (experimental kernel variant switch, profiles/r1_skinny_isa_notes.txt): the row, gamma and beta are requested up
-// front on clamped, unconditional addresses (the shipped code emits one predicated load + vmcnt(0) per register and
-// fetches gamma / beta only after both reductions).  Same values, same arithmetic.
-template <int MAXV, bool FL = false>
+template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
@@ -56,24 +53,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
     }
     float4 v[MAXV];
-    float4 gpre[FL ? (MAXV <= 4 ? MAXV : 1) : 1], bpre[FL ? (MAXV <= 4 ? MAXV : 1) : 1];  // gamma / beta up front (C <= 1024)
     float s = 0.f;
-    if (FL) {
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) v[i] = xr[min(lane + 64 * i, nv - 1)];
-        if (MAXV <= 4) {
-#pragma unroll
-            for (int i = 0; i < MAXV; ++i) {
-                gpre[i] = reinterpret_cast<const float4*>(gamma)[min(lane + 64 * i, nv - 1)];
-                bpre[i] = reinterpret_cast<const float4*>(beta)[min(lane + 64 * i, nv - 1)];
-            }
-        }
-    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + 64 * i;
-        if (FL) v[i] = idx < nv ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        else v[i] = idx < nv ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = idx < nv ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) / (float)C;
@@ -94,14 +78,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + 64 * i;
         if (idx < nv) {
-            float4 g, b;
-            if (FL && MAXV <= 4) {
-                g = gpre[MAXV <= 4 ? i : 0];
-                b = bpre[MAXV <= 4 ? i : 0];
-            } else {
-                g = g4[idx];
-                b = b4[idx];
-            }
+            const float4 g = g4[idx], b = b4[idx];
             float4 o;
             o.x = act_f((v[i].x - mean) * rstd * g.x + b.x, act);
             o.y = act_f((v[i].y - mean) * rstd * g.y + b.y, act);
@@ -127,10 +104,7 @@ void launch_layernorm_split(const float* x, int64_t ldx, const float* gamma, con
     if (rows <= 0) return;
     dim3 grid(cdiv(rows, 4));
     float* none = nullptr;
-    const bool fl = (skinny_variant() & KV_LAYERNORM) != 0;  // experimental: loads up front (same bits)
-    if (C <= 256 && fl) hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
-    else if (C <= 1024 && fl) hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
-    else if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
+    if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
     else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
     else hipLaunchKernelGGL((layernorm_kernel<16>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
     SC_LAUNCH_CHECK();
@@ -144,12 +118,7 @@ void launch_layernorm(const float* x, int64_t ldx, const float* gamma, const flo
     SC_CHECK(C <= 4096, "layernorm: C=%d > 4096 unsupported", C);
     if (rows <= 0) return;
     dim3 grid(cdiv(rows, 4));
-    const bool fl = (skinny_variant() & KV_LAYERNORM) != 0;  // experimental: loads up front (same bits)
-    if (C <= 256 && fl) {
-        hipLaunchKernelGGL((layernorm_kernel<1, true>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch, (__half*)nullptr, (__half*)nullptr, (int64_t)0);
-    } else if (C <= 1024 && fl) {
-        hipLaunchKernelGGL((layernorm_kernel<4, true>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch, (__half*)nullptr, (__half*)nullptr, (int64_t)0);
-    } else if (C <= 256) {
+    if (C <= 256) {
         hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch, (__half*)nullptr, (__half*)nullptr, (int64_t)0);
     } else if (C <= 1024) {
         hipLaunchKernelGGL((layernorm_kernel<4>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch, (__half*)nullptr, (__half*)nullptr, (int64_t)0);

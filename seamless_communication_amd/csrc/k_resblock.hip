@@ -131,36 +131,7 @@ __device__ __forceinline__ void stage_weights(const __half* __restrict__ W, int6
     }
 }
 
-// Same staging with four loads in flight per thread (FL variant below).
 template <int C>
-__device__ __forceinline__ void stage_weights_fl(const __half* __restrict__ W, int64_t ldw, int k0, int width, _Float16* sW, int ldb,
-                                                 int tid) {
-    const int vpr = width >> 3;
-    const int items = C * vpr;
-    for (int i0 = tid; i0 < items; i0 += 1024) {
-        half8_t w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = min(i0 + 256 * u, items - 1);
-            const int col = i / vpr, v = i - col * vpr;
-            w[u] = *reinterpret_cast<const half8_t*>(W + (int64_t)col * ldw + k0 + v * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + 256 * u;
-            if (i >= items) continue;
-            const int col = i / vpr, v = i - col * vpr;
-            *reinterpret_cast<half8_t*>(sW + col * ldb + v * 8) = w[u];
-        }
-    }
-}
-
-// FL (experimental, decoder-kernel variant switch): the x tile and the residual / average operands of the epilogue are
-// loaded four at a time on clamped, unconditional addresses instead of one predicated load per loop trip (the shipped
-// loops pay one memory round trip per trip: ~12 for the C = 64 tile with its halo); weight rows are staged four loads at a
-// time, and with per-tap staging (C = 64) the next tap's weights are requested into registers BEFORE the current tap is
-// multiplied and written to LDS after it, so that their latency hides behind the MFMAs.  Same values, same arithmetic.
-template <int C, bool FL = false>
 __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int tiles) {
     constexpr int CS = C + 8;          // halfs per LDS row: 16-byte fragment reads of consecutive rows hit distinct banks
     constexpr int NF = (C + 31) / 32;  // 32-wide output column fragments (C = 16 uses half of one)
@@ -190,75 +161,22 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
     const float slope = p.slope;
 
     // ---- 1. x tile (+ halo) -> LeakyReLU -> hi/lo planes --------------------------------------
-    if (FL) {
-        const int items = R0 * VPR;
-        for (int i0 = tid; i0 < items; i0 += 1024) {
-            f32x4_t xv[4];
+    for (int i = tid; i < R0 * VPR; i += 256) {
+        const int r = i / VPR, c4 = i - r * VPR;
+        const int t = t0 - H2 - H1 + r;
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < T) v = *reinterpret_cast<const f32x4_t*>(xn + (int64_t)t * C + c4 * 4);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = min(i0 + 256 * u, items - 1);
-                const int r = i / VPR, c4 = i - r * VPR;
-                const int t = min(max(t0 - H2 - H1 + r, 0), T - 1);
-                xv[u] = *reinterpret_cast<const f32x4_t*>(xn + (int64_t)t * C + c4 * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + 256 * u;
-                if (i >= items) continue;
-                const int r = i / VPR, c4 = i - r * VPR;
-                const int t = t0 - H2 - H1 + r;
-                f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-                if (t >= 0 && t < T) v = xv[u];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = lrelu(v[j], slope);
-                const half4_t hi = __builtin_convertvector(v, half4_t);
-                const f32x4_t back = __builtin_convertvector(hi, f32x4_t);
-                const half4_t lo = __builtin_convertvector(v - back, half4_t);
-                *reinterpret_cast<half4_t*>(xh + r * CS + c4 * 4) = hi;
-                *reinterpret_cast<half4_t*>(xl + r * CS + c4 * 4) = lo;
-            }
-        }
-    } else {
-        for (int i = tid; i < R0 * VPR; i += 256) {
-            const int r = i / VPR, c4 = i - r * VPR;
-            const int t = t0 - H2 - H1 + r;
-            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t < T) v = *reinterpret_cast<const f32x4_t*>(xn + (int64_t)t * C + c4 * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = lrelu(v[j], slope);
-            const half4_t hi = __builtin_convertvector(v, half4_t);
-            const f32x4_t back = __builtin_convertvector(hi, f32x4_t);
-            const half4_t lo = __builtin_convertvector(v - back, half4_t);
-            *reinterpret_cast<half4_t*>(xh + r * CS + c4 * 4) = hi;
-            *reinterpret_cast<half4_t*>(xl + r * CS + c4 * 4) = lo;
-        }
+        for (int j = 0; j < 4; ++j) v[j] = lrelu(v[j], slope);
+        const half4_t hi = __builtin_convertvector(v, half4_t);
+        const f32x4_t back = __builtin_convertvector(hi, f32x4_t);
+        const half4_t lo = __builtin_convertvector(v - back, half4_t);
+        *reinterpret_cast<half4_t*>(xh + r * CS + c4 * 4) = hi;
+        *reinterpret_cast<half4_t*>(xl + r * CS + c4 * 4) = lo;
     }
-    if (FL) {
-        if (PER_TAP) stage_weights_fl<C>(p.w1, p.ldw1, 0, C, sW, ldb, tid);
-        else stage_weights_fl<C>(p.w1, p.ldw1, 0, k * C, sW, ldb, tid);
-    } else {
-        if (PER_TAP) stage_weights<C>(p.w1, p.ldw1, 0, C, sW, ldb, tid);
-        else stage_weights<C>(p.w1, p.ldw1, 0, k * C, sW, ldb, tid);
-    }
+    if (PER_TAP) stage_weights<C>(p.w1, p.ldw1, 0, C, sW, ldb, tid);
+    else stage_weights<C>(p.w1, p.ldw1, 0, k * C, sW, ldb, tid);
     __syncthreads();
-
-    // FL + per-tap staging: one tap = C rows x C halfs = C * C / 8 vectors = exactly two per thread at C = 64
-    half8_t tapw[2];
-#define RB_TAP_LOAD(WP, LDW, K0)                                                                                   \
-    do {                                                                                                            \
-        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                             \
-            const int i = tid + 256 * u;                                                                            \
-            tapw[u] = *reinterpret_cast<const half8_t*>((WP) + (int64_t)(i / (C / 8)) * (LDW) + (K0) + (i % (C / 8)) * 8); \
-        }                                                                                                           \
-    } while (0)
-#define RB_TAP_STORE(DST)                                                                                          \
-    do {                                                                                                            \
-        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                             \
-            const int i = tid + 256 * u;                                                                            \
-            *reinterpret_cast<half8_t*>((DST) + (i / (C / 8)) * ldb + (i % (C / 8)) * 8) = tapw[u];                 \
-        }                                                                                                           \
-    } while (0)
-    static_assert(!FL || C != 64 || C * (C / 8) == 512, "two vectors per thread");
 
     // ---- 2. conv1 (k taps, dilation d) for tmp rows [32*wave, 32*wave + 32) ---------------------
     {
@@ -267,14 +185,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
         for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
-        if (PER_TAP && FL) {
-            for (int t = 0; t < k; ++t) {  // tap t+1 travels global -> registers while tap t is multiplied, then -> LDS
-                if (t + 1 < k) RB_TAP_LOAD(p.w1, p.ldw1, (t + 1) * C);
-                conv_from_lds_w<C, NF>(xh, xl, 32 * wave, dil, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc);
-                if (t + 1 < k) RB_TAP_STORE(sW + ((t + 1) & 1) * C * ldb);
-                __syncthreads();
-            }
-        } else if (PER_TAP) {
+        if (PER_TAP) {
             for (int t = 0; t < k; ++t) {  // tap t from buffer t&1 while tap t+1 is staged into the other one
                 if (t + 1 < k) stage_weights<C>(p.w1, p.ldw1, (t + 1) * C, C, sW + ((t + 1) & 1) * C * ldb, ldb, tid);
                 conv_from_lds_w<C, NF>(xh, xl, 32 * wave, dil, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc);
@@ -284,13 +195,8 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
             conv_from_lds_w<C, NF>(xh, xl, 32 * wave, dil, 0, k, sW, ldb, lane, acc);
             __syncthreads();  // every wave is done reading x (and W1) before the tmp tile / W2 overwrite them
         }
-        if (FL) {
-            if (PER_TAP) stage_weights_fl<C>(p.w2, p.ldw2, 0, C, sW, ldb, tid);
-            else stage_weights_fl<C>(p.w2, p.ldw2, 0, k * C, sW, ldb, tid);
-        } else {
-            if (PER_TAP) stage_weights<C>(p.w2, p.ldw2, 0, C, sW, ldb, tid);
-            else stage_weights<C>(p.w2, p.ldw2, 0, k * C, sW, ldb, tid);
-        }
+        if (PER_TAP) stage_weights<C>(p.w2, p.ldw2, 0, C, sW, ldb, tid);
+        else stage_weights<C>(p.w2, p.ldw2, 0, k * C, sW, ldb, tid);
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
             const int col = nf * 32 + (lane & 31);
@@ -317,16 +223,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
         for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
-        if (PER_TAP && FL) {
-            for (int t = 0; t < k; ++t) {
-                if (t + 1 < k) RB_TAP_LOAD(p.w2, p.ldw2, (t + 1) * C);
-                conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc);
-                if (t + 1 < k) {
-                    RB_TAP_STORE(sW + ((t + 1) & 1) * C * ldb);
-                    __syncthreads();
-                }
-            }
-        } else if (PER_TAP) {
+        if (PER_TAP) {
             for (int t = 0; t < k; ++t) {
                 if (t + 1 < k) stage_weights<C>(p.w2, p.ldw2, (t + 1) * C, C, sW + ((t + 1) & 1) * C * ldb, ldb, tid);
                 conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc);
@@ -335,8 +232,6 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
         } else {
             conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, 0, k, sW, ldb, lane, acc);
         }
-#undef RB_TAP_LOAD
-#undef RB_TAP_STORE
         // epilogue through LDS: (acc + bias) as a row-major fp32 tile over the (now dead) tmp planes, then 16 bytes per
         // lane: residual read, optional 3-way average and store are 4x fewer (and fully coalesced) memory instructions
         // than the column-per-lane accumulator layout allows
@@ -356,49 +251,17 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
         }
         __syncthreads();
         float* __restrict__ outn = p.out + (int64_t)n * T * C;
-        if (FL) {
-            const int items = TT * VPR;
-            const bool avg = p.avg_a != nullptr;
-            for (int idx0 = tid; idx0 < items; idx0 += 1024) {
-                f32x4_t xr[4], aa[4], ab[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = min(idx0 + 256 * u, items - 1);
-                    const int i = idx / VPR, c4 = idx - i * VPR;
-                    const int64_t off = (int64_t)min(t0 + i, T - 1) * C + c4 * 4;
-                    xr[u] = *reinterpret_cast<const f32x4_t*>(xn + off);
-                    if (avg) {
-                        const int64_t g = (int64_t)n * T * C + off;
-                        aa[u] = *reinterpret_cast<const f32x4_t*>(p.avg_a + g);
-                        ab[u] = *reinterpret_cast<const f32x4_t*>(p.avg_b + g);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = idx0 + 256 * u;
-                    if (idx >= items) continue;
-                    const int i = idx / VPR, c4 = idx - i * VPR;
-                    const int t = t0 + i;
-                    if (t >= T) continue;
-                    const int64_t off = (int64_t)t * C + c4 * 4;
-                    f32x4_t v = *reinterpret_cast<const f32x4_t*>(ep + i * EPS + c4 * 4) + xr[u];
-                    if (avg) v = ((aa[u] + ab[u]) + v) / 3.0f;
-                    *reinterpret_cast<f32x4_t*>(outn + off) = v;
-                }
+        for (int idx = tid; idx < TT * VPR; idx += 256) {
+            const int i = idx / VPR, c4 = idx - i * VPR;
+            const int t = t0 + i;
+            if (t >= T) continue;
+            const int64_t off = (int64_t)t * C + c4 * 4;
+            f32x4_t v = *reinterpret_cast<const f32x4_t*>(ep + i * EPS + c4 * 4) + *reinterpret_cast<const f32x4_t*>(xn + off);
+            if (p.avg_a) {
+                const int64_t g = (int64_t)n * T * C + off;
+                v = ((*reinterpret_cast<const f32x4_t*>(p.avg_a + g) + *reinterpret_cast<const f32x4_t*>(p.avg_b + g)) + v) / 3.0f;
             }
-        } else {
-            for (int idx = tid; idx < TT * VPR; idx += 256) {
-                const int i = idx / VPR, c4 = idx - i * VPR;
-                const int t = t0 + i;
-                if (t >= T) continue;
-                const int64_t off = (int64_t)t * C + c4 * 4;
-                f32x4_t v = *reinterpret_cast<const f32x4_t*>(ep + i * EPS + c4 * 4) + *reinterpret_cast<const f32x4_t*>(xn + off);
-                if (p.avg_a) {
-                    const int64_t g = (int64_t)n * T * C + off;
-                    v = ((*reinterpret_cast<const f32x4_t*>(p.avg_a + g) + *reinterpret_cast<const f32x4_t*>(p.avg_b + g)) + v) / 3.0f;
-                }
-                *reinterpret_cast<f32x4_t*>(outn + off) = v;
-            }
+            *reinterpret_cast<f32x4_t*>(outn + off) = v;
         }
     }
 }
@@ -415,8 +278,6 @@ void launch_cfg(const ResPairArgs& a, hipStream_t s) {
     if (!attr_set) {
         SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<C>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<C, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
         attr_set = true;
     }
     const int H2 = (a.k - 1) / 2, H1 = a.dil * (a.k - 1) / 2;
@@ -429,10 +290,7 @@ void launch_cfg(const ResPairArgs& a, hipStream_t s) {
     const double rows = (double)a.nb * a.T;
     prof::Scope scope(name, 2.0 * 2.0 * rows * C * (double)C * a.k,
                       4.0 * rows * C * (a.avg_a ? 4.0 : 2.0) + 2.0 * 2.0 * C * (double)C * a.k, s);
-    if (skinny_variant() & KV_RESBLOCK)  // experimental: batched unconditional loads (same bits)
-        hipLaunchKernelGGL((resblock_pair_kernel<C, true>), dim3((unsigned)(a.nb * tiles)), dim3(256), lds, s, a, tiles);
-    else
-        hipLaunchKernelGGL((resblock_pair_kernel<C>), dim3((unsigned)(a.nb * tiles)), dim3(256), lds, s, a, tiles);
+    hipLaunchKernelGGL((resblock_pair_kernel<C>), dim3((unsigned)(a.nb * tiles)), dim3(256), lds, s, a, tiles);
 }
 
 }  // namespace

@@ -276,7 +276,6 @@ void launch_skinny(const SkinnyArgs& a0, hipStream_t s) {
                       2.0 * a.N * (double)a.K + 4.0 * a.M * ((double)a.K + (double)a.N * a.splits), s);
     SC_CHECK(!a.am_part || a.splits == 1, "skinny gemm: arg-max epilogue cannot be combined with split-K");
     if (a.am_part) a.am_tiles = (int)grid.x;
-    if ((skinny_variant() & KV_SKINNY) && launch_skinny2(a, grid, nt, s)) return;  // experimental pipelined variant (k_skinny2.hip)
     if (a.M <= 32) {
         if (nt == 4) hipLaunchKernelGGL((skinny_kernel<1, 4, 2>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((skinny_kernel<1, 1, 4>), grid, dim3(256), 0, s, a);
@@ -450,100 +449,13 @@ __global__ __launch_bounds__(256) void reduce_res_ln_row_kernel(const float* __r
     }
 }
 
-// EXPERIMENTAL (decoder-kernel variant 1, see k_skinny2.hip): reduce_res_ln_row_kernel with every global load of the
-// kernel — partials (split index clamped, surplus discarded by a select), bias, residual, gamma, beta — issued up front,
-// so that the row pays one memory round trip instead of one per phase.  Same addition order, same bits.
-__global__ __launch_bounds__(256) void reduce_res_ln_row2_kernel(const float* __restrict__ partial, int splits,
-                                                                 const float* __restrict__ bias, float* __restrict__ x,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 float* __restrict__ h, int rows, int C) {
-    __shared__ float red[8];
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const int nv = C >> 2;
-    const bool on = tid < nv;
-    const int t = on ? tid : 0;  // idle lanes read element 0 and discard it
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4* xr = reinterpret_cast<float4*>(x + (int64_t)row * C);
-    float4 pv[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-        pv[u] = reinterpret_cast<const float4*>(partial + ((int64_t)min(u, splits - 1) * rows + row) * C)[t];
-    const float4 bb = bias ? reinterpret_cast<const float4*>(bias)[t] : zero;
-    const float4 r = xr[t];
-    const float4 g = h ? reinterpret_cast<const float4*>(gamma)[t] : zero;
-    const float4 be = h ? reinterpret_cast<const float4*>(beta)[t] : zero;
-    float4 a = zero;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        if (u < splits) {
-            a.x += pv[u].x;
-            a.y += pv[u].y;
-            a.z += pv[u].z;
-            a.w += pv[u].w;
-        }
-    }
-    for (int sp0 = 8; sp0 < splits; sp0 += 8) {  // more than 8 K ranges: further batches of 8
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            pv[u] = reinterpret_cast<const float4*>(partial + ((int64_t)min(sp0 + u, splits - 1) * rows + row) * C)[t];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (sp0 + u < splits) {
-                a.x += pv[u].x;
-                a.y += pv[u].y;
-                a.z += pv[u].z;
-                a.w += pv[u].w;
-            }
-        }
-    }
-    if (bias) {
-        a.x += bb.x;
-        a.y += bb.y;
-        a.z += bb.z;
-        a.w += bb.w;
-    }
-    a.x += r.x;
-    a.y += r.y;
-    a.z += r.z;
-    a.w += r.w;
-    if (on) xr[tid] = a;
-    if (!h) return;
-    float s = on ? (a.x + a.y) + (a.z + a.w) : 0.f;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((tid & 63) == 0) red[tid >> 6] = s;
-    __syncthreads();
-    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)C;
-    float q = 0.f;
-    if (on) {
-        const float d0 = a.x - mean, d1 = a.y - mean, d2 = a.z - mean, d3 = a.w - mean;
-        q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
-    __syncthreads();
-    const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)C + 1e-5f);
-    if (on) {
-        float4 o;
-        o.x = (a.x - mean) * rstd * g.x + be.x;
-        o.y = (a.y - mean) * rstd * g.y + be.y;
-        o.z = (a.z - mean) * rstd * g.z + be.z;
-        o.w = (a.w - mean) * rstd * g.w + be.w;
-        reinterpret_cast<float4*>(h + (int64_t)row * C)[tid] = o;
-    }
-}
-
 void launch_reduce_res_ln(const float* partial, int splits, const float* bias, float* x, const float* gamma,
                           const float* beta, float* h, int rows, int C, hipStream_t s) {
     SC_CHECK(C % 4 == 0 && C <= 4096, "reduce_res_ln: C=%d unsupported", C);
     SC_CHECK(splits >= 1 && partial, "reduce_res_ln: need at least one partial");
     if (rows <= 0) return;
     if (C <= 1024) {
-        if (skinny_variant() & KV_REDUCE)
-            hipLaunchKernelGGL(reduce_res_ln_row2_kernel, dim3(rows), dim3(256), 0, s, partial, splits, bias, x, gamma, beta, h, rows, C);
-        else
-            hipLaunchKernelGGL(reduce_res_ln_row_kernel, dim3(rows), dim3(256), 0, s, partial, splits, bias, x, gamma, beta, h, rows, C);
+        hipLaunchKernelGGL(reduce_res_ln_row_kernel, dim3(rows), dim3(256), 0, s, partial, splits, bias, x, gamma, beta, h, rows, C);
         SC_LAUNCH_CHECK();
         return;
     }

@@ -134,20 +134,6 @@ struct SkinnyArgs {
     int am_pad_idx = -1, am_eos_idx = -1, am_unk_idx = -1;
     float am_unk_penalty = 0.f;
 };
-// Experimental kernel variants (profiles/r1_skinny_isa_notes.txt), a bit mask; 0 = the kernels measured in round 1.
-// SC_KERNEL_VARIANT=<mask> (or "all") in the environment, sc_op_set_skinny_variant(mask) at run time.
-enum KernelVariantBits {
-    KV_SKINNY = 1,         // skinny2_kernel (k_skinny2.hip) for the decoder-step products
-    KV_REDUCE = 2,         // reduce_res_ln_row2_kernel
-    KV_DECODE_ATTN = 4,    // decode_attn2_kernel
-    KV_ATTN_PREFETCH = 8,  // attn_mfma_kernel<SHAW, PF = true>
-    KV_RESBLOCK = 16,      // resblock_pair_kernel<C, FL = true>
-    KV_LAYERNORM = 32,     // layernorm_kernel<MAXV, FL = true>
-    KV_ALL = 63,
-};
-extern std::atomic<int> g_skinny_variant;
-int skinny_variant();
-bool launch_skinny2(const SkinnyArgs& a, dim3 grid, int nt, hipStream_t s);
 // number of am_part tiles launch_skinny will write for N output features and M rows
 int skinny_argmax_tiles(int M, int N);
 void launch_argmax_finalize(const float4* part, int tiles, int nb, const float* eos_logit, const int* d_pos,

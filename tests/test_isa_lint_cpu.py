@@ -1,10 +1,11 @@
-"""CPU: ISA-level regression checks of the latency-critical loops (hipcc cross-compiles gfx950 without a GPU).
+"""CPU: ISA-level regression checks of the latency-critical decoder-step kernels (hipcc cross-compiles gfx950 without a GPU).
 
-profiles/r1_skinny_isa_notes.txt records why the shipped decoder-step kernels sit at 4-17 us per launch: predicated loads
-become exec-masked branches and the compiler then waits with vmcnt(0) before every consumer.  The rewritten kernels avoid
-that by construction; these tests keep it that way: the slab loop of skinny2_kernel must stay ONE basic block with no
-`s_waitcnt vmcnt(0)`, no exec-masked branch and no accumulator moves, and the prefetching attention loop must not wait
-for its prefetch before the matrix instructions of the current tile."""
+profiles/r1_skinny_isa_notes.txt records why the first-generation decoder-step kernels sat at 4-17 us per launch: predicated
+loads become exec-masked branches and the compiler then waits with vmcnt(0) before every consumer, so a launch pays one
+memory round trip per slab.  The second-generation kernels (csrc/k_dstep.hip) issue every load of a wave unconditionally
+up front; these tests keep it that way: all buffer loads of the product kernel come before its first matrix instruction,
+the waits are counted (vmcnt(N) with N falling), and the attention kernel has its projections' partial sums AND the first
+64 keys / values in flight before its first wait."""
 import re
 import shutil
 import subprocess
@@ -51,36 +52,33 @@ def _innermost_loop_with(fn: list, *needles: str) -> list:
 
 
 @pytest.fixture(scope="module")
-def skinny2_isa(tmp_path_factory):
-    return _isa("k_skinny2.hip", tmp_path_factory.mktemp("skinny2"))
+def dstep_isa(tmp_path_factory):
+    return _isa("k_dstep.hip", tmp_path_factory.mktemp("dstep"))
 
 
-@pytest.mark.parametrize("inst,mfmas,loads", [("skinny2_kernelILi1ELi1EE", 16, 24), ("skinny2_kernelILi2ELi1EE", 32, 40),
-                                              ("skinny2_kernelILi1ELi4EE", 64, 48)])
-def test_skinny2_slab_loop_is_straight_line_and_pipelined(skinny2_isa, inst, mfmas, loads):
-    loop = _innermost_loop_with(_function(skinny2_isa, inst), "v_mfma_f32_32x32x16")
-    text = "\n".join(loop)
-    assert text.count("v_mfma_f32_32x32x16") == mfmas        # two slabs per trip, hi + lo per fragment
-    assert text.count("buffer_load_dwordx4") == loads        # both register sets are refilled inside the trip
-    assert "vmcnt(0)" not in text                            # never drains the loads of the next slab
-    assert "s_cbranch_execz" not in text and "s_cbranch_execnz" not in text   # no predicated loads
-    assert sum(1 for l in loop if re.match(r"^\.LBB", l)) == 1                # one basic block
-    assert "v_accvgpr" not in text                           # accumulators stay in the accumulation registers
-    assert "scratch_" not in text
+def _ops(fn):
+    return [l.strip() for l in fn if l.startswith("\t") and not l.strip().startswith((";", "."))]
 
 
-def test_attention_prefetch_is_not_drained_before_the_matrix_instructions(tmp_path):
-    isa = _isa("k_attn.hip", tmp_path)
-    for inst in ("attn_mfma_kernelILb1ELb1EE", "attn_mfma_kernelILb0ELb1EE"):
-        loop = _innermost_loop_with(_function(isa, inst), "v_mfma_f32_32x32x2", "global_load_dwordx4")
-        idx_load = [i for i, l in enumerate(loop) if "global_load_dwordx4" in l]
-        idx_mfma = [i for i, l in enumerate(loop) if "v_mfma_f32_32x32x2" in l]
-        assert len(idx_load) == 4 and len(idx_mfma) == 64
-        assert max(idx_load) < min(idx_mfma)                 # the prefetch is issued before the tile is multiplied
-        between = "\n".join(loop[max(idx_load): min(idx_mfma)])
-        assert "vmcnt(0)" not in between and not re.search(r"vmcnt\([0-3]\)", between)   # ... and not waited for there
-    # the shipped instantiation has no prefetch: its loads are consumed (stored to LDS) before the barrier
-    shipped = _innermost_loop_with(_function(isa, "attn_mfma_kernelILb1ELb0EE"), "v_mfma_f32_32x32x2", "global_load_dwordx4")
-    first_mfma = min(i for i, l in enumerate(shipped) if "v_mfma_f32_32x32x2" in l)
-    last_load = max(i for i, l in enumerate(shipped) if "global_load_dwordx4" in l)
-    assert "vmcnt(0)" in "\n".join(shipped[last_load:first_mfma])  # the tile is waited for before it is multiplied
+@pytest.mark.parametrize("inst,loads,mfmas", [("gemvp_kernelILi1ELi4ELi0E", 32, 32), ("gemvp_kernelILi1ELi1ELi0E", 12, 8),
+                                              ("gemvp_kernelILi2ELi2ELi0E", 40, 32)])
+def test_gemvp_loads_are_issued_up_front_with_counted_waits(dstep_isa, inst, loads, mfmas):
+    ops = _ops(_function(dstep_isa, inst))
+    first_mfma = next(i for i, o in enumerate(ops) if o.startswith("v_mfma_f32_32x32x16"))
+    head = ops[:first_mfma]
+    assert sum(o.startswith("buffer_load_dwordx4") for o in head) == loads  # W0 A0 W1 A1 W2 W3 before any product
+    last_mfma = max(i for i, o in enumerate(ops) if o.startswith("v_mfma_f32_32x32x16"))
+    body = ops[first_mfma: last_mfma + 1]
+    assert sum(o.startswith("v_mfma_f32_32x32x16") for o in body) == mfmas
+    waits = [int(re.search(r"vmcnt\((\d+)\)", o).group(1)) for o in ops[: last_mfma + 1] if "vmcnt(" in o]
+    assert waits and waits[0] > 0 and waits[-1] == 0  # the first products start while later fragments are still in flight
+    assert not any(o.startswith("s_cbranch") for o in body)  # one basic block from the first product to the last
+    assert not any(o.startswith(("v_accvgpr_read", "v_accvgpr_write", "scratch_")) for o in body)
+
+
+@pytest.mark.parametrize("inst,loads", [("dattn_kernelILb0E", 12 + 32), ("dattn_kernelILb1E", 4 + 32)])
+def test_decoder_attention_has_its_operands_in_flight_before_the_first_wait(dstep_isa, inst, loads):
+    ops = _ops(_function(dstep_isa, inst))
+    first_wait = next(i for i, o in enumerate(ops) if "vmcnt(" in o)
+    assert sum(o.startswith("global_load_dwordx4") for o in ops[:first_wait]) >= loads
+    assert not any(o.startswith("scratch_") for o in ops)

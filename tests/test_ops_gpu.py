@@ -576,147 +576,3 @@ def test_skinny_fused_argmax(lib, report_dir, M, N, K, mode):
     err = float((lp.cpu().double() - ref_lp).abs().max()) if mode != "unk_pen" else 0.0
     _log(report_dir, "skinny_argmax", M=M, N=N, K=K, mode=mode, err=err)
     assert err < 1e-4
-
-
-# --------------------------------------------------------------------------------------------------------- #
-# Experimental software-pipelined decoder-step product (k_skinny2.hip).  Written without GPU time left in round 1:
-# the tests below are the first thing to run on hardware (SC_TEST_EXPERIMENTAL=1) before any of them is made the default (SC_KERNEL_VARIANT bit mask).
-# --------------------------------------------------------------------------------------------------------- #
-import os  # noqa: E402
-
-_EXPERIMENTAL = pytest.mark.skipif(os.environ.get("SC_TEST_EXPERIMENTAL") != "1",
-                                   reason="skinny2_kernel has not run on hardware yet: set SC_TEST_EXPERIMENTAL=1")
-
-
-@pytest.fixture
-def skinny_variants(lib):
-    def run(fn):
-        outs = []
-        try:
-            for v in (0, 63):  # 0 = shipped kernels, 63 = every experimental variant (KernelVariantBits)
-                check(lib, lib.sc_op_set_skinny_variant(v))
-                outs.append(fn())
-        finally:
-            lib.sc_op_set_skinny_variant(0)
-        return outs
-    return run
-
-
-@_EXPERIMENTAL
-@pytest.mark.parametrize("M,N,K", SKINNY_SHAPES + [(64, 8192, 1024), (64, 1024, 8192), (32, 256102, 1024), (64, 256102, 1024)])
-def test_skinny2_linear_bit_identical(lib, skinny_variants, M, N, K):
-    g = torch.Generator().manual_seed(M * 11 + N * 5 + K)
-    x = dev(torch.randn(M, K, generator=g) * 2.0)
-    w = dev((torch.randn(N, K, generator=g) / math.sqrt(K)).half())
-    b = dev(torch.randn(N, generator=g) * 0.1)
-    r = dev(torch.randn(M, N, generator=g))
-
-    def one():
-        y = torch.full((M, N), float("nan"), device="cuda")
-        check(lib, lib.sc_op_skinny_linear(P(x), P(w), P(b), P(r), P(y), M, N, K, 1, 0.5))
-        return y.cpu()
-
-    a, b2 = skinny_variants(one)
-    assert torch.equal(a, b2), float((a - b2).abs().max())
-
-
-@_EXPERIMENTAL
-@pytest.mark.parametrize("M,N,K,splits", [(16, 1024, 1024, 0), (16, 1024, 8192, 0), (64, 1024, 8192, 4), (3, 128, 256, 0),
-                                          (64, 1024, 1024, 2), (32, 3072, 1024, 0), (1, 1024, 1024, 0)])
-def test_skinny2_split_k_bit_identical(lib, skinny_variants, M, N, K, splits):
-    g = torch.Generator().manual_seed(M + N + K + splits)
-    inp = dev(torch.randn(M, K, generator=g))
-    w = dev((torch.randn(N, K, generator=g) / math.sqrt(K)).half())
-    b = dev(torch.randn(N, generator=g) * 0.1)
-    x0 = torch.randn(M, N, generator=g)
-    gam, bet = dev(torch.rand(N, generator=g) + 0.5), dev(torch.randn(N, generator=g) * 0.1)
-
-    def one():
-        x, h = dev(x0.clone()), torch.empty(M, N, device="cuda")
-        check(lib, lib.sc_op_skinny_res_ln(P(inp), P(w), P(b), P(x), P(gam), P(bet), P(h), M, N, K, splits))
-        return x.cpu(), h.cpu()
-
-    (xa, ha), (xb, hb) = skinny_variants(one)
-    assert torch.equal(xa, xb) and torch.equal(ha, hb)
-
-
-@_EXPERIMENTAL
-@pytest.mark.parametrize("M,N,K", [(16, 256102, 1024), (1, 256102, 1024), (5, 1200, 128), (40, 10082, 1024), (64, 256102, 1024)])
-def test_skinny2_fused_argmax_bit_identical(lib, skinny_variants, M, N, K):
-    g = torch.Generator().manual_seed(M + N + K)
-    x = dev(torch.randn(M, K, generator=g))
-    w = dev((torch.randn(N, K, generator=g) / math.sqrt(K)).half())
-
-    def one():
-        idx = torch.empty(M, dtype=torch.int32, device="cuda")
-        lp = torch.empty(M, device="cuda")
-        check(lib, lib.sc_op_skinny_argmax(P(x), P(w), M, N, K, 5, 0, -1, 0, 3, 1, 0.0, P(idx), P(lp)))
-        return idx.cpu(), lp.cpu()
-
-    (ia, la), (ib, lb) = skinny_variants(one)
-    assert torch.equal(ia, ib) and torch.equal(la, lb)
-
-
-@_EXPERIMENTAL
-@pytest.mark.parametrize("case", ATTN_CASES)
-def test_attention_register_prefetch_bit_identical(lib, skinny_variants, case):
-    """attn_mfma_kernel<SHAW, PF=true> (K/V tiles prefetched into registers) against the shipped instantiation."""
-    nb, H, Sq, Skv, lens, causal, shaw = case
-    g = torch.Generator().manual_seed(Sq * 13 + Skv)
-    M = H * 64
-    q, k, v = (dev(torch.randn(nb, S, M, generator=g)) for S in (Sq, Skv, Skv))
-    rel = dev(torch.randn(73, 64, generator=g) * 0.3) if shaw else None
-    d_lens = dev(torch.tensor(lens, dtype=torch.int32)) if lens is not None else None
-
-    def one():
-        out = torch.full((nb, Sq, M), float("nan"), device="cuda")
-        check(lib, lib.sc_op_attention(P(q), P(k), P(v), P(out), nb, H, Sq, Skv, M, M, M, M, P(d_lens), int(causal),
-                                       P(rel) if shaw else None, 64 if shaw else 0, 8 if shaw else 0))
-        return out.cpu()
-
-    a, b = skinny_variants(one)
-    assert torch.equal(a, b), float((a - b).abs().max())
-
-
-@_EXPERIMENTAL
-@pytest.mark.parametrize("nb,T,C_,k,dil,avg", RESPAIR_CASES)
-def test_resblock_pair_batched_loads_bit_identical(lib, skinny_variants, nb, T, C_, k, dil, avg):
-    """resblock_pair_kernel<C, FL=true> (batched unconditional loads, per-tap weights prefetched into registers) against
-    the shipped instantiation."""
-    g = torch.Generator().manual_seed(T * 13 + C_ * 5 + k + dil)
-    x = dev(torch.randn(nb, T, C_, generator=g))
-    w1 = (torch.randn(C_, C_, k, generator=g) / math.sqrt(C_ * k)).half()
-    w2 = (torch.randn(C_, C_, k, generator=g) / math.sqrt(C_ * k)).half()
-    b1, b2 = dev(torch.randn(C_, generator=g) * 0.1), dev(torch.randn(C_, generator=g) * 0.1)
-    ra, rb = dev(torch.randn(nb, T, C_, generator=g)), dev(torch.randn(nb, T, C_, generator=g))
-    kpad = (C_ * k + 31) // 32 * 32
-    wp1 = torch.zeros(C_, kpad, dtype=torch.float16, device="cuda")
-    wp2 = torch.zeros(C_, kpad, dtype=torch.float16, device="cuda")
-    check(lib, lib.sc_op_pack_conv_weight(P(dev(w1)), P(wp1), C_, C_, k))
-    check(lib, lib.sc_op_pack_conv_weight(P(dev(w2)), P(wp2), C_, C_, k))
-
-    def one():
-        got = torch.full((nb, T, C_), float("nan"), device="cuda")
-        check(lib, lib.sc_op_resblock_pair(P(x), P(wp1), P(b1), P(wp2), P(b2), P(got), nb, T, C_, k, dil, 0.1,
-                                           P(ra) if avg else None, P(rb) if avg else None))
-        return got.cpu()
-
-    a, b = skinny_variants(one)
-    assert not torch.isnan(a).any() and torch.equal(a, b), float((a - b).abs().max())
-
-
-@_EXPERIMENTAL
-@pytest.mark.parametrize("rows,C_,act", [(37, 1024, 0), (5, 128, 2), (1000, 1024, 0), (3, 256, 1), (64, 160, 0)])
-def test_layernorm_loads_up_front_bit_identical(lib, skinny_variants, rows, C_, act):
-    """layernorm_kernel<MAXV, FL=true> against the shipped instantiation."""
-    g = torch.Generator().manual_seed(rows + C_)
-    x = dev(torch.randn(rows, C_, generator=g) * 3 + 0.5)
-    gam, bet = dev(torch.rand(C_, generator=g) + 0.5), dev(torch.randn(C_, generator=g) * 0.1)
-
-    def one():
-        y = torch.full((rows, C_), float("nan"), device="cuda")
-        check(lib, lib.sc_op_layernorm(P(x), P(gam), P(bet), P(y), rows, C_, act))
-        return y.cpu()
-
-    a, b = skinny_variants(one)
-    assert not torch.isnan(a).any() and torch.equal(a, b)

@@ -319,34 +319,6 @@ def test_translator_accepts_ngram_step_processor():
         tr.predict(wav, "S2TT", "fra", text_generation_opts=SequenceGeneratorOptions(beam_size=1, step_processor=object()))
 
 
-@pytest.mark.skipif(__import__("os").environ.get("SC_TEST_EXPERIMENTAL") != "1",
-                    reason="skinny2_kernel / decode_attn2_kernel have not run on hardware yet: set SC_TEST_EXPERIMENTAL=1")
-def test_experimental_decoder_kernels_bit_identical(env):
-    """Variant 1 of the decoder-step kernels (k_skinny2.hip, decode_attn2_kernel) must reproduce variant 0 bit for bit:
-    greedy ids, scores and the decoder outputs of every fed position, eager and graph-captured, plus beam search."""
-    cfg, tt, ct, orc, hip = env
-    fb, lens = orc.collate_fbank(common.waves((2.0, 1.37, 0.9)))
-    enc, enc_lens = hip.encode_speech(fb.cuda(), lens.tolist())
-    prefix = tt.target_prefix("fra")
-    lib = hip.lib
-    results = []
-    try:
-        for variant in (0, 63):  # shipped kernels / every experimental variant
-            assert lib.sc_op_set_skinny_variant(variant) == 0
-            runs = []
-            for use_graph in (False, True):
-                ids, out_lens, scores, hidden = hip.generate_text(enc, enc_lens.tolist(), prefix, hard_max_seq_len=20, use_graph=use_graph)
-                runs.append((ids.copy(), out_lens.copy(), scores.copy(), hidden.cpu()))
-            bids, blens, bscores, bhidden = hip.generate_text(enc, enc_lens.tolist(), prefix, beam_size=4, hard_max_seq_len=14)
-            runs.append((bids.copy(), blens.copy(), bscores.copy(), bhidden.cpu()))
-            results.append(runs)
-    finally:
-        lib.sc_op_set_skinny_variant(0)
-    for a, b in zip(*results):
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-        assert torch.equal(a[3], b[3])
-
-
 def test_ragged_vocoder_and_bucketed_t2u_match_the_padded_batch(env, report_dir):
     """Length buckets (sc_vocode_ragged; the bucketed NAR decoder inside sc_t2u_nar): every kept sample / unit equals the
     padded batch's.  Items of very different lengths, so that several buckets form; the padded batch is the reference
