@@ -93,7 +93,7 @@ def roofline_of(fams):
     sec = f["ms"] * 1e-3
     avg_us = 1e3 * f["ms"] / max(1, f["launches"])
     base = name.split(":")[-1]
-    if base.startswith(("gemv", "skinny", "resblock_pair_c16", "resblock_pair_c32")):
+    if base.startswith(("gemv", "skinny", "step_graph", "resblock_pair_c16", "resblock_pair_c32")):
         # weight streaming (decoder step) / narrow vocoder stages: HBM-bound kernels
         ach = f["bytes"] / sec / 1e9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
@@ -395,15 +395,13 @@ def main():
         lib = model.lib
         lib.sc_prof_reset()
         lib.sc_prof_enable(1)
-        for v in batcher.views:
-            v.use_graph = False  # launches inside a captured graph cannot carry events
+        # the decoder step stays a replayed graph like in the timed passes: its launches cannot carry events, each
+        # replay is one record ("dec:step_graph") with the step's algorithmic bytes
         step(single_stream=args.profile_single_stream or batcher.groups == 1)
         torch.cuda.synchronize()
         lib.sc_prof_enable(0)
         fams = prof_report(lib)
         log("profiled step done")
-        for v in batcher.views:
-            v.use_graph = not args.no_graph
         if rank == 0:
             roof, shares = roofline_of(fams)
             result["roofline"] = roof

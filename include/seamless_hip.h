@@ -94,7 +94,7 @@ typedef struct sc_config {
  * (inference/generator.py:59-84) that the HIP path honours. */
 typedef struct sc_gen_opts {
     int32_t beam_size;        /* 1: greedy arg-max with a graph-captured step; 2..8: beam search (host-driven steps) */
-    float soft_max_seq_len_a; /* max_len = min(hard, int(a*S_src) + b), prefix included */
+    float soft_max_seq_len_a; /* max_len = min(hard, int(a*source_len) + b), prefix included */
     int32_t soft_max_seq_len_b;
     int32_t hard_max_seq_len;
     int32_t min_seq_len;
@@ -107,6 +107,11 @@ typedef struct sc_gen_opts {
      * present in the row's sequence (prompt included) gets log-probability -inf.  Runs the host-driven
      * step loop for every beam_size (1 included). */
     int32_t no_repeat_ngram_size;
+    /* Length of the SOURCE sequence the soft length rule is applied to.  fairseq2's generator is handed the source
+     * sequences themselves (fbank frames for speech input, tokens for text input: inference/generator.py:261-263) and
+     * computes int(a * source_len + b) from their padded length; 0 = use the encoder output length (the rule of the
+     * ggml port, fairseq2.cpp:1097-1105, which is 8 x shorter for speech). */
+    int32_t source_len;
 } sc_gen_opts;
 
 typedef struct sc_model sc_model;

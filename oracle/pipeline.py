@@ -55,25 +55,26 @@ class OracleS2ST:
     def s2tt(self, fbank: Tensor, lens: Tensor, tgt_lang: str, soft_max_seq_len=(1, 200),
              hard_max_seq_len: int = 1024, beam_size: int = 1):
         enc, enc_lens = ou.encode_speech(self.P, self.cfg, fbank, lens)
-        return self._text_from_encoder(enc, enc_lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size)
+        # the generator is called with the fbank sequences: their padded length feeds the soft length rule
+        return self._text_from_encoder(enc, enc_lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size, int(fbank.shape[1]))
 
     @torch.inference_mode()
     def t2tt(self, tokens: Tensor, lens: Tensor, tgt_lang: str, soft_max_seq_len=(1, 200),
              hard_max_seq_len: int = 1024, beam_size: int = 1):
         """Text input (UnitYModel.encode_text, models/unity/model.py:138-151) -> the same generation."""
         enc = ou.encode_text(self.P, self.cfg, tokens, lens, self.pos_table)
-        return self._text_from_encoder(enc, lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size)
+        return self._text_from_encoder(enc, lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size, int(tokens.shape[1]))
 
     def _text_from_encoder(self, enc: Tensor, enc_lens: Tensor, tgt_lang: str, soft_max_seq_len, hard_max_seq_len: int,
-                           beam_size: int):
+                           beam_size: int, source_len: int = 0):
         prefix = self.text_tok.target_prefix(tgt_lang)
         if beam_size > 1:
             seqs = ou.beam_search_generate(self.P, self.cfg, enc, enc_lens, prefix, beam_size, soft_max_seq_len,
-                                           hard_max_seq_len, pos_table=self.pos_table)
+                                           hard_max_seq_len, pos_table=self.pos_table, source_len=source_len)
             return seqs, enc, enc_lens, None
         seqs, margins = ou.greedy_generate(
             self.P, self.cfg, enc, enc_lens, prefix, soft_max_seq_len, hard_max_seq_len,
-            pos_table=self.pos_table, return_margins=True,
+            pos_table=self.pos_table, return_margins=True, source_len=source_len,
         )
         return seqs, enc, enc_lens, margins
 

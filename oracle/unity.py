@@ -291,9 +291,12 @@ def greedy_generate(
     P: Params, cfg, enc: Tensor, enc_lens: Tensor, prefix: Sequence[int],
     soft_max_seq_len: Tuple[float, int] = (1, 200), hard_max_seq_len: int = 1024,
     min_seq_len: int = 1, unk_penalty: float = 0.0, pos_table: Optional[Tensor] = None,
-    return_margins: bool = False,
+    return_margins: bool = False, source_len: int = 0,
 ):
-    """Beam search with beam_size=1 == greedy arg-max with the step rules of
+    """``source_len``: padded length of the sequences the generator was called with (fbank frames for speech input;
+    fairseq2 computes the soft limit from them, inference/generator.py:261-263); 0 = the encoder output length (ggml).
+
+    Beam search with beam_size=1 == greedy arg-max with the step rules of
     ggml/examples/unity/fairseq2.cpp:1269-1305,1463-1594 (echo_prompt=True:
     hypotheses start with the prompt).  Runs each batch item independently
     like the reference (no cross-item arithmetic)."""
@@ -305,7 +308,7 @@ def greedy_generate(
     margins: List[List[float]] = []
     for b in range(N):
         # The reference runs the whole batch with the batch-max source length.
-        max_len = max_seq_len_rule(soft_max_seq_len[0], soft_max_seq_len[1], hard_max_seq_len, enc.shape[1])
+        max_len = max_seq_len_rule(soft_max_seq_len[0], soft_max_seq_len[1], hard_max_seq_len, source_len or enc.shape[1])
         max_len = min(max_len, cfg.text_max_seq_len)
         dec = IncrementalDecoder(P, cfg, enc[b : b + 1], enc_lens[b : b + 1], pos_table)
         seq = list(prefix)
@@ -360,7 +363,7 @@ def beam_search_generate(
     P: Params, cfg, enc: Tensor, enc_lens: Tensor, prefix: Sequence[int], beam_size: int = 5,
     soft_max_seq_len: Tuple[float, int] = (1, 200), hard_max_seq_len: int = 1024, min_seq_len: int = 1,
     len_penalty: float = 1.0, unk_penalty: float = 0.0, normalize_scores: bool = True,
-    pos_table: Optional[Tensor] = None, return_all: bool = False, no_repeat_ngram_size: int = 0,
+    pos_table: Optional[Tensor] = None, return_all: bool = False, no_repeat_ngram_size: int = 0, source_len: int = 0,
 ):
     """BeamSearchSeq2SeqGenerator as the reference constructs it (inference/generator.py:147-156,
     beam_size=5 by default translator.py:311-313), restated from the in-tree C++ port of fairseq2's
@@ -390,7 +393,7 @@ def beam_search_generate(
     best: List[List[int]] = []
     everything = []
     for n in range(N):
-        max_len = min(max_seq_len_rule(soft_max_seq_len[0], soft_max_seq_len[1], hard_max_seq_len, enc.shape[1]), cfg.text_max_seq_len)
+        max_len = min(max_seq_len_rule(soft_max_seq_len[0], soft_max_seq_len[1], hard_max_seq_len, source_len or enc.shape[1]), cfg.text_max_seq_len)
         enc_b = enc[n : n + 1].expand(B, -1, -1)
         lens_b = enc_lens[n : n + 1].expand(B)
         dec = IncrementalDecoder(P, cfg, enc_b, lens_b, pos_table)
@@ -434,9 +437,15 @@ def beam_search_generate(
                 order = [i for _, i in pairs]
             beams, toks, scs = [], [], []
             done = False
-            for c in order:
+            for rank, c in enumerate(order):
                 beam, token, s = c // V, c % V, float(flat[c])
                 if token == cfg.eos_idx and s != -math.inf:
+                    # fairseq2's BeamSearchSeq2SeqGenerator (what the reference Translator runs; like fairseq before it)
+                    # considers an EOS candidate only when it ranks among the top `beam_size` of the 2 x beam candidates;
+                    # a lower-ranked EOS is neither finalised nor continued.  The ggml port (fairseq2.cpp:1542-1565)
+                    # finalises every EOS it meets before `beam_size` live beams are collected: it deviates here.
+                    if rank >= B:
+                        continue
                     final = s / float((step_nr + 1) ** len_penalty) if normalize_scores else s
                     finished.append((final, seqs[beam, : step_nr + 1].tolist() + [token]))
                     if len(finished) == B:

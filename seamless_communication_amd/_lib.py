@@ -70,7 +70,7 @@ class sc_gen_opts(C.Structure):
     _fields_ = [
         ("beam_size", _i), ("soft_max_seq_len_a", C.c_float), ("soft_max_seq_len_b", _i),
         ("hard_max_seq_len", _i), ("min_seq_len", _i), ("unk_penalty", C.c_float), ("use_graph", _i),
-        ("len_penalty", C.c_float), ("normalize_scores", _i), ("no_repeat_ngram_size", _i),
+        ("len_penalty", C.c_float), ("normalize_scores", _i), ("no_repeat_ngram_size", _i), ("source_len", _i),
     ]
 
 

@@ -216,17 +216,19 @@ def convert_unity_checkpoint(checkpoint: Mapping[str, Any], char_spm_tokens: Opt
 
 
 def convert_vocoder_checkpoint(checkpoint: Mapping[str, Any]) -> Dict[str, torch.Tensor]:
-    """models/vocoder/loader.py:20-36: fairseq ``generator.*`` keys become
-    ``code_generator.*``; an already converted state dict passes through."""
-    sd = checkpoint["model"] if "model" in checkpoint else checkpoint
-    if any(k.startswith("code_generator.") for k in sd):
-        return dict(sd)
-    out = {}
-    for k, v in sd.items():
-        if k.startswith("generator."):
-            k = "code_generator." + k[len("generator."):]
-        out[k] = v
-    return out
+    """models/vocoder/loader.py:20-36.  The published fairseq vocoder checkpoint is ``{"generator": {<unprefixed keys>}}``:
+    every key becomes ``code_generator.<key>``.  A checkpoint that already carries ``model`` with
+    ``code_generator.resblocks.0.convs1.0.weight_g`` (the reference's own test for "converted") passes through.  Returns
+    the state dict (the reference returns the checkpoint whose ``model`` entry is that dict)."""
+    if "model" in checkpoint and "code_generator.resblocks.0.convs1.0.weight_g" in checkpoint["model"]:
+        return dict(checkpoint["model"])
+    if "generator" not in checkpoint:
+        # not a layout the reference's converter accepts (it would raise KeyError): a bare, already prefixed state dict is
+        # accepted as a convenience, anything else is an error rather than a silently wrong weight table
+        if any(k.startswith("code_generator.") for k in checkpoint):
+            return dict(checkpoint)
+        raise KeyError("vocoder checkpoint holds neither 'generator' (fairseq layout) nor a converted 'model' state dict")
+    return {f"code_generator.{k}": v for k, v in checkpoint["generator"].items()}
 
 
 def load_converted_checkpoint(path: str, kind: str, char_spm_tokens: Optional[Sequence[str]] = None) -> Dict[str, torch.Tensor]:

@@ -76,6 +76,7 @@ struct GemmPsArgs {
     int M = 0, N = 0, K = 0;
     int act = ACT_NONE;
     float alpha = 1.0f;
+    int split = 1;  // 0: only the hi plane is multiplied (A rounded to fp16 once) - precision study, never the default
 };
 void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s);
 

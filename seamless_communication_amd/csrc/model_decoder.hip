@@ -17,8 +17,9 @@ static std::mutex g_capture_mutex;
 
 int text_max_len(const Model& m, const sc_gen_opts& o, int s_enc) {
     int max_len;
-    if (s_enc <= 0 || o.soft_max_seq_len_a <= 0) max_len = o.hard_max_seq_len;
-    else max_len = std::min(o.hard_max_seq_len, (int)(o.soft_max_seq_len_a * (float)s_enc) + o.soft_max_seq_len_b);
+    const int src = o.source_len > 0 ? o.source_len : s_enc;  // what fairseq2 calls max_source_len (see sc_gen_opts.source_len)
+    if (src <= 0 || o.soft_max_seq_len_a <= 0) max_len = o.hard_max_seq_len;
+    else max_len = std::min(o.hard_max_seq_len, (int)(o.soft_max_seq_len_a * (float)src) + o.soft_max_seq_len_b);
     return std::min(max_len, m.cfg.text_max_seq_len);
 }
 
@@ -804,7 +805,16 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
                 SC_HIP(hipStreamEndCapture(m.stream, &S->graph));
                 SC_HIP(hipGraphInstantiate(&S->exec, S->graph, nullptr, nullptr, 0));
             }
-            SC_HIP(hipGraphLaunch(S->exec, m.stream));
+            {
+                // one profiler record per replayed step (launches inside the graph cannot carry events): the algorithmic
+                // bytes of a step are the fp16 weights of the layers and of the tied projection, read once for all rows,
+                // plus the fp32 K/V rows the attention kernels read (self: positions 0..step, cross: every encoder row)
+                const double w_bytes = 2.0 * ((double)cfg.dec_layers * (4.0 * M * M + 2.0 * M * M + 2.0 * (double)M * cfg.dec_ffn_dim) +
+                                              (double)cfg.text_vocab_size * M);
+                const double kv_bytes = 4.0 * cfg.dec_layers * (double)n * M * (2.0 * (step + 1) + 2.0 * s_enc);
+                prof::Scope scope("step_graph", (double)n * w_bytes, w_bytes + kv_bytes, m.stream);
+                SC_HIP(hipGraphLaunch(S->exec, m.stream));
+            }
         } else {
             decoder_step(m, c, true);
         }
@@ -1031,6 +1041,10 @@ void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, cons
                 const float sc = cand_val[(size_t)u * K + i];
                 const int beam = cidx / V, token = cidx % V;
                 if (token == cfg.eos_idx && sc != -INFINITY) {
+                    // fairseq2 (the generator the reference Translator constructs, inference/generator.py:147-156) looks at
+                    // an EOS candidate only among the top `beam_size` of the 2 x beam candidates; a lower-ranked EOS is
+                    // dropped, not finalised (the ggml port, fairseq2.cpp:1542-1565, finalises it: followed fairseq2)
+                    if (i >= B) continue;
                     Hyp hy;
                     hy.score = normalize ? sc / powf((float)(step + 1), len_penalty) : sc;
                     const int32_t* sp = &seqs[(size_t)(u * B + beam) * max_len];

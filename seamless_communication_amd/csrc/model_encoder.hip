@@ -140,6 +140,10 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
         a.K = L.in;
         a.act = act;
         a.alpha = alpha;
+        // SC_SPLIT_MODE=1 (precision study, scripts/split_study.py; never the default): the Conformer products use the
+        // hi plane only, i.e. the activation operand is rounded to fp16 once instead of being carried to ~2^-22
+        static const bool single = getenv("SC_SPLIT_MODE") && atoi(getenv("SC_SPLIT_MODE")) == 1;
+        a.split = single ? 0 : 1;
         launch_gemm_presplit(a, m.stream);
     };
 

@@ -69,7 +69,9 @@ int begin(const char* name, double flops, double bytes, hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return -1;
     std::lock_guard<std::mutex> lock(g_mu);
-    if (g_recs.size() > 200000) drain();
+    // tokens are indices into g_recs and other host threads may hold some: records are only drained by reset() / report();
+    // beyond the cap further launches simply go unrecorded
+    if (g_recs.size() > 200000) return -1;
     Rec r;
     r.name = g_tag.empty() ? std::string(name) : g_tag + ":" + name;
     r.flops = flops;

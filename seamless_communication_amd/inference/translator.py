@@ -377,6 +377,9 @@ class Translator:
             no_repeat_ngram_size=ngram,
             use_graph=trace.get("use_graph", True),
             want_hidden=want_speech,
+            # fairseq2 applies int(a * source_len + b) to the sequences the generator is called with: the fbank frames
+            # (speech) or the source tokens (text), generator.py:261-263 -- not to the adaptor's 8x shorter output
+            source_len=int(seqs.shape[1]),
         )
         t2 = time.perf_counter()
         text_ids = [ids[b, : out_lens[b]].tolist() for b in range(ids.shape[0])]

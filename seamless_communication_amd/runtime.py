@@ -228,7 +228,7 @@ class HipS2STModel:
         return int(index[0]), pch, feats
 
     def _gen_opts(self, beam_size, soft_max_seq_len, hard_max_seq_len, min_seq_len, unk_penalty, use_graph,
-                  len_penalty=1.0, normalize_scores=True, no_repeat_ngram_size=0):
+                  len_penalty=1.0, normalize_scores=True, no_repeat_ngram_size=0, source_len=0):
         o = _lib.sc_gen_opts()
         o.beam_size = int(beam_size)
         o.soft_max_seq_len_a = float(soft_max_seq_len[0])
@@ -240,17 +240,21 @@ class HipS2STModel:
         o.len_penalty = float(len_penalty)
         o.normalize_scores = int(bool(normalize_scores))
         o.no_repeat_ngram_size = int(no_repeat_ngram_size)
+        o.source_len = int(source_len)
         return o
 
     def generate_text(self, enc: torch.Tensor, enc_lens: Sequence[int], prefix: Sequence[int], beam_size: int = 1,
                       soft_max_seq_len=(1, 200), hard_max_seq_len: int = 1024, min_seq_len: int = 1,
                       unk_penalty: float = 0.0, use_graph: bool = True, want_hidden: bool = True,
-                      len_penalty: float = 1.0, normalize_scores: bool = True, no_repeat_ngram_size: int = 0):
-        """-> (ids (n, max_len) int32, lens (n,), scores (n,), hidden (n, max_len-1, M) or None)."""
+                      len_penalty: float = 1.0, normalize_scores: bool = True, no_repeat_ngram_size: int = 0,
+                      source_len: int = 0):
+        """-> (ids (n, max_len) int32, lens (n,), scores (n,), hidden (n, max_len-1, M) or None).
+        ``source_len``: padded length of the source sequences the soft length rule refers to (fbank frames for speech);
+        0 = the encoder output length."""
         assert enc.is_cuda and enc.is_contiguous()
         n, s_enc, M = enc.shape
         o = self._gen_opts(beam_size, soft_max_seq_len, hard_max_seq_len, min_seq_len, unk_penalty, use_graph, len_penalty,
-                           normalize_scores, no_repeat_ngram_size)
+                           normalize_scores, no_repeat_ngram_size, source_len)
         max_len = self.lib.sc_text_max_len(self.handle, C.byref(o), s_enc)
         ids = np.zeros((n, max_len), dtype=np.int32)
         lens = np.zeros(n, dtype=np.int32)

@@ -5,6 +5,8 @@ against the reference's own ``convert_unity_checkpoint`` / ``_fairseq_key_map`` 
 import json
 from pathlib import Path
 
+from typing import Any, Mapping
+
 import pytest
 import torch
 
@@ -65,6 +67,29 @@ def test_char_embedding_needs_the_piece_list():
         ck.convert_unity_checkpoint({"model": fs})
 
 
-def test_vocoder_prefix_rename():
-    out = ck.convert_vocoder_checkpoint({"model": {"generator.conv_pre.bias": torch.zeros(2), "other": torch.ones(1)}})
-    assert set(out) == {"code_generator.conv_pre.bias", "other"}
+def test_vocoder_checkpoint_conversion_matches_the_reference_converter():
+    """The reference's own convert_vocoder_checkpoint (models/vocoder/loader.py:20-36), cut out of its file and executed
+    when /root/reference is present; the expectations below are its outputs either way."""
+    fairseq = {"generator": {"conv_pre.bias": torch.zeros(2), "resblocks.0.convs1.0.weight_g": torch.ones(1), "dict.weight": torch.ones(3)}}
+    out = ck.convert_vocoder_checkpoint(fairseq)
+    assert set(out) == {"code_generator.conv_pre.bias", "code_generator.resblocks.0.convs1.0.weight_g", "code_generator.dict.weight"}
+    assert out["code_generator.dict.weight"] is fairseq["generator"]["dict.weight"]
+    converted = {"model": dict(out)}
+    again = ck.convert_vocoder_checkpoint(converted)
+    assert again.keys() == out.keys() and all(again[k] is out[k] for k in out)
+    assert ck.convert_vocoder_checkpoint(dict(out)).keys() == out.keys()  # bare converted state dict
+    with pytest.raises(KeyError):
+        ck.convert_vocoder_checkpoint({"model": {"generator.conv_pre.bias": torch.zeros(2)}})  # not a published layout
+    import ast
+    from pathlib import Path
+
+    ref = Path("/root/reference/src/seamless_communication/models/vocoder/loader.py")
+    if ref.exists():
+        tree = ast.parse(ref.read_text())
+        fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "convert_vocoder_checkpoint")
+        ns = {"Mapping": Mapping, "Any": Any, "VocoderConfig": object}
+        exec(compile(ast.Module([fn], []), str(ref), "exec"), ns)
+        ref_out = ns["convert_vocoder_checkpoint"]({"generator": dict(fairseq["generator"])}, None)
+        assert set(ref_out["model"]) == set(out) and "generator" not in ref_out
+        ref_pass = ns["convert_vocoder_checkpoint"]({"model": dict(out)}, None)
+        assert set(ref_pass["model"]) == set(out)

@@ -352,3 +352,14 @@ def test_ragged_vocoder_and_bucketed_t2u_match_the_padded_batch(env, report_dir)
         u1, ul1, _, _, _ = hip.t2u_nar(hidden[b : b + 1].contiguous(), ids[b : b + 1, :-1].copy(), [int(out_lens[b]) - 1], 1.0)
         assert int(ul1[0]) == int(ul_all[b]) and u1[0, : ul1[0]].tolist() == u_all[b, : ul_all[b]].tolist()
     assert pad["t2u_rows_computed"] <= pad["t2u_rows_padded"]
+
+
+def test_soft_length_rule_uses_the_source_length(env):
+    """fairseq2 computes int(a * source_len + b) from the sequences the generator is called with (fbank frames for
+    speech, inference/generator.py:261-263); sc_gen_opts.source_len carries that, 0 falls back to the encoder length."""
+    import ctypes as C
+
+    cfg, tt, ct, orc, hip = env
+    for source_len, s_enc, want in ((0, 13, min(13 + 5, 200)), (100, 13, min(100 + 5, 200)), (1000, 13, 200)):
+        o = hip._gen_opts(1, (1, 5), 200, 1, 0.0, True, source_len=source_len)
+        assert hip.lib.sc_text_max_len(hip.handle, C.byref(o), s_enc) == min(want, cfg.text_max_seq_len)

@@ -37,14 +37,15 @@ class OracleModel:
 
     def generate_text(self, enc, enc_lens, prefix, beam_size=1, soft_max_seq_len=(1, 200), hard_max_seq_len=1024, min_seq_len=1,
                       unk_penalty=0.0, use_graph=True, want_hidden=True, len_penalty=1.0, normalize_scores=True,
-                      no_repeat_ngram_size=0):
+                      no_repeat_ngram_size=0, source_len=0):
         self.calls.append(dict(beam_size=beam_size, no_repeat_ngram_size=no_repeat_ngram_size, unk_penalty=unk_penalty,
                                hard_max_seq_len=hard_max_seq_len, want_hidden=want_hidden))
         lens = torch.tensor(enc_lens)
         seqs = ou.beam_search_generate(self.orc.P, self.cfg, enc, lens, prefix, beam_size, soft_max_seq_len, hard_max_seq_len,
                                        min_seq_len, len_penalty, unk_penalty, normalize_scores, self.orc.pos_table,
-                                       no_repeat_ngram_size=no_repeat_ngram_size)
-        max_len = min(ou.max_seq_len_rule(soft_max_seq_len[0], soft_max_seq_len[1], hard_max_seq_len, enc.shape[1]), self.cfg.text_max_seq_len)
+                                       no_repeat_ngram_size=no_repeat_ngram_size, source_len=source_len)
+        max_len = min(ou.max_seq_len_rule(soft_max_seq_len[0], soft_max_seq_len[1], hard_max_seq_len, source_len or enc.shape[1]),
+                      self.cfg.text_max_seq_len)
         ids = np.full((len(seqs), max_len), self.cfg.pad_idx, dtype=np.int32)
         for b, s in enumerate(seqs):
             ids[b, : len(s)] = s
