@@ -262,7 +262,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from seamless_communication_amd import cards, synthetic as syn
-    from seamless_communication_amd.distributed import MicroBatcher, all_gather_ragged_ids
+    from seamless_communication_amd.distributed import MicroBatcher, all_gather_ragged_lists
     from seamless_communication_amd.inference import SequenceGeneratorOptions, Translator
     from seamless_communication_amd.inference.translator import DEFAULT_CARDS, Modality
 
@@ -305,8 +305,7 @@ def main():
             stage_ms.clear()
             stage_ms.update(st)
         if world > 1:  # the only exchange of the data-parallel path: ids, a few hundred KB
-            all_text = all_gather_ragged_ids(text_ids, device)
-            all_units = all_gather_ragged_ids(units, device)
+            all_text, all_units = all_gather_ragged_lists([text_ids, units], device)
             assert len(all_text) == len(all_units) == world * B
         last.update(texts=texts, units=units, wavs=wavs, text_ids=text_ids)
 
@@ -333,8 +332,7 @@ def main():
         outs = batcher.predict_steps(wav_dev, ns, args.steps, "S2ST", "fra", stagger_s=stagger, text_generation_opts=opts)
         for texts, units, wavs, text_ids, st in outs:
             if world > 1:
-                all_text = all_gather_ragged_ids(text_ids, device)
-                all_units = all_gather_ragged_ids(units, device)
+                all_text, all_units = all_gather_ragged_lists([text_ids, units], device)
                 assert len(all_text) == len(all_units) == world * B
         texts, units, wavs, text_ids, st = outs[-1]
         stage_ms.clear()

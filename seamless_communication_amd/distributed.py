@@ -24,59 +24,90 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_ragged_ids(seqs: Sequence[Sequence[int]], device: torch.device, pad: int = -1) -> List[List[int]]:
-    """Gathers every rank's ragged int sequences; returns them in rank order.
+def _gather_rows(t: torch.Tensor, world: int) -> torch.Tensor:
+    """all-gather of equally shaped (rows, cols) int32 tensors into one (world, rows, cols) tensor on the same device:
+    one collective, no host round trip (RCCL on GPUs; gloo on CPU for the tests)."""
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    try:
+        dist.all_gather_into_tensor(out.view(-1), t.reshape(-1))
+    except (RuntimeError, NotImplementedError):  # a backend without the flat form
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        out = torch.stack(parts)
+    return out
 
-    Works on any initialised process group (``nccl`` == RCCL on GPUs, ``gloo``
-    on CPU for the tests).  Without a process group it returns the input."""
-    local = [list(map(int, s)) for s in seqs]
+
+def all_gather_ragged_lists(columns: Sequence[Sequence[Sequence[int]]], device: torch.device, pad: int = -1) -> List[List[List[int]]]:
+    """Gathers several ragged int lists per item at once (text ids and unit ids of every utterance): ``columns[c][i]`` is
+    list c of local item i.  Returns the same structure over the items of ALL ranks, in rank order.
+
+    Two collectives in all: the shard sizes / longest lists (a few ints per rank), then ONE fixed-shape all-gather of
+    ``[max_items, n_columns + sum(max_len_c)]`` rows (lengths first, then the ids padded with ``pad``).  The payload
+    is assembled once on the host (the ids come from host arrays), crosses to the device once, is gathered there and
+    comes back with a single copy.  A rank with an empty shard takes part with zero rows of its own.
+    Without a process group the input is returned."""
+    ncol = len(columns)
+    local = [[list(map(int, s)) for s in col] for col in columns]
+    n_local = len(local[0]) if ncol else 0
+    assert all(len(col) == n_local for col in local), "every column must describe the same items"
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local
     world = dist.get_world_size()
-    # 1) shard sizes and the global max length (2 ints per rank)
-    meta = torch.tensor([len(local), max((len(s) for s in local), default=0)], dtype=torch.int64, device=device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    counts = [int(m[0]) for m in metas]
-    max_count, max_len = max(counts), max(int(m[1]) for m in metas)
-    # 2) one fixed-shape all-gather of [max_count, 1 + max_len] (length column + padded ids)
-    buf = np.full((max_count, 1 + max_len), pad, dtype=np.int32)
-    for i, s in enumerate(local):
-        buf[i, 0] = len(s)
-        buf[i, 1 : 1 + len(s)] = s
-    t = torch.from_numpy(buf).to(device)
-    outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t)
-    result: List[List[int]] = []
+    meta = torch.tensor([n_local] + [max((len(s) for s in col), default=0) for col in local], dtype=torch.int32, device=device)
+    metas = _gather_rows(meta.view(1, -1), world).view(world, -1).cpu()
+    counts = metas[:, 0].tolist()
+    max_count = max(counts)
+    widths = [int(metas[:, 1 + c].max()) for c in range(ncol)]
+    offs = np.cumsum([ncol] + widths)
+    buf = np.full((max(max_count, 1), int(offs[-1])), pad, dtype=np.int32)
+    for i in range(n_local):
+        for c in range(ncol):
+            s = local[c][i]
+            buf[i, c] = len(s)
+            buf[i, offs[c]: offs[c] + len(s)] = s
+    gathered = _gather_rows(torch.from_numpy(buf).to(device), world).cpu().numpy()
+    result: List[List[List[int]]] = [[] for _ in range(ncol)]
     for r in range(world):
-        a = outs[r].cpu().numpy()
         for i in range(counts[r]):
-            result.append(a[i, 1 : 1 + int(a[i, 0])].tolist())
+            row = gathered[r, i]
+            for c in range(ncol):
+                result[c].append(row[offs[c]: offs[c] + int(row[c])].tolist())
     return result
 
 
-def predict_batch_dp(translator, waveforms: Sequence[torch.Tensor], task_str: str, tgt_lang: str, **predict_kwargs):
-    """Shards ``waveforms`` over the ranks, runs ``translator.predict`` on the
-    local shard (one batched call) and all-gathers text ids / units.
+def all_gather_ragged_ids(seqs: Sequence[Sequence[int]], device: torch.device, pad: int = -1) -> List[List[int]]:
+    """One ragged int list per item (see all_gather_ragged_lists)."""
+    return all_gather_ragged_lists([seqs], device, pad)[0]
 
-    Returns (texts_local, speech_output_local, all_unit_ids) where
-    ``all_unit_ids`` holds the units of every utterance of the global batch in
-    the original order.  Waveforms stay rank-local (41 MB per 64 utterances)."""
+
+def predict_batch_dp(translator, waveforms: Sequence[torch.Tensor], task_str: str, tgt_lang: str, **predict_kwargs):
+    """Shards ``waveforms`` over the ranks, runs ``translator.predict`` on the local shard (one batched call) and
+    all-gathers the decoded text ids and unit ids (north star: "RCCL all-gather of decoded text/unit ids").
+
+    Returns (texts_local, speech_output_local, all_text_ids, all_unit_ids): the last two hold every utterance of the
+    global batch in the original order.  Waveforms stay rank-local (41 MB per 64 utterances).  A rank whose shard is
+    empty (fewer utterances than ranks) runs nothing and still takes part in the gather."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     lo, hi = shard_range(len(waveforms), rank, world)
     shard = waveforms[lo:hi]
-    n = max(int(w.numel()) for w in shard)
-    wav = torch.zeros(len(shard), n, dtype=torch.float32)
-    for i, w in enumerate(shard):
-        wav[i, : w.numel()] = w.reshape(-1)
-    model = translator.model
-    fb, frames = model.fbank(wav.to(translator.device), [int(w.numel()) for w in shard])
-    src = {"seqs": fb, "seq_lens": torch.tensor(frames.astype(np.int64)), "is_ragged": len(set(frames.tolist())) > 1}
-    texts, speech = translator.predict(src, task_str, tgt_lang, **predict_kwargs)
-    units = speech.units if speech is not None else [[] for _ in shard]
-    all_units = all_gather_ragged_ids(units, translator.device)
-    return texts, speech, all_units
+    texts: List[str] = []
+    speech = None
+    text_ids: List[List[int]] = []
+    units: List[List[int]] = []
+    if len(shard) > 0:
+        n = max(int(w.numel()) for w in shard)
+        wav = torch.zeros(len(shard), n, dtype=torch.float32)
+        for i, w in enumerate(shard):
+            wav[i, : w.numel()] = w.reshape(-1)
+        model = translator.model
+        fb, frames = model.fbank(wav.to(translator.device), [int(w.numel()) for w in shard])
+        src = {"seqs": fb, "seq_lens": torch.tensor(frames.astype(np.int64)), "is_ragged": len(set(frames.tolist())) > 1}
+        texts, speech = translator.predict(src, task_str, tgt_lang, **predict_kwargs)
+        text_ids = [list(t) for t in translator.last_text_ids]
+        units = speech.units if speech is not None else [[] for _ in shard]
+    all_text, all_units = all_gather_ragged_lists([text_ids, units], translator.device)
+    return texts, speech, all_text, all_units
 
 
 class MicroBatcher:

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from seamless_communication_amd.distributed import all_gather_ragged_ids, shard_range
+from seamless_communication_amd.distributed import all_gather_ragged_ids, all_gather_ragged_lists, predict_batch_dp, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -27,6 +27,28 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+class _FakeTranslator:
+    """The surface predict_batch_dp uses: model.fbank, predict, last_text_ids, device."""
+
+    device = torch.device("cpu")
+
+    class _M:
+        def fbank(self, wav, ns):
+            import numpy as np
+
+            return torch.zeros(wav.shape[0], 4, 80), np.asarray([4] * wav.shape[0])
+
+    model = _M()
+    last_text_ids = []
+
+    def predict(self, src, task, lang, **kw):
+        from seamless_communication_amd.inference import BatchedSpeechOutput
+
+        n = src["seqs"].shape[0]
+        self.last_text_ids = [[3, 7, 800] for _ in range(n)]
+        return ["t"] * n, BatchedSpeechOutput(units=[[5, 5] for _ in range(n)], audio_wavs=[torch.zeros(1, 1, 8)] * n)
+
+
 def _worker(rank: int, world: int, port: int, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,6 +62,17 @@ def _worker(rank: int, world: int, port: int, q):
         lo, hi = shard_range(len(few), rank, world)
         got2 = all_gather_ragged_ids(few[lo:hi], torch.device("cpu"))
         q.put((rank, got2 == few, got2))
+        # text ids and unit ids of every utterance in one collective
+        text = [[3, 256000 + i] + list(range(i % 4)) for i in range(5)]
+        units = [[100 * i + k for k in range(3 * i)] for i in range(5)]
+        lo, hi = shard_range(5, rank, world)
+        gt, gu = all_gather_ragged_lists([text[lo:hi], units[lo:hi]], torch.device("cpu"))
+        q.put((rank, gt == text and gu == units, (gt, gu)))
+        # predict_batch_dp with fewer utterances than ranks: rank 1's shard is empty and it must neither crash nor hang
+        tr = _FakeTranslator()
+        texts, speech, all_text, all_units = predict_batch_dp(tr, [torch.ones(800)], "S2ST", "fra")
+        ok = all_text == [[3, 7, 800]] and all_units == [[5, 5]] and (len(texts) == (1 if rank == 0 else 0))
+        q.put((rank, ok, (texts, all_text, all_units)))
     finally:
         dist.destroy_process_group()
 
@@ -52,7 +85,7 @@ def test_all_gather_ragged_ids_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=100) for _ in range(4)]
+    results = [q.get(timeout=100) for _ in range(8)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
