@@ -216,6 +216,17 @@ int sc_vocode(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, c
  * the padded batch while the padding itself is not synthesised.  Samples behind that window read as zero. */
 int sc_vocode_ragged(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, const int32_t* h_unit_lens,
                      const int32_t* h_lang_idx, const int32_t* h_spkr_idx, float* d_wav);
+/* The whole speech-to-speech chain of Translator.predict(fbank SequenceData, "S2ST") in one call (inference/translator.py:
+ * 304-428 without the string conversions): sc_encode_speech -> sc_generate_text -> sc_t2u_nar -> sc_vocode_ragged on
+ * buffers the library owns.  d_fbank [n][t_frames][80] on the device; h_text_ids [n][text_cap] (pad filled, text_cap >=
+ * sc_text_max_len(opts with source_len = t_frames)), h_text_lens [n]; h_units [n][unit_cap] (pad = unit_pad_idx) and
+ * h_unit_lens [n]; d_wav [n][unit_cap * hop] on the device, row i valid up to h_unit_lens[i] * hop samples (what the
+ * proportional trim of translator.py:411-419 keeps at most), zero behind.  *out_s_unit_max = the batch's longest unit
+ * sequence (the reference's padded width, needed for that trim).  SC_ERR_* when a capacity is too small. */
+int sc_s2st(sc_model* m, const float* d_fbank, int32_t n, int32_t t_frames, const int32_t* h_frame_lens, const sc_gen_opts* opts,
+            const int32_t* h_prefix, int32_t prefix_len, float duration_factor, const int32_t* h_lang_idx, const int32_t* h_spkr_idx,
+            int32_t* h_text_ids, int32_t text_cap, int32_t* h_text_lens, int32_t* h_units, int32_t unit_cap, int32_t* h_unit_lens,
+            float* d_wav, int32_t* out_s_unit_max);
 /* Unit rows the last sc_t2u_nar call computed in its length buckets / would have computed padded to the batch maximum,
  * and the unit frames the last sc_vocode* call computed (measurement: padding is not useful work). */
 int sc_last_padding(sc_model* m, int64_t* t2u_rows_computed, int64_t* t2u_rows_padded, int64_t* vocoder_rows_computed);

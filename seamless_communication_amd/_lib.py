@@ -103,6 +103,7 @@ SIGNATURES = {
     "sc_vocode": (C.c_int, [_P, _P, _i, _i, _P, _P, _P]),
     "sc_vocode_ragged": (C.c_int, [_P, _P, _i, _i, _P, _P, _P, _P]),
     "sc_last_padding": (C.c_int, [_P, _P, _P, _P]),
+    "sc_s2st": (C.c_int, [_P, _P, _i, _i, _P, C.POINTER(sc_gen_opts), _P, _i, C.c_float, _P, _P, _P, _i, _P, _P, _i, _P, _P, _P]),
     "sc_prof_enable": (C.c_int, [C.c_int]),
     "sc_prof_reset": (C.c_int, []),
     "sc_prof_report": (C.c_int64, [C.c_char_p, C.c_int64]),

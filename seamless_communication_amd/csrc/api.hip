@@ -253,6 +253,57 @@ int sc_vocode_ragged(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_u
     SC_API_END
 }
 
+int sc_s2st(sc_model* m, const float* d_fbank, int32_t n, int32_t t_frames, const int32_t* h_frame_lens, const sc_gen_opts* opts,
+            const int32_t* h_prefix, int32_t prefix_len, float duration_factor, const int32_t* h_lang_idx, const int32_t* h_spkr_idx,
+            int32_t* h_text_ids, int32_t text_cap, int32_t* h_text_lens, int32_t* h_units, int32_t unit_cap, int32_t* h_unit_lens,
+            float* d_wav, int32_t* out_s_unit_max) {
+    SC_API_BEGIN
+    SC_CHECK(m && d_fbank && h_frame_lens && opts && h_prefix && h_lang_idx && h_spkr_idx && h_text_ids && h_text_lens && h_units &&
+                 h_unit_lens && d_wav,
+             "sc_s2st: null argument");
+    Model& M = m->m;
+    SC_HIP(hipSetDevice(M.device));
+    const int D = M.cfg.model_dim;
+    // speech encoder
+    const int s_enc = encoder_out_len(M, t_frames);
+    Buf<float> enc(&M.pool, (size_t)n * s_enc * D);
+    std::vector<int32_t> enc_lens(n);
+    run_encode_speech(M, d_fbank, n, t_frames, h_frame_lens, enc, enc_lens.data());
+    // text generation (the soft length rule refers to the fbank frames unless the caller says otherwise)
+    sc_gen_opts o = *opts;
+    if (o.source_len <= 0) o.source_len = t_frames;
+    const int max_len = text_max_len(M, o, s_enc);
+    SC_CHECK(text_cap >= max_len, "sc_s2st: text_cap %d < effective maximum text length %d (sc_text_max_len)", text_cap, max_len);
+    std::vector<int32_t> ids((size_t)n * max_len), lens(n);
+    Buf<float> hidden(&M.pool, (size_t)n * (max_len - 1) * D);
+    run_generate_text(M, enc, n, s_enc, enc_lens.data(), o, h_prefix, prefix_len, ids.data(), lens.data(), nullptr, hidden, nullptr, 0);
+    // generator.py:281-291: the last column is trimmed, every length shrinks by one
+    std::vector<int32_t> text_seqs((size_t)n * (max_len - 1)), text_lens(n);
+    for (int b = 0; b < n; ++b) {
+        std::copy(ids.begin() + (size_t)b * max_len, ids.begin() + (size_t)b * max_len + max_len - 1, text_seqs.begin() + (size_t)b * (max_len - 1));
+        text_lens[b] = lens[b] - 1;
+        for (int t = 0; t < text_cap; ++t) h_text_ids[(size_t)b * text_cap + t] = t < max_len ? ids[(size_t)b * max_len + t] : M.cfg.pad_idx;
+        h_text_lens[b] = lens[b];
+    }
+    // NAR text-to-unit
+    int32_t su = 0, sc_ = 0;
+    run_t2u_nar(M, hidden, n, max_len - 1, text_lens.data(), text_seqs.data(), duration_factor, h_unit_lens, &su, &sc_);
+    SC_CHECK(su <= unit_cap, "sc_s2st: %d units exceed unit_cap %d", su, unit_cap);
+    for (int b = 0; b < n; ++b)
+        for (int t = 0; t < unit_cap; ++t) h_units[(size_t)b * unit_cap + t] = t < su ? M.last_units[(size_t)b * su + t] : M.cfg.unit_pad_idx;
+    // vocoder on the padded unit matrix, only what the proportional trim keeps is synthesised; rows land at the caller's stride
+    int hop = 1;
+    for (int i = 0; i < M.cfg.voc_num_upsamples; ++i) hop *= M.cfg.voc_upsample_rates[i];
+    Buf<float> wav(&M.pool, (size_t)n * su * hop);
+    run_vocode(M, M.last_units.data(), n, su, h_lang_idx, h_spkr_idx, wav, h_unit_lens);
+    SC_HIP(hipMemsetAsync(d_wav, 0, (size_t)n * unit_cap * hop * sizeof(float), M.stream));
+    SC_HIP(hipMemcpy2DAsync(d_wav, (size_t)unit_cap * hop * sizeof(float), wav.get(), (size_t)su * hop * sizeof(float),
+                            (size_t)su * hop * sizeof(float), n, hipMemcpyDeviceToDevice, M.stream));
+    SC_HIP(hipStreamSynchronize(M.stream));
+    if (out_s_unit_max) *out_s_unit_max = su;
+    SC_API_END
+}
+
 int sc_last_padding(sc_model* m, int64_t* t2u_rows_computed, int64_t* t2u_rows_padded, int64_t* vocoder_rows_computed) {
     SC_API_BEGIN
     SC_CHECK(m, "sc_last_padding: null handle");

@@ -319,6 +319,29 @@ class HipS2STModel:
             check(self.lib.sc_vocode_ragged(self.handle, _ptr(u), n, s_u, _ptr(ul), _ptr(li), _ptr(si), _ptr(wav)), "sc_vocode_ragged")
         return wav
 
+    def s2st(self, fbank: torch.Tensor, frame_lens: Sequence[int], prefix: Sequence[int], lang_idx: Sequence[int],
+             spkr_idx: Sequence[int], unit_cap: int, duration_factor: float = 1.0, **gen_kwargs):
+        """``sc_s2st``: the whole chain in one library call.  -> (text ids (n, max_len), text lens, units (n, unit_cap),
+        unit lens, wav (n, 1, unit_cap * hop) valid up to unit_lens * hop, longest unit sequence)."""
+        assert fbank.is_cuda and fbank.dtype == torch.float32 and fbank.is_contiguous() and fbank.dim() == 3
+        n, T, _ = fbank.shape
+        o = self._gen_opts(gen_kwargs.pop("beam_size", 1), gen_kwargs.pop("soft_max_seq_len", (1, 200)),
+                           gen_kwargs.pop("hard_max_seq_len", 1024), gen_kwargs.pop("min_seq_len", 1), gen_kwargs.pop("unk_penalty", 0.0),
+                           gen_kwargs.pop("use_graph", True), source_len=T, **gen_kwargs)
+        max_len = self.lib.sc_text_max_len(self.handle, C.byref(o), self.lib.sc_encoder_out_len(self.handle, T))
+        ids = np.zeros((n, max_len), dtype=np.int32)
+        tlens = np.zeros(n, dtype=np.int32)
+        units = np.zeros((n, unit_cap), dtype=np.int32)
+        ulens = np.zeros(n, dtype=np.int32)
+        wav = torch.empty(n, 1, unit_cap * self.hop, dtype=torch.float32, device=self.device)
+        su = C.c_int32(0)
+        fl, pre, li, si = _i32(frame_lens), _i32(prefix), _i32(lang_idx), _i32(spkr_idx)
+        self._after_torch()
+        check(self.lib.sc_s2st(self.handle, _ptr(fbank), n, T, _ptr(fl), C.byref(o), _ptr(pre), len(pre), float(duration_factor),
+                               _ptr(li), _ptr(si), _ptr(ids), max_len, _ptr(tlens), _ptr(units), unit_cap, _ptr(ulens), _ptr(wav),
+                               C.byref(su)), "sc_s2st")
+        return ids, tlens, units, ulens, wav, su.value
+
     def last_padding(self) -> Dict[str, int]:
         """Unit rows computed by the last t2u_nar / vocode calls (length buckets) vs the padded batch."""
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)

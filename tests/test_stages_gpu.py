@@ -363,3 +363,27 @@ def test_soft_length_rule_uses_the_source_length(env):
     for source_len, s_enc, want in ((0, 13, min(13 + 5, 200)), (100, 13, min(100 + 5, 200)), (1000, 13, 200)):
         o = hip._gen_opts(1, (1, 5), 200, 1, 0.0, True, source_len=source_len)
         assert hip.lib.sc_text_max_len(hip.handle, C.byref(o), s_enc) == min(want, cfg.text_max_seq_len)
+
+
+def test_sc_s2st_one_call_equals_the_staged_calls(env):
+    """sc_s2st (the fused convenience entry of SURVEY section 8b) returns what the four staged calls return."""
+    from oracle import vocoder as ov
+
+    cfg, tt, ct, orc, hip = env
+    ws = common.waves((1.6, 0.9, 1.2))
+    wav, ns = common.pad_waves(ws)
+    fb, frames = hip.fbank(torch.from_numpy(wav).cuda(), ns)
+    prefix = tt.target_prefix("fra")
+    lang_idx, spkr_idx = ov.resolve_lang_spkr(orc.lang_spkr_idx_map, ["fra"] * 3, [-1] * 3)
+    enc, enc_lens = hip.encode_speech(fb, frames.tolist())
+    ids, out_lens, _, hidden = hip.generate_text(enc, enc_lens.tolist(), prefix, hard_max_seq_len=14, source_len=fb.shape[1])
+    units, ulens, _, _, _ = hip.t2u_nar(hidden, ids[:, :-1].copy(), (out_lens - 1).tolist(), 1.0)
+    wav_ref = hip.vocode(units, lang_idx, spkr_idx, ulens)
+    ids2, tl2, units2, ul2, wav2, su = hip.s2st(fb, frames.tolist(), prefix, lang_idx, spkr_idx, unit_cap=units.shape[1] + 7, hard_max_seq_len=14)
+    assert su == units.shape[1] and ids2.tolist() == ids.tolist() and tl2.tolist() == out_lens.tolist() and ul2.tolist() == ulens.tolist()
+    assert units2[:, :su].tolist() == units.tolist() and (units2[:, su:] == cfg.unit_pad_idx).all()
+    for b in range(3):
+        k = int(ulens[b]) * hip.hop
+        assert torch.equal(wav2[b, :, :k], wav_ref[b, :, :k])
+    with pytest.raises(Exception, match="unit_cap"):
+        hip.s2st(fb, frames.tolist(), prefix, lang_idx, spkr_idx, unit_cap=3, hard_max_seq_len=14)
