@@ -508,7 +508,9 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
             const int j = j0 + 4 * i + g;
             float4 vv = vreg[i];
             if (!CROSS && j == pos) vv = vn;
-            if (CROSS && j >= kv_len) vv = zero;  // a masked row may hold anything finite or not: keep it out of the sum
+            // a masked key's value row may hold anything (cross: a padded encoder position; self: the clamped re-read of
+            // row `pos`, which is uninitialised memory until this launch appends it): 0 * NaN would poison the sum
+            if (j >= kv_len) vv = zero;
             const float e = expf(sc[i] - m_new);  // exp(-inf) = 0 for masked keys
             ls += e;
             a4.x = fmaf(e, vv.x, a4.x);

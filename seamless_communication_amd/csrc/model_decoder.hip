@@ -7,6 +7,7 @@
 //   inference/generator.py:281-299           teacher-forced second decoder pass
 // Step rules restated from ggml/examples/unity/fairseq2.cpp:1097-1126 (max length),
 // :1269-1305 (_tweak_lprobs), :1463-1594 (step loop).
+#include <cstdlib>
 #include <mutex>
 
 #include "model.h"

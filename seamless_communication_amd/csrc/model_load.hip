@@ -3,6 +3,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <cstdlib>
+
 #include "model.h"
 
 namespace sc {
@@ -14,14 +16,36 @@ DevicePool::~DevicePool() { release_all(); }
 // large.  Workloads whose shapes keep growing (a streaming session re-encodes an ever longer source) leave a trail of
 // too-small blocks behind: when the device runs out of memory the cache is dropped and the allocation retried.  (No
 // proactive limit: a steady-state batch keeps tens of GB cached on purpose, and trimming that would re-malloc every pass.)
+// SC_DEBUG_FILL=<byte> (debugging / the GPU test suite sets 0xff = NaN patterns): every block handed out is filled with
+// that byte first, so that a kernel which reads scratch memory nobody wrote fails deterministically instead of depending on
+// what the block held before.  The fill is a device-wide synchronisation: never set it when timing.
+static int debug_fill_byte() {
+    static const int v = [] {
+        const char* e = getenv("SC_DEBUG_FILL");
+        return e && *e ? (int)strtol(e, nullptr, 0) & 0xff : -1;
+    }();
+    return v;
+}
+
+static void* debug_filled(void* p, size_t bytes) {
+    const int v = debug_fill_byte();
+    if (v >= 0 && p) {
+        (void)hipDeviceSynchronize();  // a recycled block may still be read by launches in flight
+        (void)hipMemset(p, v, bytes);
+        (void)hipDeviceSynchronize();
+    }
+    return p;
+}
+
 void* DevicePool::get(size_t bytes) {
     bytes = (size_t)align_up((int64_t)std::max<size_t>(bytes, 256), 256);
     auto it = free_.lower_bound(bytes);
     if (it != free_.end() && it->first <= bytes * 2 + (1 << 20)) {
         void* p = it->second;
+        const size_t have = it->first;
         cached_bytes_ -= it->first;
         free_.erase(it);
-        return p;
+        return debug_filled(p, have);
     }
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) {
@@ -30,7 +54,7 @@ void* DevicePool::get(size_t bytes) {
         SC_HIP(hipMalloc(&p, bytes));
     }
     size_[p] = bytes;
-    return p;
+    return debug_filled(p, bytes);
 }
 
 void DevicePool::put(void* p) {

@@ -144,13 +144,19 @@ def test_dstep_self_attention(lib, report_dir, nb, heads, cap, pos, S):
 
     w = (hd(q[:, None]) @ hd(kr[:, : pos + 1]).transpose(-1, -2)) * 0.125
     ref = (torch.softmax(w, -1) @ hd(vr[:, : pos + 1])).transpose(1, 2).reshape(nb, M)
-    d_k, d_v = dev(kc), dev(vc)
+    # rows from `pos` on are uninitialised memory in the product (the step appends row `pos` itself): NaN there must
+    # not reach the result (regression: the clamped re-read of row `pos` once entered the value sum as 0 * NaN)
+    kc_in, vc_in = kc.clone(), vc.clone()
+    kc_in[:, pos:] = float("nan")
+    vc_in[:, pos:] = float("nan")
+    d_k, d_v = dev(kc_in), dev(vc_in)
     out = torch.full((nb, M), float("nan"), device="cuda")
     check(lib, lib.sc_op_dstep_attention(P(dev(proj)), S, P(dev(bias)), P(d_k), P(d_v), cap, pos, P(None), 0, nb, heads, P(out)))
+    assert not torch.isnan(out).any()
     err = float((out.cpu().double() - ref).abs().max())
     # the cache rows: `pos` holds the new row (fp32 of the partial sums), every other row is untouched
-    ek = float((d_k.cpu().double() - kr).abs().max())
-    ev = float((d_v.cpu().double() - vr).abs().max())
+    ek = float((d_k.cpu().double()[:, : pos + 1] - kr[:, : pos + 1]).abs().max())
+    ev = float((d_v.cpu().double()[:, : pos + 1] - vr[:, : pos + 1]).abs().max())
     _log(report_dir, "dstep_self_attention", nb=nb, heads=heads, cap=cap, pos=pos, err=err, ek=ek, ev=ev)
     assert err < 2e-5 and ek < 1e-5 and ev < 1e-5
 
@@ -175,8 +181,11 @@ def test_dstep_cross_attention(lib, report_dir, nb, heads, s_enc, lens, S):
     mask = torch.arange(s_enc)[None, :] < torch.tensor(lens)[:, None]
     w = w.masked_fill(~mask[:, None, None, :], float("-inf"))
     ref = (torch.softmax(w, -1) @ hd(v)).transpose(1, 2).reshape(nb, M)
+    kv_in = kv.clone()
+    for b, l in enumerate(lens):  # keys behind a row's length are masked: whatever they hold must not matter
+        kv_in[b, l:] = float("nan")
     out = torch.full((nb, M), float("nan"), device="cuda")
-    check(lib, lib.sc_op_dstep_attention(P(dev(proj)), S, P(dev(bias)), P(dev(kv)), P(None), s_enc, 0,
+    check(lib, lib.sc_op_dstep_attention(P(dev(proj)), S, P(dev(bias)), P(dev(kv_in)), P(None), s_enc, 0,
                                          P(dev(torch.tensor(lens, dtype=torch.int32))), 1, nb, heads, P(out)))
     err = float((out.cpu().double() - ref).abs().max())
     _log(report_dir, "dstep_cross_attention", nb=nb, heads=heads, s_enc=s_enc, err=err)
