@@ -64,7 +64,8 @@ def parse_args():
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement")
     ap.add_argument("--profile-single-stream", action="store_true",
                     help="run the HIP-event profiled pass as ONE slice on one stream instead of the timed micro-batch slicing "
-                         "(default: the profiled pass uses the slicing of the timed passes, so its kernel shapes are theirs)")
+                         "(default: the profiled pass runs the slices of the timed passes - same rows per slice, same kernel "
+                         "instantiations, graph replay - one after the other, so that per-launch durations do not overlap)")
     ap.add_argument("--no-graph", action="store_true", help="launch decoder steps eagerly instead of hipGraph replay")
     ap.add_argument("--free-run", action="store_true",
                     help="let the micro-batch slices free-run over the K steps (joined once) instead of joining them after "
@@ -288,9 +289,25 @@ def main():
     batcher = MicroBatcher(translator, min(args.microbatches, B))
     last = {}
 
-    def step(single_stream: bool = False):
+    def step(single_stream: bool = False, sequential_slices: bool = False):
         """One pass of the hot path over the per-GPU batch (fbank included)."""
-        if single_stream:
+        if sequential_slices:
+            # the slices of the timed passes (same rows per slice, same kernels, graph replay), one after the other instead
+            # of concurrently: per-launch HIP-event durations are then not stretched by a second slice sharing the chip
+            from seamless_communication_amd.distributed import shard_range
+
+            texts, units, wavs, text_ids = [], [], [], []
+            for i, view in enumerate(batcher.views):
+                lo, hi = shard_range(B, i, batcher.groups)
+                t, speech, ids, st = batcher._one(view, wav_dev[lo:hi].contiguous(), ns[lo:hi], "S2ST", "fra", {"text_generation_opts": opts})
+                texts += t
+                text_ids += ids
+                units += speech.units
+                wavs += speech.audio_wavs
+                if i == 0:
+                    stage_ms.clear()
+                    stage_ms.update(st)
+        elif single_stream:
             t0 = time.perf_counter()
             fb, frames = model.fbank(wav_dev, ns, standardize=True, pad_to_multiple=2)
             t1 = time.perf_counter()
@@ -395,13 +412,16 @@ def main():
         lib.sc_prof_enable(1)
         # the decoder step stays a replayed graph like in the timed passes: its launches cannot carry events, each
         # replay is one record ("dec:step_graph") with the step's algorithmic bytes
-        step(single_stream=args.profile_single_stream or batcher.groups == 1)
+        step(single_stream=args.profile_single_stream or batcher.groups == 1, sequential_slices=not args.profile_single_stream and batcher.groups > 1)
         torch.cuda.synchronize()
         lib.sc_prof_enable(0)
         fams = prof_report(lib)
         log("profiled step done")
         if rank == 0:
             roof, shares = roofline_of(fams)
+            if roof is not None:
+                roof["profiled_pass"] = ("one slice, one stream" if (args.profile_single_stream or batcher.groups == 1) else
+                                         f"the {batcher.groups} slices of the timed passes run one after the other (un-overlapped launch durations)")
             result["roofline"] = roof
             result["kernel_families_profiled_step"] = shares
             result["stage_ms_profiled_step"] = {k: round(v, 3) for k, v in stage_ms.items()}
