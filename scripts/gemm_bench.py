@@ -69,8 +69,11 @@ CONV = [  # (nb, T, cin, cout, k, stride, pad, dil, in_act)
 ]
 
 QUICK = "--quick" in sys.argv
+PS_ONLY = "--presplit-only" in sys.argv
 if QUICK:
-    LINEAR = [(7984, 4096, 1024), (7984, 1024, 4096), (7984, 1024, 1024), (8320, 8192, 1024), (31936, 4096, 1024)]
+    # the encoder's products for a 32-utterance slice (15968 rows) and for 64 utterances
+    LINEAR = [(15968, 4096, 1024), (15968, 1024, 4096), (15968, 3072, 1024), (15968, 2048, 1024), (15968, 1024, 1024),
+              (31936, 4096, 1024), (31936, 1024, 4096), (31936, 1024, 1024)]
     CONV = [(16, 520, 1024, 1024, 7, 1, 3, 1, 0), (16, 2600, 256, 256, 11, 1, 25, 5, 1)]
 def timed_presplit(fn, reps=6):
     fn()
@@ -91,9 +94,10 @@ for M, N, K in LINEAR:
     b = torch.randn(N, device="cuda")
     y = torch.empty(M, N, device="cuda")
     torch.cuda.synchronize()
-    show(f"linear M={M} N={N} K={K}", timed(lambda: lib.sc_op_linear(P(x), P(w), P(b), None, P(y), M, N, K, 0, 1.0, 1, 0)))
+    if not PS_ONLY:
+        show(f"linear M={M} N={N} K={K}", timed(lambda: lib.sc_op_linear(P(x), P(w), P(b), None, P(y), M, N, K, 0, 1.0, 1, 0)))
     show(f"linear M={M} N={N} K={K}", timed_presplit(lambda: lib.sc_op_linear_presplit(P(x), P(w), P(b), None, P(y), None, None, M, N, K, 0, 1.0)))
-for nb, T, cin, cout, k, stride, pad, dil, in_act in CONV:
+for nb, T, cin, cout, k, stride, pad, dil, in_act in ([] if PS_ONLY else CONV):
     x = torch.randn(nb, T, cin, device="cuda")
     wp = (torch.randn(cout, cin * k, device="cuda") / math.sqrt(cin * k)).half()
     b = torch.randn(cout, device="cuda")

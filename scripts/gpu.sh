@@ -11,6 +11,7 @@
 #   dstep        scripts/dstep_bench.py (decoder step timing per batch size)         dtrace   kernel trace of it + gap analysis
 #   chain        scripts/chain_bench.py (each decoder-step kernel as a dependent chain in a replayed graph)
 #   micro        every scripts/micro/*.hip compiled with hipcc and run
+#   pstest       GEMM op tests (bit identity of the kernel variants)       gemmab   scripts/gemm_bench.py at SC_PS_TILE=128 / 256
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -80,6 +81,12 @@ for task in "$@"; do
         b=/tmp/$(basename $src .hip)
         ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $src -o $b && timeout 120 $b > ${O}_micro_$(basename $src .hip).txt 2>&1 ); head -40 ${O}_micro_$(basename $src .hip).txt
       done ;;
+    pstest)
+      ( timeout 400 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "presplit or gemm" > ${O}_pytest_ps.log 2>&1; echo "pytest exit $?" >> ${O}_pytest_ps.log )
+      grep -E "^FAILED|^ERROR|passed|failed|^E  |exit" ${O}_pytest_ps.log | head -20 ;;
+    gemmab)
+      # pre-split GEMM: round-1 tile choice (128 x 128) against the 8-wave 256 x 256 tile, encoder shapes
+      for t in 128 256; do ( SC_PS_TILE=$t timeout 200 python scripts/gemm_bench.py --quick --presplit-only > ${O}_gemm_tile$t.txt 2>&1 ); grep presplit ${O}_gemm_tile$t.txt | cut -c1-170; done ;;
     *) echo "unknown task $task" ;;
   esac
 done

@@ -18,6 +18,7 @@
 //   * rows beyond M / N get an out-of-range buffer offset and arrive as zeros;
 //   * same MFMA order as the other kernels: per 16-wide K chunk and fragment pair, hi then lo.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -119,21 +120,27 @@ __device__ __forceinline__ void ps_epilogue(const GemmPsArgs& p, const float* ep
 // the block form the matrix pipe of the SIMD idles through them unless the other resident workgroup happens to be in its
 // compute phase.  Same instructions, same arithmetic order: bit-identical results.
 // SPLIT = false (measurement only, SC_SPLIT_MODE): the lo plane is neither fetched nor multiplied - A rounded to fp16 once.
-template <int BM, int BN, bool ILV, bool SPLIT>
-__global__ __launch_bounds__(256) void gemm_ps_kernel(GemmPsArgs p, int tiles_n, int tiles_total, int tiles_per_xcd,
-                                                      uint32_t a_bytes, uint32_t w_bytes) {
-    constexpr int WM = BM / 2, WN = BN / 2;  // 2 x 2 waves
+// WGM x WGN waves per workgroup.  2 x 2 waves on a 128 x 128 (64 x 64) tile is the round-1 shape; 4 x 2 waves on a
+// 256 x 256 tile (wave tile 64 x 128) halves the barriers per MFMA (32 matrix instructions per slab and wave instead of
+// 16) and takes the fragment reads from 0.75 to 0.5 ds_read_b128 per MFMA at the same 6 DMAs per wave and slab; its
+// three stages fill 144 KB of the 160 KB LDS (one workgroup of 8 waves per CU = the same 2 waves per SIMD).
+template <int BM, int BN, int WGM, int WGN, bool ILV, bool SPLIT>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, int tiles_n, int tiles_total, int tiles_per_xcd,
+                                                                 uint32_t a_bytes, uint32_t w_bytes) {
+    constexpr int NWAVE = WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int ACH = BM / 64;  // 1 KB chunks (16 rows) of the A tile per wave
-    constexpr int BCH = BN / 64;
+    constexpr int ACH = BM / (16 * NWAVE);  // 1 KB chunks (16 rows) of the A tile per wave
+    constexpr int BCH = BN / (16 * NWAVE);
     constexpr uint32_t OOB = 0x80000000u;
     constexpr int A_TILE = BM * 32, B_TILE = BN * 32;  // halfs per stage
 
     // three stages of [A_hi | A_lo | W] tiles; after the K loop the same memory holds one fp32 tile per wave for the
     // transposed (row-major, 16 bytes per lane) epilogue
     constexpr int STAGE_BYTES = (2 * A_TILE + B_TILE) * 2;
-    constexpr int EP_LD = WN + 4;  // floats per row of a wave's epilogue tile
-    static_assert(4 * WM * EP_LD * 4 <= 3 * STAGE_BYTES, "epilogue tiles must fit in the stage memory");
+    constexpr int EPN = WN < 64 ? WN : 64;  // columns of a wave's tile that go through LDS per epilogue pass
+    constexpr int EP_LD = EPN + 4;          // floats per row of a wave's epilogue tile
+    static_assert(NWAVE * WM * EP_LD * 4 <= 3 * STAGE_BYTES, "epilogue tiles must fit in the stage memory");
     __shared__ __attribute__((aligned(16))) char smem[3 * STAGE_BYTES];
     _Float16* const sAh0 = reinterpret_cast<_Float16*>(smem);
     _Float16* const sAl0 = sAh0 + A_TILE;
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_ps_kernel(GemmPsArgs p, int tiles_n,
     const int tm = tile / tiles_n;
     const int tn = tile - tm * tiles_n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const i32x4_t rah = make_rsrc_words(p.Ah, a_bytes);
@@ -323,21 +330,30 @@ __global__ __launch_bounds__(256) void gemm_ps_kernel(GemmPsArgs p, int tiles_n,
     __builtin_amdgcn_s_barrier();  // every wave is done reading the last stage
     asm volatile("" ::: "memory");
     float* ep = reinterpret_cast<float*>(smem) + wave * (WM * EP_LD);
+    const int m0w = m0 + wm * WM;
+    // the wave's tile leaves in passes of EPN columns through its private LDS region (the LDS queue of a wave is in
+    // order: a pass's writes follow the previous pass's reads)
+    auto pass = [&](auto hc) {  // compile-time pass number: the accumulator registers are indexed by constants
+        constexpr int h = decltype(hc)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < EPN / 32; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
-    const int m0w = m0 + wm * WM, n0w = n0 + wn * WN;
-    if (p.act == ACT_NONE) ps_epilogue<WM, WN, EP_LD, ACT_NONE>(p, ep, m0w, n0w, lane);
-    else if (p.act == ACT_RELU) ps_epilogue<WM, WN, EP_LD, ACT_RELU>(p, ep, m0w, n0w, lane);
-    else if (p.act == ACT_SILU) ps_epilogue<WM, WN, EP_LD, ACT_SILU>(p, ep, m0w, n0w, lane);
-    else ps_epilogue<WM, WN, EP_LD, ACT_TANH>(p, ep, m0w, n0w, lane);
+                for (int r = 0; r < 16; ++r)
+                    ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] = acc[i][h * (EPN / 32) + j][r];
+        const int n0w = n0 + wn * WN + h * EPN;
+        if (p.act == ACT_NONE) ps_epilogue<WM, EPN, EP_LD, ACT_NONE>(p, ep, m0w, n0w, lane);
+        else if (p.act == ACT_RELU) ps_epilogue<WM, EPN, EP_LD, ACT_RELU>(p, ep, m0w, n0w, lane);
+        else if (p.act == ACT_SILU) ps_epilogue<WM, EPN, EP_LD, ACT_SILU>(p, ep, m0w, n0w, lane);
+        else ps_epilogue<WM, EPN, EP_LD, ACT_TANH>(p, ep, m0w, n0w, lane);
+    };
+    static_assert(WN / EPN == 1 || WN / EPN == 2, "one or two epilogue passes");
+    pass(std::integral_constant<int, 0>{});
+    if constexpr (WN / EPN == 2) pass(std::integral_constant<int, 1>{});
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WGM, int WGN>
 void launch_ps_cfg(const GemmPsArgs& a, hipStream_t s) {
     const int tiles_m = cdiv(a.M, BM), tiles_n = cdiv(a.N, BN);
     const int tiles_total = tiles_m * tiles_n;
@@ -347,11 +363,11 @@ void launch_ps_cfg(const GemmPsArgs& a, hipStream_t s) {
     prof::Scope scope(name, 2.0 * a.M * (double)a.N * a.K,
                       4.0 * a.M * (double)a.K + 2.0 * a.N * (double)a.K + 4.0 * a.M * (double)a.N * (a.res ? 2.0 : 1.0), s);
     static const bool ilv = !(getenv("SC_PS_ILV") && atoi(getenv("SC_PS_ILV")) == 0);  // A/B switch (development)
-    const dim3 grid(tiles_per_xcd * 8);
+    const dim3 grid(tiles_per_xcd * 8), block(WGM * WGN * 64);
     const uint32_t ab = (uint32_t)((int64_t)a.M * a.lda * 2), wb = (uint32_t)((int64_t)a.N * a.ldw * 2);
-    if (!a.split) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, true, false>), grid, dim3(256), 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
-    else if (ilv) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, true, true>), grid, dim3(256), 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
-    else hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
+    if (!a.split) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
+    else if (ilv) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
+    else hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
 }
 
 }  // namespace
@@ -367,9 +383,15 @@ void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s) {
                  ((reinterpret_cast<uintptr_t>(a.Ch) | reinterpret_cast<uintptr_t>(a.Cl)) & 7) == 0,
              "presplit gemm: operands must be 16-byte aligned");
     SC_CHECK((int64_t)a.M * a.lda * 2 < (1ll << 31) && (int64_t)a.N * a.ldw * 2 < (1ll << 31), "presplit gemm: operand larger than 2 GB");
+    // tile choice: 256 x 256 (8 waves) once it fills the chip about once, 128 x 128 down to one round of 256 tiles,
+    // 64 x 64 below.  SC_PS_TILE=128 (development A/B) keeps the round-1 choice.  All three accumulate every output
+    // element in the same order (16-wide K chunks, hi then lo): identical bits.
+    static const int max_tile = getenv("SC_PS_TILE") ? atoi(getenv("SC_PS_TILE")) : 256;
     const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
-    if (tiles128 >= 256) launch_ps_cfg<128, 128>(a, s);
-    else launch_ps_cfg<64, 64>(a, s);
+    const int64_t tiles256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
+    if (max_tile >= 256 && tiles256 >= 224) launch_ps_cfg<256, 256, 4, 2>(a, s);
+    else if (tiles128 >= 256) launch_ps_cfg<128, 128, 2, 2>(a, s);
+    else launch_ps_cfg<64, 64, 2, 2>(a, s);
     SC_LAUNCH_CHECK();
 }
 

@@ -279,8 +279,10 @@ def test_fast_gemm_bit_identical_to_general_conv_transpose(lib, report_dir, nb, 
 
 
 PRESPLIT_SHAPES = [
-    (7984, 4096, 1024),  # 128x128 tiles, 32 slabs
-    (4100, 1024, 4096),  # ragged M
+    (7984, 4096, 1024),  # 256x256 tiles (8 waves), 32 slabs
+    (15968, 1024, 1024),  # 256x256 tiles, exactly one round of 252 tiles (the 32-utterance encoder slice)
+    (20011, 2000, 96),   # 256x256 tiles, ragged M and N, 3 slabs
+    (4100, 1024, 4096),  # 128x128 tiles, ragged M
     (20000, 2048, 96),   # 3 slabs
     (20000, 2048, 64),   # 2 slabs
     (20000, 2048, 32),   # 1 slab
