@@ -56,6 +56,7 @@ sc_model* sc_load(const sc_tensor_desc* tensors, size_t n_tensors, const sc_conf
         h->m.cfg = *cfg;
         h->m.device = device;
         SC_HIP(hipStreamCreateWithFlags(&h->m.stream, hipStreamNonBlocking));
+        h->m.pool.set_stream(h->m.stream);
         load_model(h->m, tensors, n_tensors);
         return h;
     } catch (const sc::Error&) {
@@ -74,6 +75,7 @@ sc_model* sc_fork(sc_model* parent) {
         h = new sc_model();
         static_cast<ModelData&>(h->m) = static_cast<const ModelData&>(parent->m);
         SC_HIP(hipStreamCreateWithFlags(&h->m.stream, hipStreamNonBlocking));
+        h->m.pool.set_stream(h->m.stream);
         return h;
     } catch (const sc::Error&) {
     } catch (const std::exception& e) {

@@ -419,6 +419,297 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------- //
+// attn_mfma16_kernel: the same transposed scheme on v_mfma_f32_32x32x16_f16 with every fp32 operand carried as two fp16
+// halves (hi = fp16(a), lo = fp16(a - hi), the split of the product kernels, kernels.h): a product a.b is the three
+// terms  a_hi.b_hi + a_hi.b_lo + a_lo.b_hi  accumulated in fp32 (the dropped a_lo.b_lo is 2^-22 of the product), i.e.
+// 12 matrix instructions of 32 cycles per 32 x 32 x 64 block instead of 32 fp32 ones of 64 cycles (5.3 x fewer matrix
+// cycles).  What changes against attn_mfma_kernel:
+//   * K tile in LDS as two fp16 planes [key][64 dims] (row stride 144 B: the 16 lanes of a ds_read_b128 group hit 16
+//     distinct 16-byte slots), A operand of S^T = K . Q^T: lane (key, half) reads dims 16c + 8 half .. + 7 of chunk c;
+//   * Q^T as 4 + 4 half8 registers per lane (hi, lo), loaded once;
+//   * V tile TRANSPOSED in LDS, two fp16 planes [dim][32 keys] (row stride 80 B), keys of a 16-chunk stored in the
+//     order the S^T accumulator registers hold them (register 8c + e of half h <-> key 16c + (e & 3) + 8 (e >> 2) + 4 h),
+//     so P^T = registers 8c .. 8c+7 converted to hi / lo IS the B operand of O^T += V^T . P^T, no data movement;
+//   * soft-max in the base-2 domain on v_exp_f32 (exp2 of (s - m) . log2 e);
+//   * the next K/V tile's global loads are issued before the current tile's arithmetic (register prefetch).
+// The q.R table of the Shaw term stays on the exact fp32 matrix instruction (once per workgroup).
+// ------------------------------------------------------------------------------------------------- //
+typedef _Float16 a16_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 a16_h4 __attribute__((ext_vector_type(4)));
+static constexpr int KH_LD = 72;  // halfs per K-plane row (64 dims + 8 pad)
+static constexpr int VT_LD = 40;  // halfs per V^T-plane row (32 keys + 8 pad)
+
+__device__ __forceinline__ void a16_split8(const float* x, a16_h8& hi, a16_h8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)x[e];
+        hi[e] = h;
+        lo[e] = (_Float16)(x[e] - (float)h);
+    }
+}
+
+template <bool SHAW>
+__global__ __launch_bounds__(256) void attn_mfma16_kernel(AttnArgs p) {
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // [0, 4*32*KS) floats: K/V planes during the loop (19 456 B), the four output tiles afterwards, the relative keys before
+    _Float16* sKh = reinterpret_cast<_Float16*>(smem);  // [32][KH_LD]
+    _Float16* sKl = sKh + MKV * KH_LD;
+    _Float16* sVh = sKl + MKV * KH_LD;  // [64][VT_LD]
+    _Float16* sVl = sVh + HD * VT_LD;
+    float* sQR = smem + 4 * 32 * KS;  // [MQ][npos]   (SHAW only)
+    float* sR = smem;                 // [npos][KS] staging of the relative keys before the loop
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const int q0 = blockIdx.x * MQ + wave * 32;
+    const int qi = q0 + ql;
+    const int kv_len = p.kv_lens ? min(p.kv_lens[n], p.Skv) : p.Skv;
+    const int shift = p.Skv - p.Sq;
+    const int qabs = qi + shift;
+    const int npos = p.rel_left + 1 + p.rel_right;
+    const bool qok = qi < p.Sq;
+    const float* qrow = p.q + ((int64_t)n * p.Sq + (qok ? qi : 0)) * p.ldq + h * HD;
+
+    if (SHAW) {
+        // (q.R)^T[e][query] = R . Q^T on the exact fp32 matrix instruction, as in attn_mfma_kernel
+        float qreg[32];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f4v v = {0.f, 0.f, 0.f, 0.f};
+            if (qok) v = *reinterpret_cast<const f4v*>(qrow + 8 * g + 4 * hh);
+            qreg[4 * g + 0] = v[0];
+            qreg[4 * g + 1] = v[1];
+            qreg[4 * g + 2] = v[2];
+            qreg[4 * g + 3] = v[3];
+        }
+        for (int idx = tid; idx < npos * (HD / 4); idx += 256) {
+            const int r = idx >> 4, c4 = idx & 15;
+            *reinterpret_cast<f4v*>(&sR[r * KS + c4 * 4]) = *reinterpret_cast<const f4v*>(p.rel_k + r * HD + c4 * 4);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int f = 0; f < 3; ++f) {
+            if (f * 32 >= npos) break;
+            f16v qr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qr[r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f4v r4 = *reinterpret_cast<const f4v*>(&sR[(f * 32 + ql) * KS + 8 * g + 4 * hh]);
+                qr = __builtin_amdgcn_mfma_f32_32x32x2f32(r4[0], qreg[4 * g + 0], qr, 0, 0, 0);
+                qr = __builtin_amdgcn_mfma_f32_32x32x2f32(r4[1], qreg[4 * g + 1], qr, 0, 0, 0);
+                qr = __builtin_amdgcn_mfma_f32_32x32x2f32(r4[2], qreg[4 * g + 2], qr, 0, 0, 0);
+                qr = __builtin_amdgcn_mfma_f32_32x32x2f32(r4[3], qreg[4 * g + 3], qr, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (e < npos) sQR[(wave * 32 + ql) * npos + e] = qr[r];
+            }
+        }
+    }
+
+    // Q^T operand: chunk c (dims 16c .. 16c+15), this lane's half holds dims 16c + 8 hh .. + 7
+    a16_h8 qh[4], qlo[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 0.f;
+        if (qok) {
+            const f4v v0 = *reinterpret_cast<const f4v*>(qrow + 16 * c + 8 * hh);
+            const f4v v1 = *reinterpret_cast<const f4v*>(qrow + 16 * c + 8 * hh + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[e] = v0[e];
+                x[4 + e] = v1[e];
+            }
+        }
+        a16_split8(x, qh[c], qlo[c]);
+    }
+
+    f16v o0, o1;  // O^T: dims 0..31 / 32..63 (rows) x queries (lanes)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        o0[r] = 0.f;
+        o1[r] = 0.f;
+    }
+    float m_i = -1e30f, l_i = 0.f;
+
+    int k_end = kv_len;
+    if (p.causal) k_end = min(k_end, (int)(blockIdx.x * MQ) + MQ - 1 + shift + 1);
+
+    // staging role of this thread: float4 pieces idx = tid, tid + 256 of the [32 keys][16 pieces] tile
+    const int sr0 = tid >> 4, sc4 = tid & 15;  // keys sr0 and sr0 + 16, dims 4 sc4 .. 4 sc4 + 3
+    f4v kf[2], vf[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = sr0 + 16 * u;
+            kf[u] = f4v{0.f, 0.f, 0.f, 0.f};
+            vf[u] = kf[u];
+            if (k0 + r < kv_len) {
+                const int64_t row = (int64_t)n * p.Skv + k0 + r;
+                kf[u] = *reinterpret_cast<const f4v*>(p.k + row * p.ldk + h * HD + sc4 * 4);
+                vf[u] = *reinterpret_cast<const f4v*>(p.v + row * p.ldv + h * HD + sc4 * 4);
+            }
+        }
+    };
+    if (k_end > 0) fetch(0);
+
+    for (int k0 = 0; k0 < k_end; k0 += MKV) {
+        __syncthreads();  // previous tile fully consumed (also orders the sQR writes before their first use)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = sr0 + 16 * u;
+            a16_h4 khi, klo, vhi, vlo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 a = (_Float16)kf[u][e];
+                khi[e] = a;
+                klo[e] = (_Float16)(kf[u][e] - (float)a);
+                const _Float16 b = (_Float16)vf[u][e];
+                vhi[e] = b;
+                vlo[e] = (_Float16)(vf[u][e] - (float)b);
+            }
+            *reinterpret_cast<a16_h4*>(&sKh[r * KH_LD + 4 * sc4]) = khi;
+            *reinterpret_cast<a16_h4*>(&sKl[r * KH_LD + 4 * sc4]) = klo;
+            // V^T: position of key r inside its 16-chunk = 8 * half + e with key = (e & 3) + 8 (e >> 2) + 4 half
+            const int w = r & 15;
+            const int pos = (r & 16) + 8 * ((w >> 2) & 1) + (w & 3) + 4 * (w >> 3);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sVh[(4 * sc4 + e) * VT_LD + pos] = vhi[e];
+                sVl[(4 * sc4 + e) * VT_LD + pos] = vlo[e];
+            }
+        }
+        if (k0 + MKV < k_end) fetch(k0 + MKV);  // in flight during this tile's arithmetic
+        __syncthreads();
+
+        // ---- Shaw terms of this tile, requested before the matrix instructions (they do not depend on them) and
+        // unconditionally: a load that is only needed under the key mask gets sunk into 16 exec-masked branches with a
+        // full LDS wait each.  Tiles that lie entirely left / right of the clamp window need one value per query.
+        float qr[16];
+        if (SHAW) {
+            const float* qrow_t = sQR + (wave * 32 + ql) * npos;
+            const int rel_max = k0 + (MKV - 1) - (q0 + shift);  // largest  key - query  over the wave's 32 x 32 block
+            const int rel_min = k0 - (q0 + 31 + shift);         // smallest
+            if (rel_max <= -p.rel_left) {
+                const float v = qrow_t[0];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) qr[r] = v;
+            } else if (rel_min >= p.rel_right) {
+                const float v = qrow_t[npos - 1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) qr[r] = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kj = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const int rel = max(-p.rel_left, min(p.rel_right, kj - qabs)) + p.rel_left;
+                    qr[r] = qrow_t[rel];
+                }
+            }
+        }
+        // ---- S^T = K . Q^T (rows = keys, lanes = queries): three terms per 16-wide chunk ------------------
+        f16v st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const a16_h8 kh = *reinterpret_cast<const a16_h8*>(&sKh[ql * KH_LD + 16 * c + 8 * hh]);
+            const a16_h8 kl = *reinterpret_cast<const a16_h8*>(&sKl[ql * KH_LD + 16 * c + 8 * hh]);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[c], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qlo[c], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[c], st, 0, 0, 0);
+        }
+        // ---- bias, scale, masks, online soft-max: register r of half hh is key (r&3) + 8*(r>>2) + 4*hh ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kj = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float sc = st[r];
+            if (SHAW) sc += qr[r];
+            const bool ok = (kj < kv_len) && (!p.causal || kj <= qabs);
+            sc = sc * 0.125f + (ok ? 0.f : -INFINITY);  // masked keys: finite + (-inf) (K rows behind the length are zeros)
+            st[r] = sc;
+            mx = fmaxf(mx, sc);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_i, mx);
+        constexpr float LOG2E = 1.44269504088896340736f;
+        const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * LOG2E);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f((st[r] - m_new) * LOG2E);
+            st[r] = pv;
+            rs += pv;
+        }
+        rs += __shfl_xor(rs, 32);
+        l_i = l_i * alpha + rs;
+        m_i = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // the running maximum moved for some query of the wave
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= alpha;
+                o1[r] *= alpha;
+            }
+        }
+        // ---- O^T += V^T . P^T: chunk c contracts the 16 keys that registers 8c .. 8c+7 of the two halves hold ----
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = st[8 * c + e];
+            a16_h8 ph, pl;
+            a16_split8(x, ph, pl);
+            const a16_h8 v0h = *reinterpret_cast<const a16_h8*>(&sVh[ql * VT_LD + 16 * c + 8 * hh]);
+            const a16_h8 v0l = *reinterpret_cast<const a16_h8*>(&sVl[ql * VT_LD + 16 * c + 8 * hh]);
+            const a16_h8 v1h = *reinterpret_cast<const a16_h8*>(&sVh[(32 + ql) * VT_LD + 16 * c + 8 * hh]);
+            const a16_h8 v1l = *reinterpret_cast<const a16_h8*>(&sVl[(32 + ql) * VT_LD + 16 * c + 8 * hh]);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, ph, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, ph, o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0h, pl, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1h, pl, o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0l, ph, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1l, ph, o1, 0, 0, 0);
+        }
+    }
+
+    // ---- O^T (dims x queries) -> this wave's [32 queries][64 dims] tile in LDS -> 16-byte row stores ----
+    __syncthreads();  // every wave is done with the K/V tiles
+    float* ot = smem + wave * (32 * KS);
+    const float inv = l_i > 0.f ? 1.0f / l_i : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        ot[ql * KS + d] = o0[r] * inv;
+        ot[ql * KS + 32 + d] = o1[r] * inv;
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const int c0 = (lane & 15) * 4;
+        const int qq = q0 + row;
+        const f4v of = *reinterpret_cast<const f4v*>(&ot[row * KS + c0]);
+        if (qq >= p.Sq) continue;
+        if (p.out_hi) {
+            const a16_h4 hi = __builtin_convertvector(of, a16_h4);
+            const f4v back = __builtin_convertvector(hi, f4v);
+            const int64_t off = ((int64_t)n * p.Sq + qq) * p.ldoh + h * HD + c0;
+            *reinterpret_cast<a16_h4*>(p.out_hi + off) = hi;
+            *reinterpret_cast<a16_h4*>(p.out_lo + off) = __builtin_convertvector(of - back, a16_h4);
+        } else {
+            *reinterpret_cast<f4v*>(p.out + ((int64_t)n * p.Sq + qq) * p.ldo + h * HD + c0) = of;
+        }
+    }
+}
+
 static bool g_attn_attr_set = false;
 
 void launch_attention(const AttnArgs& a, hipStream_t s) {
@@ -443,6 +734,10 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
             SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma16_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma16_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
             mfma_attr = true;
         }
         prof::Scope scope(a.rel_k ? "attention_shaw" : "attention", 4.0 * a.nb * a.heads * (double)a.Sq * a.Skv * HD,
@@ -451,8 +746,15 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         SC_CHECK(npos <= 96, "attention: relative table too large");
         if (a.rel_k) lds += (size_t)(MQ * npos) * sizeof(float);
         dim3 grid(cdiv(a.Sq, MQ), a.heads, a.nb);
-        if (a.rel_k) hipLaunchKernelGGL((attn_mfma_kernel<true>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((attn_mfma_kernel<false>), grid, dim3(256), lds, s, a);
+        // SC_ATTN_F32=1: the exact-fp32 matrix instruction (round 1) instead of the three-term fp16 split (development A/B)
+        static const bool f32_mfma = getenv("SC_ATTN_F32") && atoi(getenv("SC_ATTN_F32")) != 0;
+        if (f32_mfma) {
+            if (a.rel_k) hipLaunchKernelGGL((attn_mfma_kernel<true>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((attn_mfma_kernel<false>), grid, dim3(256), lds, s, a);
+        } else {
+            if (a.rel_k) hipLaunchKernelGGL((attn_mfma16_kernel<true>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((attn_mfma16_kernel<false>), grid, dim3(256), lds, s, a);
+        }
         SC_LAUNCH_CHECK();
         return;
     }

@@ -22,8 +22,12 @@ class DevicePool {
     void put(void* p);
     void release_all();
     void trim();  // hipFree every cached (not handed out) block
+    // the one stream every user of this pool's blocks launches on (the handle's): the SC_DEBUG_FILL fill is ordered on it
+    void set_stream(hipStream_t s) { stream_ = s; }
 
    private:
+    void* debug_filled(void* p, size_t bytes);
+    hipStream_t stream_ = nullptr;
     std::multimap<size_t, void*> free_;
     std::unordered_map<void*, size_t> size_;
     size_t cached_bytes_ = 0;  // bytes sitting in free_

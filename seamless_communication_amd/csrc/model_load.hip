@@ -18,7 +18,11 @@ DevicePool::~DevicePool() { release_all(); }
 // proactive limit: a steady-state batch keeps tens of GB cached on purpose, and trimming that would re-malloc every pass.)
 // SC_DEBUG_FILL=<byte> (debugging / the GPU test suite sets 0xff = NaN patterns): every block handed out is filled with
 // that byte first, so that a kernel which reads scratch memory nobody wrote fails deterministically instead of depending on
-// what the block held before.  The fill is a device-wide synchronisation: never set it when timing.
+// what the block held before.  The fill is an asynchronous memset on the pool's stream - the stream every launch that
+// touches the block is on - so it is ordered behind the previous user of a recycled block and ahead of the next one
+// without a device-wide synchronisation (a synchronous hipMemset on the legacy stream from one host thread invalidated
+// another handle's graph capture).  Blocks requested while the stream is capturing are not filled: the memset would
+// become a node of the graph.
 static int debug_fill_byte() {
     static const int v = [] {
         const char* e = getenv("SC_DEBUG_FILL");
@@ -27,12 +31,12 @@ static int debug_fill_byte() {
     return v;
 }
 
-static void* debug_filled(void* p, size_t bytes) {
+void* DevicePool::debug_filled(void* p, size_t bytes) {
     const int v = debug_fill_byte();
-    if (v >= 0 && p) {
-        (void)hipDeviceSynchronize();  // a recycled block may still be read by launches in flight
-        (void)hipMemset(p, v, bytes);
-        (void)hipDeviceSynchronize();
+    if (v >= 0 && p && stream_) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream_, &st) == hipSuccess && st == hipStreamCaptureStatusNone)
+            (void)hipMemsetAsync(p, v, bytes, stream_);
     }
     return p;
 }
