@@ -8,9 +8,11 @@
 //   penalty), + the beam's cumulative score, then the best K = 2*beam candidates over the flattened
 //   (beam, token) space (first step: beam 0 only), best first, ties to the lower flattened index.
 //   HBM traffic: each logit row is read three times (max, sum, scan), L2 resident (1 MB per row).
-//   Step processor (NGramRepeatBlockProcessor): the host passes, per row, the tokens that would complete
-//   an n-gram already in the row's sequence (CSR: ban_off / ban_tok); they are overwritten with -inf in the
-//   logit row AFTER the row's log-sum-exp is known, i.e. the log-probability is blocked, not renormalised.
+//   Step processor (NGramRepeatBlockProcessor): the tokens that would complete an n-gram already in the row's
+//   sequence (read from the device-resident sequence buffer) are overwritten with -inf in the logit row AFTER
+//   the row's log-sum-exp is known, i.e. the log-probability is blocked, not renormalised.
+// beam_select_kernel: the per-step candidate walk (finalise EOS hypotheses, refill the beams, append tokens);
+//   sequences, finished hypotheses and counters live in device memory, the host only polls `remaining`.
 // row_token_lprob_kernel: log-softmax value of ONE given token per row (scores of the echoed prompt).
 // gather_cache_kernel: K/V cache rows re-ordered by the surviving beams (all layers in one launch).
 #include "kernels.h"
@@ -45,8 +47,8 @@ __global__ __launch_bounds__(256) void beam_candidates_kernel(float* logits, int
                                                               const float* __restrict__ cum, int first_step, int no_eos,
                                                               int force_eos, int pad_idx, int eos_idx, int unk_idx,
                                                               float unk_penalty, int K, float* __restrict__ cand_val,
-                                                              int* __restrict__ cand_idx, const int* __restrict__ ban_off,
-                                                              const int* __restrict__ ban_tok) {
+                                                              int* __restrict__ cand_idx, const int* __restrict__ seqs,
+                                                              int seq_ld, int S, int G) {
     __shared__ float red[4];
     __shared__ float lse[BEAM_MAX_K];
     __shared__ float s_val[256];
@@ -65,11 +67,19 @@ __global__ __launch_bounds__(256) void beam_candidates_kernel(float* logits, int
         if (tid == 0) lse[b] = mx + logf(sm);
     }
     __syncthreads();
-    if (ban_off) {  // every thread is past its reads for the log-sum-exp (barrier above)
+    if (seqs && G > 0 && G < S) {  // every thread is past its reads for the log-sum-exp (barrier above)
+        // NGramRepeatBlockProcessor(G): every window seq[j .. j+G) whose first G-1 tokens equal the last G-1 tokens of the
+        // row's sequence (S tokens so far, prompt included) blocks its last token; G == 1 blocks every token of seq
         for (int b = 0; b < nb; ++b) {
             float* row = logits + ((int64_t)n * beams + b) * ld;
-            const int r = n * beams + b;
-            for (int i = ban_off[r] + tid; i < ban_off[r + 1]; i += 256) row[ban_tok[i]] = -INFINITY;
+            const int* seq = seqs + ((int64_t)n * beams + b) * seq_ld;
+            const int* tail = seq + S - (G - 1);
+            for (int j = tid; j + G <= S; j += 256) {
+                bool same = true;
+                for (int e = 0; e + 1 < G; ++e) same = same && (seq[j + e] == tail[e]);
+                const int t = seq[j + G - 1];
+                if (same && t >= 0 && t < V) row[t] = -INFINITY;
+            }
         }
         __syncthreads();
     }
@@ -162,6 +172,83 @@ __global__ __launch_bounds__(256) void row_token_lprob_kernel(const float* __res
     if (threadIdx.x == 0) out[blockIdx.x] = row[token] - (mx + logf(sm));
 }
 
+// beam_select_kernel: the candidate walk of one search step, one workgroup per utterance (the loop the host ran in
+// round 1: fairseq2.cpp:1463-1594 with fairseq2's EOS rule, see model_decoder.hip).  Thread 0 walks the K = 2 * beam
+// candidates (best first): an EOS candidate among the first `beam` ranks becomes a finished hypothesis (score
+// normalised by (step+1)^len_penalty), lower-ranked EOS candidates are dropped; the first `beam` other candidates
+// become the live beams.  Then the whole workgroup copies the sequences: finished hypotheses into their slots, the
+// surviving beams' rows from the current into the other sequence buffer with the new token appended.  Outputs for the
+// next step: token and source row per beam row (K/V re-order), cumulative scores.
+__global__ __launch_bounds__(256) void beam_select_kernel(BeamSelectArgs a) {
+    __shared__ int sh_beam[BEAM_MAX_K], sh_tok[BEAM_MAX_K], sh_fbeam[BEAM_MAX_K], sh_fslot[BEAM_MAX_K];
+    __shared__ float sh_sc[BEAM_MAX_K], sh_fscore[BEAM_MAX_K];
+    __shared__ int sh_nfin, sh_done;
+    const int u = blockIdx.x, tid = threadIdx.x, B = a.beams, K = a.K, step = a.step, L = a.max_len;
+    if (tid == 0) {
+        int done = a.done[u], nfin = 0;
+        if (!done) {
+            int count = a.fin_count[u], live = 0;
+            for (int i = 0; i < K && !done; ++i) {
+                const int cidx = a.cand_idx[(int64_t)u * K + i];
+                const float sc = a.cand_val[(int64_t)u * K + i];
+                const int beam = cidx / a.V, token = cidx - beam * a.V;
+                if (token == a.eos_idx && sc != -INFINITY) {
+                    if (i >= B) continue;  // fairseq2: an EOS candidate counts only among the top `beam` ranks
+                    sh_fbeam[nfin] = beam;
+                    sh_fslot[nfin] = count;
+                    sh_fscore[nfin] = a.normalize ? sc / powf((float)(step + 1), a.len_penalty) : sc;
+                    ++nfin;
+                    ++count;
+                    if (count == B) {
+                        done = 1;
+                        atomicSub(a.remaining, 1);
+                    }
+                    continue;
+                }
+                if (live < B) {
+                    sh_beam[live] = beam;
+                    sh_tok[live] = token;
+                    sh_sc[live] = sc;
+                    ++live;
+                }
+                if (live >= B) break;
+            }
+            a.fin_count[u] = count;
+            a.done[u] = done;
+            for (; live < B; ++live) {  // fewer live candidates than beams: dead copies of the first one
+                sh_beam[live] = live > 0 ? sh_beam[0] : 0;
+                sh_tok[live] = a.pad_idx;
+                sh_sc[live] = -INFINITY;
+            }
+        }
+        sh_nfin = nfin;
+        sh_done = done;
+    }
+    __syncthreads();
+    for (int f = 0; f < sh_nfin; ++f) {
+        const int* src = a.seqs_cur + (int64_t)(u * B + sh_fbeam[f]) * L;
+        int* dst = a.fin_seq + (int64_t)(u * B + sh_fslot[f]) * L;
+        for (int t = tid; t < L; t += 256) dst[t] = t <= step ? src[t] : (t == step + 1 ? a.eos_idx : a.pad_idx);
+        if (tid == 0) {
+            a.fin_len[u * B + sh_fslot[f]] = step + 2;
+            a.fin_score[u * B + sh_fslot[f]] = sh_fscore[f];
+        }
+    }
+    for (int b = 0; b < B; ++b) {
+        const int r = u * B + b;
+        // a finished utterance keeps running on its own rows (results ignored): token EOS, rows in place
+        const int sr = sh_done ? r : u * B + sh_beam[b];
+        const int* src = a.seqs_cur + (int64_t)sr * L;
+        int* dst = a.seqs_new + (int64_t)r * L;
+        for (int t = tid; t < L; t += 256) dst[t] = (!sh_done && t == step + 1) ? sh_tok[b] : src[t];
+        if (tid == 0) {
+            a.src_row[r] = sr;
+            a.tok[r] = sh_done ? a.eos_idx : sh_tok[b];
+            if (!sh_done) a.cum[r] = sh_sc[b];
+        }
+    }
+}
+
 // dst[l][r][t][:] = src[l][src_row[r]][t][:] for t < len; blockIdx = (t, r, l)
 __global__ __launch_bounds__(256) void gather_cache_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                            const int* __restrict__ src_row, int cap, int M, int64_t layer_stride) {
@@ -175,12 +262,18 @@ __global__ __launch_bounds__(256) void gather_cache_kernel(const float* __restri
 
 void launch_beam_candidates(float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step,
                             int no_eos, int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K,
-                            float* cand_val, int* cand_idx, const int* ban_off, const int* ban_tok, hipStream_t s) {
+                            float* cand_val, int* cand_idx, const int* seqs, int seq_ld, int S, int G, hipStream_t s) {
     SC_CHECK(K >= 1 && K <= BEAM_MAX_K && beams >= 1 && beams <= BEAM_MAX_K, "beam search: beam_size %d / K %d out of range (max %d candidates)",
              beams, K, BEAM_MAX_K);
     SC_CHECK((int64_t)beams * V < (1ll << 31) - 1, "beam search: beam * vocabulary overflows the candidate index");
     hipLaunchKernelGGL(beam_candidates_kernel, dim3(n_utt), dim3(256), 0, s, logits, ld, beams, V, cum, first_step, no_eos, force_eos,
-                       pad_idx, eos_idx, unk_idx, unk_penalty, K, cand_val, cand_idx, ban_off, ban_tok);
+                       pad_idx, eos_idx, unk_idx, unk_penalty, K, cand_val, cand_idx, seqs, seq_ld, S, G);
+    SC_LAUNCH_CHECK();
+}
+
+void launch_beam_select(const BeamSelectArgs& a, int n_utt, hipStream_t s) {
+    SC_CHECK(a.beams >= 1 && a.beams <= BEAM_MAX_K && a.K <= BEAM_MAX_K, "beam select: beam_size %d / K %d out of range", a.beams, a.K);
+    hipLaunchKernelGGL(beam_select_kernel, dim3(n_utt), dim3(256), 0, s, a);
     SC_LAUNCH_CHECK();
 }
 

@@ -265,10 +265,31 @@ void launch_decode_attention(const float* q, int64_t ldq, const float* k_new, co
                              const float* bias_k = nullptr, const float* bias_v = nullptr);
 
 // beam search (k_beam.hip)
-// ban_off [n_utt*beams+1] / ban_tok: per-row tokens blocked by the step processor (null = none); logits is modified
+// seqs [n_utt*beams][seq_ld] (nullable): the rows' sequences so far (S tokens) for the n-gram step processor (G = n-gram
+// size, 0 = off); logits is modified (blocked tokens)
 void launch_beam_candidates(float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step,
                             int no_eos, int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K,
-                            float* cand_val, int* cand_idx, const int* ban_off, const int* ban_tok, hipStream_t s);
+                            float* cand_val, int* cand_idx, const int* seqs, int seq_ld, int S, int G, hipStream_t s);
+// device-resident beam-search state of one sc_generate_text call (k_beam.hip: beam_select_kernel)
+struct BeamSelectArgs {
+    const float* cand_val = nullptr;  // [n][K] best first
+    const int* cand_idx = nullptr;    // [n][K] flattened beam * V + token
+    const int* seqs_cur = nullptr;    // [n*beams][max_len]
+    int* seqs_new = nullptr;
+    float* fin_score = nullptr;  // [n][beams]
+    int* fin_len = nullptr;      // [n][beams]
+    int* fin_seq = nullptr;      // [n][beams][max_len]
+    int* fin_count = nullptr;    // [n]
+    int* done = nullptr;         // [n]
+    int* remaining = nullptr;    // [1] utterances still searching
+    int* tok = nullptr;          // [n*beams] token fed at the next step
+    int* src_row = nullptr;      // [n*beams] row whose K/V cache the beam continues
+    float* cum = nullptr;        // [n*beams] cumulative scores
+    int beams = 0, K = 0, V = 0, max_len = 0, step = 0;
+    int eos_idx = 0, pad_idx = 0, normalize = 1;
+    float len_penalty = 1.f;
+};
+void launch_beam_select(const BeamSelectArgs& a, int n_utt, hipStream_t s);
 void launch_row_token_lprob(const float* logits, int64_t ld, int rows, int V, int row_stride, int token, float* out, hipStream_t s);
 void launch_gather_cache(const float* src, float* dst, const int* src_row, int rows, int len, int cap, int M, int layers,
                          int64_t layer_stride, hipStream_t s);

@@ -849,9 +849,10 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
 // restated from ggml/examples/unity/fairseq2.cpp:1371-1608 (see oracle/unity.py: beam_search_generate).
 // Row r = utterance * beam + b of every decoder buffer is one live beam.  Per step: decoder step for all
 // rows, vocabulary projection, beam_candidates_kernel (log-softmax + step rules + cumulative score +
-// best 2*beam candidates per utterance), then the host walks the candidates (finalise EOS hypotheses,
-// refill the beams), and the K/V caches are re-ordered on the device (double buffered, all layers in one
-// launch).  One host round trip per step; not graph-captured (the beam bookkeeping lives on the host).
+// best 2*beam candidates per utterance), beam_select_kernel (the candidate walk: finalise EOS hypotheses,
+// refill the beams, append the tokens - sequences and finished hypotheses stay in device memory), and the
+// K/V caches are re-ordered on the device (double buffered, all layers in one launch).  No host round trip
+// per step: the host polls the count of unfinished utterances every fourth step.
 // Step processor: NGramRepeatBlockProcessor(G) (fairseq2 0.2 generation/step_processor.py, not under
 // /root/reference; call site cli/m4t/predict/predict.py:172-175) — see ngram_blocked_tokens below.
 // --------------------------------------------------------------------------------------------- //
@@ -959,28 +960,35 @@ void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, cons
     proj.in = M;
     proj.out = V;
 
-    // ---- host state: sequences, cumulative scores, finished hypotheses ------------------------------
-    std::vector<int32_t> seqs((size_t)nb * max_len, cfg.pad_idx), init(8 + 5 * nb, 0), tok(nb), src_row(nb);
-    std::vector<float> scores((size_t)nb * max_len, 0.f), cum(nb, 0.f);
+    // ---- search state: device resident (sequences, cumulative scores, finished hypotheses, counters) ----------
+    std::vector<int32_t> seqs((size_t)nb * max_len, cfg.pad_idx), init(8 + 5 * nb, 0), tok(nb);
+    std::vector<float> cum(nb, 0.f);
     for (int r = 0; r < nb; ++r) {
         for (int t = 0; t < prefix_len; ++t) seqs[(size_t)r * max_len + t] = h_prefix[t];
         init[8 + r] = h_prefix[0];
         init[8 + 3 * nb + r] = h_enc_lens[r / B];
     }
     SC_HIP(hipMemcpyAsync(ints.get(), init.data(), init.size() * 4, hipMemcpyHostToDevice, m.stream));
-    struct Hyp {
-        float score;
-        std::vector<int32_t> seq;
-    };
-    std::vector<std::vector<Hyp>> finished(n);
-    std::vector<char> done(n, 0);
-    std::vector<float> cand_val((size_t)n * K), pref(n);
-    std::vector<int32_t> cand_idx((size_t)n * K);
+    Buf<int> d_seqs_a(&m.pool, (size_t)nb * max_len), d_seqs_b(&m.pool, (size_t)nb * max_len), d_fin_seq(&m.pool, (size_t)nb * max_len),
+        d_fin_len(&m.pool, (size_t)nb), d_state(&m.pool, (size_t)2 * n + 1);
+    Buf<float> d_fin_score(&m.pool, (size_t)nb);
+    int* d_seqs_cur = d_seqs_a;
+    int* d_seqs_new = d_seqs_b;
+    int* d_fin_count = d_state;
+    int* d_done = d_state.get() + n;
+    int* d_remaining = d_state.get() + 2 * n;
+    {
+        std::vector<int32_t> st((size_t)2 * n + 1, 0);
+        st[2 * n] = n;
+        SC_HIP(hipMemcpyAsync(d_state.get(), st.data(), st.size() * 4, hipMemcpyHostToDevice, m.stream));
+        SC_HIP(hipMemcpyAsync(d_seqs_cur, seqs.data(), seqs.size() * 4, hipMemcpyHostToDevice, m.stream));
+        SC_HIP(hipMemsetAsync(d_fin_len.get(), 0, (size_t)nb * 4, m.stream));
+        SC_HIP(hipStreamSynchronize(m.stream));  // `st` is a host temporary
+    }
+    std::vector<float> pref(n);
     const int G = o.no_repeat_ngram_size;
-    std::vector<int32_t> ban_off, ban_tok;
-    Buf<int> d_ban(&m.pool, G > 0 ? (size_t)(nb + 1) + (size_t)nb * max_len : 1);  // offsets, then tokens (<= S per row)
 
-    // ---- prompt echo: feed prefix[:-1]; scores[i] = sum_{j<=i} lprob(prefix[j] | prefix[<j]) ---------
+    // ---- prompt echo: feed prefix[:-1]; cum = sum_j lprob(prefix[j] | prefix[<j]) (the same for every beam row) ----
     for (int t = 0; t + 1 < prefix_len; ++t) {
         decoder_step(m, c, /*project=*/false);
         linear(m, c.hN, M, proj, nullptr, 0, c.logits, V, nb, ACT_NONE, 1.f);
@@ -989,131 +997,75 @@ void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, cons
         SC_HIP(hipMemcpyAsync(pref.data(), d_pref.get(), (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
         SC_HIP(hipMemcpyAsync(c.d_tok, tok.data(), (size_t)nb * 4, hipMemcpyHostToDevice, m.stream));
         SC_HIP(hipStreamSynchronize(m.stream));
-        for (int r = 0; r < nb; ++r) {
-            const float prev = scores[(size_t)r * max_len + t];
-            scores[(size_t)r * max_len + t + 1] = prev + pref[r / B];
-        }
+        for (int r = 0; r < nb; ++r) cum[r] += pref[r / B];
     }
+    SC_HIP(hipMemcpyAsync(d_cum.get(), cum.data(), (size_t)nb * 4, hipMemcpyHostToDevice, m.stream));
 
-    // ---- search ------------------------------------------------------------------------------------
+    // ---- search: every step is device work only; the host polls the `remaining` counter every 4th step --------
     const int start = prefix_len - 1;
     int remaining = n;
     for (int step = start; step <= max_len - 2 && remaining > 0; ++step) {
         decoder_step(m, c, /*project=*/false);  // feeds d_tok at position `step`, advances *d_pos
         linear(m, c.hN, M, proj, nullptr, 0, c.logits, V, nb, ACT_NONE, 1.f);
-        for (int r = 0; r < nb; ++r) cum[r] = scores[(size_t)r * max_len + step];
-        SC_HIP(hipMemcpyAsync(d_cum.get(), cum.data(), (size_t)nb * 4, hipMemcpyHostToDevice, m.stream));
-        const int* d_ban_off = nullptr;
-        if (G > 0 && step != max_len - 2) {  // not on the forced-EOS step: blocking EOS there would leave no hypothesis
-            ban_off.assign(1, 0);
-            ban_tok.clear();
-            for (int r = 0; r < nb; ++r) {
-                if (!done[r / B]) ngram_blocked_tokens(&seqs[(size_t)r * max_len], step + 1, G, ban_tok);
-                ban_off.push_back((int32_t)ban_tok.size());
-            }
-            if (!ban_tok.empty()) {
-                d_ban_off = d_ban.get();
-                SC_HIP(hipMemcpyAsync(d_ban.get(), ban_off.data(), ban_off.size() * 4, hipMemcpyHostToDevice, m.stream));
-                SC_HIP(hipMemcpyAsync(d_ban.get() + nb + 1, ban_tok.data(), ban_tok.size() * 4, hipMemcpyHostToDevice, m.stream));
-            }
-        }
+        // n-gram processor: not on the forced-EOS step (blocking EOS there would leave no hypothesis)
+        const bool ban = G > 0 && step != max_len - 2;
         launch_beam_candidates(c.logits, V, n, B, V, d_cum, step == start, step < o.min_seq_len, step == max_len - 2, cfg.pad_idx,
-                               cfg.eos_idx, cfg.unk_idx, o.unk_penalty, K, d_cand_val, d_cand_idx, d_ban_off,
-                               d_ban.get() + nb + 1, m.stream);
-        SC_HIP(hipMemcpyAsync(cand_val.data(), d_cand_val.get(), cand_val.size() * 4, hipMemcpyDeviceToHost, m.stream));
-        SC_HIP(hipMemcpyAsync(cand_idx.data(), d_cand_idx.get(), cand_idx.size() * 4, hipMemcpyDeviceToHost, m.stream));
-        SC_HIP(hipStreamSynchronize(m.stream));
-        bool reorder = false;
-        std::vector<int32_t> new_seqs(seqs);
-        std::vector<float> new_scores(scores);
-        for (int u = 0; u < n; ++u) {
-            if (done[u]) {  // finished utterance: its rows keep running on their own caches, results ignored
-                for (int b = 0; b < B; ++b) {
-                    src_row[u * B + b] = u * B + b;
-                    tok[u * B + b] = cfg.eos_idx;
-                }
-                continue;
-            }
-            int live = 0;
-            int beams[8], toks[8];
-            float scs[8];
-            for (int i = 0; i < K && !done[u]; ++i) {
-                const int cidx = cand_idx[(size_t)u * K + i];
-                const float sc = cand_val[(size_t)u * K + i];
-                const int beam = cidx / V, token = cidx % V;
-                if (token == cfg.eos_idx && sc != -INFINITY) {
-                    // fairseq2 (the generator the reference Translator constructs, inference/generator.py:147-156) looks at
-                    // an EOS candidate only among the top `beam_size` of the 2 x beam candidates; a lower-ranked EOS is
-                    // dropped, not finalised (the ggml port, fairseq2.cpp:1542-1565, finalises it: followed fairseq2)
-                    if (i >= B) continue;
-                    Hyp hy;
-                    hy.score = normalize ? sc / powf((float)(step + 1), len_penalty) : sc;
-                    const int32_t* sp = &seqs[(size_t)(u * B + beam) * max_len];
-                    hy.seq.assign(sp, sp + step + 1);
-                    hy.seq.push_back(token);
-                    finished[u].push_back(std::move(hy));
-                    if ((int)finished[u].size() == B) {
-                        done[u] = 1;
-                        --remaining;
-                    }
-                    continue;
-                }
-                if (live < B) {
-                    beams[live] = beam;
-                    toks[live] = token;
-                    scs[live] = sc;
-                    ++live;
-                }
-                if (live >= B) break;
-            }
-            if (done[u]) {
-                for (int b = 0; b < B; ++b) {
-                    src_row[u * B + b] = u * B + b;
-                    tok[u * B + b] = cfg.eos_idx;
-                }
-                continue;
-            }
-            for (; live < B; ++live) {  // fewer live candidates than beams: dead copies of the first one
-                beams[live] = live > 0 ? beams[0] : 0;
-                toks[live] = cfg.pad_idx;
-                scs[live] = -INFINITY;
-            }
-            for (int b = 0; b < B; ++b) {
-                const int r = u * B + b, sr = u * B + beams[b];
-                src_row[r] = sr;
-                tok[r] = toks[b];
-                if (sr != r) reorder = true;
-                std::copy(&seqs[(size_t)sr * max_len], &seqs[(size_t)sr * max_len] + max_len, &new_seqs[(size_t)r * max_len]);
-                std::copy(&scores[(size_t)sr * max_len], &scores[(size_t)sr * max_len] + max_len, &new_scores[(size_t)r * max_len]);
-                new_seqs[(size_t)r * max_len + step + 1] = toks[b];
-                new_scores[(size_t)r * max_len + step + 1] = scs[b];
-            }
+                               cfg.eos_idx, cfg.unk_idx, o.unk_penalty, K, d_cand_val, d_cand_idx, ban ? d_seqs_cur : nullptr, max_len,
+                               step + 1, G, m.stream);
+        BeamSelectArgs a;
+        a.cand_val = d_cand_val;
+        a.cand_idx = d_cand_idx;
+        a.seqs_cur = d_seqs_cur;
+        a.seqs_new = d_seqs_new;
+        a.fin_score = d_fin_score;
+        a.fin_len = d_fin_len;
+        a.fin_seq = d_fin_seq;
+        a.fin_count = d_fin_count;
+        a.done = d_done;
+        a.remaining = d_remaining;
+        a.tok = c.d_tok;
+        a.src_row = d_src_row;
+        a.cum = d_cum;
+        a.beams = B;
+        a.K = K;
+        a.V = V;
+        a.max_len = max_len;
+        a.step = step;
+        a.eos_idx = cfg.eos_idx;
+        a.pad_idx = cfg.pad_idx;
+        a.normalize = normalize ? 1 : 0;
+        a.len_penalty = len_penalty;
+        launch_beam_select(a, n, m.stream);
+        std::swap(d_seqs_cur, d_seqs_new);
+        // K/V rows follow their beams (all layers, one launch; rows of finished utterances map onto themselves)
+        launch_gather_cache(kv_cur, kv_alt, d_src_row, nb, step + 1, max_len, M, 2 * L, layer_stride, m.stream);
+        std::swap(kv_cur, kv_alt);
+        bind_caches(kv_cur);
+        if (((step - start) & 3) == 3 || step == max_len - 2) {
+            SC_HIP(hipMemcpyAsync(&remaining, d_remaining, 4, hipMemcpyDeviceToHost, m.stream));
+            SC_HIP(hipStreamSynchronize(m.stream));
         }
-        seqs.swap(new_seqs);
-        scores.swap(new_scores);
-        if (remaining == 0) break;
-        SC_HIP(hipMemcpyAsync(c.d_tok, tok.data(), (size_t)nb * 4, hipMemcpyHostToDevice, m.stream));
-        if (reorder) {
-            SC_HIP(hipMemcpyAsync(d_src_row, src_row.data(), (size_t)nb * 4, hipMemcpyHostToDevice, m.stream));
-            launch_gather_cache(kv_cur, kv_alt, d_src_row, nb, step + 1, max_len, M, 2 * L, layer_stride, m.stream);
-            std::swap(kv_cur, kv_alt);
-            bind_caches(kv_cur);
-        }
-        SC_HIP(hipStreamSynchronize(m.stream));  // tok / src_row are reused by the next iteration
     }
 
     // ---- best hypothesis per utterance (sorted by score, fairseq2.cpp:1597-1602) ----------------------
+    std::vector<int32_t> fin_seq((size_t)nb * max_len), fin_len(nb), fin_count(n);
+    std::vector<float> fin_score(nb);
+    SC_HIP(hipMemcpyAsync(fin_seq.data(), d_fin_seq.get(), fin_seq.size() * 4, hipMemcpyDeviceToHost, m.stream));
+    SC_HIP(hipMemcpyAsync(fin_len.data(), d_fin_len.get(), fin_len.size() * 4, hipMemcpyDeviceToHost, m.stream));
+    SC_HIP(hipMemcpyAsync(fin_score.data(), d_fin_score.get(), fin_score.size() * 4, hipMemcpyDeviceToHost, m.stream));
+    SC_HIP(hipMemcpyAsync(fin_count.data(), d_fin_count, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
+    SC_HIP(hipStreamSynchronize(m.stream));
     int longest = 0;
     for (int u = 0; u < n; ++u) {
-        SC_CHECK(!finished[u].empty(), "sc_generate_text: beam search returned no hypothesis for item %d", u);
-        size_t best = 0;
-        for (size_t i = 1; i < finished[u].size(); ++i)
-            if (finished[u][i].score > finished[u][best].score) best = i;
-        const Hyp& hy = finished[u][best];
-        const int len = (int)hy.seq.size();
-        for (int t = 0; t < max_len; ++t) h_out_ids[(size_t)u * max_len + t] = t < len ? hy.seq[t] : cfg.pad_idx;
+        SC_CHECK(fin_count[u] > 0, "sc_generate_text: beam search returned no hypothesis for item %d", u);
+        int best = 0;
+        for (int i = 1; i < fin_count[u]; ++i)
+            if (fin_score[u * B + i] > fin_score[u * B + best]) best = i;
+        const int len = fin_len[u * B + best];
+        const int32_t* hs = &fin_seq[(size_t)(u * B + best) * max_len];
+        for (int t = 0; t < max_len; ++t) h_out_ids[(size_t)u * max_len + t] = t < len ? hs[t] : cfg.pad_idx;
         h_out_lens[u] = len;
-        if (h_scores) h_scores[u] = hy.score;
+        if (h_scores) h_scores[u] = fin_score[u * B + best];
         longest = std::max(longest, len);
     }
     // ---- decoder outputs of the chosen hypotheses: the reference's teacher-forced pass (generator.py:281-299)
