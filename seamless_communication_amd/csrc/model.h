@@ -167,6 +167,12 @@ struct ModelData {
     const __half* mma_embed_p = nullptr;
     std::vector<DecoderLayer> mma_dec;
     std::vector<PChooseLayer> mma_pc;
+    // query-side energy MLPs of all layers as device pointer tables [energy_layers][mma_layers] (weights fp16 [M][ldw],
+    // biases fp32 [M]) + the per-layer energy bias pointers: one batched launch per MLP level (model_decoder.hip)
+    const __half* const* mma_qe_w = nullptr;
+    const float* const* mma_qe_b = nullptr;
+    const float* const* mma_ebias = nullptr;
+    int mma_qe_ldw = 0;
     LNorm mma_final_ln;
     // text encoder (text-input tasks; shares the embedding frontend with the decoder)
     std::vector<EncoderLayer> text_enc;

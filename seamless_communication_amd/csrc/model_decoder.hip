@@ -55,8 +55,9 @@ struct StepCtx {
     bool pchoose = false;           // compute p_choose[layer][head] of this step's (single) row
     const float* d_kenergy = nullptr;  // [layers][M]: k_energy_proj of the last pooled encoder position
     float* d_pchoose = nullptr;        // [layers][heads]
-    float* qe0 = nullptr;              // [M] scratch x2 for the query energy MLP
+    float* qe0 = nullptr;              // [layers][M] scratch x2 for the query energy MLPs
     float* qe1 = nullptr;
+    float* d_hq = nullptr;             // [layers][M]: every layer's normed cross-attention input of the p_choose step
     // second-generation step (k_dstep.hip): activations between the launches as split fp16 planes [K/8][rb][8]
     int rb = 0;  // row slots of the planes (32 or 64); 0 = first-generation step
     int am_ntl = 4;  // 32-feature tiles per workgroup of the fused vocabulary projection
@@ -92,6 +93,65 @@ __global__ void pchoose_kernel(const float* __restrict__ q, const float* __restr
         float e = acc * rsqrtf((float)head_dim);
         if (energy_bias) e += energy_bias[0];
         out[h] = 1.f / (1.f + expf(-(e / temperature)));
+    }
+}
+
+// One level of the query-side EnergyProjection of EVERY layer in one launch (the streaming step's p_choose hook):
+//   out[l][n] = relu(b[l][n] + W[l][n][:] . in[l][:])      one row per layer, fp16 weights, fp32 arithmetic.
+// grid (M / 32, layers); a wave owns 8 output features: all 16 weight loads (8 features x 2 K halves of 512) are issued
+// before the first use, the row vector sits in registers (16 floats per lane), wave reduction by shuffles.
+__global__ __launch_bounds__(256) void energy_level_kernel(const __half* const* __restrict__ Wt, const float* const* __restrict__ Bt,
+                                                           int ldw, const float* __restrict__ in, float* __restrict__ out, int M) {
+    typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+    const int l = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 32 + wave * 8;
+    const __half* W = Wt[l];
+    const float* x = in + (int64_t)l * M;
+    float xv[2][8];
+    h8_t w[8][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int k = c * 512 + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[c][e] = k + e < M ? x[k + e] : 0.f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            h8_t z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+            w[f][c] = (k < M && n0 + f < M) ? *reinterpret_cast<const h8_t*>(W + (int64_t)(n0 + f) * ldw + k) : z;
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf((float)w[f][c][e], xv[c][e], acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0 && n0 + f < M) {
+            const float v = acc + (Bt[l] ? Bt[l][n0 + f] : 0.f);
+            out[(int64_t)l * M + n0 + f] = v > 0.f ? v : 0.f;
+        }
+    }
+}
+
+// p_choose of every (layer, head): grid (heads, layers), see pchoose_kernel
+__global__ void pchoose_all_kernel(const float* __restrict__ q, const float* __restrict__ k, int M, int head_dim,
+                                   const float* const* __restrict__ energy_bias, float temperature, float* __restrict__ out) {
+    const int h = blockIdx.x, l = blockIdx.y, lane = threadIdx.x, H = gridDim.x;
+    const float* ql = q + (int64_t)l * M + h * head_dim;
+    const float* kl = k + (int64_t)l * M + h * head_dim;
+    float acc = 0.f;
+    for (int c = lane; c < head_dim; c += 64) acc = fmaf(ql[c], kl[c], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        float e = acc * rsqrtf((float)head_dim);
+        if (energy_bias[l]) e += energy_bias[l][0];
+        out[l * H + h] = 1.f / (1.f + expf(-(e / temperature)));
     }
 }
 
@@ -240,8 +300,10 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
         a.heads = H;
         launch_dattn(a, /*cross=*/false, m.stream);
         gemv2(m, c, c.attH, c.attL, l.self_out, 4, &sp);
+        // monotonic decoder, p_choose step: the normed cross-attention input (monotonic_decoder_layer.py:170-172) of every
+        // layer is kept as an fp32 row; the energy MLPs of all layers run batched after the last layer
         launch_reduce_ln(c.partial, sp, l.self_out.b, c.x, l.cross_ln.g, l.cross_ln.b, c.hH, c.hL, c.rb, nullptr, 0, 0, nullptr, nb, M,
-                         m.stream);
+                         m.stream, c.pchoose ? c.d_hq + (int64_t)li * M : nullptr);
         // encoder-decoder attention over the K/V projected once per utterance
         gemv2(m, c, c.hH, c.hL, l.cross_q, 4, &sp);
         DAttnArgs x;
@@ -293,6 +355,22 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
             launch_reduce_ln(c.partial, sp, l.ffn_out.b, c.x, next.g, next.b, c.hH, c.hL, c.rb, nullptr, 0, 0, nullptr, nb, M, m.stream);
         }
     }
+    if (c.pchoose) {
+        SC_CHECK(nb == 1 && W.pchoose && m.mma_qe_w && M <= 1024, "p_choose hook: one row on the monotonic stack only");
+        const int E = cfg.mma_energy_layers;
+        const float* src = c.d_hq;
+        float* dst = c.qe0;
+        for (int e = 0; e < E; ++e) {
+            hipLaunchKernelGGL(energy_level_kernel, dim3(cdiv(M, 32), n_layers), dim3(256), 0, m.stream, m.mma_qe_w + (size_t)e * n_layers,
+                               m.mma_qe_b + (size_t)e * n_layers, m.mma_qe_ldw, src, dst, M);
+            SC_LAUNCH_CHECK();
+            src = dst;
+            dst = (dst == c.qe0) ? c.qe1 : c.qe0;
+        }
+        hipLaunchKernelGGL(pchoose_all_kernel, dim3(H, n_layers), dim3(64), 0, m.stream, src, c.d_kenergy, M, M / H, m.mma_ebias,
+                           cfg.mma_temperature, c.d_pchoose);
+        SC_LAUNCH_CHECK();
+    }
     if (project) {
         GemvPArgs v;
         v.Wp = W.embed_p;
@@ -329,7 +407,7 @@ void decoder_step(Model& m, StepCtx& c, bool project) {
     const int M = cfg.model_dim, nb = c.nb;
     const DecStack own = unity_stack(m);
     const DecStack& W = c.stack ? *c.stack : own;
-    if (c.rb > 0 && !c.pchoose) {
+    if (c.rb > 0) {
         decoder_step2(m, c, project, W);
         return;
     }
@@ -444,7 +522,7 @@ __global__ void fill_indices_kernel(float* __restrict__ row, const int* __restri
 }
 
 struct MmaWork {  // slices of MmaState::work
-    float *x, *h, *att, *hN, *wide, *partial, *logits, *qe0, *qe1, *pooled;
+    float *x, *h, *att, *hN, *wide, *partial, *logits, *qe0, *qe1, *pooled, *hq;
 };
 
 MmaWork mma_work(const Model& m, float* base, size_t* total) {
@@ -466,9 +544,10 @@ MmaWork mma_work(const Model& m, float* base, size_t* total) {
     w.wide = take(wideN);
     w.partial = take(part);
     w.logits = take(c.text_vocab_size);
-    w.qe0 = take(M);
-    w.qe1 = take(M);
+    w.qe0 = take((size_t)std::max(1, c.mma_layers) * M);
+    w.qe1 = take((size_t)std::max(1, c.mma_layers) * M);
     w.pooled = take(M);
+    w.hq = take((size_t)std::max(1, c.mma_layers) * M);
     if (total) *total = o;
     return w;
 }
@@ -561,7 +640,9 @@ void run_mma_step(Model& m, const int32_t* h_tokens, int n_tokens, const int32_t
     c.logits = w.logits;
     c.qe0 = w.qe0;
     c.qe1 = w.qe1;
+    c.d_hq = w.hq;
     c.stack = &W;
+    if (step2_eligible(m, W, 1)) alloc_step2(m, c, cfg.mma_ffn_dim);  // second-generation step kernels, p_choose hook batched
     c.d_kenergy = st.kenergy.get();
     c.d_pchoose = st.pchoose.get();
     const int64_t layer_stride = (int64_t)st.cap * M;
