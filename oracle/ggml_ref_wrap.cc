@@ -112,6 +112,7 @@ int gref_add_token(void* h, const char* tok, int id) {
 //   "LayerNorm" "Linear" "StandardFeedForwardNetwork" "SiluFeedForwardNetwork"
 //   "StandardTransformerEncoderLayer" "StandardTransformerEncoder"
 //   "StandardConformerEncoderAdaptorLayer"                         x only
+//   "RelativePositionMHA" "ConvModule" "StandardConformerEncoderLayer"   x only (v1 w2v-BERT blocks, 16 heads hard-coded)
 //   "MultiheadAttention"            x = queries, y = keys = values (y may alias x), causal mask optional
 //   "StandardTransformerDecoderLayer" "StandardTransformerDecoder"  x = seqs, y = encoder output, causal mask
 // Returns the number of output elements (negative: caller buffer too small; 0: failure).
@@ -139,6 +140,10 @@ int64_t gref_forward(void* h, const char* kind_c, const char* prefix_c, const fl
     else if (kind == "StandardTransformerEncoderLayer") res = StandardTransformerEncoderLayer_forward(model, prefix, tx, nullptr);
     else if (kind == "StandardTransformerEncoder") res = StandardTransformerEncoder_forward(model, prefix, tx, nullptr);
     else if (kind == "StandardConformerEncoderAdaptorLayer") res = StandardConformerEncoderAdaptorLayer_forward(model, prefix, tx, nullptr);
+    // v1 speech encoder blocks (fairseq2.cpp:605-756); the first two include their LayerNorm and the residual add
+    else if (kind == "RelativePositionMHA") res = RelativePositionMHA_forward(model, prefix, tx);
+    else if (kind == "ConvModule") res = ConvModule_forward(model, prefix, tx);
+    else if (kind == "StandardConformerEncoderLayer") res = StandardConformerEncoderLayer_forward(model, prefix, tx, nullptr);
     else if (kind == "MultiheadAttention") {
         ggml_tensor* kv = ty ? ty : tx;
         ggml_tensor* mask = nullptr;

@@ -165,6 +165,94 @@ def conformer_block(P: Params, cfg, prefix: str, x: Tensor, lens: Tensor) -> Ten
     return P.layer_norm(x, prefix + ".layer_norm")
 
 
+# --------------------------------------------------------------------------- #
+# v1 speech encoder (seamlessM4T_medium / seamlessM4T_large: w2v-BERT with Transformer-XL style relative positions and a
+# BatchNorm convolution module; models/unity/builder.py:109-162 -> fairseq2 w2vbert "300m" / "600m").  Unlike the v2 blocks
+# these ARE restated executably in the reference tree: ggml/examples/unity/fairseq2.cpp:605-756 (RelativePositionMHA_forward,
+# ConvModule_forward, StandardConformerEncoderLayer_forward) - tests/test_oracle_v1.py runs them - and independently in HF
+# transformers' SeamlessM4T (v1) port (tests/golden/make_hf_goldens.py).
+# --------------------------------------------------------------------------- #
+def rel_pos_table(S: int, dim: int) -> Tensor:
+    """fairseq2 RelativePositionalEncoding rows for relative positions +(S-1) ... 0 ... -(S-1) (keys to the LEFT of the
+    query are positive): interleaved sin / cos, frequencies exp(-2i ln(1e4)/dim).  The table itself lives in fairseq2 (the
+    ggml converter copies it, ggml/ggml_convert.py:394-402: `speech_encoder.pos_enc`, sliced around its centre row by
+    fairseq2.cpp:627-642); the formula is the ESPnet one that HF's port states (modeling_seamless_m4t.py:287-317)."""
+    pos = torch.arange(S - 1, -S, -1, dtype=torch.float32)[:, None]  # (2S-1, 1)
+    div = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * -(math.log(10000.0) / dim))
+    out = torch.zeros(2 * S - 1, dim, dtype=torch.float32)
+    out[:, 0::2] = torch.sin(pos * div)
+    out[:, 1::2] = torch.cos(pos * div)
+    return out
+
+
+def mha_relpos(P: Params, prefix: str, x: Tensor, num_heads: int, key_lens: Optional[Tensor] = None,
+               pos_table: Optional[Tensor] = None) -> Tensor:
+    """StandardMultiheadAttention + fairseq2 RelativePositionSDPA (ggml/examples/unity/fairseq2.cpp:605-696):
+    logits[i][j] = ((q_i + u).k_j + (q_i + v).r_{i-j}) / sqrt(d), r = r_proj(table) split per head; the (S, 2S-1) -> (S, S)
+    "shift" of the reference picks column S-1+j-i of the position scores."""
+    N, S, M = x.shape
+    H = num_heads
+    D = M // H
+    q = P.linear(x, prefix + ".q_proj").view(N, S, H, D).transpose(1, 2)
+    k = P.linear(x, prefix + ".k_proj").view(N, S, H, D).transpose(1, 2)
+    v = P.linear(x, prefix + ".v_proj").view(N, S, H, D).transpose(1, 2)
+    tab = rel_pos_table(S, M) if pos_table is None else pos_table
+    r = F.linear(tab, P[prefix + ".sdpa.r_proj.weight"]).view(2 * S - 1, H, D)  # (P, H, D)
+    u = P[prefix + ".sdpa.u_bias"].view(1, H, 1, D)
+    vb = P[prefix + ".sdpa.v_bias"].view(1, H, 1, D)
+    ac = torch.matmul(q + u, k.transpose(-1, -2))
+    bd_raw = torch.einsum("nhsd,phd->nhsp", q + vb, r)
+    col = (S - 1) + torch.arange(S)[None, :] - torch.arange(S)[:, None]  # [i, j] -> S-1+j-i
+    bd = torch.gather(bd_raw, 3, col[None, None].expand(N, H, S, S))
+    w = (ac + bd) * (D ** -0.5)
+    if key_lens is not None:
+        km = padding_mask(key_lens, S)
+        w = w.masked_fill(~km[:, None, None, :], float("-inf"))
+    a = torch.softmax(w, dim=-1)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(N, S, M)
+    return P.linear(o, prefix + ".output_proj")
+
+
+def conformer_conv_v1(P: Params, cfg, prefix: str, x: Tensor, lens: Tensor) -> Tensor:
+    """fairseq2 ConformerConvolution with the defaults of the w2v-BERT builder (non-causal depthwise conv with K // 2
+    zeros on both sides, BatchNorm1d in inference mode, SiLU); ggml/examples/unity/fairseq2.cpp:698-731."""
+    N, S, M = x.shape
+    x = x * padding_mask(lens, S)[:, :, None]
+    x = x.transpose(1, 2)
+    x = F.conv1d(x, P[prefix + ".pointwise_conv1.weight"])
+    x = F.glu(x, dim=1)
+    K = cfg.depthwise_conv_kernel_size
+    x = F.conv1d(x, P[prefix + ".depthwise_conv.weight"], groups=M, padding=K // 2)
+    x = F.batch_norm(x, P[prefix + ".batch_norm.running_mean"], P[prefix + ".batch_norm.running_var"],
+                     P[prefix + ".batch_norm.weight"], P[prefix + ".batch_norm.bias"], training=False, eps=1e-5)
+    x = F.silu(x)
+    x = F.conv1d(x, P[prefix + ".pointwise_conv2.weight"])
+    return x.transpose(1, 2)
+
+
+def conformer_block_v1(P: Params, cfg, prefix: str, x: Tensor, lens: Tensor, pos_table: Optional[Tensor] = None) -> Tensor:
+    """ConformerBlock of the v1 encoder (fairseq2.cpp:733-756): same order as v2, other attention / conv modules."""
+    x = x + 0.5 * ffn(P, prefix + ".ffn1", P.layer_norm(x, prefix + ".ffn1_layer_norm"), "silu")
+    h = P.layer_norm(x, prefix + ".self_attn_layer_norm")
+    x = x + mha_relpos(P, prefix + ".self_attn", h, cfg.num_heads, key_lens=lens, pos_table=pos_table)
+    x = x + conformer_conv_v1(P, cfg, prefix + ".conv", P.layer_norm(x, prefix + ".conv_layer_norm"), lens)
+    x = x + 0.5 * ffn(P, prefix + ".ffn2", P.layer_norm(x, prefix + ".ffn2_layer_norm"), "silu")
+    return P.layer_norm(x, prefix + ".layer_norm")
+
+
+def encode_speech_v1(P: Params, cfg, fbank: Tensor, lens: Tensor) -> Tuple[Tensor, Tensor]:
+    """UnitYModel.encode_speech for the v1 architectures: the same frontend and adaptor around v1 Conformer blocks."""
+    x, lens = speech_frontend(P, cfg, fbank, lens)
+    tab = rel_pos_table(x.shape[1], cfg.model_dim)
+    for i in range(cfg.enc_layers):
+        x = conformer_block_v1(P, cfg, f"speech_encoder.inner.layers.{i}", x, lens, tab)
+    x = P.layer_norm(x, "speech_encoder.inner_layer_norm")
+    x = x + 0.5 * P.linear(F.relu(P.linear(x, "speech_encoder.proj1")), "speech_encoder.proj2")
+    x, lens = adaptor_layer(P, cfg, "speech_encoder.adaptor_layers.0", x, lens)
+    x = P.layer_norm(x, "speech_encoder.layer_norm")
+    return x, lens
+
+
 def adaptor_layer(P: Params, cfg, prefix: str, x: Tensor, lens: Tensor) -> Tuple[Tensor, Tensor]:
     """UnitYTransformerAdaptorLayer (models/unity/adaptor_block.py:237-314)."""
     k, s = cfg.adaptor_kernel_size, cfg.adaptor_stride

@@ -180,7 +180,91 @@ def main():
     out.update({"std_in": feats, "std_out_hf_formula": std.astype(np.float32)})
 
     np.savez_compressed(HERE / "hf_conformer_ref.npz", **out)
+    make_v1(g)
     print("wrote", HERE / "hf_conformer_ref.npz", {k: v.shape for k, v in out.items() if not k.startswith("w:")})
+
+
+V1_LAYER_MAP = [
+    ("ffn1_layer_norm", "ffn1_layer_norm"),
+    ("ffn1.intermediate_dense", "ffn1.inner_proj"),
+    ("ffn1.output_dense", "ffn1.output_proj"),
+    ("self_attn_layer_norm", "self_attn_layer_norm"),
+    ("self_attn.linear_q", "self_attn.q_proj"),
+    ("self_attn.linear_k", "self_attn.k_proj"),
+    ("self_attn.linear_v", "self_attn.v_proj"),
+    ("self_attn.linear_out", "self_attn.output_proj"),
+    ("self_attn.linear_pos", "self_attn.sdpa.r_proj"),
+    ("conv_module.layer_norm", "conv_layer_norm"),
+    ("conv_module.pointwise_conv1", "conv.pointwise_conv1"),
+    ("conv_module.depthwise_conv", "conv.depthwise_conv"),
+    ("conv_module.batch_norm", "conv.batch_norm"),
+    ("conv_module.pointwise_conv2", "conv.pointwise_conv2"),
+    ("ffn2_layer_norm", "ffn2_layer_norm"),
+    ("ffn2.intermediate_dense", "ffn2.inner_proj"),
+    ("ffn2.output_dense", "ffn2.output_proj"),
+    ("final_layer_norm", "layer_norm"),
+]
+
+
+def make_v1(g):
+    """tests/golden/hf_conformer_v1_ref.npz: one Conformer layer of HF's SeamlessM4T (v1) port - Transformer-XL relative
+    positions (linear_pos, pos_bias_u / pos_bias_v, the shift) and the BatchNorm convolution module - executed, for the
+    oracle's conformer_block_v1.  The reference's own C++ restatement of the same layer is executed by
+    tests/test_oracle_v1.py through oracle/_ref/libggml_ref.so; this fixture adds the position table formula (which the
+    reference takes from fairseq2) and a head size of 64."""
+    import transformers
+    from transformers import SeamlessM4TConfig
+    from transformers.models.seamless_m4t import modeling_seamless_m4t as hf
+
+    cfg = SeamlessM4TConfig(hidden_size=128, speech_encoder_attention_heads=2, speech_encoder_intermediate_size=256,
+                            speech_encoder_layers=1, conv_depthwise_kernel_size=31, position_embeddings_type="relative",
+                            speech_encoder_hidden_act="swish", speech_encoder_dropout=0.0, max_source_positions=512,
+                            vocab_size=64, t2u_vocab_size=64, encoder_layers=1, decoder_layers=1, t2u_encoder_layers=1,
+                            t2u_decoder_layers=1, encoder_ffn_dim=64, decoder_ffn_dim=64, t2u_encoder_ffn_dim=64, t2u_decoder_ffn_dim=64)
+    torch.manual_seed(20240902)
+    layer = hf.SeamlessM4TConformerEncoderLayer(cfg).eval().float()
+    pe = hf.SeamlessM4TConformerRelPositionalEmbedding(cfg)
+    with torch.no_grad():
+        for name, p in layer.named_parameters():
+            if name.endswith("norm.weight"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            elif name.endswith(".bias"):
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+            elif "pos_bias" in name:
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+            else:
+                p.mul_(4.0)
+        bn = layer.conv_module.batch_norm
+        bn.running_mean.copy_(0.2 * torch.randn(bn.running_mean.shape, generator=g))
+        bn.running_var.copy_(0.5 + torch.rand(bn.running_var.shape, generator=g))
+    hsd = layer.state_dict()
+    out = {"transformers_version": np.array(transformers.__version__)}
+    pfx = "speech_encoder.inner.layers.0."
+    used = set()
+    for a, b in V1_LAYER_MAP:
+        for suffix in (".weight", ".bias", ".running_mean", ".running_var"):
+            if a + suffix in hsd:
+                out["w:" + pfx + b + suffix] = hsd[a + suffix].detach().float().numpy()
+                used.add(a + suffix)
+    out["w:" + pfx + "self_attn.sdpa.u_bias"] = hsd["self_attn.pos_bias_u"].float().numpy()
+    out["w:" + pfx + "self_attn.sdpa.v_bias"] = hsd["self_attn.pos_bias_v"].float().numpy()
+    used |= {"self_attn.pos_bias_u", "self_attn.pos_bias_v", "conv_module.batch_norm.num_batches_tracked"}
+    assert not (set(hsd) - used), sorted(set(hsd) - used)
+    N, S, M = 2, 90, cfg.hidden_size
+    x = torch.randn(N, S, M, generator=g)
+    lens = torch.tensor([90, 41])
+    am = (torch.arange(S)[None, :] < lens[:, None])
+    ext = (1.0 - am[:, None, None, :].float()).expand(N, 1, S, S) * torch.finfo(torch.float32).min
+    with torch.no_grad():
+        rel = pe(x)  # (1, 2S-1, M)
+        y, _ = layer(x, attention_mask=ext, relative_position_embeddings=rel, conv_attention_mask=am)
+        h = layer.self_attn_layer_norm(x)
+        att, _ = layer.self_attn(hidden_states=h, attention_mask=ext, relative_position_embeddings=rel)
+        cv = layer.conv_module(x, attention_mask=am)
+    out.update({"x": x.numpy(), "lens": lens.numpy(), "y": y.numpy(), "attn_in": h.numpy(), "attn_out": att.numpy(), "conv_out": cv.numpy(),
+                "pos_table": rel[0].numpy()})
+    np.savez_compressed(HERE / "hf_conformer_v1_ref.npz", **out)
+    print("wrote", HERE / "hf_conformer_v1_ref.npz")
 
 
 if __name__ == "__main__":
