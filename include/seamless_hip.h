@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 4
+#define SC_ABI_VERSION 5
 #define SC_MAX_UPSAMPLES 8
 #define SC_MAX_RESBLOCK_KERNELS 4
 #define SC_MAX_RESBLOCK_DILATIONS 4
@@ -88,6 +88,12 @@ typedef struct sc_config {
      * Its tensors carry the fairseq2 names of convert_monotonic_checkpoint under the prefix "monotonic_decoder.". */
     int32_t mma_layers, mma_ffn_dim, mma_energy_layers, mma_pre_decision_ratio;
     float mma_temperature;
+    /* speech encoder family (ABI v5).  0: Conformer-Shaw of seamlessM4T_v2_large (Shaw relative keys, causal depthwise
+     * convolution + LayerNorm; models/conformer_shaw/builder.py:127-156).  1: w2v-BERT of the v1 models seamlessM4T_medium /
+     * seamlessM4T_large (models/unity/builder.py:109-162): Transformer-XL relative positions (tensors
+     * `...self_attn.sdpa.{r_proj.weight,u_bias,v_bias}`) and a centred depthwise convolution + BatchNorm1d
+     * (`...conv.batch_norm.{weight,bias,running_mean,running_var}`); restated in ggml/examples/unity/fairseq2.cpp:605-756. */
+    int32_t enc_variant;
 } sc_config;
 
 /* Text generation options: the fields of SequenceGeneratorOptions

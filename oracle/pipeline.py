@@ -51,10 +51,16 @@ class OracleS2ST:
             out[b, : len(i)] = i
         return out, lens
 
+    def encode_speech(self, fbank: Tensor, lens: Tensor) -> Tuple[Tensor, Tensor]:
+        """UnitYModel.encode_speech for the configured encoder family (v2 Conformer-Shaw or the v1 w2v-BERT)."""
+        if getattr(self.cfg, "enc_variant", 0) == 1:
+            return ou.encode_speech_v1(self.P, self.cfg, fbank, lens)
+        return ou.encode_speech(self.P, self.cfg, fbank, lens)
+
     @torch.inference_mode()
     def s2tt(self, fbank: Tensor, lens: Tensor, tgt_lang: str, soft_max_seq_len=(1, 200),
              hard_max_seq_len: int = 1024, beam_size: int = 1):
-        enc, enc_lens = ou.encode_speech(self.P, self.cfg, fbank, lens)
+        enc, enc_lens = self.encode_speech(fbank, lens)
         # the generator is called with the fbank sequences: their padded length feeds the soft length rule
         return self._text_from_encoder(enc, enc_lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size, int(fbank.shape[1]))
 

@@ -11,7 +11,7 @@ from typing import Optional
 
 LIB_PATH = Path(__file__).resolve().parent / "libseamless_hip.so"
 
-SC_ABI_VERSION = 4
+SC_ABI_VERSION = 5
 SC_MAX_UPSAMPLES = 8
 SC_MAX_RESBLOCK_KERNELS = 4
 SC_MAX_RESBLOCK_DILATIONS = 4
@@ -63,6 +63,7 @@ class sc_config(C.Structure):
         ("text_enc_layers", _i), ("text_enc_ffn_dim", _i),
         ("mma_layers", _i), ("mma_ffn_dim", _i), ("mma_energy_layers", _i), ("mma_pre_decision_ratio", _i),
         ("mma_temperature", C.c_float),
+        ("enc_variant", _i),
     ]
 
 
@@ -206,4 +207,5 @@ def make_config(cfg, has_t2u: bool = True, has_vocoder: bool = True, has_text_en
     c.mma_energy_layers = int(cfg.mma_energy_layers)
     c.mma_pre_decision_ratio = int(cfg.mma_pre_decision_ratio)
     c.mma_temperature = float(cfg.mma_temperature)
+    c.enc_variant = int(getattr(cfg, "enc_variant", 0))
     return c

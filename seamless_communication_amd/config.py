@@ -55,7 +55,9 @@ class S2STConfig:
     model_dim: int = 1024
     num_heads: int = 16  # head_dim must be 64 (kernels are specialised for it)
 
-    # speech encoder: W2v-BERT 2.0 Conformer with Shaw rel-pos attention
+    # speech encoder: W2v-BERT 2.0 Conformer with Shaw rel-pos attention (enc_variant 0, the v2 model) or the v1 w2v-BERT
+    # (enc_variant 1: Transformer-XL relative positions + BatchNorm conv module; models/unity/builder.py:109-162)
+    enc_variant: int = 0
     num_fbank_channels: int = 80
     fbank_stride: int = 2
     enc_layers: int = 24
@@ -121,6 +123,28 @@ class S2STConfig:
 
 def seamless_m4t_v2_large() -> S2STConfig:
     return S2STConfig()
+
+
+def seamless_m4t_large() -> S2STConfig:
+    """seamlessM4T_large (v1), unity arch `base` (models/unity/builder.py:109-134): w2v-BERT 600m with relative positions,
+    NLLB dense_1b, vocabulary 256102.  The speech encoder, text encoder / decoder run on this path; the v1 autoregressive T2U
+    and the vocoder's duration predictor are not built."""
+    return S2STConfig(name="seamlessM4T_large", enc_variant=1, text_max_seq_len=1024)
+
+
+def seamless_m4t_medium() -> S2STConfig:
+    """seamlessM4T_medium (v1), unity arch `medium` (models/unity/builder.py:137-162): w2v-BERT 300m (12 layers), NLLB
+    dense_600m (12 + 12 layers, FFN 4096), NLLB-200 vocabulary 256206.  BASELINE configs[0] (T2TT plumbing) names it."""
+    return S2STConfig(name="seamlessM4T_medium", enc_variant=1, enc_layers=12, text_enc_layers=12, text_enc_ffn_dim=4096,
+                      dec_layers=12, dec_ffn_dim=4096, text_vocab_size=256206, text_max_seq_len=1024)
+
+
+def tiny_v1_config() -> S2STConfig:
+    """tiny_config() with the v1 speech encoder (parity tests of row f5)."""
+    c = tiny_config()
+    c.name = "tiny_v1"
+    c.enc_variant = 1
+    return c
 
 
 def tiny_config() -> S2STConfig:

@@ -449,8 +449,11 @@ __device__ __forceinline__ void a16_split8(const float* x, a16_h8& hi, a16_h8& l
     }
 }
 
-template <bool SHAW>
+// MODE 0: plain, 1: Shaw relative keys (v2 encoder), 2: Transformer-XL relative positions (v1 encoder, see AttnArgs)
+template <int MODE>
 __global__ __launch_bounds__(256) void attn_mfma16_kernel(AttnArgs p) {
+    constexpr bool SHAW = MODE == 1;
+    constexpr bool RELPOS = MODE == 2;
     typedef float f16v __attribute__((ext_vector_type(16)));
     typedef float f4v __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -460,6 +463,7 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(AttnArgs p) {
     _Float16* sVh = sKl + MKV * KH_LD;  // [64][VT_LD]
     _Float16* sVl = sVh + HD * VT_LD;
     float* sQR = smem + 4 * 32 * KS;  // [MQ][npos]   (SHAW only)
+    float* sT = smem + 4 * 32 * KS;   // [4 waves][64 window rows][32 queries]   (RELPOS only)
     float* sR = smem;                 // [npos][KS] staging of the relative keys before the loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -513,8 +517,9 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(AttnArgs p) {
         }
     }
 
-    // Q^T operand: chunk c (dims 16c .. 16c+15), this lane's half holds dims 16c + 8 hh .. + 7
-    a16_h8 qh[4], qlo[4];
+    // Q^T operand: chunk c (dims 16c .. 16c+15), this lane's half holds dims 16c + 8 hh .. + 7.  RELPOS: q + u for the
+    // content term, q + v (second operand set) for the position term.
+    a16_h8 qh[4], qlo[4], qvh[RELPOS ? 4 : 1], qvl[RELPOS ? 4 : 1];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         float x[8];
@@ -529,7 +534,18 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(AttnArgs p) {
                 x[4 + e] = v1[e];
             }
         }
-        a16_split8(x, qh[c], qlo[c]);
+        if (RELPOS) {
+            float xu[8], xv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xu[e] = x[e] + p.q_bias_u[h * HD + 16 * c + 8 * hh + e];
+                xv[e] = x[e] + p.q_bias_v[h * HD + 16 * c + 8 * hh + e];
+            }
+            a16_split8(xu, qh[c], qlo[c]);
+            a16_split8(xv, qvh[c], qvl[c]);
+        } else {
+            a16_split8(x, qh[c], qlo[c]);
+        }
     }
 
     f16v o0, o1;  // O^T: dims 0..31 / 32..63 (rows) x queries (lanes)
@@ -615,6 +631,50 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(AttnArgs p) {
                 }
             }
         }
+        if (RELPOS) {
+            // position scores of the wave's 32 queries against the 63 relative positions its 32 x 32 block touches:
+            // window row w <-> table row t0w + w (key - query = w - 31), T^T[w][query] = r_w . (q + v) on the matrix cores
+            // (rows straight from the L2-resident table, split in registers), parked in the wave's LDS window and gathered
+            // per (key, query): register r of this lane needs window row  key_in_tile - query_in_wave + 31.
+            const int t0w = (p.Skv - 1) - (q0 + shift) + k0 - 31;
+            const int t_max = 2 * p.Skv - 2;
+            float* tw = sT + wave * (64 * 32);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int trow = min(max(t0w + blk * 32 + ql, 0), t_max);
+                const float* rrow = p.rp_table + (int64_t)trow * p.rp_ld + h * HD + 8 * hh;
+                f4v ra[4][2];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ra[c][0] = *reinterpret_cast<const f4v*>(rrow + 16 * c);
+                    ra[c][1] = *reinterpret_cast<const f4v*>(rrow + 16 * c + 4);
+                }
+                f16v tt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tt[r] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = ra[c][0][e];
+                        x[4 + e] = ra[c][1][e];
+                    }
+                    a16_h8 rh, rl;
+                    a16_split8(x, rh, rl);
+                    tt = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh, qvh[c], tt, 0, 0, 0);
+                    tt = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh, qvl[c], tt, 0, 0, 0);
+                    tt = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl, qvh[c], tt, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tw[(blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + ql] = tt[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                qr[r] = tw[(jl - ql + 31) * 32 + ql];
+            }
+        }
         // ---- S^T = K . Q^T (rows = keys, lanes = queries): three terms per 16-wide chunk ------------------
         f16v st;
 #pragma unroll
@@ -633,7 +693,7 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) {
             const int kj = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             float sc = st[r];
-            if (SHAW) sc += qr[r];
+            if (SHAW || RELPOS) sc += qr[r];
             const bool ok = (kj < kv_len) && (!p.causal || kj <= qabs);
             sc = sc * 0.125f + (ok ? 0.f : -INFINITY);  // masked keys: finite + (-inf) (K rows behind the length are zeros)
             st[r] = sc;
@@ -734,9 +794,11 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
             SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma16_kernel<true>),
+            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma16_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma16_kernel<false>),
+            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma16_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+            SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma16_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
             mfma_attr = true;
         }
@@ -745,6 +807,11 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         size_t lds = (size_t)(4 * 32 * KS) * sizeof(float);  // K/V tiles, later the four output tiles
         SC_CHECK(npos <= 96, "attention: relative table too large");
         if (a.rel_k) lds += (size_t)(MQ * npos) * sizeof(float);
+        if (a.rp_table) {
+            SC_CHECK(!a.rel_k && !a.causal && a.Sq == a.Skv && a.q_bias_u && a.q_bias_v && a.rp_ld % 4 == 0 && !use_valu,
+                     "attention: relative positions need self-attention (Sq == Skv), both query biases and a 16-byte aligned table");
+            lds += (size_t)(4 * 64 * 32) * sizeof(float);
+        }
         dim3 grid(cdiv(a.Sq, MQ), a.heads, a.nb);
         // SC_ATTN_F32=1: the exact-fp32 matrix instruction (round 1) instead of the three-term fp16 split (development A/B)
         static const bool f32_mfma = getenv("SC_ATTN_F32") && atoi(getenv("SC_ATTN_F32")) != 0;
@@ -752,8 +819,9 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
             if (a.rel_k) hipLaunchKernelGGL((attn_mfma_kernel<true>), grid, dim3(256), lds, s, a);
             else hipLaunchKernelGGL((attn_mfma_kernel<false>), grid, dim3(256), lds, s, a);
         } else {
-            if (a.rel_k) hipLaunchKernelGGL((attn_mfma16_kernel<true>), grid, dim3(256), lds, s, a);
-            else hipLaunchKernelGGL((attn_mfma16_kernel<false>), grid, dim3(256), lds, s, a);
+            if (a.rp_table) hipLaunchKernelGGL((attn_mfma16_kernel<2>), grid, dim3(256), lds, s, a);
+            else if (a.rel_k) hipLaunchKernelGGL((attn_mfma16_kernel<1>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((attn_mfma16_kernel<0>), grid, dim3(256), lds, s, a);
         }
         SC_LAUNCH_CHECK();
         return;

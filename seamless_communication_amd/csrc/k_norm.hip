@@ -161,11 +161,16 @@ void launch_glu(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, in
 // its channel through registers (GLU applied on load, rows outside [0,len)
 // read as zero = the module's padding-mask + causal left pad) and emits TT
 // outputs.  Consecutive threads own consecutive channels -> coalesced rows.
+// `left` = taps to the left of the output position (K - 1: causal, the v2 module; K / 2: centred, the v1 module).
+// bn_scale / bn_shift (nullable): y = SiLU(conv * scale[c] + shift[c]) - BatchNorm1d in inference mode folded to one
+// multiply-add per channel + the activation of the v1 module (fairseq2.cpp:718-724).
 template <int K, int TT>
 __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict__ x, int64_t ldx,
                                                          const float* __restrict__ w,
                                                          float* __restrict__ y, int64_t ldy, int T,
-                                                         int C, const int* __restrict__ lens) {
+                                                         int C, const int* __restrict__ lens, int left,
+                                                         const float* __restrict__ bn_scale,
+                                                         const float* __restrict__ bn_shift) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int t0 = blockIdx.y * TT;
     const int n = blockIdx.z;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict
     float g[TT + K - 1];
 #pragma unroll
     for (int i = 0; i < TT + K - 1; ++i) {
-        const int t = t0 - (K - 1) + i;
+        const int t = t0 - left + i;
         float v = 0.f;
         if (t >= 0 && t < len) {
             const float* xr = x + ((int64_t)n * T + t) * ldx;
@@ -194,6 +199,10 @@ __global__ __launch_bounds__(256) void glu_dwconv_kernel(const float* __restrict
             float acc = 0.f;
 #pragma unroll
             for (int j = 0; j < K; ++j) acc = fmaf(wr[j], g[tt + j], acc);
+            if (bn_scale) {
+                acc = fmaf(acc, bn_scale[c], bn_shift[c]);
+                acc = acc / (1.f + expf(-acc));
+            }
             y[((int64_t)n * T + t) * ldy + c] = acc;
         }
     }
@@ -204,7 +213,9 @@ __global__ __launch_bounds__(256) void glu_dwconv_generic_kernel(const float* __
                                                                  const float* __restrict__ w,
                                                                  float* __restrict__ y, int64_t ldy,
                                                                  int T, int C, int K,
-                                                                 const int* __restrict__ lens) {
+                                                                 const int* __restrict__ lens, int left,
+                                                                 const float* __restrict__ bn_scale,
+                                                                 const float* __restrict__ bn_shift) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int t = blockIdx.y;
     const int n = blockIdx.z;
@@ -212,25 +223,65 @@ __global__ __launch_bounds__(256) void glu_dwconv_generic_kernel(const float* __
     const int len = lens ? min(lens[n], T) : T;
     float acc = 0.f;
     for (int j = 0; j < K; ++j) {
-        const int ts = t - (K - 1) + j;
+        const int ts = t - left + j;
         if (ts >= 0 && ts < len) {
             const float* xr = x + ((int64_t)n * T + ts) * ldx;
             acc = fmaf(w[c * K + j], xr[c] / (1.f + expf(-xr[C + c])), acc);
         }
     }
+    if (bn_scale) {
+        acc = fmaf(acc, bn_scale[c], bn_shift[c]);
+        acc = acc / (1.f + expf(-acc));
+    }
     y[((int64_t)n * T + t) * ldy + c] = acc;
 }
 
+// scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+__global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ mean,
+                               const float* __restrict__ var, float eps, int C, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = g[c] / sqrtf(var[c] + eps);
+    scale[c] = sc;
+    shift[c] = b[c] - mean[c] * sc;
+}
+
+void launch_bn_fold(const float* g, const float* b, const float* mean, const float* var, float eps, int C, float* scale, float* shift,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, g, b, mean, var, eps, C, scale, shift);
+    SC_LAUNCH_CHECK();
+}
+
+// Transformer-XL relative position table of the v1 encoder: row t = position (S - 1) - t, interleaved sin / cos
+// (oracle/unity.py: rel_pos_table; HF modeling_seamless_m4t.py:287-317)
+__global__ void relpos_table_kernel(int S, int M, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = M / 2;
+    if (idx >= (2 * S - 1) * half) return;
+    const int t = idx / half, i = idx - t * half;
+    const float pos = (float)((S - 1) - t);
+    const float div = expf((float)(2 * i) * -(logf(10000.0f) / (float)M));
+    const float a = pos * div;
+    out[(int64_t)t * M + 2 * i] = sinf(a);
+    out[(int64_t)t * M + 2 * i + 1] = cosf(a);
+}
+
+void launch_relpos_table(int S, int M, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(relpos_table_kernel, dim3(cdiv((2 * S - 1) * (M / 2), 256)), dim3(256), 0, s, S, M, out);
+    SC_LAUNCH_CHECK();
+}
+
 void launch_glu_dwconv(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy, int nb, int T,
-                       int C, int ksize, const int* lens, hipStream_t s) {
+                       int C, int ksize, const int* lens, hipStream_t s, int left, const float* bn_scale, const float* bn_shift) {
     if (nb <= 0 || T <= 0) return;
+    if (left < 0) left = ksize - 1;
     if (ksize == 31) {
         constexpr int TT = 16;
         dim3 grid(cdiv(C, 256), cdiv(T, TT), nb);
-        hipLaunchKernelGGL((glu_dwconv_kernel<31, TT>), grid, dim3(256), 0, s, x, ldx, w, y, ldy, T, C, lens);
+        hipLaunchKernelGGL((glu_dwconv_kernel<31, TT>), grid, dim3(256), 0, s, x, ldx, w, y, ldy, T, C, lens, left, bn_scale, bn_shift);
     } else {
         dim3 grid(cdiv(C, 256), T, nb);
-        hipLaunchKernelGGL(glu_dwconv_generic_kernel, grid, dim3(256), 0, s, x, ldx, w, y, ldy, T, C, ksize, lens);
+        hipLaunchKernelGGL(glu_dwconv_generic_kernel, grid, dim3(256), 0, s, x, ldx, w, y, ldy, T, C, ksize, lens, left, bn_scale, bn_shift);
     }
     SC_LAUNCH_CHECK();
 }

@@ -233,8 +233,13 @@ void launch_split_f32(const float* x, __half* hi, __half* lo, int64_t n, hipStre
 void launch_glu(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int C, hipStream_t s);
 
 // Conformer conv middle: g = GLU(x) (masked by lens), y = causal depthwise conv_k(g)
-void launch_glu_dwconv(const float* x, int64_t ldx, const float* w /*[C][k]*/, float* y, int64_t ldy,
-                       int nb, int T, int C, int ksize, const int* lens, hipStream_t s);
+void launch_glu_dwconv(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy, int nb, int T,
+                       int C, int ksize, const int* lens, hipStream_t s, int left = -1, const float* bn_scale = nullptr,
+                       const float* bn_shift = nullptr);
+// v1 speech encoder helpers (k_norm.hip): BatchNorm1d (inference) folded to scale / shift; relative position table
+void launch_bn_fold(const float* g, const float* b, const float* mean, const float* var, float eps, int C, float* scale, float* shift,
+                    hipStream_t s);
+void launch_relpos_table(int S, int M, float* out, hipStream_t s);
 
 struct AttnArgs {
     const float* q = nullptr;  // [nb*Sq rows][ldq], head h at column h*64
@@ -247,6 +252,13 @@ struct AttnArgs {
     int causal = 0;                // key j visible iff j <= i + (Skv - Sq)
     const float* rel_k = nullptr;  // Shaw relative keys [left+1+right][64] (nullable)
     int rel_left = 0, rel_right = 0;
+    // Transformer-XL relative positions of the v1 speech encoder (fairseq2 RelativePositionSDPA, fairseq2.cpp:605-696; self-
+    // attention only): logits[i][j] = ((q_i + u).k_j + (q_i + v).r_{i-j}) / 8.  rp_table = r_proj(position table), fp32
+    // [2*Skv-1][rp_ld], row t = relative position (Skv-1) - t, head h at column h*64; q_bias_u / q_bias_v fp32 [heads*64]
+    const float* rp_table = nullptr;
+    int64_t rp_ld = 0;
+    const float* q_bias_u = nullptr;
+    const float* q_bias_v = nullptr;
     // optional: write the result as two fp16 planes (hi, lo) for launch_gemm_presplit instead of `out`
     __half* out_hi = nullptr;
     __half* out_lo = nullptr;

@@ -92,8 +92,14 @@ struct ConvT {
 struct ConformerLayer {
     LNorm ffn1_ln, attn_ln, conv_ln, conv_inner_ln, ffn2_ln, final_ln;
     Linear ffn1_in, ffn1_out, ffn2_in, ffn2_out, qkv, attn_out, pw1, pw2;
-    const float* rel_k = nullptr;  // [npos][64] fp32
+    const float* rel_k = nullptr;  // [npos][64] fp32 (enc_variant 0)
     const float* dw = nullptr;     // [C][k] fp32
+    // enc_variant 1 (v1 w2v-BERT): Transformer-XL relative positions + BatchNorm folded to scale / shift
+    Linear r_proj;
+    const float* u_bias = nullptr;    // [heads * 64]
+    const float* v_bias = nullptr;    // [heads * 64]
+    const float* bn_scale = nullptr;  // [C]
+    const float* bn_shift = nullptr;  // [C]
 };
 struct AdaptorLayer {
     LNorm res_ln, attn_ln, ffn_ln;

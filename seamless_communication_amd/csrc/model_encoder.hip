@@ -106,7 +106,11 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
     // the residual stream x and the tensors read by element-wise kernels stay fp32.  SC_PRESPLIT=0 selects the
     // on-the-fly split path (same bits).
     static const bool presplit = !(getenv("SC_PRESPLIT") && atoi(getenv("SC_PRESPLIT")) == 0);
-    const bool ps_ok = presplit && M % 32 == 0 && c.enc_ffn_dim % 32 == 0 && (int64_t)rows * std::max(M, c.enc_ffn_dim) * 2 < (1ll << 31);
+    const bool v1 = c.enc_variant == 1;  // w2v-BERT of the v1 models: fp32-operand path below (not the throughput path)
+    const bool ps_ok = !v1 && presplit && M % 32 == 0 && c.enc_ffn_dim % 32 == 0 && (int64_t)rows * std::max(M, c.enc_ffn_dim) * 2 < (1ll << 31);
+    // v1: position table [2S-1][M] once per call, its projection r_proj(table) per layer
+    Buf<float> rp_tab(&m.pool, v1 ? (size_t)(2 * S - 1) * M : 0), rp_proj(&m.pool, v1 ? (size_t)(2 * S - 1) * M : 0);
+    if (v1) launch_relpos_table(S, M, rp_tab, m.stream);
     Buf<__half> hs(&m.pool, ps_ok ? (size_t)2 * rows * M : 0), ws(&m.pool, ps_ok ? (size_t)2 * rows * c.enc_ffn_dim : 0),
         as(&m.pool, ps_ok ? (size_t)2 * rows * M : 0);
     __half* hs_hi = hs.get();
@@ -195,16 +199,42 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
         layernorm(m, x, l.ffn1_ln, h, rows);
         linear(m, h, M, l.ffn1_in, nullptr, 0, wide, c.enc_ffn_dim, rows, ACT_SILU, 1.f);
         linear(m, wide, c.enc_ffn_dim, l.ffn1_out, x, M, x, M, rows, ACT_NONE, 0.5f);
-        // x += MHA_shaw(LN(x))
+        // x += MHA_shaw(LN(x))   (v1: Transformer-XL relative positions, fairseq2.cpp:605-696)
         layernorm(m, x, l.attn_ln, h, rows);
         linear(m, h, M, l.qkv, nullptr, 0, wide, 3 * M, rows, ACT_NONE, 1.f);
-        attention_self(m, wide, M, att, n, S, d_lens, l.rel_k);
+        if (v1) {
+            linear(m, rp_tab, M, l.r_proj, nullptr, 0, rp_proj, M, 2 * S - 1, ACT_NONE, 1.f);
+            AttnArgs a;
+            a.q = wide;
+            a.k = wide.get() + M;
+            a.v = wide.get() + 2 * M;
+            a.out = att;
+            a.ldq = a.ldk = a.ldv = 3 * M;
+            a.ldo = M;
+            a.nb = n;
+            a.heads = c.num_heads;
+            a.Sq = S;
+            a.Skv = S;
+            a.kv_lens = d_lens;
+            a.rp_table = rp_proj;
+            a.rp_ld = M;
+            a.q_bias_u = l.u_bias;
+            a.q_bias_v = l.v_bias;
+            launch_attention(a, m.stream);
+        } else {
+            attention_self(m, wide, M, att, n, S, d_lens, l.rel_k);
+        }
         linear(m, att, M, l.attn_out, x, M, x, M, rows, ACT_NONE, 1.f);
         // x += Conv(LN(x))
         layernorm(m, x, l.conv_ln, h, rows);
         linear(m, h, M, l.pw1, nullptr, 0, wide, 2 * M, rows, ACT_NONE, 1.f);
-        launch_glu_dwconv(wide, 2 * M, l.dw, att, M, n, S, M, c.depthwise_conv_kernel_size, d_lens, m.stream);
-        layernorm(m, att, l.conv_inner_ln, h, rows, ACT_SILU);
+        if (v1) {  // centred depthwise conv + BatchNorm (folded) + SiLU in one pass (fairseq2.cpp:698-731)
+            launch_glu_dwconv(wide, 2 * M, l.dw, h, M, n, S, M, c.depthwise_conv_kernel_size, d_lens, m.stream,
+                              c.depthwise_conv_kernel_size / 2, l.bn_scale, l.bn_shift);
+        } else {
+            launch_glu_dwconv(wide, 2 * M, l.dw, att, M, n, S, M, c.depthwise_conv_kernel_size, d_lens, m.stream);
+            layernorm(m, att, l.conv_inner_ln, h, rows, ACT_SILU);
+        }
         linear(m, h, M, l.pw2, x, M, x, M, rows, ACT_NONE, 1.f);
         // x += 0.5 * FFN2(LN(x)); x = LN(x)
         layernorm(m, x, l.ffn2_ln, h, rows);

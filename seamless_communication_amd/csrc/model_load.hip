@@ -363,11 +363,26 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
         l.attn_ln = L.ln(p + ".self_attn_layer_norm", M);
         l.qkv = L.fuse({p + ".self_attn.q_proj", p + ".self_attn.k_proj", p + ".self_attn.v_proj"}, M, M);
         l.attn_out = L.lin(p + ".self_attn.output_proj", M, M);
-        l.rel_k = L.f32(p + ".self_attn.sdpa.rel_k_embed.weight", {npos, 64});
         l.conv_ln = L.ln(p + ".conv_layer_norm", M);
         l.pw1 = L.lin_pw(p + ".conv.pointwise_conv1", 2 * M, M);
         l.dw = L.f32(p + ".conv.depthwise_conv.weight", {M, 1, c.depthwise_conv_kernel_size});
-        l.conv_inner_ln = L.ln(p + ".conv.layer_norm", M);
+        if (c.enc_variant == 1) {
+            // v1: fairseq2 RelativePositionSDPA + BatchNorm1d (keys as in ggml/examples/unity/fairseq2.cpp:640-647, 718-719)
+            l.r_proj = L.lin(p + ".self_attn.sdpa.r_proj", M, M, /*bias=*/false);
+            l.u_bias = L.f32(p + ".self_attn.sdpa.u_bias", {c.num_heads, 64});
+            l.v_bias = L.f32(p + ".self_attn.sdpa.v_bias", {c.num_heads, 64});
+            const float* g = L.f32(p + ".conv.batch_norm.weight", {M});
+            const float* b = L.f32(p + ".conv.batch_norm.bias", {M});
+            const float* mu = L.f32(p + ".conv.batch_norm.running_mean", {M});
+            const float* var = L.f32(p + ".conv.batch_norm.running_var", {M});
+            float* fold = static_cast<float*>(L.dalloc((size_t)2 * M * 4));
+            launch_bn_fold(g, b, mu, var, 1e-5f, M, fold, fold + M, m.stream);
+            l.bn_scale = fold;
+            l.bn_shift = fold + M;
+        } else {
+            l.rel_k = L.f32(p + ".self_attn.sdpa.rel_k_embed.weight", {npos, 64});
+            l.conv_inner_ln = L.ln(p + ".conv.layer_norm", M);
+        }
         l.pw2 = L.lin_pw(p + ".conv.pointwise_conv2", M, M);
         l.ffn2_ln = L.ln(p + ".ffn2_layer_norm", M);
         l.ffn2_in = L.lin(p + ".ffn2.inner_proj", c.enc_ffn_dim, M);

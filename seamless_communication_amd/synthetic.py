@@ -96,11 +96,22 @@ def make_unity_state_dict(
             g.ffn(f"{p}.{f}", M, cfg.enc_ffn_dim)
         g.layer_norm(f"{p}.self_attn_layer_norm", M)
         g.mha(f"{p}.self_attn", M)
-        g.normal(f"{p}.self_attn.sdpa.rel_k_embed.weight", (cfg.shaw_num_pos, cfg.head_dim), cfg.head_dim ** -0.5)
+        v1 = getattr(cfg, "enc_variant", 0) == 1
+        if v1:  # fairseq2 RelativePositionSDPA: r_proj (no bias), u_bias / v_bias (heads, head_dim)
+            g.normal(f"{p}.self_attn.sdpa.r_proj.weight", (M, M), M ** -0.5)
+            g.normal(f"{p}.self_attn.sdpa.u_bias", (cfg.num_heads, cfg.head_dim), 0.3)
+            g.normal(f"{p}.self_attn.sdpa.v_bias", (cfg.num_heads, cfg.head_dim), 0.3)
+        else:
+            g.normal(f"{p}.self_attn.sdpa.rel_k_embed.weight", (cfg.shaw_num_pos, cfg.head_dim), cfg.head_dim ** -0.5)
         g.layer_norm(f"{p}.conv_layer_norm", M)
         g.conv1d(f"{p}.conv.pointwise_conv1", 2 * M, M, 1, bias=False)
         g.conv1d(f"{p}.conv.depthwise_conv", M, 1, cfg.depthwise_conv_kernel_size, bias=False)
-        g.layer_norm(f"{p}.conv.layer_norm", M)
+        if v1:  # BatchNorm1d with running statistics
+            g.layer_norm(f"{p}.conv.batch_norm", M)
+            g.normal(f"{p}.conv.batch_norm.running_mean", (M,), 0.2)
+            g.uniform(f"{p}.conv.batch_norm.running_var", (M,), 0.5, center=1.0)
+        else:
+            g.layer_norm(f"{p}.conv.layer_norm", M)
         g.conv1d(f"{p}.conv.pointwise_conv2", M, M, 1, bias=False)
         g.layer_norm(f"{p}.layer_norm", M)
 
