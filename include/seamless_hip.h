@@ -94,6 +94,10 @@ typedef struct sc_config {
      * `...self_attn.sdpa.{r_proj.weight,u_bias,v_bias}`) and a centred depthwise convolution + BatchNorm1d
      * (`...conv.batch_norm.{weight,bias,running_mean,running_var}`); restated in ggml/examples/unity/fairseq2.cpp:605-756. */
     int32_t enc_variant;
+    /* Code-HiFi-GAN duration predictor (models/vocoder/codehifigan.py:46-48, builder.py:53-58: VariancePredictor on the unit
+     * embeddings, hidden dim / kernel size); 0 = not loaded.  Used by sc_vocoder_durations (v1 models: the autoregressive T2U
+     * emits de-duplicated units and Translator.predict calls the vocoder with dur_prediction=True, translator.py:385-389). */
+    int32_t voc_dur_pred_hidden_dim, voc_dur_pred_kernel_size;
 } sc_config;
 
 /* Text generation options: the fields of SequenceGeneratorOptions
@@ -216,6 +220,12 @@ int sc_get_durations(sc_model* m, int32_t* h_durations /* [n][s_char_max] */, in
 int32_t sc_vocoder_hop(const sc_model* m);
 int sc_vocode(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, const int32_t* h_lang_idx,
               const int32_t* h_spkr_idx, float* d_wav);
+/* CodeGenerator.forward with dur_prediction=True, first half (models/vocoder/codehifigan.py:79-88): durations
+ * clamp(round(exp(dur_predictor(dict(units))) - 1), min=1) of every unit position, h_durations [n][s_units].  The caller
+ * repeats each unit by its duration (embedding lookup and repeat_interleave commute) and passes the expanded sequence to
+ * sc_vocode.  Like the reference there is no padding mask: every position of the [n][s_units] matrix gets a duration. */
+int sc_vocoder_durations(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, int32_t* h_durations);
+
 /* The same for a padded batch of which only the first h_unit_lens[i] * hop samples of row i will be kept (the
  * proportional trim of Translator.predict, inference/translator.py:411-419, never keeps more): rows are vocoded in length
  * buckets, each on min(s_units, unit_lens[i] + receptive field) frames of the padded row, so the kept samples are those of

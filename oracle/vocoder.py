@@ -34,11 +34,33 @@ def get_padding(kernel_size: int, dilation: int = 1) -> int:
     return (kernel_size * dilation - dilation) // 2  # hifigan.py:31-32
 
 
-def vocode(
-    sd: Dict[str, Tensor], vcfg, units: Tensor, lang_idx: Sequence[int], spkr_idx: Sequence[int]
-) -> Tensor:
-    """units (N, S_u) int64 -> waveform (N, 1, S_u * hop)."""
+def vocoder_durations(sd: Dict[str, Tensor], vcfg, units: Tensor) -> Tensor:
+    """CodeGenerator.forward with dur_prediction=True, codehifigan.py:79-83: VariancePredictor (models/unity/
+    length_regulator.py:172-222, no padding mask, no FiLM) on the unit embeddings -> clamp(round(exp(.) - 1), min=1).
+    units (N, T) int64 -> durations (N, T) int64.  Pinned against the executed reference classes
+    (tests/golden/make_reference_goldens.py: vocoder_dur_ref.npz)."""
     P = "code_generator"
+    sd = {k: v.float() for k, v in sd.items()}
+    d = f"{P}.dur_predictor"
+    K = vcfg.dur_pred_kernel_size
+    x = F.embedding(units, sd[f"{P}.dict.weight"])  # (N, T, E)
+    h = F.relu(F.conv1d(x.transpose(1, 2), sd[f"{d}.conv1.0.weight"], sd[f"{d}.conv1.0.bias"], padding=K // 2)).transpose(1, 2)
+    h = F.layer_norm(h, (h.shape[-1],), sd[f"{d}.ln1.weight"], sd[f"{d}.ln1.bias"], 1e-5)
+    h = F.relu(F.conv1d(h.transpose(1, 2), sd[f"{d}.conv2.0.weight"], sd[f"{d}.conv2.0.bias"], padding=K // 2)).transpose(1, 2)
+    h = F.layer_norm(h, (h.shape[-1],), sd[f"{d}.ln2.weight"], sd[f"{d}.ln2.bias"], 1e-5)
+    log_dur = F.linear(h, sd[f"{d}.proj.weight"], sd[f"{d}.proj.bias"]).squeeze(-1)
+    return torch.clamp(torch.round(torch.exp(log_dur) - 1).long(), min=1)
+
+
+def vocode(
+    sd: Dict[str, Tensor], vcfg, units: Tensor, lang_idx: Sequence[int], spkr_idx: Sequence[int], dur_prediction: bool = False
+) -> Tensor:
+    """units (N, S_u) int64 -> waveform (N, 1, S_u * hop).  ``dur_prediction``: every unit repeated by its predicted
+    duration first (codehifigan.py:84-88; like the reference the items must expand to one common length)."""
+    P = "code_generator"
+    if dur_prediction:
+        dur = vocoder_durations(sd, vcfg, units)
+        units = torch.stack([torch.repeat_interleave(units[i], dur[i]) for i in range(units.shape[0])])
     sd = {k: v.float() for k, v in sd.items()}
     x = F.embedding(units, sd[f"{P}.dict.weight"]).transpose(1, 2)  # (N, 1280, T)
     T = x.shape[-1]

@@ -64,6 +64,7 @@ class sc_config(C.Structure):
         ("mma_layers", _i), ("mma_ffn_dim", _i), ("mma_energy_layers", _i), ("mma_pre_decision_ratio", _i),
         ("mma_temperature", C.c_float),
         ("enc_variant", _i),
+        ("voc_dur_pred_hidden_dim", _i), ("voc_dur_pred_kernel_size", _i),
     ]
 
 
@@ -103,6 +104,7 @@ SIGNATURES = {
     "sc_vocoder_hop": (_i, [_P]),
     "sc_vocode": (C.c_int, [_P, _P, _i, _i, _P, _P, _P]),
     "sc_vocode_ragged": (C.c_int, [_P, _P, _i, _i, _P, _P, _P, _P]),
+    "sc_vocoder_durations": (C.c_int, [_P, _P, _i, _i, _P]),
     "sc_last_padding": (C.c_int, [_P, _P, _P, _P]),
     "sc_s2st": (C.c_int, [_P, _P, _i, _i, _P, C.POINTER(sc_gen_opts), _P, _i, C.c_float, _P, _P, _P, _i, _P, _P, _i, _P, _P, _P]),
     "sc_prof_enable": (C.c_int, [C.c_int]),
@@ -164,7 +166,7 @@ def check(status: int, what: str) -> None:
 
 
 def make_config(cfg, has_t2u: bool = True, has_vocoder: bool = True, has_text_encoder: bool = False,
-                has_monotonic_decoder: bool = False) -> sc_config:
+                has_monotonic_decoder: bool = False, has_vocoder_dur_predictor: bool = False) -> sc_config:
     c = sc_config()
     c.abi_version = SC_ABI_VERSION
     for f in (
@@ -208,4 +210,6 @@ def make_config(cfg, has_t2u: bool = True, has_vocoder: bool = True, has_text_en
     c.mma_pre_decision_ratio = int(cfg.mma_pre_decision_ratio)
     c.mma_temperature = float(cfg.mma_temperature)
     c.enc_variant = int(getattr(cfg, "enc_variant", 0))
+    c.voc_dur_pred_hidden_dim = int(v.dur_pred_hidden_dim) if has_vocoder_dur_predictor else 0
+    c.voc_dur_pred_kernel_size = int(v.dur_pred_kernel_size)
     return c

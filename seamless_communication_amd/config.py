@@ -34,6 +34,9 @@ class VocoderConfig:
     num_langs: int = 36
     spkr_embedding_dim: int = 256
     num_spkrs: int = 200
+    # duration predictor on the unit embeddings (builder.py:53-58; used with dur_prediction=True, the v1 AR-T2U path)
+    dur_pred_hidden_dim: int = 1280
+    dur_pred_kernel_size: int = 3
 
     @property
     def model_in_dim(self) -> int:
@@ -189,5 +192,6 @@ def tiny_config() -> S2STConfig:
             num_langs=36,
             spkr_embedding_dim=8,
             num_spkrs=200,
+            dur_pred_hidden_dim=64,
         ),
     )

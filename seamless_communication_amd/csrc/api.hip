@@ -246,6 +246,14 @@ int sc_vocode(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, c
     SC_API_END
 }
 
+int sc_vocoder_durations(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, int32_t* h_durations) {
+    SC_API_BEGIN
+    SC_CHECK(m && h_units && h_durations, "sc_vocoder_durations: null argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    run_vocoder_durations(m->m, h_units, n, s_units, h_durations);
+    SC_API_END
+}
+
 int sc_vocode_ragged(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, const int32_t* h_unit_lens,
                      const int32_t* h_lang_idx, const int32_t* h_spkr_idx, float* d_wav) {
     SC_API_BEGIN

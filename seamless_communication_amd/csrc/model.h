@@ -193,6 +193,11 @@ struct ModelData {
     float pos_alpha = 1.f, pos_alpha_char = 1.f;
     Conv dp_conv1, dp_conv2;
     LNorm dp_ln1, dp_ln2;
+    // vocoder duration predictor (codehifigan.py:46-48); vdp_proj_w == null: not loaded
+    Conv vdp_conv1, vdp_conv2;
+    LNorm vdp_ln1, vdp_ln2;
+    const float* vdp_proj_w = nullptr;
+    const float* vdp_proj_b = nullptr;
     const float* dp_proj_w = nullptr;
     const float* dp_proj_b = nullptr;
     std::vector<FFTLayer> t2u_dec;
@@ -270,6 +275,7 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
                  int32_t* out_sc);
 // h_unit_lens == null: the whole padded batch.  Otherwise only the first h_unit_lens[i] * hop samples of row i are
 // guaranteed (computed exactly as in the padded batch), the rest of the row is zero.
+void run_vocoder_durations(Model& m, const int32_t* h_units, int n, int s_units, int32_t* h_durations);
 void run_vocode(Model& m, const int32_t* h_units, int n, int s_units, const int32_t* h_lang, const int32_t* h_spkr,
                 float* d_wav, const int32_t* h_unit_lens = nullptr);
 std::vector<std::vector<int>> plan_length_groups(const std::vector<int>& lens, int overhead_rows, int max_groups);

@@ -570,6 +570,17 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
             }
         }
         m.voc_post = L.conv_wn(P + ".conv_post", 1, ch, 7);
+        if (c.voc_dur_pred_hidden_dim > 0) {
+            const std::string d = P + ".dur_predictor";
+            const int H = c.voc_dur_pred_hidden_dim, K = c.voc_dur_pred_kernel_size;
+            SC_CHECK(K % 2 == 1 && K >= 1, "sc_load: vocoder duration predictor needs an odd kernel size (got %d)", K);
+            m.vdp_conv1 = L.conv(d + ".conv1.0", H, E, K);
+            m.vdp_ln1 = L.ln(d + ".ln1", H);
+            m.vdp_conv2 = L.conv(d + ".conv2.0", H, H, K);
+            m.vdp_ln2 = L.ln(d + ".ln2", H);
+            m.vdp_proj_w = L.f32(d + ".proj.weight", {1, H});
+            m.vdp_proj_b = L.f32(d + ".proj.bias", {1});
+        }
     }
     SC_HIP(hipStreamSynchronize(m.stream));
 }

@@ -466,6 +466,39 @@ int vocoder_halo_units(const Model& m) {
 
 }  // namespace
 
+// rows of fp16 embeddings as fp32: out[r][:] = table[idx[r]][:]
+__global__ void embed_rows_f16_kernel(const int* __restrict__ idx, const __half* __restrict__ table, int E, float* __restrict__ out) {
+    const int r = blockIdx.x;
+    const __half* src = table + (int64_t)idx[r] * E;
+    for (int c = threadIdx.x; c < E; c += blockDim.x) out[(int64_t)r * E + c] = __half2float(src[c]);
+}
+
+// CodeGenerator.forward, dur_prediction=True (models/vocoder/codehifigan.py:79-83): the VariancePredictor
+// (length_regulator.py:172-222: conv k -> ReLU -> LN -> conv k -> ReLU -> LN -> Linear(.,1)) on the unit embeddings, no
+// padding mask, durations = clamp(round(exp(.) - 1), min=1).
+void run_vocoder_durations(Model& m, const int32_t* h_units, int n, int T, int32_t* h_durations) {
+    const sc_config& c = m.cfg;
+    SC_CHECK(c.has_vocoder && m.vdp_proj_w, "sc_vocoder_durations: the model was loaded without the vocoder's duration predictor");
+    SC_CHECK(n > 0 && T > 0, "sc_vocoder_durations: empty batch");
+    prof::set_tag("voc");
+    const int E = c.voc_embedding_dim, H = c.voc_dur_pred_hidden_dim, K = c.voc_dur_pred_kernel_size;
+    const int rows = n * T;
+    for (int i = 0; i < rows; ++i)
+        SC_CHECK(h_units[i] >= 0 && h_units[i] < c.voc_num_embeddings, "sc_vocoder_durations: unit %d outside the vocoder dictionary", h_units[i]);
+    Buf<int> d_units(&m.pool, rows), d_dur(&m.pool, rows);
+    SC_HIP(hipMemcpyAsync(d_units.get(), h_units, (size_t)rows * 4, hipMemcpyHostToDevice, m.stream));
+    Buf<float> x(&m.pool, (size_t)rows * E), a(&m.pool, (size_t)rows * H), b(&m.pool, (size_t)rows * H);
+    hipLaunchKernelGGL(embed_rows_f16_kernel, dim3(rows), dim3(256), 0, m.stream, d_units.get(), m.voc_dict, E, x.get());
+    SC_LAUNCH_CHECK();
+    conv1d(m, x, m.vdp_conv1, nullptr, a, n, T, 1, K / 2, 1, nullptr, IN_NONE, ACT_RELU);
+    layernorm(m, a, m.vdp_ln1, b, rows);
+    conv1d(m, b, m.vdp_conv2, nullptr, a, n, T, 1, K / 2, 1, nullptr, IN_NONE, ACT_RELU);
+    layernorm(m, a, m.vdp_ln2, b, rows);
+    launch_durations(b, H, m.vdp_proj_w, m.vdp_proj_b, rows, H, T, nullptr, 1.0f, 1, d_dur, m.stream);
+    SC_HIP(hipMemcpyAsync(h_durations, d_dur.get(), (size_t)rows * 4, hipMemcpyDeviceToHost, m.stream));
+    SC_HIP(hipStreamSynchronize(m.stream));
+}
+
 void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h_lang, const int32_t* h_spkr, float* d_wav,
                 const int32_t* h_unit_lens) {
     const sc_config& c = m.cfg;

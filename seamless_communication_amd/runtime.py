@@ -85,9 +85,7 @@ class HipS2STModel:
                     tensors["monotonic_decoder." + k] = v
         if vocoder_state_dict is not None:
             for k, v in vocoder_state_dict.items():
-                if ".dur_predictor." in k:
-                    continue  # unused with dur_prediction=False (translator.py:392-394)
-                tensors[k] = v
+                tensors[k] = v  # dur_predictor.* included: sc_vocoder_durations (dur_prediction=True, translator.py:385-389)
         keep: List[torch.Tensor] = []
         descs = (_lib.sc_tensor_desc * len(tensors))()
         for i, (k, v) in enumerate(tensors.items()):
@@ -103,8 +101,11 @@ class HipS2STModel:
                 d.shape[j] = s
             d.data = v.data_ptr()
             d.on_device = 1 if v.is_cuda else 0
+        self.has_vocoder_dur_predictor = vocoder_state_dict is not None and any(
+            ".dur_predictor." in k for k in vocoder_state_dict)
         ccfg = _lib.make_config(cfg, has_t2u=has_t2u, has_vocoder=vocoder_state_dict is not None,
-                                has_text_encoder=self.has_text_encoder, has_monotonic_decoder=self.has_monotonic_decoder)
+                                has_text_encoder=self.has_text_encoder, has_monotonic_decoder=self.has_monotonic_decoder,
+                                has_vocoder_dur_predictor=self.has_vocoder_dur_predictor)
         self.handle = self.lib.sc_load(descs, len(tensors), C.byref(ccfg), self.device_index)
         if not self.handle:
             msg = self.lib.sc_last_error()
@@ -302,11 +303,31 @@ class HipS2STModel:
         check(self.lib.sc_get_durations(self.handle, _ptr(dur), _ptr(cids), _ptr(clens)), "sc_get_durations")
         return units, ulens, dur, cids, clens
 
+    def vocoder_durations(self, units: np.ndarray) -> np.ndarray:
+        """``CodeGenerator`` duration prediction (codehifigan.py:79-83): units (n, S_u) -> durations (n, S_u), each >= 1."""
+        if not self.has_vocoder_dur_predictor:
+            raise SeamlessHipError("the vocoder checkpoint holds no dur_predictor tensors")
+        u = _i32(units)
+        n, s_u = u.shape
+        dur = np.zeros((n, s_u), dtype=np.int32)
+        check(self.lib.sc_vocoder_durations(self.handle, _ptr(u), n, s_u, _ptr(dur)), "sc_vocoder_durations")
+        return dur
+
     def vocode(self, units: np.ndarray, lang_idx: Sequence[int], spkr_idx: Sequence[int],
-               unit_lens: Optional[Sequence[int]] = None) -> torch.Tensor:
+               unit_lens: Optional[Sequence[int]] = None, dur_prediction: bool = False) -> torch.Tensor:
         """units (n, S_u) padded batch -> waveform (n, 1, S_u * hop).  With ``unit_lens`` only the first
         ``unit_lens[i] * hop`` samples of row i are guaranteed (``sc_vocode_ragged``: length buckets, the padding is not
-        synthesised); the rest of the row reads as zero."""
+        synthesised); the rest of the row reads as zero.  ``dur_prediction=True`` (reference: the v1 AR-T2U path,
+        translator.py:385-389): every unit is first repeated by its predicted duration (codehifigan.py:79-88); like the
+        reference this needs the items of a batch to expand to the same length."""
+        if dur_prediction:
+            assert unit_lens is None
+            dur = self.vocoder_durations(units)
+            rows = [np.repeat(np.asarray(units[i]), dur[i]) for i in range(len(units))]
+            if len({len(r) for r in rows}) != 1:
+                raise ValueError("dur_prediction: the items of the batch expand to different lengths "
+                                 "(the reference concatenates them, codehifigan.py:85-88)")
+            units = np.stack(rows)
         u = _i32(units)
         n, s_u = u.shape
         wav = torch.empty(n, 1, s_u * self.hop, dtype=torch.float32, device=self.device)

@@ -265,7 +265,7 @@ def make_monotonic_decoder_state_dict(cfg: S2STConfig, seed: int = DEFAULT_SEED,
 
 
 def make_vocoder_state_dict(
-    cfg: S2STConfig, seed: int = DEFAULT_SEED, dtype: torch.dtype = torch.float16
+    cfg: S2STConfig, seed: int = DEFAULT_SEED, dtype: torch.dtype = torch.float16, with_dur_predictor: bool = False
 ) -> Dict[str, torch.Tensor]:
     """Code-HiFi-GAN weights, weight-norm parametrised (``weight_g`` /
     ``weight_v``) as in the published ``vocoder_v2.pt`` (hifigan.py:143-176)."""
@@ -300,6 +300,18 @@ def make_vocoder_state_dict(
                 wn_conv(f"{r}.convs1.{m}", ch, ch, rk)
                 wn_conv(f"{r}.convs2.{m}", ch, ch, rk)
     wn_conv(f"{P}.conv_post", 1, ch, 7)
+    if with_dur_predictor:
+        # CodeGenerator.dur_predictor = VariancePredictor(embedding_dim, hidden, kernel) (codehifigan.py:46-48); every other
+        # tensor keeps its value (each is drawn from its own (seed, key) generator).  The projection bias centres the
+        # log-durations so that the rounded durations spread over 1..4.
+        d = f"{P}.dur_predictor"
+        H, K = v.dur_pred_hidden_dim, v.dur_pred_kernel_size
+        g.conv1d(f"{d}.conv1.0", H, v.embedding_dim, K)
+        g.layer_norm(f"{d}.ln1", H)
+        g.conv1d(f"{d}.conv2.0", H, H, K)
+        g.layer_norm(f"{d}.ln2", H)
+        g.uniform(f"{d}.proj.weight", (1, H), 1.5 * math.sqrt(3.0 / H))
+        g.sd[f"{d}.proj.bias"] = torch.tensor([0.9]).to(dtype)
     return g.sd
 
 

@@ -211,6 +211,40 @@ def make_nar_frontend(cfg, lr, stub):
     print("nar_frontend_ref.npz", {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
+def make_vocoder_dur(cfg, lr):
+    """vocoder_dur_ref.npz: the reference CodeGenerator WITH its duration predictor (codehifigan.py:46-48, built from
+    dur_predictor_params like models/vocoder/builder.py:53-58,109), forward(dur_prediction=True) executed on single
+    utterances (the reference concatenates the expanded items of a batch, so a ragged batch raises)."""
+    load_ref("seamless_communication.models.vocoder.hifigan", "models/vocoder/hifigan.py")
+    sys.modules["seamless_communication.models.unity"].VariancePredictor = lr.VariancePredictor
+    codehifigan = load_ref("seamless_communication.models.vocoder.codehifigan", "models/vocoder/codehifigan.py")
+    vocoder = load_ref("seamless_communication.models.vocoder.vocoder", "models/vocoder/vocoder.py")
+    v = cfg.vocoder
+    params = {"encoder_embed_dim": v.embedding_dim, "var_pred_hidden_dim": v.dur_pred_hidden_dim,
+              "var_pred_kernel_size": v.dur_pred_kernel_size, "var_pred_dropout": 0.5}
+    gen = codehifigan.CodeGenerator(
+        v.upsample_rates, v.upsample_kernel_sizes, v.upsample_initial_channel, v.resblock_kernel_sizes,
+        v.resblock_dilation_sizes, v.model_in_dim, v.num_embeddings, v.embedding_dim, params, v.lang_embedding_dim,
+        v.num_langs, v.spkr_embedding_dim, v.num_spkrs,
+    )
+    voc = vocoder.Vocoder(gen, cards.vocoder_lang_spkr_idx_map())
+    sd = syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED, with_dur_predictor=True)
+    voc.load_state_dict({k: t.float() for k, t in sd.items()}, strict=True)
+    voc.eval()
+    rng = np.random.RandomState(17)
+    out = {"sd_sha256": np.array(sd_checksum(sd))}
+    for tag, T in (("a", 31), ("b", 9)):
+        units = torch.from_numpy(rng.randint(0, v.num_embeddings, size=(1, T)).astype(np.int64))
+        with torch.inference_mode():
+            x = gen.dict(units)
+            log_dur = gen.dur_predictor(x, None)
+            dur = torch.clamp(torch.round((torch.exp(log_dur) - 1)).long(), min=1)
+            wav = voc(units[0], "fra", -1, dur_prediction=True)
+        out.update({f"{tag}_units": units.numpy(), f"{tag}_dur": dur.numpy(), f"{tag}_log_dur": log_dur.numpy(), f"{tag}_wav": wav.numpy()})
+        print("vocoder_dur_ref", tag, dur.flatten().tolist()[:12], tuple(wav.shape))
+    np.savez_compressed(HERE / "vocoder_dur_ref.npz", **out)
+
+
 # --------------------------------------------------------------------------- #
 def make_fft_layer(cfg, stub):
     fl = load_ref("seamless_communication.models.unity.fft_decoder_layer", "models/unity/fft_decoder_layer.py")
@@ -258,6 +292,7 @@ def main():
     load_ref("seamless_communication.models.unity.film", "models/unity/film.py")
     lr = load_ref("seamless_communication.models.unity.length_regulator", "models/unity/length_regulator.py")
     make_vocoder(cfg, lr)
+    make_vocoder_dur(cfg, lr)
     make_unit_tokenizer()
     make_nar_frontend(cfg, lr, stub)
     make_fft_layer(cfg, stub)

@@ -169,3 +169,29 @@ def test_cxx_char_rules_match_reference_frontend(bundle):
     assert lib.sc_text_to_char_seqs(len(tok_len), *[P(a) for a in arr], cfg.pad_idx, cfg.unk_idx, cfg.eos_idx, P(text), n, s_text,
                                     P(char_lens), P(char_ids), 3, P(seq_lens)) < 0
     assert b"capacity" in lib.sc_last_error()
+
+
+def test_vocoder_duration_predictor_matches_reference():
+    """CodeGenerator.forward(dur_prediction=True) (codehifigan.py:79-88), executed by the reference's own classes
+    (tests/golden/make_reference_goldens.py: vocoder_dur_ref.npz): durations exact, waveform of the expanded units 2e-5."""
+    from oracle import vocoder as ov
+    from seamless_communication_amd import cards, synthetic as syn
+    from seamless_communication_amd.config import tiny_config
+    from tests.golden.make_reference_goldens import sd_checksum
+
+    gold = np.load(G / "vocoder_dur_ref.npz")
+    cfg = tiny_config()
+    sd = syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED, with_dur_predictor=True)
+    assert sd_checksum(sd) == str(gold["sd_sha256"])
+    base = syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED)
+    assert all(torch.equal(sd[k], v) for k, v in base.items())  # the predictor tensors are additions only
+    lang_idx, spkr_idx = ov.resolve_lang_spkr(cards.vocoder_lang_spkr_idx_map(), ["fra"], [-1])
+    for tag in ("a", "b"):
+        units = torch.from_numpy(gold[f"{tag}_units"])
+        dur = ov.vocoder_durations(sd, cfg.vocoder, units)
+        assert dur.tolist() == gold[f"{tag}_dur"].tolist()
+        assert dur.min() >= 1 and dur.max() > 1
+        wav = ov.vocode(sd, cfg.vocoder, units, lang_idx, spkr_idx, dur_prediction=True)
+        want = torch.from_numpy(gold[f"{tag}_wav"])
+        assert wav.shape == want.shape == (1, 1, int(dur.sum()) * cfg.vocoder.hop)
+        assert float((wav - want).abs().max()) < 2e-5

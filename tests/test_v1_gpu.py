@@ -76,3 +76,32 @@ def test_v1_speech_to_text_ids_exact():
     ids, out_lens, _, _ = hip.generate_text(enc, enc_lens.tolist(), tt.target_prefix("fra"), hard_max_seq_len=12)
     got = [ids[b, : out_lens[b]].tolist() for b in range(len(ws))]
     assert got == [list(s) for s in seqs]
+
+
+def test_vocoder_duration_prediction_matches_reference_golden():
+    """sc_vocoder_durations + sc_vocode on the expanded units = CodeGenerator.forward(dur_prediction=True)
+    (codehifigan.py:79-88; the v1 path of Translator.predict, translator.py:385-389), against the reference-executed
+    fixture tests/golden/vocoder_dur_ref.npz: durations exact, waveform within 2e-3."""
+    from pathlib import Path
+
+    from oracle import vocoder as ov
+    from seamless_communication_amd.config import tiny_config
+    from seamless_communication_amd.runtime import HipS2STModel
+
+    gold = np.load(Path(__file__).parent / "golden" / "vocoder_dur_ref.npz")
+    cfg = tiny_config()
+    sd = syn.make_unity_state_dict(cfg, syn.DEFAULT_SEED)
+    vsd = syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED, with_dur_predictor=True)
+    hip = HipS2STModel(cfg, sd, vsd, device=0)
+    lang_idx, spkr_idx = ov.resolve_lang_spkr(cards.vocoder_lang_spkr_idx_map(), ["fra"], [-1])
+    for tag in ("a", "b"):
+        units = gold[f"{tag}_units"]
+        dur = hip.vocoder_durations(units)
+        assert dur.tolist() == gold[f"{tag}_dur"].tolist()
+        wav = hip.vocode(units, lang_idx, spkr_idx, dur_prediction=True).cpu()
+        want = torch.from_numpy(gold[f"{tag}_wav"])
+        assert wav.shape == want.shape
+        assert float((wav - want).abs().max()) < 2e-3
+    plain = HipS2STModel(cfg, sd, syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED), device=0)
+    with pytest.raises(Exception):
+        plain.vocoder_durations(gold["a_units"])
