@@ -98,6 +98,10 @@ typedef struct sc_config {
      * embeddings, hidden dim / kernel size); 0 = not loaded.  Used by sc_vocoder_durations (v1 models: the autoregressive T2U
      * emits de-duplicated units and Translator.predict calls the vocoder with dur_prediction=True, translator.py:385-389). */
     int32_t voc_dur_pred_hidden_dim, voc_dur_pred_kernel_size;
+    /* T2U family.  0: UnitY2 non-autoregressive T2U (sc_t2u_nar).  1: the v1 autoregressive UnitYT2UModel
+     * (models/unity/t2u_builder.py:140-183: encoder + unit embedding frontend + pre-LN decoder, beam search over units;
+     * inference/generator.py:316-336): sc_t2u_ar. */
+    int32_t t2u_variant;
 } sc_config;
 
 /* Text generation options: the fields of SequenceGeneratorOptions
@@ -220,6 +224,15 @@ int sc_get_durations(sc_model* m, int32_t* h_durations /* [n][s_char_max] */, in
 int32_t sc_vocoder_hop(const sc_model* m);
 int sc_vocode(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, const int32_t* h_lang_idx,
               const int32_t* h_spkr_idx, float* d_wav);
+/* v1 models: UnitYT2UModel generation (inference/generator.py:316-336).  d_dec_hidden [n][s_text][model_dim]: decoder
+ * outputs of the text sequences without their final EOS (as for sc_t2u_nar), h_text_lens their lengths.  Beam search over
+ * the unit decoder with `opts` (the reference's unit_opts: beam_size 5, soft_max_seq_len (25, 50)) from the prompt
+ * `h_prefix` (UnitTokenizer encoder prefix: [eos, lang]).  h_out_ids [n][unit_cap] (prompt echoed, EOS included, padded
+ * with the unit pad index), unit_cap >= sc_t2u_ar_max_len(...). */
+int sc_t2u_ar(sc_model* m, const float* d_dec_hidden, int32_t n, int32_t s_text, const int32_t* h_text_lens, const sc_gen_opts* opts,
+              const int32_t* h_prefix, int32_t prefix_len, int32_t* h_out_ids, int32_t unit_cap, int32_t* h_out_lens, float* h_scores);
+int32_t sc_t2u_ar_max_len(sc_model* m, const sc_gen_opts* opts, int32_t s_text);
+
 /* CodeGenerator.forward with dur_prediction=True, first half (models/vocoder/codehifigan.py:79-88): durations
  * clamp(round(exp(dur_predictor(dict(units))) - 1), min=1) of every unit position, h_durations [n][s_units].  The caller
  * repeats each unit by its duration (embedding lookup and repeat_interleave commute) and passes the expanded sequence to

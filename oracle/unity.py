@@ -692,6 +692,38 @@ def t2u_encoder(P: Params, cfg, x: Tensor, lens: Optional[Tensor]) -> Tensor:
     return P.layer_norm(x, "t2u_model.encoder.layer_norm")
 
 
+def t2u_ar_generate(
+    P: Params, cfg, dec_out: Tensor, text_lens: Tensor, prefix: Sequence[int], beam_size: int = 5,
+    soft_max_seq_len: Tuple[float, int] = (25, 50), hard_max_seq_len: int = 1024, min_seq_len: int = 1,
+    len_penalty: float = 1.0, unk_penalty: float = 0.0, normalize_scores: bool = True, return_all: bool = False,
+):
+    """The v1 models' unit generation (inference/generator.py:316-336, unit_opts :183-191): UnitYT2UModel
+    (models/unity/t2u_builder.py:430-517; model.py:300-360) = the T2U encoder over the text decoder output, then
+    BeamSearchSeq2SeqGenerator over a TransformerEmbeddingFrontend (unit embedding, sinusoidal positions) +
+    pre-LN StandardTransformerDecoder + TiedProjection - the SAME module classes as the text decoder, so the search is
+    ``beam_search_generate`` on the unit tensors under the text decoder's names, with the unit vocabulary's special
+    symbols (bos 0, pad 1, eos 2, unk 3; t2u_builder.py:143-147) and the source length = the text length."""
+    import copy
+
+    enc = t2u_encoder(P, cfg, dec_out, text_lens)
+    ren = {}
+    for k, v in P.sd.items():
+        if k.startswith("t2u_model.decoder.layers."):
+            ren["text_decoder.layers." + k[len("t2u_model.decoder.layers."):]] = v
+    ren["text_decoder.layer_norm.weight"] = P["t2u_model.decoder.layer_norm.weight"]
+    ren["text_decoder.layer_norm.bias"] = P["t2u_model.decoder.layer_norm.bias"]
+    ren["text_decoder_frontend.embed.weight"] = P["t2u_model.decoder_frontend.embed.weight"]
+    ren["final_proj.weight"] = P["t2u_model.final_proj.weight"]
+    c2 = copy.copy(cfg)
+    c2.dec_layers = cfg.t2u_dec_layers
+    c2.text_max_seq_len = cfg.unit_max_seq_len
+    c2.pad_idx, c2.unk_idx, c2.bos_idx, c2.eos_idx = cfg.unit_pad_idx, 3, 0, cfg.unit_eos_idx
+    pos = sinusoidal_table(cfg.unit_max_seq_len, cfg.model_dim, cfg.unit_pad_idx)
+    return beam_search_generate(Params(ren), c2, enc, text_lens, prefix, beam_size, soft_max_seq_len, hard_max_seq_len, min_seq_len,
+                                len_penalty, unk_penalty, normalize_scores, pos_table=pos, return_all=return_all,
+                                source_len=int(dec_out.shape[1]))
+
+
 def t2u_nar(
     P: Params, cfg, dec_out: Tensor, dec_lens: Tensor, text_seqs: Tensor, text_tok, char_tok,
     duration_factor: float = 1.0,

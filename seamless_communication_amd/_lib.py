@@ -65,6 +65,7 @@ class sc_config(C.Structure):
         ("mma_temperature", C.c_float),
         ("enc_variant", _i),
         ("voc_dur_pred_hidden_dim", _i), ("voc_dur_pred_kernel_size", _i),
+        ("t2u_variant", _i),
     ]
 
 
@@ -105,6 +106,8 @@ SIGNATURES = {
     "sc_vocode": (C.c_int, [_P, _P, _i, _i, _P, _P, _P]),
     "sc_vocode_ragged": (C.c_int, [_P, _P, _i, _i, _P, _P, _P, _P]),
     "sc_vocoder_durations": (C.c_int, [_P, _P, _i, _i, _P]),
+    "sc_t2u_ar": (C.c_int, [_P, _P, _i, _i, _P, C.POINTER(sc_gen_opts), _P, _i, _P, _i, _P, _P]),
+    "sc_t2u_ar_max_len": (_i, [_P, C.POINTER(sc_gen_opts), _i]),
     "sc_last_padding": (C.c_int, [_P, _P, _P, _P]),
     "sc_s2st": (C.c_int, [_P, _P, _i, _i, _P, C.POINTER(sc_gen_opts), _P, _i, C.c_float, _P, _P, _P, _i, _P, _P, _i, _P, _P, _P]),
     "sc_prof_enable": (C.c_int, [C.c_int]),
@@ -212,4 +215,5 @@ def make_config(cfg, has_t2u: bool = True, has_vocoder: bool = True, has_text_en
     c.enc_variant = int(getattr(cfg, "enc_variant", 0))
     c.voc_dur_pred_hidden_dim = int(v.dur_pred_hidden_dim) if has_vocoder_dur_predictor else 0
     c.voc_dur_pred_kernel_size = int(v.dur_pred_kernel_size)
+    c.t2u_variant = int(getattr(cfg, "t2u_variant", 0))
     return c

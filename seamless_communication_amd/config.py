@@ -95,7 +95,9 @@ class S2STConfig:
     bos_idx: int = 2
     eos_idx: int = 3
 
-    # UnitY2 NAR T2U
+    # UnitY2 NAR T2U (t2u_variant 0) or the v1 autoregressive UnitYT2UModel (t2u_variant 1: unit embedding frontend +
+    # pre-LN decoder, beam search; models/unity/t2u_builder.py:140-183)
+    t2u_variant: int = 0
     t2u_enc_layers: int = 6
     t2u_dec_layers: int = 6
     t2u_ffn_dim: int = 8192
@@ -131,15 +133,16 @@ def seamless_m4t_v2_large() -> S2STConfig:
 def seamless_m4t_large() -> S2STConfig:
     """seamlessM4T_large (v1), unity arch `base` (models/unity/builder.py:109-134): w2v-BERT 600m with relative positions,
     NLLB dense_1b, vocabulary 256102.  The speech encoder, text encoder / decoder run on this path; the v1 autoregressive T2U
-    and the vocoder's duration predictor are not built."""
-    return S2STConfig(name="seamlessM4T_large", enc_variant=1, text_max_seq_len=1024)
+    (beam search over units) and the vocoder's duration predictor complete the v1 chain."""
+    return S2STConfig(name="seamlessM4T_large", enc_variant=1, text_max_seq_len=1024, t2u_variant=1, unit_max_seq_len=2048)
 
 
 def seamless_m4t_medium() -> S2STConfig:
     """seamlessM4T_medium (v1), unity arch `medium` (models/unity/builder.py:137-162): w2v-BERT 300m (12 layers), NLLB
     dense_600m (12 + 12 layers, FFN 4096), NLLB-200 vocabulary 256206.  BASELINE configs[0] (T2TT plumbing) names it."""
     return S2STConfig(name="seamlessM4T_medium", enc_variant=1, enc_layers=12, text_enc_layers=12, text_enc_ffn_dim=4096,
-                      dec_layers=12, dec_ffn_dim=4096, text_vocab_size=256206, text_max_seq_len=1024)
+                      dec_layers=12, dec_ffn_dim=4096, text_vocab_size=256206, text_max_seq_len=1024, t2u_variant=1,
+                      t2u_enc_layers=4, t2u_dec_layers=4, unit_max_seq_len=2048)
 
 
 def tiny_v1_config() -> S2STConfig:
@@ -147,6 +150,7 @@ def tiny_v1_config() -> S2STConfig:
     c = tiny_config()
     c.name = "tiny_v1"
     c.enc_variant = 1
+    c.t2u_variant = 1
     return c
 
 

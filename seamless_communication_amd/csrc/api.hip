@@ -246,6 +246,33 @@ int sc_vocode(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, c
     SC_API_END
 }
 
+static int t2u_ar_len(const sc::Model& M, const sc_gen_opts& o, int s_text) {
+    const int src = o.source_len > 0 ? o.source_len : s_text;
+    int max_len = o.soft_max_seq_len_a > 0 ? std::min(o.hard_max_seq_len, (int)(o.soft_max_seq_len_a * (float)src) + o.soft_max_seq_len_b)
+                                           : o.hard_max_seq_len;
+    return std::min(max_len, M.cfg.unit_max_seq_len);
+}
+
+int32_t sc_t2u_ar_max_len(sc_model* m, const sc_gen_opts* opts, int32_t s_text) {
+    if (!m || !opts) return -1;
+    return t2u_ar_len(m->m, *opts, s_text);
+}
+
+int sc_t2u_ar(sc_model* m, const float* d_dec_hidden, int32_t n, int32_t s_text, const int32_t* h_text_lens, const sc_gen_opts* opts,
+              const int32_t* h_prefix, int32_t prefix_len, int32_t* h_out_ids, int32_t unit_cap, int32_t* h_out_lens, float* h_scores) {
+    SC_API_BEGIN
+    SC_CHECK(m && d_dec_hidden && h_text_lens && opts && h_prefix && h_out_ids && h_out_lens, "sc_t2u_ar: null argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    SC_CHECK(opts->beam_size >= 1 && opts->beam_size <= 8, "sc_t2u_ar: beam_size %d out of range (1..8)", opts->beam_size);
+    const int max_len = t2u_ar_len(m->m, *opts, s_text);
+    SC_CHECK(unit_cap >= max_len, "sc_t2u_ar: unit_cap %d < effective maximum length %d (sc_t2u_ar_max_len)", unit_cap, max_len);
+    std::vector<int32_t> ids((size_t)n * max_len);
+    run_t2u_ar(m->m, d_dec_hidden, n, s_text, h_text_lens, *opts, h_prefix, prefix_len, ids.data(), h_out_lens, h_scores);
+    for (int b = 0; b < n; ++b)
+        for (int t = 0; t < unit_cap; ++t) h_out_ids[(size_t)b * unit_cap + t] = t < max_len ? ids[(size_t)b * max_len + t] : m->m.cfg.unit_pad_idx;
+    SC_API_END
+}
+
 int sc_vocoder_durations(sc_model* m, const int32_t* h_units, int32_t n, int32_t s_units, int32_t* h_durations) {
     SC_API_BEGIN
     SC_CHECK(m && h_units && h_durations, "sc_vocoder_durations: null argument");

@@ -124,6 +124,8 @@ struct DecStack {
     const LNorm* final_ln = nullptr;
     int ffn_dim = 0;
     const std::vector<PChooseLayer>* pchoose = nullptr;
+    // vocabulary of the stack (beam search): size, special symbols, longest sequence of the position table
+    int vocab = 0, pad_idx = 0, unk_idx = 1, eos_idx = 3, max_seq_len = 0;
 };
 struct EncoderLayer {  // standard pre-LN transformer encoder layer (T2U encoder)
     LNorm attn_ln, ffn_ln;
@@ -193,6 +195,11 @@ struct ModelData {
     float pos_alpha = 1.f, pos_alpha_char = 1.f;
     Conv dp_conv1, dp_conv2;
     LNorm dp_ln1, dp_ln2;
+    // v1 autoregressive T2U (UnitYT2UModel, models/unity/t2u_builder.py:140-183): unit embedding frontend + pre-LN decoder
+    const __half* t2u_ar_embed = nullptr;  // [unit_vocab][M]; the tied output projection
+    const float* t2u_ar_pos = nullptr;     // [unit_max_seq_len][M]
+    std::vector<DecoderLayer> t2u_ar_dec;
+    LNorm t2u_ar_final_ln;
     // vocoder duration predictor (codehifigan.py:46-48); vdp_proj_w == null: not loaded
     Conv vdp_conv1, vdp_conv2;
     LNorm vdp_ln1, vdp_ln2;
@@ -276,6 +283,13 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
 // h_unit_lens == null: the whole padded batch.  Otherwise only the first h_unit_lens[i] * hop samples of row i are
 // guaranteed (computed exactly as in the padded batch), the rest of the row is zero.
 void run_vocoder_durations(Model& m, const int32_t* h_units, int n, int s_units, int32_t* h_durations);
+void run_t2u_ar(Model& m, const float* d_dec_hidden, int n, int s_text, const int32_t* h_text_lens, const sc_gen_opts& o,
+                const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids, int32_t* h_out_lens, float* h_scores);
+// T2U encoder (pre-LN StandardTransformerEncoder over the text decoder output; shared by the NAR and the AR T2U)
+void run_t2u_encoder(Model& m, const float* d_dec_hidden, int n, int s_text, const int* d_text_lens, float* d_out);
+void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens, const sc_gen_opts& o,
+                       const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids, int32_t* h_out_lens, float* h_scores,
+                       float* d_dec_hidden, int max_len);
 void run_vocode(Model& m, const int32_t* h_units, int n, int s_units, const int32_t* h_lang, const int32_t* h_spkr,
                 float* d_wav, const int32_t* h_unit_lens = nullptr);
 std::vector<std::vector<int>> plan_length_groups(const std::vector<int>& lens, int overhead_rows, int max_groups);

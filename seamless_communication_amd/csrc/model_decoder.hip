@@ -76,6 +76,29 @@ DecStack unity_stack(const Model& m) {
     w.final_ln = &m.dec_final_ln;
     w.ffn_dim = m.cfg.dec_ffn_dim;
     w.pchoose = nullptr;
+    w.vocab = m.cfg.text_vocab_size;
+    w.pad_idx = m.cfg.pad_idx;
+    w.unk_idx = m.cfg.unk_idx;
+    w.eos_idx = m.cfg.eos_idx;
+    w.max_seq_len = m.cfg.text_max_seq_len;
+    return w;
+}
+
+// the v1 autoregressive T2U decoder (unit vocabulary: bos 0, pad 1, eos 2, unk 3; t2u_builder.py:143-147)
+DecStack t2u_ar_stack(const Model& m) {
+    DecStack w;
+    w.embed = m.t2u_ar_embed;
+    w.embed_p = nullptr;
+    w.pos = m.t2u_ar_pos;
+    w.layers = &m.t2u_ar_dec;
+    w.final_ln = &m.t2u_ar_final_ln;
+    w.ffn_dim = m.cfg.t2u_ffn_dim;
+    w.pchoose = nullptr;
+    w.vocab = m.cfg.unit_vocab_size;
+    w.pad_idx = m.cfg.unit_pad_idx;
+    w.unk_idx = 3;
+    w.eos_idx = m.cfg.unit_eos_idx;
+    w.max_seq_len = m.cfg.unit_max_seq_len;
     return w;
 }
 
@@ -954,13 +977,50 @@ void ngram_blocked_tokens(const int32_t* seq, int S, int G, std::vector<int32_t>
 void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens, const sc_gen_opts& o,
                             const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids, int32_t* h_out_lens, float* h_scores,
                             float* d_dec_hidden) {
+    const DecStack W = unity_stack(m);
+    run_generate_beam(m, W, d_enc, n, s_enc, h_enc_lens, o, h_prefix, prefix_len, h_out_ids, h_out_lens, h_scores, d_dec_hidden,
+                      text_max_len(m, o, s_enc));
+}
+
+// UnitYT2UModel generation of the v1 models (inference/generator.py:316-336): T2U encoder over the text decoder output,
+// then BeamSearchSeq2SeqGenerator over the unit decoder (unit_opts: beam_size 5, soft_max_seq_len (25, 50),
+// generator.py:183-191) with the prompt [eos, lang] of the unit tokenizer.  Same search as the text decoder, other stack.
+void run_t2u_ar(Model& m, const float* d_dec_hidden, int n, int s_text, const int32_t* h_text_lens, const sc_gen_opts& o,
+                const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids, int32_t* h_out_lens, float* h_scores) {
     const sc_config& cfg = m.cfg;
-    const int M = cfg.model_dim, V = cfg.text_vocab_size, B = o.beam_size, L = cfg.dec_layers;
+    SC_CHECK(cfg.has_t2u && cfg.t2u_variant == 1 && m.t2u_ar_embed, "sc_t2u_ar: the model was loaded without an autoregressive T2U");
+    SC_CHECK(n > 0 && s_text > 0, "sc_t2u_ar: empty batch");
+    prof::set_tag("t2u");
+    const int M = cfg.model_dim;
+    Buf<int> d_tlens(&m.pool, n);
+    SC_HIP(hipMemcpyAsync(d_tlens.get(), h_text_lens, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+    Buf<float> enc(&m.pool, (size_t)n * s_text * M);
+    run_t2u_encoder(m, d_dec_hidden, n, s_text, d_tlens, enc);
+    const DecStack W = t2u_ar_stack(m);
+    // length rule of the unit generator: min(hard, int(a * S_text) + b), prompt included, capped by the position table
+    sc_gen_opts uo = o;
+    const int src = uo.source_len > 0 ? uo.source_len : s_text;
+    int max_len = uo.soft_max_seq_len_a > 0 ? std::min(uo.hard_max_seq_len, (int)(uo.soft_max_seq_len_a * (float)src) + uo.soft_max_seq_len_b)
+                                            : uo.hard_max_seq_len;
+    max_len = std::min(max_len, W.max_seq_len);
+    run_generate_beam(m, W, enc, n, s_text, h_text_lens, uo, h_prefix, prefix_len, h_out_ids, h_out_lens, h_scores, nullptr, max_len);
+}
+
+// Beam search over one decoder stack (the UnitY text decoder or the v1 autoregressive unit decoder).
+void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens, const sc_gen_opts& o,
+                       const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids, int32_t* h_out_lens, float* h_scores,
+                       float* d_dec_hidden, int max_len) {
+    struct VocabView {  // the names the body used for the text vocabulary, now the stack's
+        int pad_idx, unk_idx, eos_idx, text_max_seq_len, model_dim, dec_ffn_dim;
+    };
+    const VocabView cfg{W.pad_idx, W.unk_idx, W.eos_idx, W.max_seq_len, m.cfg.model_dim, W.ffn_dim};
+    const std::vector<DecoderLayer>& dec_layers = *W.layers;
+    const int M = cfg.model_dim, V = W.vocab, B = o.beam_size, L = (int)dec_layers.size();
     const int nb = n * B;
     const int K = std::min(2 * B, V - 1);
     SC_CHECK(B <= 8, "sc_generate_text: beam_size %d > 8", B);
     SC_CHECK(prefix_len >= 1, "sc_generate_text: the prompt must hold at least one token");
-    const int max_len = text_max_len(m, o, s_enc);
+    SC_CHECK(d_dec_hidden == nullptr || W.layers == &m.dec, "beam search: decoder outputs are captured for the text decoder only");
     SC_CHECK(o.min_seq_len <= max_len, "sc_generate_text: min_seq_len %d > effective max length %d", o.min_seq_len, max_len);
     SC_CHECK(prefix_len < max_len, "sc_generate_text: prompt length %d >= effective max length %d", prefix_len, max_len);
     SC_CHECK(max_len <= 4096 && max_len <= cfg.text_max_seq_len + 1, "sc_generate_text: length %d exceeds the decoder limit", max_len);
@@ -983,6 +1043,7 @@ void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, cons
     }
 
     StepCtx c;
+    c.stack = &W;
     c.nb = nb;
     c.cap = max_len;
     c.s_enc = s_enc;
@@ -1010,7 +1071,6 @@ void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, cons
     c.hN = hN;
     c.logits = logits;
     {
-        const DecStack W = unity_stack(m);
         if (step2_eligible(m, W, nb)) alloc_step2(m, c, cfg.dec_ffn_dim);  // second-generation step kernels (<= 64 live rows)
     }
     // self-attention K/V caches of all layers in one allocation, twice (re-ordered from one into the other)
@@ -1032,10 +1092,10 @@ void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, cons
     for (int li = 0; li < L; ++li) {
         cross.emplace_back(&m.pool, (size_t)nb * s_enc * 2 * M);
         c.cross_kv.push_back(cross.back());
-        linear(m, enc_rep, M, m.dec[li].cross_kv, nullptr, 0, c.cross_kv.back(), 2 * M, nb * s_enc, ACT_NONE, 1.f);
+        linear(m, enc_rep, M, dec_layers[li].cross_kv, nullptr, 0, c.cross_kv.back(), 2 * M, nb * s_enc, ACT_NONE, 1.f);
     }
     Linear proj;
-    proj.w = m.text_embed;
+    proj.w = W.embed;
     proj.ldw = M;
     proj.kpad = M;
     proj.in = M;

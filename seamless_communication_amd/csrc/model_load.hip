@@ -515,6 +515,29 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
         m.t2u_enc_ln = L.ln("t2u_model.encoder.layer_norm", M);
         const std::string f = "t2u_model.decoder_frontend";
         m.unit_embed = L.f16(f + ".embed.weight", {c.unit_vocab_size, M});
+      if (c.t2u_variant == 1) {
+        // v1 autoregressive UnitYT2UModel (t2u_builder.py:140-183, 430-517): TransformerEmbeddingFrontend (unit embedding,
+        // sinusoidal positions) + pre-LN StandardTransformerDecoder; final_proj is tied to the embedding
+        m.t2u_ar_embed = m.unit_embed;
+        m.t2u_ar_pos = L.f32(f + ".pos_encoder.freqs", {c.unit_max_seq_len, M});
+        m.t2u_ar_dec.resize(c.t2u_dec_layers);
+        for (int i = 0; i < c.t2u_dec_layers; ++i) {
+            const std::string p = "t2u_model.decoder.layers." + std::to_string(i);
+            DecoderLayer& l = m.t2u_ar_dec[i];
+            l.self_ln = L.ln(p + ".self_attn_layer_norm", M);
+            l.qkv = L.fuse({p + ".self_attn.q_proj", p + ".self_attn.k_proj", p + ".self_attn.v_proj"}, M, M);
+            l.self_out = L.lin(p + ".self_attn.output_proj", M, M);
+            l.cross_ln = L.ln(p + ".encoder_decoder_attn_layer_norm", M);
+            l.cross_q = L.lin(p + ".encoder_decoder_attn.q_proj", M, M);
+            l.cross_kv = L.fuse({p + ".encoder_decoder_attn.k_proj", p + ".encoder_decoder_attn.v_proj"}, M, M);
+            l.cross_out = L.lin(p + ".encoder_decoder_attn.output_proj", M, M);
+            l.ffn_ln = L.ln(p + ".ffn_layer_norm", M);
+            l.ffn_in = L.lin(p + ".ffn.inner_proj", c.t2u_ffn_dim, M);
+            l.ffn_out = L.lin(p + ".ffn.output_proj", M, c.t2u_ffn_dim);
+            L.pack_decoder_layer(l);
+        }
+        m.t2u_ar_final_ln = L.ln("t2u_model.decoder.layer_norm", M);
+      } else {
         m.char_embed = L.f16(f + ".embed_char.weight", {c.char_vocab_size, M});
         m.char_pos = L.f32(f + ".char_pos_encoder.freqs", {c.char_max_seq_len, M});
         m.unit_pos = L.f32(f + ".unit_pos_encoder.freqs", {c.unit_max_seq_len, M});
@@ -541,6 +564,7 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
             l.conv_ln = L.ln(p + ".conv1d_layer_norm", M);
         }
         m.t2u_dec_ln = L.ln("t2u_model.decoder.layer_norm", M);
+      }
     }
 
     // ---- vocoder -------------------------------------------------------------------

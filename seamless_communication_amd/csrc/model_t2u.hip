@@ -182,6 +182,26 @@ void run_encode_text(Model& m, const int32_t* h_tokens, int n, int s_text, const
     SC_HIP(hipStreamSynchronize(m.stream));  // h_tokens / h_lens are the caller's; outputs complete on return
 }
 
+// T2U encoder: pre-LN StandardTransformerEncoder + final LayerNorm over the text decoder output (UnitYT2UModel.encode /
+// UnitYNART2UModel.encode, models/unity/model.py:330-343, 404-412), key padding mask from d_text_lens.
+void run_t2u_encoder(Model& m, const float* d_dec_hidden, int n, int s_text, const int* d_text_lens, float* x) {
+    const sc_config& c = m.cfg;
+    const int M = c.model_dim, rows = n * s_text;
+    const int wideN = std::max(3 * M, c.t2u_ffn_dim);
+    Buf<float> h(&m.pool, (size_t)rows * M), wide(&m.pool, (size_t)rows * wideN), att(&m.pool, (size_t)rows * M);
+    SC_HIP(hipMemcpyAsync(x, d_dec_hidden, (size_t)rows * M * 4, hipMemcpyDeviceToDevice, m.stream));
+    for (const EncoderLayer& l : m.t2u_enc) {
+        layernorm(m, x, l.attn_ln, h, rows);
+        linear(m, h, M, l.qkv, nullptr, 0, wide, 3 * M, rows, ACT_NONE, 1.f);
+        attention_self(m, wide, M, att, n, s_text, d_text_lens);
+        linear(m, att, M, l.attn_out, x, M, x, M, rows, ACT_NONE, 1.f);
+        layernorm(m, x, l.ffn_ln, h, rows);
+        linear(m, h, M, l.ffn_in, nullptr, 0, wide, c.t2u_ffn_dim, rows, ACT_RELU, 1.f);
+        linear(m, wide, c.t2u_ffn_dim, l.ffn_out, x, M, x, M, rows, ACT_NONE, 1.f);
+    }
+    layernorm(m, x, m.t2u_enc_ln, x, rows);
+}
+
 void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const int32_t* h_text_lens,
                  const int32_t* h_text_seqs, float duration_factor, int32_t* h_unit_lens, int32_t* out_su,
                  int32_t* out_sc) {
@@ -197,20 +217,7 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
     // ---- T2U encoder (model.py:404-412) --------------------------------------------
     const int wideN = std::max(3 * M, std::max(c.t2u_ffn_dim, c.t2u_conv_inner_dim));
     Buf<float> x(&m.pool, (size_t)rows * M);
-    {
-        Buf<float> h(&m.pool, (size_t)rows * M), wide(&m.pool, (size_t)rows * wideN), att(&m.pool, (size_t)rows * M);
-        SC_HIP(hipMemcpyAsync(x.get(), d_dec_hidden, (size_t)rows * M * 4, hipMemcpyDeviceToDevice, m.stream));
-        for (const EncoderLayer& l : m.t2u_enc) {
-            layernorm(m, x, l.attn_ln, h, rows);
-            linear(m, h, M, l.qkv, nullptr, 0, wide, 3 * M, rows, ACT_NONE, 1.f);
-            attention_self(m, wide, M, att, n, s_text, d_tlens);
-            linear(m, att, M, l.attn_out, x, M, x, M, rows, ACT_NONE, 1.f);
-            layernorm(m, x, l.ffn_ln, h, rows);
-            linear(m, h, M, l.ffn_in, nullptr, 0, wide, c.t2u_ffn_dim, rows, ACT_RELU, 1.f);
-            linear(m, wide, c.t2u_ffn_dim, l.ffn_out, x, M, x, M, rows, ACT_NONE, 1.f);
-        }
-        layernorm(m, x, m.t2u_enc_ln, x, rows);
-    }
+    run_t2u_encoder(m, d_dec_hidden, n, s_text, d_tlens, x);
 
     // ---- host: characters ---------------------------------------------------------
     std::vector<int32_t> char_lens;

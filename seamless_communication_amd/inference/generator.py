@@ -4,7 +4,7 @@
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Any, Optional, Tuple
+from typing import List,  Any, Optional, Tuple
 
 
 class NGramRepeatBlockProcessor:
@@ -64,3 +64,20 @@ class SequenceGeneratorOptions:
 
     len_penalty: float = 1.0
     """The length penalty (beam search only)."""
+
+
+def remove_consecutive_repeated_ngrams(sequence: List[int], min_size: int = 1, max_size: int = 40) -> List[int]:
+    """Unit post-filter of the autoregressive T2U (reference: inference/generator.py:39-56, used at :355-362 when
+    ``unit_generation_ngram_filtering`` is set, batch size 1 only): scanning from the left, an n-gram (longest first)
+    that is immediately followed by a copy of itself loses its first copy."""
+    assert 1 <= min_size <= max_size
+    drop = set()
+    start = 0
+    while start < len(sequence):
+        for k in range(max_size, min_size - 1, -1):
+            if sequence[start: start + k] == sequence[start + k: start + 2 * k]:
+                drop.update(range(start, start + k))
+                start += k - 1
+                break
+        start += 1
+    return [tok for i, tok in enumerate(sequence) if i not in drop]

@@ -29,7 +29,7 @@ from torch import Tensor
 
 from .. import cards as _cards
 from .. import synthetic as _syn
-from ..config import S2STConfig, seamless_m4t_v2_large, tiny_config
+from ..config import S2STConfig, seamless_m4t_large, seamless_m4t_medium, seamless_m4t_v2_large, tiny_config, tiny_v1_config
 from ..runtime import HipS2STModel
 from ..tokenizer import CharTokenizer, NllbTextTokenizer, UnitTokenizer
 from .generator import NGramRepeatBlockProcessor, SequenceGeneratorOptions
@@ -65,7 +65,10 @@ class BatchedSpeechOutput:
     """Sample rate of the audio waveforms."""
 
 
-_ARCHS = {"base_v2": seamless_m4t_v2_large, "tiny_v2": tiny_config}
+# unity architectures (models/unity/builder.py:109-192): `base` / `medium` are the v1 models (w2v-BERT with relative
+# positions, autoregressive T2U, duration-predicting vocoder), `base_v2` the UnitY2 model of the north-star path
+_ARCHS = {"base_v2": seamless_m4t_v2_large, "tiny_v2": tiny_config, "base": seamless_m4t_large, "medium": seamless_m4t_medium,
+          "tiny_v1": tiny_v1_config}
 
 DEFAULT_CARDS: Dict[str, Dict[str, Any]] = {
     "seamlessM4T_v2_large": {
@@ -75,6 +78,19 @@ DEFAULT_CARDS: Dict[str, Dict[str, Any]] = {
     },
     "vocoder_v2": {
         "name": "vocoder_v2", "model_arch": "base", "checkpoint": "synthetic://20240901",
+        "model_config": {"lang_spkr_idx_map": _cards.vocoder_lang_spkr_idx_map()},
+    },
+    # v1 models (cards/seamlessM4T_medium.yaml, seamlessM4T_large.yaml, vocoder_36langs.yaml)
+    "seamlessM4T_medium": {
+        "name": "seamlessM4T_medium", "model_arch": "medium", "checkpoint": "synthetic://20240901",
+        "num_units": _cards.NUM_UNITS, "unit_langs": _cards.UNIT_LANGS, "langs": _cards.TEXT_LANGS, "default_lang": "eng",
+    },
+    "seamlessM4T_large": {
+        "name": "seamlessM4T_large", "model_arch": "base", "checkpoint": "synthetic://20240901",
+        "num_units": _cards.NUM_UNITS, "unit_langs": _cards.UNIT_LANGS, "langs": _cards.TEXT_LANGS, "default_lang": "eng",
+    },
+    "vocoder_36langs": {
+        "name": "vocoder_36langs", "model_arch": "base", "checkpoint": "synthetic://20240901", "dur_predictor": True,
         "model_config": {"lang_spkr_idx_map": _cards.vocoder_lang_spkr_idx_map()},
     },
 }
@@ -95,7 +111,7 @@ def _load_state_dict(card: Dict[str, Any], cfg: S2STConfig, kind: str, with_t2u:
         seed = int(uri[len("synthetic://"):] or _syn.DEFAULT_SEED)
         if kind == "unity":
             return _syn.make_unity_state_dict(cfg, seed, with_t2u=with_t2u, with_text_encoder=with_text_encoder)
-        return _syn.make_vocoder_state_dict(cfg, seed)
+        return _syn.make_vocoder_state_dict(cfg, seed, with_dur_predictor=bool(card.get("dur_predictor", False)))
     if uri.startswith("file://"):
         from ..checkpoint import load_converted_checkpoint
 
@@ -156,7 +172,7 @@ class Translator:
             vocoder_sd = _load_state_dict(vcard, self.cfg, "vocoder", True)
             self.lang_spkr_idx_map = vcard.get("model_config", {}).get("lang_spkr_idx_map") or _cards.vocoder_lang_spkr_idx_map()
         self.model = HipS2STModel(self.cfg, unity_sd, vocoder_sd, device=dev.index or 0)
-        if with_t2u:
+        if with_t2u and getattr(self.model, "t2u_variant", 0) == 0:
             self.model.set_nar_tables(self.text_tokenizer, self.char_tokenizer)
         self.has_vocoder = vocoder_sd is not None
         self.apply_mintox = False
@@ -292,6 +308,8 @@ class Translator:
         t4 = time.perf_counter()
         units = units_t.numpy()
         pad = self.unit_tokenizer.vocab_info.pad_idx
+        if getattr(self.model, "t2u_variant", 0) == 1:
+            return texts, self._speech_from_ar_units(units[:, 1:], pad, tgt_lang, spkr, sample_rate, t4)
         # translator.py:398-404: drops every pad (and every genuine unit equal to the pad value)
         speech_units = [[int(u) for u in units[i] if u != pad] for i in range(units.shape[0])]
         audio_wavs: List[Tensor] = []
@@ -313,6 +331,27 @@ class Translator:
                 keep = int(wav.size(-1) * len(speech_units[i]) / units.shape[1])
                 audio_wavs.append(wav[i, :, :keep].unsqueeze(0))
         return texts, BatchedSpeechOutput(units=speech_units, audio_wavs=audio_wavs, sample_rate=sample_rate)
+
+    def _speech_from_ar_units(self, units: np.ndarray, pad: int, tgt_lang: str, spkr: Optional[int], sample_rate: int,
+                              t_start: float) -> BatchedSpeechOutput:
+        """translator.py:385-428 for the autoregressive T2U of the v1 models: the language token is already removed
+        (``units[:, 1:]``), the vocoder predicts the durations (``dur_prediction=True``).  The reference concatenates the
+        expanded items of a batch (codehifigan.py:85-88), which only works when they expand to the same length, i.e. in
+        practice for one utterance; here every item is synthesised on its own units."""
+        speech_units = [[int(u) for u in units[i] if u != pad] for i in range(units.shape[0])]
+        audio_wavs: List[Tensor] = []
+        if self.has_vocoder:
+            lang_map = self.lang_spkr_idx_map
+            lang_idx = [lang_map["multilingual"][tgt_lang]]
+            spkr_idx = [lang_map["multispkr"][tgt_lang][0] if spkr in (None, -1) else spkr]
+            for i in range(units.shape[0]):
+                row = np.asarray(speech_units[i], dtype=np.int64)[None, :]
+                if row.shape[1] == 0:
+                    audio_wavs.append(torch.zeros(1, 1, 0, device=self.model.device))
+                    continue
+                audio_wavs.append(self.model.vocode(row, lang_idx, spkr_idx, dur_prediction=True))
+            self.last_stage_ms["vocoder"] = (time.perf_counter() - t_start) * 1e3
+        return BatchedSpeechOutput(units=speech_units, audio_wavs=audio_wavs, sample_rate=sample_rate)
 
     # translator.py:155-196
     @classmethod
@@ -395,6 +434,23 @@ class Translator:
         text_seqs = ids[:, :-1]
         text_lens = (out_lens - 1).tolist()
         t3 = time.perf_counter()
+        if getattr(model, "t2u_variant", 0) == 1:
+            # generator.py:316-336: UnitYT2UModel + BeamSearchSeq2SeqGenerator from the unit tokenizer's prompt [eos, lang]
+            uo = unit_generation_opts or SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(25, 50))
+            prefix_u = unit_tokenizer.create_encoder(tgt_lang).prefix_indices.tolist()
+            uids, ulens, _ = model.t2u_ar(hidden, text_lens, prefix_u, beam_size=uo.beam_size, soft_max_seq_len=uo.soft_max_seq_len,
+                                          hard_max_seq_len=uo.hard_max_seq_len, len_penalty=uo.len_penalty, unk_penalty=uo.unk_penalty)
+            unit_seqs = uids[:, : int(ulens.max())].astype(np.int64)  # pad_seqs: rows padded with the unit pad index
+            units = unit_tokenizer.create_decoder()(unit_seqs)
+            if unit_generation_ngram_filtering:  # generator.py:355-362
+                if units.shape[0] > 1:
+                    raise NotImplementedError("unit ngram_filtering is not implemented for batch_size > 1.")
+                from .generator import remove_consecutive_repeated_ngrams
+
+                units = np.asarray([remove_consecutive_repeated_ngrams(units[0].tolist())], dtype=np.int64)
+            trace["stage_ms"]["t2u"] = (time.perf_counter() - t3) * 1e3
+            trace["t2u"] = None
+            return texts, torch.from_numpy(units)
         units, unit_lens, dur, cids, clens = model.t2u_nar(hidden, text_seqs, text_lens, duration_factor)
         trace["stage_ms"]["t2u"] = (time.perf_counter() - t3) * 1e3
         trace["t2u"] = {"units": units, "unit_lens": unit_lens, "durations": dur, "char_ids": cids, "char_seq_lens": clens}

@@ -73,7 +73,11 @@ class HipS2STModel:
                 continue  # the decoder's frontend module (builder.py:443-446): same embedding storage
             tensors[k] = v
         tensors["text_decoder_frontend.pos_encoder.freqs"] = sinusoidal_freqs(cfg.text_max_seq_len, cfg.model_dim, 1)
-        if has_t2u:
+        self.t2u_variant = int(getattr(cfg, "t2u_variant", 0)) if has_t2u else 0
+        if has_t2u and self.t2u_variant == 1:
+            # v1 autoregressive T2U: TransformerEmbeddingFrontend with a plain sinusoidal encoder (t2u_builder.py:441-449)
+            tensors["t2u_model.decoder_frontend.pos_encoder.freqs"] = sinusoidal_freqs(cfg.unit_max_seq_len, cfg.model_dim, cfg.unit_pad_idx)
+        elif has_t2u:
             f = "t2u_model.decoder_frontend"
             tensors[f + ".char_pos_encoder.freqs"] = sinusoidal_freqs(cfg.char_max_seq_len, cfg.model_dim, cfg.unit_pad_idx)
             tensors[f + ".unit_pos_encoder.freqs"] = sinusoidal_freqs(cfg.unit_max_seq_len, cfg.model_dim, cfg.unit_pad_idx)
@@ -302,6 +306,28 @@ class HipS2STModel:
         clens = np.zeros(n, dtype=np.int32)
         check(self.lib.sc_get_durations(self.handle, _ptr(dur), _ptr(cids), _ptr(clens)), "sc_get_durations")
         return units, ulens, dur, cids, clens
+
+    def t2u_ar(self, dec_hidden: torch.Tensor, text_lens: Sequence[int], prefix: Sequence[int], beam_size: int = 5,
+               soft_max_seq_len=(25, 50), hard_max_seq_len: int = 1024, min_seq_len: int = 1, unk_penalty: float = 0.0,
+               len_penalty: float = 1.0, normalize_scores: bool = True):
+        """v1 autoregressive T2U (``UnitYT2UModel`` + beam search, inference/generator.py:316-336; defaults = the
+        reference's ``unit_opts``, generator.py:183-191).  dec_hidden (n, s_text, M): decoder outputs of the text
+        sequences without their final EOS; prefix: the unit tokenizer's encoder prefix [eos, lang].
+        -> (unit token ids (n, max_len) int32 incl. prompt and EOS, pad = unit_pad_idx; lens (n,); scores (n,))."""
+        if self.t2u_variant != 1:
+            raise SeamlessHipError("the checkpoint holds no autoregressive T2U (t2u_variant != 1)")
+        assert dec_hidden.is_cuda and dec_hidden.is_contiguous() and dec_hidden.dtype == torch.float32
+        n, s_text, _ = dec_hidden.shape
+        o = self._gen_opts(beam_size, soft_max_seq_len, hard_max_seq_len, min_seq_len, unk_penalty, False, len_penalty, normalize_scores)
+        cap = int(self.lib.sc_t2u_ar_max_len(self.handle, C.byref(o), s_text))
+        ids = np.full((n, cap), self.cfg.unit_pad_idx, dtype=np.int32)
+        lens = np.zeros(n, dtype=np.int32)
+        scores = np.zeros(n, dtype=np.float32)
+        tl, pre = _i32(text_lens), _i32(prefix)
+        self._after_torch()
+        check(self.lib.sc_t2u_ar(self.handle, _ptr(dec_hidden), n, s_text, _ptr(tl), C.byref(o), _ptr(pre), len(pre), _ptr(ids), cap,
+                                 _ptr(lens), _ptr(scores)), "sc_t2u_ar")
+        return ids, lens, scores
 
     def vocoder_durations(self, units: np.ndarray) -> np.ndarray:
         """``CodeGenerator`` duration prediction (codehifigan.py:79-83): units (n, S_u) -> durations (n, S_u), each >= 1."""

@@ -191,6 +191,22 @@ def make_unity_state_dict(
     g.sd[f"{f}.embed.weight"][:4].zero_()
     g.sd[f"{f}.embed.weight"][4 + n_units:].zero_()
     g.sd["t2u_model.final_proj.weight"] = g.sd[f"{f}.embed.weight"]
+    if getattr(cfg, "t2u_variant", 0) == 1:
+        # v1 autoregressive UnitYT2UModel (t2u_builder.py:430-517): pre-LN decoder layers with encoder-decoder attention.
+        # As for the text decoder the branches are damped and the last FFN amplified so that the synthetic model does
+        # not just echo its input unit; the EOS row gets a small embedding so that hypotheses finish before the limit.
+        g.sd[f"{f}.embed.weight"][cfg.unit_eos_idx] = (torch.randn(M, generator=g._g("unit_eos")) * (0.6 * M ** -0.5)).to(dtype)
+        g.sd["t2u_model.final_proj.weight"] = g.sd[f"{f}.embed.weight"]
+        for i in range(cfg.t2u_dec_layers):
+            p = f"t2u_model.decoder.layers.{i}"
+            g.layer_norm(f"{p}.self_attn_layer_norm", M)
+            g.mha(f"{p}.self_attn", M)
+            g.layer_norm(f"{p}.encoder_decoder_attn_layer_norm", M)
+            g.mha(f"{p}.encoder_decoder_attn", M)
+            g.layer_norm(f"{p}.ffn_layer_norm", M)
+            g.ffn(f"{p}.ffn", M, cfg.t2u_ffn_dim)
+        g.layer_norm("t2u_model.decoder.layer_norm", M)
+        return g.sd
     g.normal(f"{f}.embed_char.weight", (cfg.char_vocab_size, M), M ** -0.5)
     g.sd[f"{f}.pos_emb_alpha"] = torch.tensor([0.9], dtype=dtype)
     g.sd[f"{f}.pos_emb_alpha_char"] = torch.tensor([1.1], dtype=dtype)

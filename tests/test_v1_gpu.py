@@ -105,3 +105,82 @@ def test_vocoder_duration_prediction_matches_reference_golden():
     plain = HipS2STModel(cfg, sd, syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED), device=0)
     with pytest.raises(Exception):
         plain.vocoder_durations(gold["a_units"])
+
+
+@pytest.mark.parametrize("beam,soft", [(5, (2, 6)), (2, (1, 9)), (1, (2, 4))])
+def test_v1_autoregressive_t2u_units_match_oracle(beam, soft):
+    """sc_t2u_ar (UnitYT2UModel + beam search over units, inference/generator.py:316-336) against
+    oracle.unity.t2u_ar_generate on the SAME decoder outputs: unit token ids exact (prompt [eos, lang] echoed, EOS
+    included), for the reference's default beam of 5 and smaller ones."""
+    from oracle import unity as ou
+
+    cfg, tt, orc, hip = _models()
+    g = torch.Generator().manual_seed(5)
+    dec_out = torch.randn(3, 9, cfg.model_dim, generator=g)
+    lens = torch.tensor([9, 6, 3])
+    prefix = [cfg.unit_eos_idx, cfg.unit_vocab_size - 2]
+    want = ou.t2u_ar_generate(orc.P, cfg, dec_out, lens, prefix, beam_size=beam, soft_max_seq_len=soft)
+    ids, out_lens, scores = hip.t2u_ar(dec_out.cuda().contiguous(), lens.tolist(), prefix, beam_size=beam, soft_max_seq_len=soft)
+    got = [ids[b, : out_lens[b]].tolist() for b in range(3)]
+    assert got == [list(w) for w in want]
+    assert all(s[0] == cfg.unit_eos_idx and s[-1] == cfg.unit_eos_idx for s in got)
+
+
+def test_v1_speech_chain_units_to_waveform():
+    """The v1 tail of Translator.predict (translator.py:385-419): unit tokens -> UnitTokenDecoder -> drop the language
+    token -> vocoder with dur_prediction=True, HIP against the oracle on one utterance."""
+    from oracle import unity as ou
+    from oracle import vocoder as ov
+    from seamless_communication_amd.runtime import HipS2STModel
+    from seamless_communication_amd.tokenizer import UnitTokenizer
+
+    cfg, sd, vsd, tt, ct = _bundle()
+    vsd = syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED, with_dur_predictor=True)
+    hip = HipS2STModel(cfg, sd, vsd, device=0)
+    P = ou.Params(sd)
+    dec_out = torch.randn(1, 7, cfg.model_dim, generator=torch.Generator().manual_seed(9))
+    lens = torch.tensor([7])
+    prefix = [cfg.unit_eos_idx, cfg.unit_vocab_size - 2]
+    want = ou.t2u_ar_generate(P, cfg, dec_out, lens, prefix, beam_size=5, soft_max_seq_len=(2, 6))
+    ids, out_lens, _ = hip.t2u_ar(dec_out.cuda().contiguous(), lens.tolist(), prefix, soft_max_seq_len=(2, 6))
+    assert ids[0, : out_lens[0]].tolist() == list(want[0])
+    utok = UnitTokenizer(cfg.vocoder.num_embeddings, cards.UNIT_LANGS, "base")
+    units = utok.create_decoder()(ids[:, : out_lens[0]].astype(np.int64))[:, 1:]  # translator.py:388: lang token removed
+    units = np.clip(units, 0, cfg.vocoder.num_embeddings - 1)  # synthetic weights may emit control symbols
+    lang_idx, spkr_idx = ov.resolve_lang_spkr(cards.vocoder_lang_spkr_idx_map(), ["fra"], [-1])
+    ref = ov.vocode(vsd, cfg.vocoder, torch.from_numpy(units), lang_idx, spkr_idx, dur_prediction=True)
+    wav = hip.vocode(units, lang_idx, spkr_idx, dur_prediction=True).cpu()
+    assert wav.shape == ref.shape
+    assert float((wav - ref).abs().max()) < 2e-3
+
+
+def test_translator_v1_card_speech_and_text_outputs():
+    """Translator on a v1-architecture card (unity arch `tiny_v1` = the structure of `base` / `medium`: relative-position
+    encoder, autoregressive T2U, duration-predicting vocoder): S2TT text ids equal the oracle's beam search, S2ST returns
+    one waveform per utterance whose length is the sum of the predicted durations x hop."""
+    from seamless_communication_amd.inference import Translator
+    from seamless_communication_amd.inference.translator import DEFAULT_CARDS
+
+    # tiny unit vocabulary (340 symbols): 300 units + 2 x (4 languages + 1) + 4 control symbols fit
+    card = dict(DEFAULT_CARDS["seamlessM4T_medium"], model_arch="tiny_v1", name="tiny_v1", num_units=300,
+                unit_langs=["eng", "fra", "deu", "spa"])
+    tr = Translator(card, "vocoder_36langs", device="cuda:0")
+    assert tr.model.t2u_variant == 1 and tr.cfg.enc_variant == 1 and tr.model.has_vocoder_dur_predictor
+    wav = torch.from_numpy(common.waves((1.6,))[0])
+    from seamless_communication_amd.inference import SequenceGeneratorOptions
+
+    topts = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(1, 200), hard_max_seq_len=10)
+    uopts = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(2, 6))
+    texts, speech = tr.predict(wav, "S2ST", "fra", text_generation_opts=topts, unit_generation_opts=uopts)
+    assert len(texts) == 1 and speech is not None and len(speech.audio_wavs) == 1
+    units = np.asarray(speech.units[0], dtype=np.int64)[None, :]
+    dur = tr.model.vocoder_durations(units)
+    assert speech.audio_wavs[0].shape == (1, 1, int(dur.sum()) * tr.cfg.vocoder.hop)
+    assert torch.isfinite(speech.audio_wavs[0]).all()
+    # text ids: the oracle's beam search on the oracle's v1 encoder output
+    cfg, tt, orc, hip = _models()
+    fb_ref, lens_ref = orc.collate_fbank([wav.numpy()])
+    want = orc.s2tt(fb_ref, lens_ref, "fra", (1, 200), 10, beam_size=5)[0]
+    assert tr.last_text_ids == [list(w) for w in want]
+    texts2, none = tr.predict(wav, "S2TT", "fra", text_generation_opts=topts)
+    assert none is None and [str(t) for t in texts2] == [str(t) for t in texts]
