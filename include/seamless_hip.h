@@ -335,6 +335,13 @@ int sc_op_conv_transpose1d(const float* d_x, const void* d_v_f16, const void* d_
  * fp16 planes, the format the next product consumes) may be requested.  Same bits as sc_op_linear(split=1). */
 int sc_op_linear_presplit(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y,
                           void* d_yh_f16, void* d_yl_f16, int32_t M, int32_t N, int32_t K, int32_t act, float alpha);
+/* Conv1d (stride 1) through the pre-split product kernel's implicit-convolution mode: x [nb][t][cin] is split into two
+ * fp16 planes, output row (i, t) reads rows t + tap*dil - pad of item i (zeros outside the item), weights packed by
+ * sc_op_pack_conv_weight.  d_row_valid (nullable, [nb*t] bytes on the device): rows with 0 are written as exact zeros.
+ * Same bits as sc_op_conv1d on the same values. */
+int sc_op_conv1d_presplit(const float* d_x, const void* d_w_f16_packed, const float* d_bias, const float* d_res, float* d_y,
+                          void* d_yh_f16, void* d_yl_f16, int32_t nb, int32_t t, int32_t cin, int32_t cout, int32_t k, int32_t pad,
+                          int32_t dil, const unsigned char* d_row_valid, int32_t act);
 /* One HiFi-GAN ResBlock dilation pair (hifigan.py:114-121) fused in one kernel for C in {16, 32, 64}:
  * out = x + conv2_{k,1}(lrelu(conv1_{k,dil}(lrelu(x)) + b1)) + b2, weights packed by sc_op_pack_conv_weight
  * (rows padded to a multiple of 32); with d_avg_a/d_avg_b: out = ((a + b) + that) / 3. */

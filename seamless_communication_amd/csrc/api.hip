@@ -877,6 +877,38 @@ int sc_op_linear_presplit(const float* d_x, const void* d_w_f16, const float* d_
     SC_API_END
 }
 
+int sc_op_conv1d_presplit(const float* d_x, const void* d_w_f16_packed, const float* d_bias, const float* d_res, float* d_y,
+                          void* d_yh_f16, void* d_yl_f16, int32_t nb, int32_t t, int32_t cin, int32_t cout, int32_t k, int32_t pad,
+                          int32_t dil, const unsigned char* d_row_valid, int32_t act) {
+    SC_API_BEGIN
+    SC_CHECK(d_x && d_w_f16_packed && (d_y || d_yh_f16), "sc_op_conv1d_presplit: null argument");
+    __half *hi = nullptr, *lo = nullptr;
+    const size_t n = (size_t)nb * t * cin;
+    SC_HIP(hipMalloc(&hi, n * 2));
+    SC_HIP(hipMalloc(&lo, n * 2));
+    try {
+        launch_split_f32(d_x, hi, lo, (int64_t)n, g_op_stream);
+        Model tmp;
+        Conv c;
+        c.w = static_cast<const __half*>(d_w_f16_packed);
+        c.b = d_bias;
+        c.cout = cout;
+        c.cin = cin;
+        c.k = k;
+        c.kpad = (int)align_up((int64_t)cin * k, 32);
+        conv1d_presplit(tmp, hi, lo, c, d_res, d_y, static_cast<__half*>(d_yh_f16), static_cast<__half*>(d_yl_f16), nb, t, pad, dil,
+                        d_row_valid, act);
+        SC_HIP(hipStreamSynchronize(g_op_stream));
+    } catch (...) {
+        (void)hipFree(hi);
+        (void)hipFree(lo);
+        throw;
+    }
+    (void)hipFree(hi);
+    (void)hipFree(lo);
+    SC_API_END
+}
+
 int sc_op_resblock_pair(const float* d_x, const void* d_w1_packed, const float* d_b1, const void* d_w2_packed,
                         const float* d_b2, float* d_out, int32_t nb, int32_t T, int32_t C, int32_t k, int32_t dil,
                         float slope, const float* d_avg_a, const float* d_avg_b) {

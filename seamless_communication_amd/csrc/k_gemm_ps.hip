@@ -85,11 +85,12 @@ __device__ __forceinline__ void ps_epilogue(const GemmPsArgs& p, const float* ep
         const int64_t m = m0w + row;
         const f4_t a = *reinterpret_cast<const f4_t*>(ep + row * EP_LD + c0);
         if (m >= p.M || col >= p.N) continue;
+        const bool dead = p.row_valid && p.row_valid[m] == 0;  // padded row of a length bucket: exact zeros
         f4_t v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = ps_act<ACT>(a[e] + b4[e]) * p.alpha;
+        for (int e = 0; e < 4; ++e) v[e] = dead ? 0.f : ps_act<ACT>(a[e] + b4[e]) * p.alpha;
         if (vec_ok) {
-            if (p.res) v += *reinterpret_cast<const f4_t*>(p.res + m * p.ldr + col);
+            if (p.res && !dead) v += *reinterpret_cast<const f4_t*>(p.res + m * p.ldr + col);
             if (p.C) *reinterpret_cast<f4_t*>(p.C + m * p.ldc + col) = v;
             if (p.Ch) {
                 const h4_t hi = __builtin_convertvector(v, h4_t);
@@ -102,7 +103,7 @@ __device__ __forceinline__ void ps_epilogue(const GemmPsArgs& p, const float* ep
             for (int e = 0; e < 4; ++e) {
                 if (col + e >= p.N) continue;
                 float x = v[e];
-                if (p.res) x += p.res[m * p.ldr + col + e];
+                if (p.res && !dead) x += p.res[m * p.ldr + col + e];
                 if (p.C) p.C[m * p.ldc + col + e] = x;
                 if (p.Ch) {
                     const _Float16 h = (_Float16)x;
@@ -124,7 +125,7 @@ __device__ __forceinline__ void ps_epilogue(const GemmPsArgs& p, const float* ep
 // 256 x 256 tile (wave tile 64 x 128) halves the barriers per MFMA (32 matrix instructions per slab and wave instead of
 // 16) and takes the fragment reads from 0.75 to 0.5 ds_read_b128 per MFMA at the same 6 DMAs per wave and slab; its
 // three stages fill 144 KB of the 160 KB LDS (one workgroup of 8 waves per CU = the same 2 waves per SIMD).
-template <int BM, int BN, int WGM, int WGN, bool ILV, bool SPLIT>
+template <int BM, int BN, int WGM, int WGN, bool ILV, bool SPLIT, bool CONV = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, int tiles_n, int tiles_total, int tiles_per_xcd,
                                                                  uint32_t a_bytes, uint32_t w_bytes) {
     constexpr int NWAVE = WGM * WGN;
@@ -168,12 +169,41 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
     // this lane's fixed LDS position inside a chunk: row (lane >> 2), segment slot (lane & 3); it fetches the
     // global segment that the swizzle maps to that slot
     uint32_t a_voff[ACH], b_voff[BCH];
+    int a_t[ACH];  // CONV: position of the lane's row inside its item
 #pragma unroll
     for (int j = 0; j < ACH; ++j) {
         const int row = 16 * (wave * ACH + j) + (lane >> 2);
         const int seg = (lane & 3) ^ ((row >> 2) & 3);
         a_voff[j] = (m0 + row) < p.M ? (uint32_t)(((int64_t)(m0 + row) * p.lda + seg * 8) * 2) : OOB;
+        a_t[j] = CONV ? (m0 + row) % p.rows_per_item : 0;
     }
+    // CONV: (tap, 32-wide channel slab) of the NEXT slab to be issued - slabs are issued strictly in K order - and the
+    // operand addresses of that slab: K byte offset inside the row (ka_) and row offset per chunk (va_), rows of another
+    // item or outside the matrix as out-of-range offsets (hardware zero fill = the convolution's zero padding)
+    int nx_tap = 0, nx_cs = 0, nx_slab = 0;
+    const int spt = CONV ? p.conv_cin / PBK : 1;
+    const uint32_t row_bytes = (uint32_t)(p.lda * 2);
+    uint32_t va_[ACH];
+    int ka_ = 0;
+#define PS_NEXT_ADDR()                                                                                  \
+    do {                                                                                                \
+        if (CONV) {                                                                                     \
+            const int dt_ = nx_tap * p.conv_dil - p.conv_pad;                                           \
+            ka_ = nx_cs * (PBK * 2);                                                                    \
+            _Pragma("unroll") for (int j = 0; j < ACH; ++j) {                                           \
+                const bool in_ = (uint32_t)(a_t[j] + dt_) < (uint32_t)p.rows_per_item && a_voff[j] != OOB; \
+                va_[j] = in_ ? a_voff[j] + (uint32_t)dt_ * row_bytes : OOB;                             \
+            }                                                                                           \
+            if (++nx_cs == spt) {                                                                       \
+                nx_cs = 0;                                                                              \
+                ++nx_tap;                                                                               \
+            }                                                                                           \
+        } else {                                                                                        \
+            ka_ = nx_slab * (PBK * 2);                                                                  \
+            _Pragma("unroll") for (int j = 0; j < ACH; ++j) va_[j] = a_voff[j];                         \
+        }                                                                                               \
+        ++nx_slab;                                                                                      \
+    } while (0)
 #pragma unroll
     for (int j = 0; j < BCH; ++j) {
         const int row = 16 * (wave * BCH + j) + (lane >> 2);
@@ -211,9 +241,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
                  : "memory")
 #define PS_ISSUE(AH, AL, BB, KOFF)                                                             \
     do {                                                                                       \
+        PS_NEXT_ADDR();                                                                        \
         _Pragma("unroll") for (int j = 0; j < ACH; ++j) {                                      \
-            PS_DMA(rah, &AH[(wave * ACH + j) * 512], a_voff[j], (KOFF));                       \
-            if (SPLIT) PS_DMA(ral, &AL[(wave * ACH + j) * 512], a_voff[j], (KOFF));            \
+            PS_DMA(rah, &AH[(wave * ACH + j) * 512], va_[j], ka_);                             \
+            if (SPLIT) PS_DMA(ral, &AL[(wave * ACH + j) * 512], va_[j], ka_);                  \
         }                                                                                      \
         _Pragma("unroll") for (int j = 0; j < BCH; ++j)                                        \
             PS_DMA(rw, &BB[(wave * BCH + j) * 512], b_voff[j], (KOFF));                        \
@@ -245,8 +276,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
 #define PS_DMA_Q(Q, AH, AL, BB, KOFF)                                                                         \
     do {                                                                                                      \
         if ((Q) < 2 * ACH) {                                                                                  \
-            if (((Q) & 1) == 0) PS_DMA(rah, &AH[(wave * ACH + (Q) / 2) * 512], a_voff[(Q) / 2], (KOFF));       \
-            else if (SPLIT) PS_DMA(ral, &AL[(wave * ACH + (Q) / 2) * 512], a_voff[(Q) / 2], (KOFF));           \
+            if (((Q) & 1) == 0) PS_DMA(rah, &AH[(wave * ACH + (Q) / 2) * 512], va_[(Q) / 2], ka_);             \
+            else if (SPLIT) PS_DMA(ral, &AL[(wave * ACH + (Q) / 2) * 512], va_[(Q) / 2], ka_);                 \
         } else {                                                                                              \
             PS_DMA(rw, &BB[(wave * BCH + ((Q) - 2 * ACH)) * 512], b_voff[(Q) - 2 * ACH], (KOFF));              \
         }                                                                                                     \
@@ -266,6 +297,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
             _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
                 bf[kc][j] = *reinterpret_cast<const half8_t*>(reinterpret_cast<const char*>(BB) + b_off[j][kc]);        \
         }                                                                                                              \
+        if (DO_ISSUE) PS_NEXT_ADDR();                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         int q_ = 0;                                                                                                    \
         _Pragma("unroll") for (int kc = 0; kc < 2; ++kc) {                                                             \
@@ -322,6 +354,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
 #undef PS_COMPUTE
 #undef PS_COMPUTE_ILV
 #undef PS_DMA_Q
+#undef PS_NEXT_ADDR
 #undef PS_ISSUE
 #undef PS_DMA
 
@@ -366,6 +399,7 @@ void launch_ps_cfg(const GemmPsArgs& a, hipStream_t s) {
     const dim3 grid(tiles_per_xcd * 8), block(WGM * WGN * 64);
     const uint32_t ab = (uint32_t)((int64_t)a.M * a.lda * 2), wb = (uint32_t)((int64_t)a.N * a.ldw * 2);
     if (!a.split) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
+    else if (a.conv_taps > 0) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (ilv) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
 }
@@ -376,13 +410,20 @@ void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s) {
     SC_CHECK(a.Ah && a.Al && a.W && (a.C || a.Ch), "presplit gemm: null operand");
     SC_CHECK((a.Ch == nullptr) == (a.Cl == nullptr), "presplit gemm: Ch/Cl must be given together");
     SC_CHECK(a.M > 0 && a.N > 0 && a.K > 0 && a.K % PBK == 0, "presplit gemm: M=%d N=%d K=%d (K must be a multiple of 32)", a.M, a.N, a.K);
-    SC_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.lda >= a.K && a.ldw >= a.K, "presplit gemm: lda=%lld ldw=%lld", (long long)a.lda,
+    SC_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldw >= a.K, "presplit gemm: lda=%lld ldw=%lld", (long long)a.lda,
              (long long)a.ldw);
     SC_CHECK(((reinterpret_cast<uintptr_t>(a.Ah) | reinterpret_cast<uintptr_t>(a.Al) | reinterpret_cast<uintptr_t>(a.W) |
                reinterpret_cast<uintptr_t>(a.C) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0 &&
                  ((reinterpret_cast<uintptr_t>(a.Ch) | reinterpret_cast<uintptr_t>(a.Cl)) & 7) == 0,
              "presplit gemm: operands must be 16-byte aligned");
     SC_CHECK((int64_t)a.M * a.lda * 2 < (1ll << 31) && (int64_t)a.N * a.ldw * 2 < (1ll << 31), "presplit gemm: operand larger than 2 GB");
+    if (a.conv_taps > 0) {
+        SC_CHECK(a.split && a.conv_cin % PBK == 0 && a.K == a.conv_taps * a.conv_cin && a.lda >= a.conv_cin && a.rows_per_item > 0 &&
+                     a.M % a.rows_per_item == 0 && a.conv_dil >= 1 && a.conv_pad >= 0,
+                 "presplit conv: taps=%d cin=%d K=%d rows_per_item=%d M=%d", a.conv_taps, a.conv_cin, a.K, a.rows_per_item, a.M);
+    } else {
+        SC_CHECK(a.lda >= a.K, "presplit gemm: lda=%lld < K=%d", (long long)a.lda, a.K);
+    }
     // tile choice: 256 x 256 (8 waves) once it fills the chip about once, 128 x 128 down to one round of 256 tiles,
     // 64 x 64 below.  SC_PS_TILE=128 (development A/B) keeps the round-1 choice.  All three accumulate every output
     // element in the same order (16-wide K chunks, hi then lo): identical bits.

@@ -37,6 +37,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     typedef float f4_t __attribute__((ext_vector_type(4)));
     h4_t* yhr = reinterpret_cast<h4_t*>(yh + (yh ? (int64_t)row * ldh : 0));
     h4_t* ylr = reinterpret_cast<h4_t*>(yl + (yl ? (int64_t)row * ldh : 0));
+    // y AND yh given ("both"): fp32 rows as well as planes; the length mask then zeroes the planes only (the fp32 copy is
+    // a residual stream, the planes are the next convolution's operand and carry its zero padding behind an item's end)
+    const bool both = y != nullptr && yh != nullptr;
+    bool masked = false;
     if (lens) {
         const int n = row / t_per_batch;
         const int t = row - n * t_per_batch;
@@ -49,7 +53,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                     yr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
-            return;
+            if (!both) return;
+            masked = true;
         }
     }
     float4 v[MAXV];
@@ -84,15 +89,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             o.y = act_f((v[i].y - mean) * rstd * g.y + b.y, act);
             o.z = act_f((v[i].z - mean) * rstd * g.z + b.z, act);
             o.w = act_f((v[i].w - mean) * rstd * g.w + b.w, act);
-            if (yh) {
+            if (yh && !masked) {
                 const f4_t of = {o.x, o.y, o.z, o.w};
                 const h4_t hi = __builtin_convertvector(of, h4_t);
                 const f4_t back = __builtin_convertvector(hi, f4_t);
                 yhr[idx] = hi;
                 ylr[idx] = __builtin_convertvector(of - back, h4_t);
-            } else {
-                yr[idx] = o;
             }
+            if (!yh || both) yr[idx] = o;
         }
     }
 }
@@ -107,6 +111,19 @@ void launch_layernorm_split(const float* x, int64_t ldx, const float* gamma, con
     if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
     else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
     else hipLaunchKernelGGL((layernorm_kernel<16>), grid, dim3(256), 0, s, x, ldx, gamma, beta, none, (int64_t)0, rows, C, act, lens, t_per_batch, yh, yl, ldh);
+    SC_LAUNCH_CHECK();
+}
+
+// fp32 rows AND split planes in one pass (planes masked by lens, fp32 not): post-LN blocks whose LayerNorm output is both
+// a residual stream and the next product's operand
+void launch_layernorm_both(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy, __half* yh,
+                           __half* yl, int64_t ldh, int rows, int C, int act, const int* lens, int t_per_batch, hipStream_t s) {
+    SC_CHECK(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldh % 4 == 0 && C <= 4096 && y && yh && yl, "layernorm_both: C=%d", C);
+    if (rows <= 0) return;
+    dim3 grid(cdiv(rows, 4));
+    if (C <= 256) hipLaunchKernelGGL((layernorm_kernel<1>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch, yh, yl, ldh);
+    else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<4>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch, yh, yl, ldh);
+    else hipLaunchKernelGGL((layernorm_kernel<16>), grid, dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, C, act, lens, t_per_batch, yh, yl, ldh);
     SC_LAUNCH_CHECK();
 }
 

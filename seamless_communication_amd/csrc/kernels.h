@@ -77,6 +77,14 @@ struct GemmPsArgs {
     int act = ACT_NONE;
     float alpha = 1.0f;
     int split = 1;  // 0: only the hi plane is multiplied (A rounded to fp16 once) - precision study, never the default
+    // implicit 1-D convolution over the rows of the planes (stride 1): the planes hold [items][rows_per_item][conv_cin]
+    // (lda = row stride), K = conv_taps * conv_cin in tap-major order (the packed Conv1d weight layout), output row (i, t)
+    // reads input rows t + tap * conv_dil - conv_pad of item i, rows outside [0, rows_per_item) as zeros.  conv_taps = 0:
+    // plain product.  conv_cin % 32 == 0 (a 32-wide K slab stays inside one tap).
+    int conv_taps = 0, conv_cin = 0, conv_dil = 1, conv_pad = 0, rows_per_item = 0;
+    // rows with row_valid[m] == 0 (nullable) are written as exact zeros in every output (padded rows of a length
+    // bucket: the next convolution's zero padding behind an item's end)
+    const unsigned char* row_valid = nullptr;
 };
 void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s);
 
@@ -226,6 +234,9 @@ void launch_layernorm(const float* x, int64_t ldx, const float* gamma, const flo
 // same, result written as two fp16 planes hi = fp16(y), lo = fp16(y - hi) (the A operand of launch_gemm_presplit)
 void launch_layernorm_split(const float* x, int64_t ldx, const float* gamma, const float* beta, __half* yh, __half* yl,
                             int64_t ldh, int rows, int C, int act, const int* lens, int t_per_batch, hipStream_t s);
+// fp32 rows AND planes in one pass; the length mask zeroes the planes only
+void launch_layernorm_both(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy, __half* yh,
+                           __half* yl, int64_t ldh, int rows, int C, int act, const int* lens, int t_per_batch, hipStream_t s);
 // hi = fp16(x), lo = fp16(x - hi), elementwise over n values (n % 4 == 0)
 void launch_split_f32(const float* x, __half* hi, __half* lo, int64_t n, hipStream_t s);
 

@@ -695,6 +695,37 @@ void conv1d(Model& m, const float* x, const Conv& c, const float* res, float* y,
     launch_gemm(a, m.stream);
 }
 
+void conv1d_presplit(Model& m, const __half* xh, const __half* xl, const Conv& c, const float* res, float* C, __half* Ch, __half* Cl,
+                     int nb, int t, int pad, int dil, const unsigned char* row_valid, int act) {
+    SC_CHECK(c.kpad == c.cin * c.k && 2 * pad == dil * (c.k - 1), "conv1d_presplit: needs an unpadded weight row and 'same' padding");
+    if (nb <= 0 || t <= 0) return;
+    GemmPsArgs a;
+    a.Ah = xh;
+    a.Al = xl;
+    a.lda = c.cin;
+    a.W = c.w;
+    a.ldw = c.kpad;
+    a.bias = c.b;
+    a.res = res;
+    a.ldr = c.cout;
+    a.C = C;
+    a.ldc = c.cout;
+    a.Ch = Ch;
+    a.Cl = Cl;
+    a.ldcs = c.cout;
+    a.M = nb * t;
+    a.N = c.cout;
+    a.K = c.kpad;
+    a.act = act;
+    a.conv_taps = c.k;
+    a.conv_cin = c.cin;
+    a.conv_dil = dil;
+    a.conv_pad = pad;
+    a.rows_per_item = t;
+    a.row_valid = row_valid;
+    launch_gemm_presplit(a, m.stream);
+}
+
 // ConvTranspose1d(k, stride s, padding (k-s)/2) as s polyphase convolutions:
 // out[q*s + r - p] = sum_j x[q - j] . w[:, :, r + s*j]   
 void conv_transpose1d(Model& m, const float* x, const ConvT& c, float* y, int nb, int t_in, int in_act) {

@@ -325,6 +325,56 @@ def test_presplit_gemm_bit_identical_to_split_gemm(lib, report_dir, M, N, K, act
     assert torch.equal(gh2.cpu(), hi)
 
 
+CONV_PS_CASES = [
+    # nb, T, cin, cout, k, dil, act, with_res, masked
+    (3, 700, 1024, 1024, 7, 1, 1, False, True),   # the T2U FFT-decoder convolution (64 x 64 / 128 x 128 tiles), masked tail rows
+    (2, 333, 256, 512, 3, 1, 0, True, False),     # ragged item length, residual
+    (32, 500, 128, 1024, 3, 2, 0, False, False),  # 256 x 256 tiles (252 of them), dilation 2, K slabs cross taps
+    (1, 5, 64, 96, 11, 1, 0, True, False),        # shorter than the kernel
+]
+
+
+@pytest.mark.parametrize("case", CONV_PS_CASES)
+def test_presplit_conv_bit_identical_to_conv1d(lib, report_dir, case):
+    """Implicit-convolution mode of the DMA GEMM (k_gemm_ps.hip: per-slab tap offset on the row address, rows of another
+    item as out-of-range offsets) against sc_op_conv1d on the same values: identical bits; rows flagged dead are exact
+    zeros in the fp32 output and in both planes."""
+    nb, T, cin, cout, k, dil, act, with_res, masked = case
+    pad = dil * (k - 1) // 2
+    g = torch.Generator().manual_seed(T * 7 + cin + k)
+    x = dev(torch.randn(nb, T, cin, generator=g) * 1.5)
+    w = (torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)).half()
+    b = dev(torch.randn(cout, generator=g) * 0.1)
+    r = dev(torch.randn(nb, T, cout, generator=g)) if with_res else None
+    kpad = cin * k
+    assert kpad % 32 == 0
+    wp = torch.zeros(cout, kpad, dtype=torch.float16, device="cuda")
+    check(lib, lib.sc_op_pack_conv_weight(P(dev(w)), P(wp), cout, cin, k))
+    want = torch.full((nb, T, cout), float("nan"), device="cuda")
+    check(lib, lib.sc_op_conv1d(P(x), P(wp), P(b), P(r), P(want), nb, T, cin, cout, k, 1, pad, dil, None, 0, act))
+    valid = None
+    if masked:
+        valid = torch.ones(nb, T, dtype=torch.uint8)
+        valid[0, T - 37:] = 0
+        valid[2, 100:] = 0
+        valid = dev(valid)
+    got = torch.full((nb, T, cout), float("nan"), device="cuda")
+    gh = torch.full((nb, T, cout), float("nan"), device="cuda", dtype=torch.float16)
+    gl = torch.full((nb, T, cout), float("nan"), device="cuda", dtype=torch.float16)
+    check(lib, lib.sc_op_conv1d_presplit(P(x), P(wp), P(b), P(r), P(got), P(gh), P(gl), nb, T, cin, cout, k, pad, dil, P(valid), act))
+    got, want = got.cpu(), want.cpu()
+    if masked:
+        dead = valid.cpu() == 0
+        assert float(got[dead].abs().max()) == 0.0 and float(gh.cpu()[dead].abs().max()) == 0.0 and float(gl.cpu()[dead].abs().max()) == 0.0
+        want[dead] = 0
+    _log(report_dir, "presplit_conv", case=case, equal=bool(torch.equal(got, want)), maxdiff=float((got - want).abs().max()))
+    assert not torch.isnan(got).any()
+    assert torch.equal(got, want)
+    hi = got.half()
+    assert torch.equal(gh.cpu(), hi)
+    assert torch.equal(gl.cpu(), (got - hi.float()).half())
+
+
 RESPAIR_CASES = [
     # nb, T, C, k, dil, avg
     (2, 1000, 32, 3, 1, False),
