@@ -475,8 +475,13 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(AttnArgs p) {
     const int shift = p.Skv - p.Sq;
     const int qabs = qi + shift;
     const int npos = p.rel_left + 1 + p.rel_right;
-    const bool qok = qi < p.Sq;
-    const float* qrow = p.q + ((int64_t)n * p.Sq + (qok ? qi : 0)) * p.ldq + h * HD;
+    // packed items: rows row_off[n] .. + kv_len, queries beyond the item's own length do not exist
+    const int sq_n = p.row_off ? kv_len : p.Sq;
+    const int64_t qbase = p.row_off ? (int64_t)p.row_off[n] : (int64_t)n * p.Sq;
+    const int64_t kvbase = p.row_off ? (int64_t)p.row_off[n] : (int64_t)n * p.Skv;
+    if (p.row_off && (int)(blockIdx.x * MQ) >= kv_len) return;  // the whole workgroup lies behind the item's end
+    const bool qok = qi < sq_n;
+    const float* qrow = p.q + (qbase + (qok ? qi : 0)) * p.ldq + h * HD;
 
     if (SHAW) {
         // (q.R)^T[e][query] = R . Q^T on the exact fp32 matrix instruction, as in attn_mfma_kernel
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(AttnArgs p) {
             kf[u] = f4v{0.f, 0.f, 0.f, 0.f};
             vf[u] = kf[u];
             if (k0 + r < kv_len) {
-                const int64_t row = (int64_t)n * p.Skv + k0 + r;
+                const int64_t row = kvbase + k0 + r;
                 kf[u] = *reinterpret_cast<const f4v*>(p.k + row * p.ldk + h * HD + sc4 * 4);
                 vf[u] = *reinterpret_cast<const f4v*>(p.v + row * p.ldv + h * HD + sc4 * 4);
             }
@@ -757,20 +762,24 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(AttnArgs p) {
         const int c0 = (lane & 15) * 4;
         const int qq = q0 + row;
         const f4v of = *reinterpret_cast<const f4v*>(&ot[row * KS + c0]);
-        if (qq >= p.Sq) continue;
+        if (qq >= sq_n) continue;
         if (p.out_hi) {
             const a16_h4 hi = __builtin_convertvector(of, a16_h4);
             const f4v back = __builtin_convertvector(hi, f4v);
-            const int64_t off = ((int64_t)n * p.Sq + qq) * p.ldoh + h * HD + c0;
+            const int64_t off = (qbase + qq) * p.ldoh + h * HD + c0;
             *reinterpret_cast<a16_h4*>(p.out_hi + off) = hi;
             *reinterpret_cast<a16_h4*>(p.out_lo + off) = __builtin_convertvector(of - back, a16_h4);
         } else {
-            *reinterpret_cast<f4v*>(p.out + ((int64_t)n * p.Sq + qq) * p.ldo + h * HD + c0) = of;
+            *reinterpret_cast<f4v*>(p.out + (qbase + qq) * p.ldo + h * HD + c0) = of;
         }
     }
 }
 
 static bool g_attn_attr_set = false;
+static bool f32_mfma_env() {
+    static const bool v = getenv("SC_ATTN_F32") && atoi(getenv("SC_ATTN_F32")) != 0;
+    return v;
+}
 
 void launch_attention(const AttnArgs& a, hipStream_t s) {
     SC_CHECK(a.nb > 0 && a.heads > 0 && a.Sq > 0 && a.Skv > 0, "attention: empty problem");
@@ -802,11 +811,13 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
             mfma_attr = true;
         }
-        prof::Scope scope(a.rel_k ? "attention_shaw" : "attention", 4.0 * a.nb * a.heads * (double)a.Sq * a.Skv * HD,
+        const double pairs = a.pairs > 0 ? a.pairs : (double)a.nb * a.Sq * a.Skv;
+        prof::Scope scope(a.rel_k ? "attention_shaw" : "attention", 4.0 * a.heads * pairs * HD,
                           4.0 * a.nb * a.heads * HD * (2.0 * a.Sq + 2.0 * a.Skv), s);
         size_t lds = (size_t)(4 * 32 * KS) * sizeof(float);  // K/V tiles, later the four output tiles
         SC_CHECK(npos <= 96, "attention: relative table too large");
         if (a.rel_k) lds += (size_t)(MQ * npos) * sizeof(float);
+        SC_CHECK(!a.row_off || (a.kv_lens && a.Sq == a.Skv && !a.causal && !f32_mfma_env()), "attention: packed rows need kv_lens, Sq == Skv and the fp16-split kernel");
         if (a.rp_table) {
             SC_CHECK(!a.rel_k && !a.causal && a.Sq == a.Skv && a.q_bias_u && a.q_bias_v && a.rp_ld % 4 == 0 && !use_valu,
                      "attention: relative positions need self-attention (Sq == Skv), both query biases and a 16-byte aligned table");
@@ -814,7 +825,7 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         }
         dim3 grid(cdiv(a.Sq, MQ), a.heads, a.nb);
         // SC_ATTN_F32=1: the exact-fp32 matrix instruction (round 1) instead of the three-term fp16 split (development A/B)
-        static const bool f32_mfma = getenv("SC_ATTN_F32") && atoi(getenv("SC_ATTN_F32")) != 0;
+        const bool f32_mfma = f32_mfma_env();
         if (f32_mfma) {
             if (a.rel_k) hipLaunchKernelGGL((attn_mfma_kernel<true>), grid, dim3(256), lds, s, a);
             else hipLaunchKernelGGL((attn_mfma_kernel<false>), grid, dim3(256), lds, s, a);
@@ -826,6 +837,7 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
         SC_LAUNCH_CHECK();
         return;
     }
+    SC_CHECK(!a.row_off && !a.rp_table, "attention: packed rows / relative positions are not built for the vector-ALU kernel");
     dim3 grid(cdiv(a.Sq, BQ), a.heads, a.nb);
     prof::Scope scope(a.rel_k ? "attention_shaw" : "attention", 4.0 * a.nb * a.heads * (double)a.Sq * a.Skv * HD,
                       4.0 * a.nb * a.heads * HD * (2.0 * a.Sq + 2.0 * a.Skv), s);

@@ -169,13 +169,25 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
     // this lane's fixed LDS position inside a chunk: row (lane >> 2), segment slot (lane & 3); it fetches the
     // global segment that the swizzle maps to that slot
     uint32_t a_voff[ACH], b_voff[BCH];
-    int a_t[ACH];  // CONV: position of the lane's row inside its item
+    int a_t[ACH];    // CONV: position of the lane's row inside its item
+    int a_len[ACH];  // CONV: length of that item (rows_per_item, or row_pos[row].y for packed items)
 #pragma unroll
     for (int j = 0; j < ACH; ++j) {
         const int row = 16 * (wave * ACH + j) + (lane >> 2);
         const int seg = (lane & 3) ^ ((row >> 2) & 3);
         a_voff[j] = (m0 + row) < p.M ? (uint32_t)(((int64_t)(m0 + row) * p.lda + seg * 8) * 2) : OOB;
-        a_t[j] = CONV ? (m0 + row) % p.rows_per_item : 0;
+        a_t[j] = 0;
+        a_len[j] = 0;
+        if (CONV) {
+            if (p.row_pos) {
+                const int2 rp = (m0 + row) < p.M ? p.row_pos[m0 + row] : make_int2(0, 0);
+                a_t[j] = rp.x;
+                a_len[j] = rp.y;
+            } else {
+                a_t[j] = (m0 + row) % p.rows_per_item;
+                a_len[j] = p.rows_per_item;
+            }
+        }
     }
     // CONV: (tap, 32-wide channel slab) of the NEXT slab to be issued - slabs are issued strictly in K order - and the
     // operand addresses of that slab: K byte offset inside the row (ka_) and row offset per chunk (va_), rows of another
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
             const int dt_ = nx_tap * p.conv_dil - p.conv_pad;                                           \
             ka_ = nx_cs * (PBK * 2);                                                                    \
             _Pragma("unroll") for (int j = 0; j < ACH; ++j) {                                           \
-                const bool in_ = (uint32_t)(a_t[j] + dt_) < (uint32_t)p.rows_per_item && a_voff[j] != OOB; \
+                const bool in_ = (uint32_t)(a_t[j] + dt_) < (uint32_t)a_len[j] && a_voff[j] != OOB;     \
                 va_[j] = in_ ? a_voff[j] + (uint32_t)dt_ * row_bytes : OOB;                             \
             }                                                                                           \
             if (++nx_cs == spt) {                                                                       \
@@ -418,8 +430,8 @@ void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s) {
              "presplit gemm: operands must be 16-byte aligned");
     SC_CHECK((int64_t)a.M * a.lda * 2 < (1ll << 31) && (int64_t)a.N * a.ldw * 2 < (1ll << 31), "presplit gemm: operand larger than 2 GB");
     if (a.conv_taps > 0) {
-        SC_CHECK(a.split && a.conv_cin % PBK == 0 && a.K == a.conv_taps * a.conv_cin && a.lda >= a.conv_cin && a.rows_per_item > 0 &&
-                     a.M % a.rows_per_item == 0 && a.conv_dil >= 1 && a.conv_pad >= 0,
+        SC_CHECK(a.split && a.conv_cin % PBK == 0 && a.K == a.conv_taps * a.conv_cin && a.lda >= a.conv_cin &&
+                     (a.row_pos || (a.rows_per_item > 0 && a.M % a.rows_per_item == 0)) && a.conv_dil >= 1 && a.conv_pad >= 0,
                  "presplit conv: taps=%d cin=%d K=%d rows_per_item=%d M=%d", a.conv_taps, a.conv_cin, a.K, a.rows_per_item, a.M);
     } else {
         SC_CHECK(a.lda >= a.K, "presplit gemm: lda=%lld < K=%d", (long long)a.lda, a.K);

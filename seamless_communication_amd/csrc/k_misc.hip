@@ -272,6 +272,21 @@ __global__ __launch_bounds__(256) void pos_add_kernel(float* __restrict__ seqs, 
         x[c] = xv + alpha * ((xv + pe[c]) - xv);
     }
 }
+__global__ __launch_bounds__(256) void pos_add_rows_kernel(float* __restrict__ seqs, int64_t ld, const float* __restrict__ pos_table,
+                                                           const int* __restrict__ row_t, float alpha, int M) {
+    const int row = blockIdx.x;
+    float* x = seqs + (int64_t)row * ld;
+    const float* pe = pos_table + (int64_t)row_t[row] * M;
+    for (int c = threadIdx.x; c < M; c += 256) {
+        const float xv = x[c];
+        x[c] = xv + alpha * ((xv + pe[c]) - xv);
+    }
+}
+void launch_pos_add_rows(float* seqs, int64_t ld, const float* pos_table, const int* row_t, float alpha, int rows, int M, hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(pos_add_rows_kernel, dim3(rows), dim3(256), 0, s, seqs, ld, pos_table, row_t, alpha, M);
+    SC_LAUNCH_CHECK();
+}
 void launch_pos_add(float* seqs, int64_t ld, const float* pos_table, int t_per_batch, float alpha, int rows, int M,
                     hipStream_t s) {
     if (rows <= 0) return;

@@ -85,6 +85,9 @@ struct GemmPsArgs {
     // rows with row_valid[m] == 0 (nullable) are written as exact zeros in every output (padded rows of a length
     // bucket: the next convolution's zero padding behind an item's end)
     const unsigned char* row_valid = nullptr;
+    // packed (varlen) convolution: row_pos[m] = {position of row m inside its item, length of that item} (nullable);
+    // replaces the uniform rows_per_item geometry: items of different lengths lie back to back, no padding rows
+    const int2* row_pos = nullptr;
 };
 void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s);
 
@@ -270,6 +273,10 @@ struct AttnArgs {
     int64_t rp_ld = 0;
     const float* q_bias_u = nullptr;
     const float* q_bias_v = nullptr;
+    // packed (varlen) self-attention: item n owns rows row_off[n] .. row_off[n] + kv_lens[n] of q / k / v / out (no padding
+    // rows between items); Sq = Skv = the longest item (grid size only).  Needs kv_lens; fp16-split MFMA kernel only.
+    const int* row_off = nullptr;
+    double pairs = 0;  // profiler only: sum over items of (queries x keys) really computed (0: nb * Sq * Skv)
     // optional: write the result as two fp16 planes (hi, lo) for launch_gemm_presplit instead of `out`
     __half* out_hi = nullptr;
     __half* out_lo = nullptr;
@@ -347,6 +354,8 @@ void launch_gather_rows(const float* src, int64_t lds, const int* row_idx /*-1 =
 void launch_char_embed_add(float* seqs /*in-place [rows][M]*/, int64_t ld, const int* char_ids,
                            const __half* embed_char, const float* pos_table, int t_per_batch,
                            float alpha, float scale, int rows, int M, hipStream_t s);
+// same with the position of every row given (packed rows of items of different lengths)
+void launch_pos_add_rows(float* seqs, int64_t ld, const float* pos_table, const int* row_t, float alpha, int rows, int M, hipStream_t s);
 void launch_pos_add(float* seqs, int64_t ld, const float* pos_table, int t_per_batch, float alpha,
                     int rows, int M, hipStream_t s);
 void launch_durations(const float* h /*[rows][H]*/, int64_t ld, const float* w, const float* b,

@@ -284,8 +284,10 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
 // guaranteed (computed exactly as in the padded batch), the rest of the row is zero.
 // Conv1d (stride 1, 'same'-style padding) on pre-split planes through the DMA GEMM (k_gemm_ps.hip, implicit-conv mode):
 // xh/xl [nb][t][cin] halfs; C (fp32) and/or Ch/Cl; row_valid: see GemmPsArgs
+// row_pos != null: packed items (rows_total rows in all, row_pos[m] = {position, item length}); nb / t are then unused
 void conv1d_presplit(Model& m, const __half* xh, const __half* xl, const Conv& c, const float* res, float* C, __half* Ch, __half* Cl,
-                     int nb, int t, int pad, int dil, const unsigned char* row_valid, int act);
+                     int nb, int t, int pad, int dil, const unsigned char* row_valid, int act, int rows_total = 0,
+                     const int2* row_pos = nullptr);
 void run_vocoder_durations(Model& m, const int32_t* h_units, int n, int s_units, int32_t* h_durations);
 void run_t2u_ar(Model& m, const float* d_dec_hidden, int n, int s_text, const int32_t* h_text_lens, const sc_gen_opts& o,
                 const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids, int32_t* h_out_lens, float* h_scores);

@@ -696,9 +696,9 @@ void conv1d(Model& m, const float* x, const Conv& c, const float* res, float* y,
 }
 
 void conv1d_presplit(Model& m, const __half* xh, const __half* xl, const Conv& c, const float* res, float* C, __half* Ch, __half* Cl,
-                     int nb, int t, int pad, int dil, const unsigned char* row_valid, int act) {
+                     int nb, int t, int pad, int dil, const unsigned char* row_valid, int act, int rows_total, const int2* row_pos) {
     SC_CHECK(c.kpad == c.cin * c.k && 2 * pad == dil * (c.k - 1), "conv1d_presplit: needs an unpadded weight row and 'same' padding");
-    if (nb <= 0 || t <= 0) return;
+    if (row_pos ? rows_total <= 0 : (nb <= 0 || t <= 0)) return;
     GemmPsArgs a;
     a.Ah = xh;
     a.Al = xl;
@@ -713,7 +713,7 @@ void conv1d_presplit(Model& m, const __half* xh, const __half* xl, const Conv& c
     a.Ch = Ch;
     a.Cl = Cl;
     a.ldcs = c.cout;
-    a.M = nb * t;
+    a.M = row_pos ? rows_total : nb * t;
     a.N = c.cout;
     a.K = c.kpad;
     a.act = act;
@@ -721,7 +721,8 @@ void conv1d_presplit(Model& m, const __half* xh, const __half* xl, const Conv& c
     a.conv_cin = c.cin;
     a.conv_dil = dil;
     a.conv_pad = pad;
-    a.rows_per_item = t;
+    a.rows_per_item = row_pos ? 0 : t;
+    a.row_pos = row_pos;
     a.row_valid = row_valid;
     launch_gemm_presplit(a, m.stream);
 }

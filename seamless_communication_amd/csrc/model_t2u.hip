@@ -290,6 +290,138 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
     static const int max_groups = getenv("SC_T2U_GROUPS") ? std::max(1, atoi(getenv("SC_T2U_GROUPS"))) : 8;
     const std::vector<std::vector<int>> groups = plan_length_groups(std::vector<int>(ulens.begin(), ulens.end()), 400, max_groups);
     int64_t rows_done = 0;
+    // result slots of the handle: apply_padding_mask(pad) + UnitTokenDecoder NAR branch (unit_tokenizer.py:232-243)
+    auto finish = [&](const std::vector<int32_t>& unit_ids, int64_t rows_computed) {
+        m.last_padded_unit_rows = rows_computed;
+        m.last_units.assign((size_t)urows, 0);
+        for (int b = 0; b < n; ++b)
+            for (int t = 0; t < Su; ++t) {
+                int32_t v = t < ulens[b] ? unit_ids[(size_t)b * Su + t] : c.unit_pad_idx;
+                if (v == c.unit_eos_idx) v = c.unit_pad_idx;
+                if (v == c.unit_pad_idx) v = c.unit_pad_idx + 4;
+                m.last_units[(size_t)b * Su + t] = v - 4;
+            }
+        m.last_durations = dur;
+        m.last_char_ids = cid_flat;
+        m.last_char_seq_lens = cseq_lens;
+        m.last_n = n;
+        m.last_su = Su;
+        m.last_sc = Sc;
+        if (out_su) *out_su = Su;
+        if (out_sc) *out_sc = Sc;
+    };
+    // ---- packed pass (default): the units of all items back to back, no padding rows at all.  Exact per item for the same
+    // reasons as the buckets below; every product sees all ~15 k rows of a 32-utterance slice at once (256 x 256 tiles of the
+    // DMA GEMM) instead of 1.5 - 4 k rows per bucket.  The attention kernel takes the items' row offsets, the convolutions
+    // the position / item length of every row.  SC_T2U_PACKED=0: length buckets.
+    {
+        static const bool want_packed = !(getenv("SC_T2U_PACKED") && atoi(getenv("SC_T2U_PACKED")) == 0) &&
+                                        !(getenv("SC_T2U_PRESPLIT") && atoi(getenv("SC_T2U_PRESPLIT")) == 0);
+        const int K = c.t2u_conv_kernel, Ci = c.t2u_conv_inner_dim;
+        int64_t R64 = 0;
+        for (int b = 0; b < n; ++b) R64 += ulens[b];
+        const bool packed = want_packed && M % 32 == 0 && Ci % 32 == 0 && K % 2 == 1 && !m.t2u_dec.empty() && M == c.num_heads * 64 &&
+                            m.t2u_dec[0].conv1.kpad == M * K && m.t2u_dec[0].conv2.kpad == Ci * K &&
+                            R64 * std::max(M, Ci) * 2 < (1ll << 31) && R64 * (int64_t)c.unit_vocab_size < (1ll << 31);
+        if (packed) {
+            const int R = (int)R64;
+            std::vector<int32_t> uidx((size_t)R), row_t((size_t)R), row_off(n), pos2((size_t)2 * R);
+            int r = 0;
+            for (int b = 0; b < n; ++b) {
+                row_off[b] = r;
+                int t = 0;
+                for (int k = 0; k < Sc; ++k)
+                    for (int q = 0; q < dur[(size_t)b * Sc + k]; ++q, ++t, ++r) {
+                        uidx[r] = b * Sc + k;
+                        row_t[r] = t;
+                        pos2[(size_t)2 * r] = t;
+                        pos2[(size_t)2 * r + 1] = ulens[b];
+                    }
+            }
+            Buf<int> d_uidx(&m.pool, R), d_row_t(&m.pool, R), d_row_off(&m.pool, n), d_pos2(&m.pool, (size_t)2 * R), d_ids(&m.pool, R);
+            SC_HIP(hipMemcpyAsync(d_uidx.get(), uidx.data(), (size_t)R * 4, hipMemcpyHostToDevice, m.stream));
+            SC_HIP(hipMemcpyAsync(d_row_t.get(), row_t.data(), (size_t)R * 4, hipMemcpyHostToDevice, m.stream));
+            SC_HIP(hipMemcpyAsync(d_row_off.get(), row_off.data(), (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+            SC_HIP(hipMemcpyAsync(d_pos2.get(), pos2.data(), (size_t)2 * R * 4, hipMemcpyHostToDevice, m.stream));
+            const int2* d_row_pos = reinterpret_cast<const int2*>(d_pos2.get());
+            double pairs = 0;
+            for (int b = 0; b < n; ++b) pairs += (double)ulens[b] * ulens[b];
+            const int wideN = 3 * M;
+            Buf<float> u(&m.pool, (size_t)R * M), y(&m.pool, (size_t)R * M), wide(&m.pool, (size_t)R * wideN);
+            Buf<__half> planes(&m.pool, (size_t)R * (6 * M + 2 * Ci));
+            __half* up_h = planes.get();
+            __half* up_l = up_h + (size_t)R * M;
+            __half* yp_h = up_l + (size_t)R * M;
+            __half* yp_l = yp_h + (size_t)R * M;
+            __half* ap_h = yp_l + (size_t)R * M;
+            __half* ap_l = ap_h + (size_t)R * M;
+            __half* wp_h = ap_l + (size_t)R * M;
+            __half* wp_l = wp_h + (size_t)R * Ci;
+            auto ps = [&](const __half* ah, const __half* al, const Linear& L, const float* res, float* C) {
+                GemmPsArgs a;
+                a.Ah = ah;
+                a.Al = al;
+                a.lda = L.in;
+                a.W = L.w;
+                a.ldw = L.ldw;
+                a.bias = L.b;
+                a.res = res;
+                a.ldr = L.out;
+                a.C = C;
+                a.ldc = L.out;
+                a.M = R;
+                a.N = L.out;
+                a.K = L.in;
+                launch_gemm_presplit(a, m.stream);
+            };
+            launch_gather_rows(cs, M, d_uidx, u, M, R, M, m.stream);
+            launch_pos_add_rows(u, M, m.unit_pos, d_row_t, m.pos_alpha, R, M, m.stream);
+            launch_split_f32(u, up_h, up_l, (int64_t)R * M, m.stream);
+            for (const FFTLayer& l : m.t2u_dec) {
+                ps(up_h, up_l, l.qkv, nullptr, wide);
+                AttnArgs a;
+                a.q = wide;
+                a.k = wide.get() + M;
+                a.v = wide.get() + 2 * M;
+                a.out_hi = ap_h;
+                a.out_lo = ap_l;
+                a.ldoh = M;
+                a.ldq = a.ldk = a.ldv = 3 * M;
+                a.ldo = M;
+                a.nb = n;
+                a.heads = c.num_heads;
+                a.Sq = Su;
+                a.Skv = Su;
+                a.kv_lens = d_ulens;
+                a.row_off = d_row_off;
+                a.pairs = pairs;
+                launch_attention(a, m.stream);
+                ps(ap_h, ap_l, l.attn_out, u, y);
+                launch_layernorm_both(y, M, l.attn_ln.g, l.attn_ln.b, y, M, yp_h, yp_l, M, R, M, ACT_NONE, nullptr, 1, m.stream);
+                conv1d_presplit(m, yp_h, yp_l, l.conv1, nullptr, nullptr, wp_h, wp_l, 0, 0, K / 2, 1, nullptr, ACT_RELU, R, d_row_pos);
+                conv1d_presplit(m, wp_h, wp_l, l.conv2, y, u, nullptr, nullptr, 0, 0, K / 2, 1, nullptr, ACT_NONE, R, d_row_pos);
+                launch_layernorm_both(u, M, l.conv_ln.g, l.conv_ln.b, u, M, up_h, up_l, M, R, M, ACT_NONE, nullptr, 1, m.stream);
+            }
+            launch_layernorm_split(u, M, m.t2u_dec_ln.g, m.t2u_dec_ln.b, up_h, up_l, M, R, M, ACT_NONE, nullptr, 1, m.stream);
+            Buf<float> logits(&m.pool, (size_t)R * c.unit_vocab_size);
+            Linear proj;
+            proj.w = m.unit_embed;
+            proj.ldw = M;
+            proj.kpad = M;
+            proj.in = M;
+            proj.out = c.unit_vocab_size;
+            ps(up_h, up_l, proj, nullptr, logits);
+            launch_argmax_rows(logits, c.unit_vocab_size, R, c.unit_vocab_size, nullptr, -1, -1, -1, -1, -1, 0.f, d_ids, nullptr, m.stream);
+            std::vector<int32_t> pids((size_t)R);
+            SC_HIP(hipMemcpyAsync(pids.data(), d_ids.get(), (size_t)R * 4, hipMemcpyDeviceToHost, m.stream));
+            SC_HIP(hipStreamSynchronize(m.stream));
+            std::vector<int32_t> ids((size_t)urows, c.unit_pad_idx);
+            for (int b = 0; b < n; ++b)
+                for (int t = 0; t < ulens[b]; ++t) ids[(size_t)b * Su + t] = pids[(size_t)row_off[b] + t];
+            finish(ids, R);
+            return;
+        }
+    }
     std::vector<std::vector<int32_t>> keep_alive;  // host staging of every group until the final synchronisation
     std::vector<Buf<int>> id_bufs;
     keep_alive.reserve(3 * groups.size());
@@ -437,24 +569,7 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
         for (size_t gi = 0; gi < grp.size(); ++gi)
             for (int t = 0; t < ulens[grp[gi]]; ++t) ids[(size_t)grp[gi] * Su + t] = gids[gi * Lg + t];
     }
-    m.last_padded_unit_rows = rows_done;
-    // apply_padding_mask(pad) + UnitTokenDecoder NAR branch (unit_tokenizer.py:232-243)
-    m.last_units.assign((size_t)urows, 0);
-    for (int b = 0; b < n; ++b)
-        for (int t = 0; t < Su; ++t) {
-            int32_t v = t < ulens[b] ? ids[(size_t)b * Su + t] : c.unit_pad_idx;
-            if (v == c.unit_eos_idx) v = c.unit_pad_idx;
-            if (v == c.unit_pad_idx) v = c.unit_pad_idx + 4;
-            m.last_units[(size_t)b * Su + t] = v - 4;
-        }
-    m.last_durations = dur;
-    m.last_char_ids = cid_flat;
-    m.last_char_seq_lens = cseq_lens;
-    m.last_n = n;
-    m.last_su = Su;
-    m.last_sc = Sc;
-    if (out_su) *out_su = Su;
-    if (out_sc) *out_sc = Sc;
+    finish(ids, rows_done);
 }
 
 namespace {
