@@ -282,7 +282,7 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
     Buf<int> d_ulens(&m.pool, n);
     SC_HIP(hipMemcpyAsync(d_ulens.get(), ulens.data(), (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
 
-    // ---- FFT decoder, one pass per length bucket -----------------------------------------------------------
+    // ---- FFT decoder: one packed pass over all items (default) or one pass per length bucket ------------------
     // Exact per item: the attention is key-masked, both convolutions see zeros behind an item's end (fft_decoder_layer.py:
     // 74-101: mask before each conv) and LayerNorm / the projection act on single rows, so an item's units do not
     // depend on what it is batched with.  SC_T2U_GROUPS=1 restores the single padded pass.
@@ -313,10 +313,11 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
     // ---- packed pass (default): the units of all items back to back, no padding rows at all.  Exact per item for the same
     // reasons as the buckets below; every product sees all ~15 k rows of a 32-utterance slice at once (256 x 256 tiles of the
     // DMA GEMM) instead of 1.5 - 4 k rows per bucket.  The attention kernel takes the items' row offsets, the convolutions
-    // the position / item length of every row.  SC_T2U_PACKED=0: length buckets.
+    // the position / item length of every row.  SC_T2U_PACKED=0: the length buckets below on the fp32-operand GEMM (the
+    // same decoder in buckets on the DMA GEMM was measured and dropped: 1.5 - 4 k rows per launch stay on 64 x 64 tiles,
+    // profiles/r2_knob_experiments.txt).
     {
-        static const bool want_packed = !(getenv("SC_T2U_PACKED") && atoi(getenv("SC_T2U_PACKED")) == 0) &&
-                                        !(getenv("SC_T2U_PRESPLIT") && atoi(getenv("SC_T2U_PRESPLIT")) == 0);
+        static const bool want_packed = !(getenv("SC_T2U_PACKED") && atoi(getenv("SC_T2U_PACKED")) == 0);
         const int K = c.t2u_conv_kernel, Ci = c.t2u_conv_inner_dim;
         int64_t R64 = 0;
         for (int b = 0; b < n; ++b) R64 += ulens[b];
@@ -425,8 +426,6 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
     std::vector<std::vector<int32_t>> keep_alive;  // host staging of every group until the final synchronisation
     std::vector<Buf<int>> id_bufs;
     keep_alive.reserve(3 * groups.size());
-    std::vector<std::vector<unsigned char>> valid_alive;
-    valid_alive.reserve(groups.size());
     for (const std::vector<int>& grp : groups) {
         const int ng = (int)grp.size();
         int Lg = 0;
@@ -454,89 +453,6 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
         launch_gather_rows(cs, M, d_uidx, u, M, grows, M, m.stream);
         launch_pos_add(u, M, m.unit_pos, Lg, m.pos_alpha, grows, M, m.stream);
         const int K = c.t2u_conv_kernel;
-        // Pre-split operand path (default): every product of the FFT decoder - the two k = 7 convolutions included - runs on
-        // the DMA-fed GEMM (k_gemm_ps.hip, implicit-conv mode); the LayerNorms write the fp32 residual stream and the fp16
-        // planes of the next operand in one pass, the planes zeroed behind an item's end (the reference masks the input of
-        // both convolutions, fft_decoder_layer.py:74-101).  Same arithmetic order as the fp32-operand path below: same bits.
-        static const bool t2u_ps = !(getenv("SC_T2U_PRESPLIT") && atoi(getenv("SC_T2U_PRESPLIT")) == 0);
-        const int Ci = c.t2u_conv_inner_dim;
-        const bool ps_ok = t2u_ps && M % 32 == 0 && Ci % 32 == 0 && K % 2 == 1 && !m.t2u_dec.empty() &&
-                           m.t2u_dec[0].conv1.kpad == M * K && m.t2u_dec[0].conv2.kpad == Ci * K &&
-                           (int64_t)grows * std::max(M, Ci) * 2 < (1ll << 31);
-        if (ps_ok) {
-            valid_alive.emplace_back((size_t)grows);  // row_valid bytes (host staging, alive until the final synchronisation)
-            unsigned char* h_valid = valid_alive.back().data();
-            for (int gi = 0; gi < ng; ++gi)
-                for (int t = 0; t < Lg; ++t) h_valid[(size_t)gi * Lg + t] = t < glens[gi] ? 1 : 0;
-            Buf<int> d_valid_store(&m.pool, (size_t)(grows + 3) / 4);
-            unsigned char* d_valid = reinterpret_cast<unsigned char*>(d_valid_store.get());
-            SC_HIP(hipMemcpyAsync(d_valid, h_valid, (size_t)grows, hipMemcpyHostToDevice, m.stream));
-            Buf<__half> planes(&m.pool, (size_t)grows * (6 * M + 2 * Ci));
-            __half* up_h = planes.get();
-            __half* up_l = up_h + (size_t)grows * M;
-            __half* yp_h = up_l + (size_t)grows * M;
-            __half* yp_l = yp_h + (size_t)grows * M;
-            __half* ap_h = yp_l + (size_t)grows * M;
-            __half* ap_l = ap_h + (size_t)grows * M;
-            __half* wp_h = ap_l + (size_t)grows * M;
-            __half* wp_l = wp_h + (size_t)grows * Ci;
-            auto ps = [&](const __half* ah, const __half* al, const Linear& L, const float* res, float* C) {
-                GemmPsArgs a;
-                a.Ah = ah;
-                a.Al = al;
-                a.lda = L.in;
-                a.W = L.w;
-                a.ldw = L.ldw;
-                a.bias = L.b;
-                a.res = res;
-                a.ldr = L.out;
-                a.C = C;
-                a.ldc = L.out;
-                a.M = grows;
-                a.N = L.out;
-                a.K = L.in;
-                launch_gemm_presplit(a, m.stream);
-            };
-            launch_split_f32(u, up_h, up_l, (int64_t)grows * M, m.stream);
-            for (const FFTLayer& l : m.t2u_dec) {
-                ps(up_h, up_l, l.qkv, nullptr, wide);
-                AttnArgs a;
-                a.q = wide;
-                a.k = wide.get() + M;
-                a.v = wide.get() + 2 * M;
-                a.out_hi = ap_h;
-                a.out_lo = ap_l;
-                a.ldoh = M;
-                a.ldq = a.ldk = a.ldv = 3 * M;
-                a.ldo = M;
-                a.nb = ng;
-                a.heads = c.num_heads;
-                a.Sq = Lg;
-                a.Skv = Lg;
-                a.kv_lens = d_glens;
-                launch_attention(a, m.stream);
-                ps(ap_h, ap_l, l.attn_out, u, y);
-                launch_layernorm_both(y, M, l.attn_ln.g, l.attn_ln.b, y, M, yp_h, yp_l, M, grows, M, ACT_NONE, d_glens, Lg, m.stream);
-                conv1d_presplit(m, yp_h, yp_l, l.conv1, nullptr, nullptr, wp_h, wp_l, ng, Lg, K / 2, 1, d_valid, ACT_RELU);
-                conv1d_presplit(m, wp_h, wp_l, l.conv2, y, u, nullptr, nullptr, ng, Lg, K / 2, 1, nullptr, ACT_NONE);
-                launch_layernorm_both(u, M, l.conv_ln.g, l.conv_ln.b, u, M, up_h, up_l, M, grows, M, ACT_NONE, nullptr, 1, m.stream);
-            }
-            launch_layernorm_split(u, M, m.t2u_dec_ln.g, m.t2u_dec_ln.b, up_h, up_l, M, grows, M, ACT_NONE, nullptr, 1, m.stream);
-            Buf<float> logits(&m.pool, (size_t)grows * c.unit_vocab_size);
-            Linear proj;
-            proj.w = m.unit_embed;
-            proj.ldw = M;
-            proj.kpad = M;
-            proj.in = M;
-            proj.out = c.unit_vocab_size;
-            ps(up_h, up_l, proj, nullptr, logits);
-            launch_argmax_rows(logits, c.unit_vocab_size, grows, c.unit_vocab_size, nullptr, -1, -1, -1, -1, -1, 0.f, d_ids, nullptr,
-                               m.stream);
-            keep_alive.emplace_back((size_t)grows);
-            SC_HIP(hipMemcpyAsync(keep_alive.back().data(), d_ids, (size_t)grows * 4, hipMemcpyDeviceToHost, m.stream));
-            // scratch of this group is released in stream order (one stream per handle)
-            continue;
-        }
         for (const FFTLayer& l : m.t2u_dec) {
             linear(m, u, M, l.qkv, nullptr, 0, wide, 3 * M, grows, ACT_NONE, 1.f);
             attention_self(m, wide, M, att, ng, Lg, d_glens);
