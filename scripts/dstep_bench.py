@@ -17,6 +17,7 @@ ap.add_argument("--rows", default="1,16,32,64")
 ap.add_argument("--text-len", type=int, default=42)
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--chains", action="store_true", help="also time the rows as 2 / 4 concurrent chains on forked handles")
 args = ap.parse_args()
 
 card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch="base_v2")
@@ -39,3 +40,30 @@ for n in [int(x) for x in args.rows.split(",")]:
     assert (ids2 == ids).all(), "generation is not deterministic"
     print(f"rows={n:3d} text_len={args.text_len} graph={not args.no_graph}: {1e3 * dt:8.2f} ms per call, {1e3 * dt / steps:6.3f} ms per step "
           f"(incl. encoder K/V projection + 1 prompt step), {1.733e9 / (dt / steps) / 1e12:5.2f} TB/s of weights", flush=True)
+
+# ---- concurrent chains: the same rows as K forked handles on K host threads (one stream each) ---------------------------
+# Tests whether several latency-bound decoder chains interleave on the GPU: 32 rows as 2 x 16 / 4 x 8 chains.
+if args.chains:
+    from concurrent.futures import ThreadPoolExecutor
+
+    for total, k in ((32, 2), (32, 4), (64, 2), (64, 4)):
+        per = total // k
+        handles = [model] + [model.fork() for _ in range(k - 1)]
+        encs = [torch.randn(per, 63, cfg.model_dim, generator=g).cuda() for _ in range(k)]
+        kw = dict(soft_max_seq_len=(1, 200), hard_max_seq_len=args.text_len, use_graph=True, want_hidden=True)
+        for h, e in zip(handles, encs):
+            h.generate_text(e, [63] * per, prefix, **kw)  # warm-up
+        torch.cuda.synchronize()
+
+        def one(i):
+            for _ in range(args.reps):
+                handles[i].generate_text(encs[i], [63] * per, prefix, **kw)
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(k) as ex:
+            list(ex.map(one, range(k)))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.reps
+        print(f"rows={total:3d} as {k} concurrent chains of {per}: {1e3 * dt:8.2f} ms per call = {1e3 * dt / (args.text_len - 2):6.3f} ms per step of all rows", flush=True)
+        for h in handles[1:]:
+            h.close()
