@@ -130,6 +130,23 @@ def pmc_traffic(family: str):
             "gemm_128x128_vecA_split": ("gemm_kernel<128, 128, 2, 2, 1, true>",), "skinny_m32": ("skinny_kernel<1, 1",),
             "skinny_m64": ("skinny_kernel<2, 1",), "gemvp_m32": ("gemvp_kernel<1,",), "gemvp_m64": ("gemvp_kernel<2,",)}.get(family.split(":")[-1])
     files = sorted(glob.glob(str(ROOT / "profiles" / "r2*pmc_hbm_traffic*.csv")))
+    if family.split(":")[-1] == "step_graph" and files:
+        # one replayed decoder step = all launches between two position increments: sum the step's kernels of the PMC run
+        # (which launches them eagerly, --no-graph) and divide by the number of steps (= add_i32 launches)
+        step_kernels = ("gemvp_kernel<", "reduce_ln_kernel", "dattn_kernel<", "argmax_finalize_kernel", "add_i32_kernel")
+        try:
+            total, steps = 0.0, 0
+            with open(files[-1], newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if any(k in row["kernel"] for k in step_kernels):
+                        total += float(row["hbm_bytes_per_launch_corrected"]) * int(row["launches"])
+                        if "add_i32_kernel" in row["kernel"]:
+                            steps = int(row["launches"])
+            if steps > 0 and total > 0:
+                return total / steps, "profiles/" + Path(files[-1]).name + " (sum over the kernels of a step / steps)"
+        except Exception:
+            return None, None
+        return None, None
     if not keys or not files:
         return None, None
     try:

@@ -68,3 +68,8 @@ def test_roofline_bookkeeping_and_pmc_lookup():
         if rows:
             val, src = bench.pmc_traffic("enc:gemm_128x128_presplit")
             assert val == float(rows[0]["hbm_bytes_per_launch_corrected"]) and src.startswith("profiles/r2")
+        # the replayed decoder step: sum of its kernels' bytes per step; must cover at least the fp16 weights it streams
+        rows = list(csv.DictReader(open(files[-1], newline="")))
+        if any("add_i32_kernel" in r["kernel"] for r in rows) and any("gemvp_kernel<" in r["kernel"] for r in rows):
+            val, src = bench.pmc_traffic("dec:step_graph")
+            assert val is not None and 1.733e9 < val < 3 * 2.2e9 and "sum over the kernels of a step" in src
