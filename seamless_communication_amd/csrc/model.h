@@ -180,6 +180,8 @@ struct ModelData {
     const __half* const* mma_qe_w = nullptr;
     const float* const* mma_qe_b = nullptr;
     const float* const* mma_ebias = nullptr;
+    const __half* const* mma_ke_w = nullptr;  // key-side energy MLPs, same table layout
+    const float* const* mma_ke_b = nullptr;
     int mma_qe_ldw = 0;
     LNorm mma_final_ln;
     // text encoder (text-input tasks; shares the embedding frontend with the decoder)
@@ -227,10 +229,22 @@ struct DecodeSession;
 void delete_decode_session(DecodeSession* s);
 
 // State bag of the streaming decoder between sc_mma_begin and the sc_mma_step calls of one policy round.
+// Kept ACROSS policy rounds while the geometry fits (max_len unchanged, encoder length within cap_enc): the buffers then
+// keep their addresses and the two captured single-token step graphs (without / with the p_choose hook) stay valid.
 struct MmaState {
     int s_enc = 0, cap = 0, pos = 0;
+    int cap_enc = 0;  // rows per layer of `cross` (>= s_enc; rows behind s_enc are never attended: key mask)
     Buf<float> kv, cross, kenergy, work, pchoose;
     Buf<int> ints;
+    Buf<__half> planes;  // split planes of the second-generation step (alloc_step2 layout)
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t exec[2] = {nullptr, nullptr};
+    ~MmaState() {
+        for (int i = 0; i < 2; ++i) {
+            if (exec[i]) (void)hipGraphExecDestroy(exec[i]);
+            if (graph[i]) (void)hipGraphDestroy(graph[i]);
+        }
+    }
 };
 
 // One handle: the model description plus its own stream, scratch pool and per-call results.

@@ -124,12 +124,13 @@ __global__ void pchoose_kernel(const float* __restrict__ q, const float* __restr
 // grid (M / 32, layers); a wave owns 8 output features: all 16 weight loads (8 features x 2 K halves of 512) are issued
 // before the first use, the row vector sits in registers (16 floats per lane), wave reduction by shuffles.
 __global__ __launch_bounds__(256) void energy_level_kernel(const __half* const* __restrict__ Wt, const float* const* __restrict__ Bt,
-                                                           int ldw, const float* __restrict__ in, float* __restrict__ out, int M) {
+                                                           int ldw, const float* __restrict__ in, int64_t in_ls,
+                                                           float* __restrict__ out, int M) {
     typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
     const int l = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 32 + wave * 8;
     const __half* W = Wt[l];
-    const float* x = in + (int64_t)l * M;
+    const float* x = in + (int64_t)l * in_ls;  // in_ls = 0: the same row for every layer
     float xv[2][8];
     h8_t w[8][2];
 #pragma unroll
@@ -271,6 +272,19 @@ void alloc_step2(Model& m, StepCtx& c, int ffn_dim) {
     c.wideL = c.wideH + pf;
 }
 
+// the same plane layout over an existing allocation (streaming state: the planes outlive the call)
+void alloc_step2_views(Model& m, StepCtx& c, int ffn_dim, __half* base) {
+    const int M = m.cfg.model_dim;
+    c.rb = c.nb <= 32 ? 32 : 64;
+    const size_t pm = (size_t)M * c.rb, pf = (size_t)ffn_dim * c.rb;
+    c.hH = base;
+    c.hL = c.hH + pm;
+    c.attH = c.hL + pm;
+    c.attL = c.attH + pm;
+    c.wideH = c.attL + pm;
+    c.wideL = c.wideH + pf;
+}
+
 static void gemv2(Model& m, StepCtx& c, const __half* Ah, const __half* Al, const Linear& L, int want_splits, int* splits) {
     GemvPArgs a;
     a.Wp = L.wp;
@@ -385,7 +399,7 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
         float* dst = c.qe0;
         for (int e = 0; e < E; ++e) {
             hipLaunchKernelGGL(energy_level_kernel, dim3(cdiv(M, 32), n_layers), dim3(256), 0, m.stream, m.mma_qe_w + (size_t)e * n_layers,
-                               m.mma_qe_b + (size_t)e * n_layers, m.mma_qe_ldw, src, dst, M);
+                               m.mma_qe_b + (size_t)e * n_layers, m.mma_qe_ldw, src, (int64_t)M, dst, M);
             SC_LAUNCH_CHECK();
             src = dst;
             dst = (dst == c.qe0) ? c.qe1 : c.qe0;
@@ -596,44 +610,67 @@ void run_mma_begin(Model& m, const float* d_enc, int s_enc, int max_len) {
     SC_CHECK(s_enc > 0 && s_enc <= 4096, "sc_mma_begin: encoder length %d out of range", s_enc);
     SC_CHECK(max_len >= 2 && max_len <= cfg.text_max_seq_len && max_len <= 4096, "sc_mma_begin: max_len %d out of range", max_len);
     prof::set_tag("mma");
-    m.mma.reset();  // the previous round's buffers go back to the pool first
-    std::unique_ptr<MmaState> st(new MmaState());
-    st->s_enc = s_enc;
-    st->cap = max_len;
-    st->pos = 0;
     size_t work_n = 0;
     mma_work(m, nullptr, &work_n);
-    st->kv = Buf<float>(&m.pool, (size_t)2 * L * max_len * M);
-    st->cross = Buf<float>(&m.pool, (size_t)L * s_enc * 2 * M);
-    st->kenergy = Buf<float>(&m.pool, (size_t)L * M);
-    st->pchoose = Buf<float>(&m.pool, (size_t)L * H);
-    st->work = Buf<float>(&m.pool, work_n);
-    st->ints = Buf<int>(&m.pool, 16 + 64);
-    const MmaWork w = mma_work(m, st->work.get(), nullptr);
+    // The state is kept across policy rounds while it fits: a streaming session calls sc_mma_begin once per segment with a
+    // growing encoder length and the same max_len; buffers that keep their addresses keep the captured step graphs valid.
+    if (!m.mma || m.mma->cap != max_len || m.mma->cap_enc < s_enc) {
+        const int grow = m.mma ? m.mma->cap_enc + m.mma->cap_enc / 2 : 0;
+        const int cap_enc = std::min(4096, (int)align_up((int64_t)std::max(s_enc, grow), 64));
+        m.mma.reset();  // the previous buffers (and graphs) go first
+        std::unique_ptr<MmaState> st(new MmaState());
+        st->cap = max_len;
+        st->cap_enc = cap_enc;
+        st->kv = Buf<float>(&m.pool, (size_t)2 * L * max_len * M);
+        st->cross = Buf<float>(&m.pool, (size_t)L * cap_enc * 2 * M);
+        st->kenergy = Buf<float>(&m.pool, (size_t)L * M);
+        st->pchoose = Buf<float>(&m.pool, (size_t)L * H);
+        st->work = Buf<float>(&m.pool, work_n);
+        st->ints = Buf<int>(&m.pool, 16 + 64);
+        m.mma = std::move(st);
+    }
+    MmaState& st = *m.mma;
+    st.s_enc = s_enc;
+    st.pos = 0;
+    const MmaWork w = mma_work(m, st.work.get(), nullptr);
     // d_pos @0, d_tok @8, finished @9, out_len @10, enc_lens @11
     const int32_t init[16] = {0, 0, 0, 0, 0, 0, 0, 0, cfg.pad_idx, 0, max_len, s_enc, 0, 0, 0, 0};
-    SC_HIP(hipMemcpyAsync(st->ints.get(), init, sizeof(init), hipMemcpyHostToDevice, m.stream));
+    SC_HIP(hipMemcpyAsync(st.ints.get(), init, sizeof(init), hipMemcpyHostToDevice, m.stream));
     // last pooled source position and its key-side energies, per layer
     const int ratio = cfg.mma_pre_decision_ratio;
     const int s_p = (s_enc + ratio - 1) / ratio;
     const int start = (s_p - 1) * ratio, count = s_enc - start;
     hipLaunchKernelGGL(mean_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, m.stream, d_enc + (int64_t)start * M, count, M, w.pooled);
     SC_LAUNCH_CHECK();
-    for (int li = 0; li < L; ++li) {
-        const DecoderLayer& l = m.mma_dec[li];
-        linear(m, d_enc, M, l.cross_kv, nullptr, 0, st->cross.get() + (int64_t)li * s_enc * 2 * M, 2 * M, s_enc, ACT_NONE, 1.f);
-        const float* ke = energy_mlp(m, m.mma_pc[li].k, w.pooled, M, w.qe0, w.qe1, 1);
-        SC_HIP(hipMemcpyAsync(st->kenergy.get() + (int64_t)li * M, ke, (size_t)M * 4, hipMemcpyDeviceToDevice, m.stream));
+    for (int li = 0; li < L; ++li)
+        linear(m, d_enc, M, m.mma_dec[li].cross_kv, nullptr, 0, st.cross.get() + (int64_t)li * st.cap_enc * 2 * M, 2 * M, s_enc, ACT_NONE, 1.f);
+    if (m.mma_ke_w && M <= 1024) {
+        // key-side EnergyProjection of every layer on the same pooled row: one batched launch per MLP level
+        const int E = cfg.mma_energy_layers;
+        const float* src = w.pooled;
+        int64_t src_ls = 0;
+        for (int e = 0; e < E; ++e) {
+            float* dst = (e + 1 == E) ? st.kenergy.get() : ((e & 1) ? w.qe1 : w.qe0);
+            hipLaunchKernelGGL(energy_level_kernel, dim3(cdiv(M, 32), L), dim3(256), 0, m.stream, m.mma_ke_w + (size_t)e * L,
+                               m.mma_ke_b + (size_t)e * L, m.mma_qe_ldw, src, src_ls, dst, M);
+            SC_LAUNCH_CHECK();
+            src = dst;
+            src_ls = M;
+        }
+    } else {
+        for (int li = 0; li < L; ++li) {
+            const float* ke = energy_mlp(m, m.mma_pc[li].k, w.pooled, M, w.qe0, w.qe1, 1);
+            SC_HIP(hipMemcpyAsync(st.kenergy.get() + (int64_t)li * M, ke, (size_t)M * 4, hipMemcpyDeviceToDevice, m.stream));
+        }
     }
     SC_HIP(hipStreamSynchronize(m.stream));  // `init` is a host temporary; d_enc may be reused by the caller
-    m.mma = std::move(st);
 }
 
 void run_mma_step(Model& m, const int32_t* h_tokens, int n_tokens, const int32_t* h_blocked, int n_blocked, int32_t* out_index,
                   float* h_pchoose, float* d_features) {
     const sc_config& cfg = m.cfg;
     const int M = cfg.model_dim, L = cfg.mma_layers, H = cfg.num_heads, V = cfg.text_vocab_size;
-    SC_CHECK(m.mma != nullptr, "sc_mma_step: call sc_mma_begin first");
+    SC_CHECK(m.mma != nullptr && m.mma->s_enc > 0, "sc_mma_step: call sc_mma_begin first");
     MmaState& st = *m.mma;
     SC_CHECK(n_tokens >= 1 && st.pos + n_tokens <= st.cap, "sc_mma_step: %d tokens at position %d exceed max_len %d", n_tokens,
              st.pos, st.cap);
@@ -646,7 +683,7 @@ void run_mma_step(Model& m, const int32_t* h_tokens, int n_tokens, const int32_t
     StepCtx c;
     c.nb = 1;
     c.cap = st.cap;
-    c.s_enc = st.s_enc;
+    c.s_enc = st.cap_enc;  // geometry of the cross K/V buffer; the valid length sits in device memory (d_enc_lens)
     c.d_pos = st.ints.get();
     c.d_tok = st.ints.get() + 8;
     c.d_finished = st.ints.get() + 9;
@@ -665,22 +702,56 @@ void run_mma_step(Model& m, const int32_t* h_tokens, int n_tokens, const int32_t
     c.qe1 = w.qe1;
     c.d_hq = w.hq;
     c.stack = &W;
-    if (step2_eligible(m, W, 1)) alloc_step2(m, c, cfg.mma_ffn_dim);  // second-generation step kernels, p_choose hook batched
     c.d_kenergy = st.kenergy.get();
     c.d_pchoose = st.pchoose.get();
+    const bool gen2 = step2_eligible(m, W, 1);
+    if (gen2) {  // second-generation step kernels, p_choose hook batched; planes live in the state (stable addresses)
+        if (!st.planes.get()) {
+            alloc_step2(m, c, cfg.mma_ffn_dim);
+            st.planes = std::move(c.planes);
+        }
+        alloc_step2_views(m, c, cfg.mma_ffn_dim, st.planes.get());
+    }
     const int64_t layer_stride = (int64_t)st.cap * M;
     for (int li = 0; li < L; ++li) {
         c.kcache.push_back(st.kv.get() + (int64_t)(2 * li) * layer_stride);
         c.vcache.push_back(st.kv.get() + (int64_t)(2 * li + 1) * layer_stride);
-        c.cross_kv.push_back(st.cross.get() + (int64_t)li * st.s_enc * 2 * M);
+        c.cross_kv.push_back(st.cross.get() + (int64_t)li * st.cap_enc * 2 * M);
     }
+    // SC_MMA_GRAPH=1: one token = one replay of a captured graph (gen-2 steps only).  Measured on the full-size model
+    // (profiles/r2_stream_latency_graph.jsonl): no gain - a one-row step is 1.3 ms of dependent GPU work + the vocabulary
+    // projection whichever way it is launched (the eager launches run ahead of the GPU) - and every growth of the encoder
+    // buffer costs a re-capture (8 ms); default: eager launches.
+    static const bool use_graph = getenv("SC_MMA_GRAPH") && atoi(getenv("SC_MMA_GRAPH")) != 0;
+    auto step = [&](bool with_pchoose) {
+        c.pchoose = with_pchoose;
+        const int gi = with_pchoose ? 1 : 0;
+        if (!gen2 || !use_graph || prof::enabled()) {
+            decoder_step(m, c, /*project=*/false);  // advances *d_pos
+            return;
+        }
+        if (!st.exec[gi]) {
+            std::lock_guard<std::mutex> lock(g_capture_mutex);
+            SC_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeThreadLocal));
+            try {
+                decoder_step(m, c, /*project=*/false);
+            } catch (...) {
+                hipGraph_t dead = nullptr;
+                (void)hipStreamEndCapture(m.stream, &dead);
+                if (dead) (void)hipGraphDestroy(dead);
+                throw;
+            }
+            SC_HIP(hipStreamEndCapture(m.stream, &st.graph[gi]));
+            SC_HIP(hipGraphInstantiate(&st.exec[gi], st.graph[gi], nullptr, nullptr, 0));
+        }
+        SC_HIP(hipGraphLaunch(st.exec[gi], m.stream));
+    };
     for (int t0 = 0; t0 < n_tokens; t0 += 32) {
         const int nt = std::min(32, n_tokens - t0);
         SC_HIP(hipMemcpyAsync(d_feed, h_tokens + t0, (size_t)nt * 4, hipMemcpyHostToDevice, m.stream));
         for (int t = 0; t < nt; ++t) {
             SC_HIP(hipMemcpyAsync(c.d_tok, d_feed + t, 4, hipMemcpyDeviceToDevice, m.stream));
-            c.pchoose = (t0 + t == n_tokens - 1);
-            decoder_step(m, c, /*project=*/false);  // advances *d_pos
+            step(t0 + t == n_tokens - 1);
             SC_HIP(hipMemcpyAsync(d_features + (int64_t)(t0 + t) * M, c.hN, (size_t)M * 4, hipMemcpyDeviceToDevice, m.stream));
         }
         SC_HIP(hipStreamSynchronize(m.stream));  // the pageable source of d_feed may be reused

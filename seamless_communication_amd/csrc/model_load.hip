@@ -464,11 +464,15 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
         {
             // pointer tables for the batched query-energy launches (level-major)
             const int E = c.mma_energy_layers, NL = c.mma_layers;
-            std::vector<const void*> tab((size_t)2 * E * NL + NL);
+            std::vector<const void*> tab((size_t)4 * E * NL + NL);
             for (int e = 0; e < E; ++e)
                 for (int i = 0; i < NL; ++i) {
                     tab[(size_t)e * NL + i] = m.mma_pc[i].q[e].w;
                     tab[(size_t)E * NL + (size_t)e * NL + i] = m.mma_pc[i].q[e].b;
+                    tab[(size_t)2 * E * NL + NL + (size_t)e * NL + i] = m.mma_pc[i].k[e].w;
+                    tab[(size_t)3 * E * NL + NL + (size_t)e * NL + i] = m.mma_pc[i].k[e].b;
+                    SC_CHECK(m.mma_pc[i].k[e].ldw == m.mma_pc[0].q[0].ldw && m.mma_pc[i].k[e].in == M && m.mma_pc[i].k[e].out == M,
+                             "sc_load: key energy projection %d of layer %d has an unexpected shape", e, i);
                     SC_CHECK(m.mma_pc[i].q[e].ldw == m.mma_pc[0].q[0].ldw && m.mma_pc[i].q[e].in == M && m.mma_pc[i].q[e].out == M,
                              "sc_load: energy projection %d of layer %d has an unexpected shape", e, i);
                 }
@@ -478,6 +482,8 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
             m.mma_qe_w = static_cast<const __half* const*>(d);
             m.mma_qe_b = reinterpret_cast<const float* const*>(static_cast<const void* const*>(d) + (size_t)E * NL);
             m.mma_ebias = reinterpret_cast<const float* const*>(static_cast<const void* const*>(d) + (size_t)2 * E * NL);
+            m.mma_ke_w = reinterpret_cast<const __half* const*>(static_cast<const void* const*>(d) + (size_t)2 * E * NL + NL);
+            m.mma_ke_b = reinterpret_cast<const float* const*>(static_cast<const void* const*>(d) + (size_t)3 * E * NL + NL);
             m.mma_qe_ldw = (int)m.mma_pc[0].q[0].ldw;
         }
         m.mma_embed_p = L.packed(m.mma_embed, M, c.text_vocab_size, M);
