@@ -113,3 +113,38 @@ def test_beam_search_with_ngram_blocking_has_no_repeats():
                     assert not _has_repeated_ngram(body, G), (beam, G, seq)
                 if beam == 1 and not _has_repeated_ngram(p, G):
                     assert b == p  # nothing to block on the path of a greedy search
+
+
+def test_ngram_block_agrees_with_hf_no_repeat_ngram_processor():
+    """NGramRepeatBlockProcessor lives in fairseq2 0.2 (not under /root/reference; restated from upstream knowledge).  The
+    rule it implements is fairseq's no-repeat-n-gram rule; HF transformers' NoRepeatNGramLogitsProcessor is an independent
+    executable implementation of the same rule: for every sequence longer than the n-gram size both block the same
+    tokens (oracle function and the library's host function sc_ngram_blocked_tokens).  At len == ngram_size fairseq2 returns
+    early (`ngram_size >= seq_len`, what the restatement follows) while HF already blocks: that edge is excluded here."""
+    import ctypes as C
+
+    import numpy as np
+    from transformers.generation.logits_process import NoRepeatNGramLogitsProcessor
+
+    from seamless_communication_amd import _lib
+
+    lib = _lib.load_library()
+    rng = np.random.RandomState(5)
+    V = 12
+    checked = 0
+    for G in (1, 2, 3, 4):
+        hf = NoRepeatNGramLogitsProcessor(G)
+        for S in range(G + 1, 24):
+            seqs = torch.from_numpy(rng.randint(0, 5, size=(6, S)).astype(np.int64))
+            want = hf(seqs, torch.zeros(6, V))
+            got = torch.zeros(6, V)
+            ou.ngram_repeat_block(seqs, got, G)
+            assert torch.equal(got == -math.inf, want == -math.inf), (G, S)
+            for r in range(6):
+                row = np.ascontiguousarray(seqs[r].numpy().astype(np.int32))
+                out = np.zeros(S + 1, dtype=np.int32)
+                cnt = lib.sc_ngram_blocked_tokens(row.ctypes.data_as(C.POINTER(C.c_int32)), S, G,
+                                                  out.ctypes.data_as(C.POINTER(C.c_int32)), S + 1)
+                assert sorted(set(out[:cnt].tolist())) == sorted(torch.nonzero(want[r] == -math.inf).flatten().tolist())
+                checked += 1
+    assert checked > 400
