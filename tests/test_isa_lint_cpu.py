@@ -82,3 +82,56 @@ def test_decoder_attention_has_its_operands_in_flight_before_the_first_wait(dste
     first_wait = next(i for i, o in enumerate(ops) if "vmcnt(" in o)
     assert sum(o.startswith("global_load_dwordx4") for o in ops[:first_wait]) >= loads
     assert not any(o.startswith("scratch_") for o in ops)
+
+
+# --------------------------------------------------------------------------------------------------------------------- #
+# round 2: the 8-wave DMA GEMM tile and the fp16-split attention kernel
+# --------------------------------------------------------------------------------------------------------------------- #
+@pytest.fixture(scope="module")
+def gemm_ps_isa(tmp_path_factory):
+    return _isa("k_gemm_ps.hip", tmp_path_factory.mktemp("gemmps"))
+
+
+@pytest.mark.parametrize("inst,mfmas_per_slab", [("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0E", 32),
+                                                 ("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb1E", 32),
+                                                 ("gemm_ps_kernelILi128ELi128ELi2ELi2ELb1ELb1ELb0E", 16)])
+def test_dma_gemm_slab_loop_keeps_its_pipeline(gemm_ps_isa, inst, mfmas_per_slab):
+    """The K loop of the pre-split GEMM (plain and implicit-conv variant): no scratch, DMAs issued as
+    `buffer_load_dwordx4 ... lds` between the matrix instructions, one s_barrier per slab, and the only full drain
+    (vmcnt(0)) is the last slab's - a drain per slab would serialise global->LDS copies and MFMAs."""
+    fn = _function(gemm_ps_isa, inst)
+    assert not any("scratch_" in l for l in fn)
+    loop = _innermost_loop_with(fn, "v_mfma_f32_32x32x16", "s_barrier")
+    ops = _ops(loop)
+    n_mfma = sum(o.startswith("v_mfma_f32_32x32x16") for o in ops)
+    n_bar = sum(o.startswith("s_barrier") for o in ops)
+    assert n_bar >= 1 and n_mfma == mfmas_per_slab * n_bar  # unrolled by the number of stages the compiler kept in the loop
+    n_dma = sum(o.startswith("buffer_load_dwordx4") and o.endswith("lds") for o in ops)
+    assert n_dma == 6 * n_bar
+    assert sum("vmcnt(0)" in o for o in ops) <= n_bar  # at most the tail branch of each unrolled step drains
+    assert any(re.search(r"vmcnt\(6\)", o) for o in ops)  # the counted wait that leaves the next slab's DMAs in flight
+    # DMAs really sit between the matrix instructions (the ILV schedule), not in a block in front of them
+    first = next(i for i, o in enumerate(ops) if o.startswith("v_mfma"))
+    last = max(i for i, o in enumerate(ops) if o.startswith("v_mfma"))
+    assert any(o.startswith("buffer_load_dwordx4") for o in ops[first:last])
+
+
+@pytest.fixture(scope="module")
+def attn_isa(tmp_path_factory):
+    return _isa("k_attn.hip", tmp_path_factory.mktemp("attn"))
+
+
+@pytest.mark.parametrize("inst,max_exec_branches", [("attn_mfma16_kernelILi0E", 2), ("attn_mfma16_kernelILi1E", 4)])
+def test_split_attention_loop_has_no_predicated_gathers(attn_isa, inst, max_exec_branches):
+    """Round 1's attention kernel spent its time in 16 exec-masked branches per key tile (the Shaw term's LDS gather sunk
+    under the key mask, one full LDS wait each).  The fp16-split kernel fetches those terms unconditionally ahead of the
+    matrix instructions: the key-tile loop holds 24 MFMAs (12 for K.Q^T, 12 for V^T.P^T), two barriers, the exec-masked
+    regions of the K/V prefetch only, and no scratch."""
+    fn = _function(attn_isa, inst)
+    assert not any("scratch_" in l for l in fn)
+    loop = _innermost_loop_with(fn, "v_mfma_f32_32x32x16", "s_barrier", "v_exp_f32")
+    ops = _ops(loop)
+    assert sum(o.startswith("v_mfma_f32_32x32x16") for o in ops) == 24
+    assert sum(o.startswith("s_barrier") for o in ops) == 2
+    assert sum(o.startswith("s_cbranch_execz") or o.startswith("s_cbranch_execnz") for o in ops) <= max_exec_branches
+    assert sum(o.startswith("v_exp_f32") for o in ops) == 17  # 16 probabilities + the rescale factor, on the hardware exp2
