@@ -53,6 +53,9 @@ def _load() -> C.CDLL:
         lib.gref_generate.argtypes = [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                       C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       _P, C.c_int, _P, _P, _P]
+        lib.gref_generate_all.argtypes = [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                          C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          _P, C.c_int, _P, _P]
         _lib = lib
     return _lib
 
@@ -168,3 +171,23 @@ class GgmlRef:
         if rc != 0:
             raise RuntimeError("gref_generate returned no hypothesis")
         return ids[: ln.value].tolist(), float(sc.value), steps[: ln.value].copy()
+
+    def generate_all(self, enc: torch.Tensor, prefix: Sequence[int], beam_size: int, soft_max_seq_len=(1, 200),
+                     hard_max_seq_len: int = 1024, min_seq_len: int = 1, len_penalty: float = 1.0, unk_penalty: float = 0.0,
+                     normalize_scores: bool = True, pad_idx: int = 0, unk_idx: int = 1, bos_idx: int = 2, eos_idx: int = 3,
+                     mem_mb: int = 256, threads: int = 4):
+        """``generate_sequence`` for ONE utterance, every finished hypothesis: [(score, ids)], best first."""
+        ea = np.ascontiguousarray(enc.detach().to(torch.float32).numpy())
+        pre = np.ascontiguousarray(np.asarray(prefix, dtype=np.int32))
+        cap = int(hard_max_seq_len) + 8
+        ids = np.zeros((beam_size, cap), dtype=np.int32)
+        lens = np.zeros(beam_size, dtype=np.int32)
+        scores = np.zeros(beam_size, dtype=np.float32)
+        rc = self.lib.gref_generate_all(self.h, ea.ctypes.data_as(_P), ea.shape[0], ea.shape[1], pre.ctypes.data_as(_P), pre.size,
+                                        beam_size, float(soft_max_seq_len[0]), int(soft_max_seq_len[1]), int(hard_max_seq_len),
+                                        int(min_seq_len), float(len_penalty), float(unk_penalty), int(normalize_scores), pad_idx,
+                                        unk_idx, bos_idx, eos_idx, mem_mb, threads, ids.ctypes.data_as(_P), cap,
+                                        lens.ctypes.data_as(_P), scores.ctypes.data_as(_P))
+        if rc < 0:
+            raise RuntimeError("gref_generate_all failed")
+        return [(float(scores[b]), ids[b, : lens[b]].tolist()) for b in range(beam_size) if lens[b] > 0]

@@ -196,55 +196,103 @@ int64_t gref_embed(void* h, const char* prefix_c, const int32_t* tokens, int n, 
     return cnt;
 }
 
-// generate_sequence (fairseq2.cpp:1371-1608) for one utterance; returns the best hypothesis.
-// enc: [s_enc][model_dim].  out_ids receives the full sequence (prompt echoed, EOS included).
+// generate_sequence (fairseq2.cpp:1371-1608) for one utterance.  The function never frees the three ggml contexts it
+// opens over its local buffers (search_ctx and the two step contexts), and ggml hands contexts out of a static pool of 64
+// slots, lowest free slot first: after ~20 calls ggml_init returns NULL and fairseq2.cpp:59 asserts.  The slots it will
+// take are found beforehand (open PROBES contexts over caller memory, note their addresses, close them) and closed again
+// after the call; closing a slot that is already free is a no-op for contexts over caller-owned memory (ggml.c ggml_free).
+struct Search {
+    static constexpr int PROBES = 6;
+    std::vector<uint8_t> buf, res_buf;
+    ggml_context* ctx = nullptr;
+    ggml_context* result_ctx = nullptr;
+    ggml_context* probe[PROBES] = {};
+    uint8_t probe_mem[PROBES][256];
+    fairseq2_model* model = nullptr;
+    Hypothesis* hyp = nullptr;
+
+    Search(Ref* r, const float* enc, int s_enc, int model_dim, const int32_t* prefix, int n_prefix, int beam_size, float soft_a,
+           int soft_b, int hard_max, int min_seq_len, float len_penalty, float unk_penalty, int normalize_scores, int pad_idx,
+           int unk_idx, int bos_idx, int eos_idx, int mem_mb, int n_threads)
+        : buf((size_t)64 << 20), res_buf((size_t)8 << 20), model(r->model) {
+        ctx = ggml_init({buf.size(), buf.data(), false});
+        result_ctx = ggml_init({res_buf.size(), res_buf.data(), false});
+        for (int i = 0; i < PROBES; ++i) probe[i] = ggml_init({sizeof(probe_mem[i]), probe_mem[i], true});
+        for (int i = 0; i < PROBES; ++i)
+            if (probe[i]) ggml_free(probe[i]);
+        model->ctx = ctx;
+        ggml_tensor* enc_t = ggml_new_tensor_2d(ctx, GGML_TYPE_F32, model_dim, s_enc);
+        std::memcpy(enc_t->data, enc, ggml_nbytes(enc_t));
+        ggml_tensor* pre = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, n_prefix);
+        std::memcpy(pre->data, prefix, (size_t)n_prefix * 4);
+        SequenceGeneratorJob job;
+        job.opts.beam_size = beam_size;
+        job.opts.min_seq_len = min_seq_len;
+        job.opts.soft_max_seq_len_a = soft_a;
+        job.opts.soft_max_seq_len_b = soft_b;
+        job.opts.hard_max_seq_len = hard_max;
+        job.opts.len_penalty = len_penalty;
+        job.opts.unk_penalty = unk_penalty;
+        job.opts.normalize_scores = normalize_scores != 0;
+        job.opts.mem_mb = mem_mb;
+        job.prefix_seq = pre;
+        job.pad_idx = pad_idx;
+        job.unk_idx = unk_idx;
+        job.bos_idx = bos_idx;
+        job.eos_idx = eos_idx;
+        job.num_threads = n_threads;
+        hyp = generate_sequence(*model, job, enc_t, nullptr, result_ctx, n_threads);
+    }
+    ~Search() {
+        model->ctx = nullptr;
+        for (int i = 0; i < PROBES; ++i)
+            if (probe[i]) ggml_free(probe[i]);  // the contexts generate_sequence left open
+        ggml_free(result_ctx);
+        ggml_free(ctx);
+    }
+};
+
+// Best hypothesis.  enc: [s_enc][model_dim].  out_ids receives the full sequence (prompt echoed, EOS included).
 int gref_generate(void* h, const float* enc, int s_enc, int model_dim, const int32_t* prefix, int n_prefix, int beam_size,
                   float soft_a, int soft_b, int hard_max, int min_seq_len, float len_penalty, float unk_penalty,
                   int normalize_scores, int pad_idx, int unk_idx, int bos_idx, int eos_idx, int mem_mb, int n_threads,
                   int32_t* out_ids, int out_cap, int* out_len, float* out_score, float* out_step_scores) {
-    Ref* r = static_cast<Ref*>(h);
-    fairseq2_model& model = *r->model;
-    std::vector<uint8_t> buf((size_t)64 << 20), res_buf((size_t)8 << 20);
-    ggml_context* ctx = ggml_init({buf.size(), buf.data(), false});
-    ggml_context* result_ctx = ggml_init({res_buf.size(), res_buf.data(), false});
-    model.ctx = ctx;
-    ggml_tensor* enc_t = ggml_new_tensor_2d(ctx, GGML_TYPE_F32, model_dim, s_enc);
-    std::memcpy(enc_t->data, enc, ggml_nbytes(enc_t));
-    ggml_tensor* pre = ggml_new_tensor_1d(ctx, GGML_TYPE_I32, n_prefix);
-    std::memcpy(pre->data, prefix, (size_t)n_prefix * 4);
-    SequenceGeneratorJob job;
-    job.opts.beam_size = beam_size;
-    job.opts.min_seq_len = min_seq_len;
-    job.opts.soft_max_seq_len_a = soft_a;
-    job.opts.soft_max_seq_len_b = soft_b;
-    job.opts.hard_max_seq_len = hard_max;
-    job.opts.len_penalty = len_penalty;
-    job.opts.unk_penalty = unk_penalty;
-    job.opts.normalize_scores = normalize_scores != 0;
-    job.opts.mem_mb = mem_mb;
-    job.prefix_seq = pre;
-    job.pad_idx = pad_idx;
-    job.unk_idx = unk_idx;
-    job.bos_idx = bos_idx;
-    job.eos_idx = eos_idx;
-    job.num_threads = n_threads;
-    Hypothesis* hyp = generate_sequence(model, job, enc_t, nullptr, result_ctx, n_threads);
-    int rc = -1;
+    Search s(static_cast<Ref*>(h), enc, s_enc, model_dim, prefix, n_prefix, beam_size, soft_a, soft_b, hard_max, min_seq_len,
+             len_penalty, unk_penalty, normalize_scores, pad_idx, unk_idx, bos_idx, eos_idx, mem_mb, n_threads);
+    Hypothesis* hyp = s.hyp;
     if (getenv("GREF_DEBUG")) fprintf(stderr, "gref_generate: hyp=%p seq=%p score=%f\n", (void*)hyp, hyp ? (void*)hyp[0].seq : nullptr, hyp ? hyp[0].score : 0.f);
-    if (hyp && hyp[0].seq) {
-        const int len = (int)hyp[0].seq->ne[0];
-        *out_len = len;
-        *out_score = hyp[0].score;
-        if (len <= out_cap) {
-            std::memcpy(out_ids, hyp[0].seq->data, (size_t)len * 4);
-            if (out_step_scores && hyp[0].step_scores) std::memcpy(out_step_scores, hyp[0].step_scores->data, (size_t)len * 4);
-            rc = 0;
-        }
+    if (!hyp || !hyp[0].seq) return -1;
+    const int len = (int)hyp[0].seq->ne[0];
+    *out_len = len;
+    *out_score = hyp[0].score;
+    if (len > out_cap) return -1;
+    std::memcpy(out_ids, hyp[0].seq->data, (size_t)len * 4);
+    if (out_step_scores && hyp[0].step_scores) std::memcpy(out_step_scores, hyp[0].step_scores->data, (size_t)len * 4);
+    return 0;
+}
+
+// Every finished hypothesis, best first (the array the function sorts at fairseq2.cpp:1597-1602).
+// out_ids: [beam_size][out_cap]; out_lens / out_scores: [beam_size] (len 0 = slot never filled).  Returns the count.
+int gref_generate_all(void* h, const float* enc, int s_enc, int model_dim, const int32_t* prefix, int n_prefix, int beam_size,
+                      float soft_a, int soft_b, int hard_max, int min_seq_len, float len_penalty, float unk_penalty,
+                      int normalize_scores, int pad_idx, int unk_idx, int bos_idx, int eos_idx, int mem_mb, int n_threads,
+                      int32_t* out_ids, int out_cap, int32_t* out_lens, float* out_scores) {
+    Search s(static_cast<Ref*>(h), enc, s_enc, model_dim, prefix, n_prefix, beam_size, soft_a, soft_b, hard_max, min_seq_len,
+             len_penalty, unk_penalty, normalize_scores, pad_idx, unk_idx, bos_idx, eos_idx, mem_mb, n_threads);
+    Hypothesis* hyp = s.hyp;
+    if (!hyp) return -1;
+    int found = 0;
+    for (int b = 0; b < beam_size; ++b) {
+        out_lens[b] = 0;
+        out_scores[b] = hyp[b].score;
+        if (!hyp[b].seq) continue;
+        const int len = (int)hyp[b].seq->ne[0];
+        if (len > out_cap) return -1;
+        std::memcpy(out_ids + (size_t)b * out_cap, hyp[b].seq->data, (size_t)len * 4);
+        out_lens[b] = len;
+        ++found;
     }
-    model.ctx = nullptr;
-    ggml_free(result_ctx);
-    ggml_free(ctx);
-    return rc;
+    return found;
 }
 
 }  // extern "C"

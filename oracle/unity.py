@@ -12,11 +12,14 @@ reference's setup.py:25, NOT vendored under /root/reference and not
 installable here), so those parts restate fairseq2's published algorithm and
 are anchored on the reference's call sites and on the in-tree C++ restatement
 (ggml/examples/unity/fairseq2.cpp).  PARITY PIN STATUS per block is listed in
-DESIGN.md: fbank is pinned against the compiled kaldi-native-fbank, the
-vocoder / unit tokenizer / NAR frontend logic against the reference's own
-Python files (tests/golden/make_reference_goldens.py); Shaw attention, the
-Conformer convolution module and the beam-search length rule are "parity
-unpinned" (no reference test or executable reference exists offline).
+DESIGN.md section 5: fbank is pinned against the compiled kaldi-native-fbank,
+the Transformer blocks, greedy and beam search against the compiled
+fairseq2.cpp (tests/test_oracle_ggml_ref.py), the vocoder / unit tokenizer /
+NAR frontend logic against the reference's own Python files
+(tests/golden/make_reference_goldens.py), Shaw attention and the Conformer
+convolution module against HF's executed port (tests/golden/make_hf_goldens.py).
+Still "parity unpinned" (no executable reference offline): fairseq2 0.2's
+length rule, its EOS-rank rule in beam search, the `_tweak_lprobs` edits.
 
 Citations `file:line` are relative to
 /root/reference/src/seamless_communication unless they start with ggml/.
@@ -452,6 +455,7 @@ def beam_search_generate(
     soft_max_seq_len: Tuple[float, int] = (1, 200), hard_max_seq_len: int = 1024, min_seq_len: int = 1,
     len_penalty: float = 1.0, unk_penalty: float = 0.0, normalize_scores: bool = True,
     pos_table: Optional[Tensor] = None, return_all: bool = False, no_repeat_ngram_size: int = 0, source_len: int = 0,
+    compiled_port_rules: bool = False,
 ):
     """BeamSearchSeq2SeqGenerator as the reference constructs it (inference/generator.py:147-156,
     beam_size=5 by default translator.py:311-313), restated from the in-tree C++ port of fairseq2's
@@ -471,6 +475,12 @@ def beam_search_generate(
         the row (nothing while G >= the sequence length); not applied on the forced-EOS step.
     Uses log-probabilities throughout (the intent of the port; see tests/test_oracle_ggml_ref.py for what
     the compiled C++ actually does to them).  Ties between equal candidates: lower (beam, token) index.
+    `compiled_port_rules` (tests only): behave like the port AS COMPILED, so that this function can be run against it for
+    beam_size > 1 - the port computes the step graph a second time after `_tweak_lprobs` (:1515-1534) with the log node
+    detached, so the edits are lost and the buffer holds soft-max PROBABILITIES when the cumulative scores are added; an
+    EOS candidate is finalised at whatever rank it is met (:1546-1556).  Bootstrap (true log-probabilities), cumulative
+    scores, candidate order, beam refill / re-order of sequences, scores and KV cache, normalisation, stopping rule and
+    final sort are the shared code.
     Returns the best hypothesis per utterance (and all finished ones with return_all)."""
     N = enc.shape[0]
     if pos_table is None:
@@ -501,14 +511,17 @@ def beam_search_generate(
         for step_nr in range(start, max_len - 1):
             h = dec(seqs[:, step_nr : step_nr + 1])
             lprobs = torch.log_softmax(F.linear(h[:, -1], W), dim=-1)  # (B, V)
-            if step_nr < min_seq_len:
-                lprobs[:, cfg.eos_idx] = -math.inf
-            if step_nr == max_len - 2:
-                lprobs[:, : cfg.eos_idx] = -math.inf
-                lprobs[:, cfg.eos_idx + 1 :] = -math.inf
-            lprobs[:, cfg.pad_idx] = -math.inf
-            if unk_penalty != 0:
-                lprobs[:, cfg.unk_idx] -= unk_penalty
+            if compiled_port_rules:
+                lprobs = torch.softmax(F.linear(h[:, -1], W), dim=-1)  # what the re-run graph leaves in the buffer
+            if not compiled_port_rules:
+                if step_nr < min_seq_len:
+                    lprobs[:, cfg.eos_idx] = -math.inf
+                if step_nr == max_len - 2:
+                    lprobs[:, : cfg.eos_idx] = -math.inf
+                    lprobs[:, cfg.eos_idx + 1 :] = -math.inf
+                lprobs[:, cfg.pad_idx] = -math.inf
+                if unk_penalty != 0:
+                    lprobs[:, cfg.unk_idx] -= unk_penalty
             if no_repeat_ngram_size > 0 and step_nr != max_len - 2:
                 ngram_repeat_block(seqs[:, : step_nr + 1], lprobs, no_repeat_ngram_size)
             if step_nr == start:
@@ -532,7 +545,7 @@ def beam_search_generate(
                     # considers an EOS candidate only when it ranks among the top `beam_size` of the 2 x beam candidates;
                     # a lower-ranked EOS is neither finalised nor continued.  The ggml port (fairseq2.cpp:1542-1565)
                     # finalises every EOS it meets before `beam_size` live beams are collected: it deviates here.
-                    if rank >= B:
+                    if rank >= B and not compiled_port_rules:
                         continue
                     final = s / float((step_nr + 1) ** len_penalty) if normalize_scores else s
                     finished.append((final, seqs[beam, : step_nr + 1].tolist() + [token]))
@@ -558,7 +571,7 @@ def beam_search_generate(
             seqs[:, step_nr + 1] = torch.tensor(toks)
             scores[:, step_nr + 1] = torch.tensor(scs)
         finished.sort(key=lambda f: -f[0])
-        best.append(finished[0][1])
+        best.append(finished[0][1] if finished else [])
         everything.append(finished)
     return (best, everything) if return_all else best
 
