@@ -244,9 +244,38 @@ def test_generate_sequence_beam_search_matches_oracle(env, seed, s_enc, stop):
     assert compared >= (5 if seed != 14 else 2)
 
 
+def test_length_rule_executed_on_the_compiled_reference(env):
+    """`_determine_max_seq_len` (fairseq2.cpp:1097-1105) observed through generate_sequence: the EOS row is crafted so that
+    the greedy hypothesis has exactly 9 tokens; the compiled reference returns it when the limit oracle.max_seq_len_rule
+    computes is 9 and returns nothing when it is 8 (the port as compiled has no forced EOS at the limit), for the soft rule
+    int(a * S_enc) + b, the hard limit and the a <= 0 case."""
+    cfg, sd, P, ref, tt, pos = env
+    s_enc = 9
+    enc = _x((1, s_enc, cfg.model_dim), 11)
+    prefix = tt.target_prefix("fra")
+    ok, P2, W = _craft_natural_eos(cfg, P, enc, prefix, pos, 7)
+    assert ok
+    want = ou.greedy_generate(P2, cfg, enc, torch.tensor([s_enc]), prefix, hard_max_seq_len=64, pos_table=pos)[0]
+    assert len(want) == 9
+    kw = dict(pad_idx=cfg.pad_idx, unk_idx=cfg.unk_idx, bos_idx=cfg.bos_idx, eos_idx=cfg.eos_idx)
+    ref2 = _decoder_ref(cfg, sd, P, W, tt, pos)
+    try:
+        for soft, hard in (((0.5, 5), 64), ((1, 0), 64), ((1, 200), 9), ((0, 3), 9), ((0.99, 1), 64), ((2.0, 200), 9)):
+            limit = ou.max_seq_len_rule(soft[0], soft[1], hard, s_enc)
+            assert limit == 9, (soft, hard, limit)
+            ids, _, _ = ref2.generate(enc[0], prefix, beam_size=1, soft_max_seq_len=soft, hard_max_seq_len=hard, **kw)
+            assert ids == want, (soft, hard)
+        for soft, hard in (((0.5, 4), 64), ((1, 200), 8), ((0, 3), 8), ((0.88, 1), 64)):
+            assert ou.max_seq_len_rule(soft[0], soft[1], hard, s_enc) == 8, (soft, hard)
+            with pytest.raises(RuntimeError, match="no hypothesis"):
+                ref2.generate(enc[0], prefix, beam_size=1, soft_max_seq_len=soft, hard_max_seq_len=hard, **kw)
+    finally:
+        ref2.close()
+
+
 def test_length_rule_matches_reference_source():
     """max_len = min(hard, int(a * S_enc) + b), prompt included: restated from fairseq2.cpp:1097-1105
-    (`_determine_max_seq_len`); the executable reference cannot show it (see _craft_natural_eos)."""
+    (`_determine_max_seq_len`); fixed expectations next to the executed check above."""
     assert ou.max_seq_len_rule(1, 200, 1024, 63) == 263
     assert ou.max_seq_len_rule(0.5, 4, 200, 6) == 7
     assert ou.max_seq_len_rule(0, 4, 200, 6) == 200
