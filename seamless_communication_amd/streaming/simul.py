@@ -2,7 +2,9 @@
 
 The reference builds its streaming pipeline on ``simuleval`` (``GenericAgent`` / ``AgentPipeline`` / segments /
 actions: imports in src/seamless_communication/streaming/agents/*.py).  simuleval is not installed here and not part
-of /root/reference, so the contract those agents rely on is restated (simuleval 1.1 semantics, parity unpinned):
+of /root/reference, so the contract those agents rely on is restated (simuleval 1.1 semantics, parity unpinned; the
+agents written on top of it ARE pinned: the reference's agent classes run on this very module in
+tests/golden/make_streaming_goldens.py and their traces are replayed on streaming/agents.py):
 
 * a pipeline is a chain of agents; ``pushpop(segment)`` feeds one source segment to the first agent and hands every
   agent's output segment to the next one; the last agent's output is returned;

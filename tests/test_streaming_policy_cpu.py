@@ -1,0 +1,105 @@
+"""CPU: the host logic of the streaming agents (seamless_communication_amd/streaming/agents.py) against traces recorded
+from the reference's own agent classes EXECUTED on the same scripted models (tests/golden/make_streaming_goldens.py ->
+tests/golden/streaming_policy_ref.json; scripts in tests/streaming_script.py):
+
+  * text decoder agents (online_text_decoder.py): read / write decisions under min / mean / median of p_choose, thresholds,
+    `no_early_stop`, the n-gram guard, the length limits, `max_consecutive_write`, `min_starting_wait`, the language tag in the
+    prefix, empty / zero-length sources; for the UnitY variant also the decoder features, the "," phrase ending and the token
+    ids handed to the unit decoder;
+  * the whole five-agent chain in the reference's UnitYAgentPipeline (residual samples of the feature extractor, re-encoding
+    of everything heard, unit chunking with `duration_start_index`, vocoder hand-off, early-stop reset);
+  * the detokenizer.
+
+Every output segment and the agents' states after every push must be identical.  SimulEval itself is not installed
+anywhere: both sides run on the restated contract of streaming/simul.py."""
+import json
+from pathlib import Path
+
+import pytest
+
+from seamless_communication_amd.streaming import agents as ag
+from seamless_communication_amd.streaming import simul
+from tests import streaming_script as ss
+
+GOLDEN = json.loads((Path(__file__).parent / "golden" / "streaming_policy_ref.json").read_text())
+
+
+def _norm(x):
+    """JSON round trip of a trace (tuples -> lists, float formatting)."""
+    return json.loads(json.dumps(x))
+
+
+def test_text_decoder_agents_follow_the_reference_traces():
+    scenarios = ss.text_decoder_scenarios()
+    assert len(scenarios) == len(GOLDEN["text_decoder"])
+    tok = ss.ScriptTokenizer()
+    stats = dict(writes=0, reads=0, finished=0, guard=0, comma=0)
+    for scn, want in zip(scenarios, GOLDEN["text_decoder"]):
+        cls = ag.UnitYMMATextDecoderAgent if scn["unity"] else ag.MMATextDecoderAgent
+        agent = cls(ss.ScriptBackend(scn["seed"]), tok, ag.default_args(**scn["opts"]))
+        got = _norm(ss.drive_text_decoder(agent, scn, simul.Segment, simul.EmptySegment))
+        assert got == want, (scn["seed"], scn["opts"])
+        for r in got:
+            stats["reads" if r["empty"] else "writes"] += 1
+            stats["finished"] += r["finished"]
+            stats["guard"] += r["state_ngram_block_count"] > 0
+            stats["comma"] += (not r["empty"]) and "tokens" in r and len(r["target_indices"]) > 0 and r["target_indices"][-1] == ss.COMMA
+    # the scripts do reach the branches this test is about
+    assert stats["writes"] > 300 and stats["reads"] > 150 and stats["finished"] > 80 and stats["guard"] > 10 and stats["comma"] > 100, stats
+
+
+def test_five_agent_chain_follows_the_reference_traces():
+    scenarios = ss.chain_scenarios()
+    assert len(scenarios) == len(GOLDEN["chain"])
+    tok = ss.ScriptTokenizer()
+    spoke = resets = 0
+    for scn, want in zip(scenarios, GOLDEN["chain"]):
+        chain = ag.SeamlessStreamingS2STAgent(ss.ScriptBackend(scn["seed"]), tok, ag.default_args(**scn["opts"]))
+        got = _norm(ss.drive_chain(chain, scn, simul.SpeechSegment))
+        assert got == want, (scn["seed"], scn["opts"])
+        spoke += sum(1 for r in got if not r["empty"] and len(r["content"]) > 0)
+        # an early stop (the chain finishes before the source does) starts every agent over
+        resets += sum(1 for r, s in zip(got, scn["segments"]) if not s["finished"] and r["encoder_frames"] == 0 and r["text_target_indices"] == []
+                      and not r["empty"])
+    assert spoke > 40 and resets > 0, (spoke, resets)
+
+
+def test_detokenizer_follows_the_reference_traces():
+    scenarios = ss.detokenizer_scenarios()
+    assert len(scenarios) == len(GOLDEN["detokenizer"])
+    for scn, want in zip(scenarios, GOLDEN["detokenizer"]):
+        agent = ag.DetokenizerAgent(ag.default_args(detokenize_only=scn["detokenize_only"]))
+        assert _norm(ss.drive_detokenizer(agent, scn, simul.TextSegment)) == want, scn
+
+
+@pytest.mark.skipif(not Path("/root/reference/src/seamless_communication/streaming/agents").exists(), reason="/root/reference is not present")
+def test_default_args_equal_the_reference_argparse_defaults():
+    """`default_args()` against the add_args of the reference agent classes, read from their source with `ast` (the values
+    the golden generator hands to the reference agents)."""
+    import ast
+
+    root = Path("/root/reference/src/seamless_communication/streaming/agents")
+    found = {}
+    for name in ("online_feature_extractor", "offline_w2v_bert_encoder", "online_text_decoder", "online_unit_decoder", "online_vocoder",
+                 "detokenizer"):
+        tree = ast.parse((root / f"{name}.py").read_text())
+        consts = {t.id: ast.literal_eval(n.value) for n in tree.body if isinstance(n, ast.Assign) for t in n.targets
+                  if isinstance(t, ast.Name) and isinstance(n.value, ast.Constant)}
+        for call in (n for n in ast.walk(tree) if isinstance(n, ast.Call) and getattr(n.func, "attr", "") == "add_argument"):
+            flag = call.args[0].value
+            kw = {k.arg: k.value for k in call.keywords}
+            if "default" in kw:
+                v = kw["default"]
+                found[flag] = consts[v.id] if isinstance(v, ast.Name) else ast.literal_eval(v)
+            elif isinstance(kw.get("action"), ast.Constant) and kw["action"].value == "store_true":
+                found[flag] = False
+    args = ag.default_args()
+    checked = 0
+    for flag, default in found.items():
+        key = {"--max-consecutive-write": "max_consecutive_write"}.get(flag, flag.lstrip("-").replace("-", "_"))
+        if key in ("vocoder_name",):
+            continue
+        assert hasattr(args, key), flag
+        assert getattr(args, key) == default, (flag, getattr(args, key), default)
+        checked += 1
+    assert checked >= 15
