@@ -56,6 +56,7 @@ def _load() -> C.CDLL:
         lib.gref_generate_all.argtypes = [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                           C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           _P, C.c_int, _P, _P]
+        lib.gref_tweak_lprobs.argtypes = [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
         _lib = lib
     return _lib
 
@@ -191,3 +192,14 @@ class GgmlRef:
         if rc < 0:
             raise RuntimeError("gref_generate_all failed")
         return [(float(scores[b]), ids[b, : lens[b]].tolist()) for b in range(beam_size) if lens[b] > 0]
+
+
+def tweak_lprobs(lprobs: torch.Tensor, step_nr: int, max_seq_len: int, min_seq_len: int, unk_penalty: float, pad_idx: int,
+                 unk_idx: int, eos_idx: int) -> torch.Tensor:
+    """The reference's compiled ``_tweak_lprobs`` on a (beam, V) tensor; returns the edited copy."""
+    a = np.ascontiguousarray(lprobs.detach().to(torch.float32).numpy()).copy()
+    rc = _load().gref_tweak_lprobs(a.ctypes.data_as(_P), a.shape[0], a.shape[1], step_nr, max_seq_len, min_seq_len, float(unk_penalty),
+                                   pad_idx, unk_idx, eos_idx)
+    if rc != 0:
+        raise RuntimeError("gref_tweak_lprobs failed")
+    return torch.from_numpy(a)

@@ -30,6 +30,9 @@ extern "C" ggml_tensor* StandardTransformerDecoder_forward(fairseq2_model& model
                                                            ggml_tensor* encoder_output,
                                                            ggml_tensor* encoder_padding_mask);
 
+// defined (external linkage, not declared in fairseq2.h) at fairseq2.cpp:1269
+void _tweak_lprobs(const SequenceGeneratorJob& job, ggml_tensor* lprobs, int step_nr, int max_seq_len, std::size_t vocab_size);
+
 namespace {
 
 struct Ref {
@@ -293,6 +296,29 @@ int gref_generate_all(void* h, const float* enc, int s_enc, int model_dim, const
         ++found;
     }
     return found;
+}
+
+
+// `_tweak_lprobs` (fairseq2.cpp:1269-1305) on caller data: lprobs [beam_size][vocab_size], edited in place.
+int gref_tweak_lprobs(float* lprobs, int beam_size, int vocab_size, int step_nr, int max_seq_len, int min_seq_len,
+                      float unk_penalty, int pad_idx, int unk_idx, int eos_idx) {
+    std::vector<uint8_t> buf((size_t)beam_size * vocab_size * 4 + (1 << 16));
+    ggml_context* ctx = ggml_init({buf.size(), buf.data(), false});
+    if (!ctx) return -1;
+    ggml_tensor* t = ggml_new_tensor_2d(ctx, GGML_TYPE_F32, vocab_size, beam_size);
+    std::memcpy(t->data, lprobs, (size_t)beam_size * vocab_size * 4);
+    SequenceGeneratorJob job;
+    job.opts.beam_size = beam_size;
+    job.opts.min_seq_len = min_seq_len;
+    job.opts.unk_penalty = unk_penalty;
+    job.pad_idx = pad_idx;
+    job.unk_idx = unk_idx;
+    job.bos_idx = 0;
+    job.eos_idx = eos_idx;
+    _tweak_lprobs(job, t, step_nr, max_seq_len, (std::size_t)vocab_size);
+    std::memcpy(lprobs, t->data, (size_t)beam_size * vocab_size * 4);
+    ggml_free(ctx);
+    return 0;
 }
 
 }  // extern "C"

@@ -19,7 +19,7 @@ NAR frontend logic against the reference's own Python files
 (tests/golden/make_reference_goldens.py), Shaw attention and the Conformer
 convolution module against HF's executed port (tests/golden/make_hf_goldens.py).
 Still "parity unpinned" (no executable reference offline): fairseq2 0.2's
-length rule, its EOS-rank rule in beam search, the `_tweak_lprobs` edits.
+EOS-rank rule in beam search and which source length it feeds the length rule.
 
 Citations `file:line` are relative to
 /root/reference/src/seamless_communication unless they start with ggml/.
@@ -378,6 +378,23 @@ def max_seq_len_rule(soft_a: float, soft_b: int, hard_max: int, source_len: int)
     return min(hard_max, int(soft_a * source_len) + soft_b)
 
 
+def tweak_lprobs(lprobs: Tensor, step_nr: int, max_len: int, min_seq_len: int, unk_penalty: float,
+                 pad_idx: int, unk_idx: int, eos_idx: int) -> Tensor:
+    """The step rules of the generator, in place on (B, V) log-probabilities: `_tweak_lprobs`,
+    ggml/examples/unity/fairseq2.cpp:1269-1305 - no EOS before the minimum length, only EOS on the last step the length
+    limit allows, never PAD, UNK penalty.  Pinned against the compiled function itself (tests/test_oracle_ggml_ref.py:
+    test_step_rules_equal_compiled_tweak_lprobs; generate_sequence as compiled loses its effect, see there)."""
+    if step_nr < min_seq_len:
+        lprobs[:, eos_idx] = -math.inf
+    if step_nr == max_len - 2:
+        lprobs[:, :eos_idx] = -math.inf
+        lprobs[:, eos_idx + 1 :] = -math.inf
+    lprobs[:, pad_idx] = -math.inf
+    if unk_penalty != 0:
+        lprobs[:, unk_idx] -= unk_penalty
+    return lprobs
+
+
 def greedy_generate(
     P: Params, cfg, enc: Tensor, enc_lens: Tensor, prefix: Sequence[int],
     soft_max_seq_len: Tuple[float, int] = (1, 200), hard_max_seq_len: int = 1024,
@@ -411,14 +428,7 @@ def greedy_generate(
             h = dec(torch.tensor([[seq[-1]]], dtype=torch.int64))
             logits = F.linear(h[0, -1], W)
             lprobs = torch.log_softmax(logits, dim=-1)
-            if step_nr < min_seq_len:
-                lprobs[cfg.eos_idx] = -math.inf
-            if step_nr == max_len - 2:
-                lprobs[: cfg.eos_idx] = -math.inf
-                lprobs[cfg.eos_idx + 1 :] = -math.inf
-            lprobs[cfg.pad_idx] = -math.inf
-            if unk_penalty != 0:
-                lprobs[cfg.unk_idx] -= unk_penalty
+            tweak_lprobs(lprobs[None], step_nr, max_len, min_seq_len, unk_penalty, cfg.pad_idx, cfg.unk_idx, cfg.eos_idx)
             top2 = torch.topk(lprobs, 2)
             mg.append(float(top2.values[0] - top2.values[1]))
             tok = int(top2.indices[0])
@@ -514,14 +524,7 @@ def beam_search_generate(
             if compiled_port_rules:
                 lprobs = torch.softmax(F.linear(h[:, -1], W), dim=-1)  # what the re-run graph leaves in the buffer
             if not compiled_port_rules:
-                if step_nr < min_seq_len:
-                    lprobs[:, cfg.eos_idx] = -math.inf
-                if step_nr == max_len - 2:
-                    lprobs[:, : cfg.eos_idx] = -math.inf
-                    lprobs[:, cfg.eos_idx + 1 :] = -math.inf
-                lprobs[:, cfg.pad_idx] = -math.inf
-                if unk_penalty != 0:
-                    lprobs[:, cfg.unk_idx] -= unk_penalty
+                tweak_lprobs(lprobs, step_nr, max_len, min_seq_len, unk_penalty, cfg.pad_idx, cfg.unk_idx, cfg.eos_idx)
             if no_repeat_ngram_size > 0 and step_nr != max_len - 2:
                 ngram_repeat_block(seqs[:, : step_nr + 1], lprobs, no_repeat_ngram_size)
             if step_nr == start:

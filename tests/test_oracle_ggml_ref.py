@@ -244,6 +244,29 @@ def test_generate_sequence_beam_search_matches_oracle(env, seed, s_enc, stop):
     assert compared >= (5 if seed != 14 else 2)
 
 
+def test_step_rules_equal_compiled_tweak_lprobs():
+    """`_tweak_lprobs` (fairseq2.cpp:1269-1305) called directly on random log-probabilities against oracle.tweak_lprobs
+    (the function both oracle searches apply every step): every combination of before / at the minimum length, before /
+    at the last step the length limit allows, with and without UNK penalty, beams 1-5, EOS at the first, a middle and the
+    last vocabulary index.  Exact: the rules only overwrite with -inf and subtract one constant."""
+    g = torch.Generator().manual_seed(4)
+    n = 0
+    for beam in (1, 2, 5):
+        for V, pad, unk, eos in ((17, 0, 1, 3), (9, 1, 3, 0), (12, 0, 1, 11), (300, 5, 7, 150)):
+            for max_len in (4, 9, 30):
+                for step_nr in sorted({1, 2, 3, max_len - 3, max_len - 2}):
+                    if step_nr < 1 or step_nr > max_len - 2:
+                        continue
+                    for min_seq_len in (1, 3, max_len):
+                        for unk_penalty in (0.0, 0.75, -1.5):
+                            lp = torch.log_softmax(torch.randn(beam, V, generator=g), dim=-1)
+                            got = ggml_ref.tweak_lprobs(lp, step_nr, max_len, min_seq_len, unk_penalty, pad, unk, eos)
+                            want = ou.tweak_lprobs(lp.clone(), step_nr, max_len, min_seq_len, unk_penalty, pad, unk, eos)
+                            assert torch.equal(got, want), (beam, V, max_len, step_nr, min_seq_len, unk_penalty)
+                            n += 1
+    assert n > 1000
+
+
 def test_length_rule_executed_on_the_compiled_reference(env):
     """`_determine_max_seq_len` (fairseq2.cpp:1097-1105) observed through generate_sequence: the EOS row is crafted so that
     the greedy hypothesis has exactly 9 tokens; the compiled reference returns it when the limit oracle.max_seq_len_rule
