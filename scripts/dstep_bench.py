@@ -18,7 +18,10 @@ ap.add_argument("--text-len", type=int, default=42)
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--chains", action="store_true", help="also time the rows as 2 / 4 concurrent chains on forked handles")
+ap.add_argument("--ids-file", default=None,
+                help="A/B runs in separate processes (environment switches): the first run writes its ids here, later runs must reproduce them")
 args = ap.parse_args()
+ids_seen = {}
 
 card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch="base_v2")
 tr = Translator(card, None, device="cuda:0", input_modality=Modality.SPEECH, output_modality=Modality.TEXT)
@@ -38,8 +41,22 @@ for n in [int(x) for x in args.rows.split(",")]:
     dt = (time.perf_counter() - t0) / args.reps
     steps = args.text_len - 2
     assert (ids2 == ids).all(), "generation is not deterministic"
+    ids_seen[str(n)] = [[int(t) for t in row] for row in ids]
     print(f"rows={n:3d} text_len={args.text_len} graph={not args.no_graph}: {1e3 * dt:8.2f} ms per call, {1e3 * dt / steps:6.3f} ms per step "
           f"(incl. encoder K/V projection + 1 prompt step), {1.733e9 / (dt / steps) / 1e12:5.2f} TB/s of weights", flush=True)
+
+if args.ids_file:
+    import json
+    import os
+
+    if os.path.exists(args.ids_file):
+        want = json.loads(Path(args.ids_file).read_text())
+        same = all(want.get(k) == v for k, v in ids_seen.items() if k in want)
+        print("ids equal to the run that wrote", args.ids_file, ":", same, flush=True)
+        assert same, "the generated ids differ from the reference run"
+    else:
+        Path(args.ids_file).write_text(json.dumps(ids_seen))
+        print("ids written to", args.ids_file, flush=True)
 
 # ---- concurrent chains: the same rows as K forked handles on K host threads (one stream each) ---------------------------
 # Tests whether several latency-bound decoder chains interleave on the GPU: 32 rows as 2 x 16 / 4 x 8 chains.

@@ -89,6 +89,8 @@ Model::~Model() {
     mma.reset();
     dec_session.reset();
     if (order_event) (void)hipEventDestroy(order_event);
+    for (hipEvent_t e : touch_events) (void)hipEventDestroy(e);
+    if (touch_stream) (void)hipStreamDestroy(touch_stream);
     pool.release_all();
     for (void* p : owned) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
