@@ -101,3 +101,14 @@ def test_host_array_arguments_convert_like_the_runtime_passes_them():
                                 _ptr(buf), _ptr(None)) == -1
     assert lib.sc_decode_text(None, _ptr(buf), 1, 2, _ptr(lens), _ptr(tok), 4, _ptr(buf)) == -1
     assert b"null" in lib.sc_last_error() or b"bad argument" in lib.sc_last_error()
+
+
+def test_integration_guide_names_every_entry_point():
+    """INTEGRATION.md is the reference-side view of the boundary: every exported entry (the kernel-level `sc_op_*` test
+    hooks are covered as a family) is named there with the reference call site it replaces."""
+    from pathlib import Path
+
+    text = (Path(__file__).resolve().parents[1] / "INTEGRATION.md").read_text()
+    missing = [s for s in declared_symbols() if not s.startswith("sc_op_") and s not in text]
+    assert not missing, missing
+    assert "sc_op_*" in text
