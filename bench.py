@@ -70,6 +70,9 @@ def parse_args():
     ap.add_argument("--free-run", action="store_true",
                     help="let the micro-batch slices free-run over the K steps (joined once) instead of joining them after "
                          "every step; measured no faster on MI355X (profiles/r1_microbatch_schedule.txt), kept for experiments")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch check only: every rank joins a gloo group on the CPU, rank 0 prints the rank count it saw "
+                         "(tests/test_bench_launch_cpu.py); no device, no model")
     ap.add_argument("--stagger", type=float, default=-1.0,
                     help="start offset between micro-batch threads in the timed region, seconds (<0: warm-up step time / threads)")
     return ap.parse_args()
@@ -262,17 +265,63 @@ def cpu_baseline(args):
                 "sample": f"the warm-up + 3 passes did not finish within {args.cpu_baseline_timeout} s"}
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks under torch.distributed.run on
+    this node (one process per GPU, rendezvous on 127.0.0.1).  Fails loudly when fewer than N devices are visible."""
+    import socket
+    import subprocess
+
+    if not args.dry_run:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} HIP device(s) visible on this node")
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), *sys.argv[1:]]
+    log(f"--gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """Launch check on the CPU (gloo): proves that the command line reaches N cooperating ranks."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        world = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen, "gpus_flag": args.gpus}), flush=True)
+
+
 def main():
     args = parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if args.dry_run:
+        return dry_run(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` (self-launching) or "
+                         f"torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no device ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -414,6 +463,7 @@ def main():
                 "out_audio_seconds_per_utt": float(np.mean(wav_secs)),
                 "s_unit_max": int(max(unit_counts)), **padding_info,
                 "parallelism": f"dp{world} (utterances sharded, full replica per GPU, all-gather of ids)",
+                "rccl_ranks": dist.get_world_size() if world > 1 else 1,
                 "hip_graph_decoder_step": bool(translator.use_graph),
                 "microbatches_in_flight": batcher.groups,
                 "microbatch_schedule": (f"free-running slices, start offsets {stagger * 1e3:.0f} ms" if free_run else "lock-step (join per pass)"),
@@ -466,15 +516,17 @@ def main():
         dist.barrier()
 
     if rank == 0:
+        # every utterance of the timed batch against the oracle's committed ids (tests/golden/fullsize_ref.json)
+        result["parity"] = parity_from_goldens(args, batcher, last, B)
         if world == 1 and not args.no_cpu_baseline:
             log("CPU baseline (oracle: warm-up + 3 passes) in a child process ...")
             base = cpu_baseline(args)
-            result["parity"] = parity_block(base, translator, model, wav_host, ns, opts, last, device)
+            # ... and two utterances against the oracle run live in this job (the cpu_baseline child)
+            result["parity"]["live_oracle"] = parity_block(base, translator, model, wav_host, ns, opts, last, device)
             base.pop("checked", None)
             result["cpu_baseline"] = base
         else:
             result["cpu_baseline"] = None
-            result["parity"] = None
         # the driver keeps `config` verbatim: the parity verdict travels there too
         result["config"]["parity"] = result["parity"]
         print(json.dumps(result), flush=True)
@@ -482,6 +534,49 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def parity_from_goldens(args, batcher, last, B):
+    """Ids of the TIMED batch (last timed pass: micro-batch slices, graph replay) against the CPU oracle's ids of the same
+    64 utterances, minted once by tests/golden/make_fullsize_goldens.py (oracle/pipeline.py, fp32): text ids / char ids /
+    durations / unit ids of every utterance, match rates, and for every mismatching unit position the oracle's own arg-max
+    margin (tests/golden/fullsize.py states the bar).  Oracle pin status: greedy generation, T2U and vocoder blocks are
+    pinned against executed reference code, the Conformer-Shaw attention / conv module against an executed independent
+    port, the fairseq2 0.2 length rules are restated from the source text: "oracle_pinned": "partial"."""
+    from seamless_communication_amd.distributed import shard_range
+    from tests.golden import fullsize as fg
+
+    try:
+        gold = fg.load()
+    except OSError as e:
+        return {"n_checked": 0, "error": f"golden fixture missing: {e}"}
+    if args.arch != gold["meta"]["arch"] or args.text_len != gold["meta"]["text_len"]:
+        return {"n_checked": 0, "error": "the golden fixture holds arch base_v2 / text length 42 only"}
+    items = fg.items_by_index(gold["b64"])
+    n = min(B, len(items))
+    reports = []
+    spans = [shard_range(B, i, batcher.groups) for i in range(batcher.groups)]
+    for i in range(n):
+        kw = dict(text_ids=last["text_ids"][i])
+        s = next(k for k, (lo, hi) in enumerate(spans) if lo <= i < hi)
+        t2u = getattr(batcher.views[s], "last_t2u", None)
+        b = i - spans[s][0]
+        if t2u is not None and len(t2u["unit_lens"]) == spans[s][1] - spans[s][0]:
+            ncs, nu = int(t2u["char_seq_lens"][b]), int(t2u["unit_lens"][b])
+            kw.update(char_ids=t2u["char_ids"][b, :ncs].tolist(), durations=t2u["durations"][b, :ncs].tolist(),
+                      units=t2u["units"][b, :nu].tolist())
+        reports.append(fg.compare(items[i], **kw))
+    out = fg.summarize(reports)
+    out.pop("utterances", None)
+    tm = [m for i in range(n) for m in items[i]["text_margins"]]
+    um = [m for i in range(n) for m in items[i]["unit_margins"]]
+    out.update({
+        "compared": "timed batch (last timed pass) vs tests/golden/fullsize_ref.json (CPU oracle, all utterances)",
+        "oracle_pinned": "partial (DESIGN.md section 5)",
+        "min_text_margin": min(tm), "min_unit_margin": min(um),
+        "text_margin_hist": _margin_hist(tm), "unit_margin_hist": _margin_hist(um),
+    })
+    return out
 
 
 def parity_block(base, translator, model, wav_host, ns, opts, last, device):

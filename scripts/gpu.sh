@@ -46,6 +46,10 @@ for task in "$@"; do
     quick)
       ( timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_stages_gpu.py -m gpu -q -x > ${O}_pytest_quick.log 2>&1; echo "pytest exit $?" >> ${O}_pytest_quick.log )
       grep -E "^FAILED|^ERROR|passed|failed|^E  |exit" ${O}_pytest_quick.log | head -20 ;;
+    pyt)
+      # any selection of test files / -k expressions: PYT="tests/test_dstep3_gpu.py -k vocab3"
+      ( timeout ${PYT_TIMEOUT:-900} python -m pytest $PYT -m gpu -q --maxfail=10 > ${O}_pytest_sel.log 2>&1; echo "pytest exit $?" >> ${O}_pytest_sel.log )
+      grep -E "^FAILED|^ERROR|passed|failed|^E  |exit" ${O}_pytest_sel.log | head -40 ;;
     smoke)
       ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > ${O}_smoke.log 2>&1; echo "smoke exit $?" >> ${O}_smoke.log ); tail -2 ${O}_smoke.log | cut -c1-300 ;;
     bench)
@@ -86,7 +90,7 @@ for task in "$@"; do
     chain)
       ( timeout 200 python scripts/chain_bench.py > ${O}_chain.txt 2>&1 ); grep -v amdgpu ${O}_chain.txt | head -40 ;;
     micro)
-      for src in scripts/micro/*.hip; do
+      for src in scripts/micro/${MICRO:-*}.hip; do
         b=/tmp/$(basename $src .hip)
         ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 $src -o $b && timeout 120 $b > ${O}_micro_$(basename $src .hip).txt 2>&1 ); head -40 ${O}_micro_$(basename $src .hip).txt
       done ;;

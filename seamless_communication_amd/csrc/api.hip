@@ -650,6 +650,104 @@ int sc_op_dstep_argmax(const float* d_x, const void* d_w_f16, int32_t M, int32_t
     SC_API_END
 }
 
+int sc_op_dstep3_gemv(int32_t mode, const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_gamma,
+                      const float* d_beta, const float* d_res, float* d_y, float* d_h, int32_t M, int32_t N, int32_t K, int32_t act,
+                      int32_t rg, int32_t shape) {
+    SC_API_BEGIN
+    SC_CHECK(mode >= 0 && mode <= 3 && d_x && d_w_f16 && d_y, "sc_op_dstep3_gemv: bad argument");
+    const int in_mode = (mode == 0 || mode == 2) ? IN3_LN : IN3_PLANES;
+    SC_CHECK(gemv3_supported(M, N, K, in_mode), "sc_op_dstep3_gemv: M=%d N=%d K=%d mode=%d unsupported", M, N, K, mode);
+    OpScratch scratch;
+    const int RB = M <= 32 ? 32 : 64;
+    __half* wp = scratch.get<__half>((size_t)packed_weight_halfs(N, K));
+    launch_pack_weight(static_cast<const __half*>(d_w_f16), K, N, K, wp, g_op_stream);
+    Gemv3Args a;
+    a.Wp = wp, a.M = M, a.N = N, a.K = K, a.in_mode = in_mode, a.RB = RB, a.rg = rg, a.bias = d_bias, a.shape = shape;
+    if (in_mode == IN3_LN) {
+        float* xg = scratch.get<float>((size_t)K * RB);
+        SC_HIP(hipMemsetAsync(xg, 0xff, (size_t)K * RB * 4, g_op_stream));  // NaN in the unused row slots: must not leak
+        launch_rows_to_kgm(d_x, K, M, K, RB, xg, g_op_stream);
+        a.xg = xg, a.gamma = d_gamma, a.beta = d_beta;
+    } else {
+        __half* ah = scratch.get<__half>((size_t)K * RB);
+        __half* al = scratch.get<__half>((size_t)K * RB);
+        SC_HIP(hipMemsetAsync(ah, 0xff, (size_t)K * RB * 2, g_op_stream));
+        SC_HIP(hipMemsetAsync(al, 0xff, (size_t)K * RB * 2, g_op_stream));
+        launch_rows_to_planes(d_x, K, M, K, RB, ah, al, g_op_stream);
+        a.Ah = ah, a.Al = al;
+    }
+    if (mode == 0) {
+        a.epi = EPI3_ROWS, a.out = d_y, a.ldo = N;
+        launch_gemv3(a, g_op_stream);
+    } else if (mode == 2) {
+        __half* oh = scratch.get<__half>((size_t)N * RB);
+        __half* ol = scratch.get<__half>((size_t)N * RB);
+        a.epi = EPI3_PLANES, a.act = act, a.Oh = oh, a.Ol = ol, a.ORB = RB;
+        launch_gemv3(a, g_op_stream);
+        launch_planes_to_rows(oh, ol, RB, d_y, N, M, N, g_op_stream);
+    } else {
+        SC_CHECK(d_res, "sc_op_dstep3_gemv: modes 1 and 3 need the residual");
+        float* xres = scratch.get<float>((size_t)N * RB);
+        SC_HIP(hipMemsetAsync(xres, 0xff, (size_t)N * RB * 4, g_op_stream));
+        launch_rows_to_kgm(d_res, N, M, N, RB, xres, g_op_stream);
+        if (mode == 1) {
+            a.epi = EPI3_RESID, a.xres = xres, a.XRB = RB;
+            launch_gemv3(a, g_op_stream);
+        } else {
+            const int S = gemv3_splits(K, shape);
+            float* partial = scratch.get<float>((size_t)S * M * N);
+            a.epi = EPI3_PARTIAL, a.out = partial, a.mt2 = 1, a.bias = nullptr;
+            launch_gemv3(a, g_op_stream);
+            Reduce3Args r;
+            r.partial = partial, r.S = S, r.bias = d_bias, r.xg = xres, r.XRB = RB, r.rows = M, r.C = N;
+            if (d_gamma) r.gamma = d_gamma, r.beta = d_beta, r.hfix = d_h, r.RB = RB;
+            launch_reduce3(r, g_op_stream);
+        }
+        launch_kgm_to_rows(xres, RB, d_y, N, M, N, g_op_stream);
+    }
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+int sc_op_dstep3_argmax(const float* d_x, const void* d_w_f16, int32_t M, int32_t N, int32_t K, int32_t step,
+                        int32_t min_step_for_eos, int32_t force_eos_step, int32_t pad_idx, int32_t eos_idx, int32_t unk_idx,
+                        float unk_penalty, int32_t* d_idx, float* d_lprob) {
+    SC_API_BEGIN
+    SC_CHECK(vocab3_supported(M, N, K), "sc_op_dstep3_argmax: M=%d N=%d K=%d unsupported", M, N, K);
+    OpScratch scratch;
+    const int RB = M <= 32 ? 32 : 64;
+    const int groups = vocab3_groups(M);
+    const int hist_ld = step + 2;
+    __half* wp = scratch.get<__half>((size_t)packed_weight_halfs(N, K));
+    __half* ah = scratch.get<__half>((size_t)K * RB);
+    __half* al = scratch.get<__half>((size_t)K * RB);
+    float4* part = scratch.get<float4>((size_t)groups * M);
+    float* eos_logit = scratch.get<float>(M);
+    int* ints = scratch.get<int>((size_t)4 + (size_t)M * hist_ld + 2 * M);
+    int* d_pos = ints;
+    int* hist = ints + 4;
+    int* finished = hist + (size_t)M * hist_ld;
+    int* out_len = finished + M;
+    SC_HIP(hipMemsetAsync(ints, 0, ((size_t)4 + (size_t)M * hist_ld + 2 * M) * 4, g_op_stream));
+    SC_HIP(hipMemsetAsync(eos_logit, 0, (size_t)M * 4, g_op_stream));
+    SC_HIP(hipMemcpyAsync(d_pos, &step, 4, hipMemcpyHostToDevice, g_op_stream));
+    SC_HIP(hipMemsetAsync(d_lprob, 0, (size_t)M * 4, g_op_stream));
+    launch_pack_weight(static_cast<const __half*>(d_w_f16), K, N, K, wp, g_op_stream);
+    SC_HIP(hipMemsetAsync(ah, 0xff, (size_t)K * RB * 2, g_op_stream));
+    SC_HIP(hipMemsetAsync(al, 0xff, (size_t)K * RB * 2, g_op_stream));
+    launch_rows_to_planes(d_x, K, M, K, RB, ah, al, g_op_stream);
+    Vocab3Args v;
+    v.Wp = wp, v.Ah = ah, v.Al = al, v.RB = RB, v.M = M, v.N = N, v.K = K;
+    v.am_part = part, v.am_tiles_cap = groups, v.am_eos_logit = eos_logit, v.am_pos = d_pos;
+    v.am_min_step_for_eos = min_step_for_eos, v.am_force_eos_step = force_eos_step;
+    v.am_pad_idx = pad_idx, v.am_eos_idx = eos_idx, v.am_unk_idx = unk_idx, v.am_unk_penalty = unk_penalty;
+    launch_vocab3(v, g_op_stream);
+    launch_argmax_finalize(part, groups, M, eos_logit, d_pos, force_eos_step, pad_idx, eos_idx, d_idx, hist, hist_ld, finished, out_len,
+                           d_lprob, g_op_stream);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
 /* Single-query attention of the decoder step.  d_proj: [S][nb][ld] partial sums of the fused projection (self: q | k | v at
  * columns 0 / M / 2M, M = heads * 64; cross: q only, ld = M).  self (cross == 0): the new key / value row is appended to the
  * caches [nb][cap][M] at position `pos`, keys 0..pos take part.  cross: d_kcache = [nb][cap][2M] with keys at column 0 and

@@ -38,6 +38,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ds_rsrc(const void* base, uint
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float* p) {  // 16-byte non-temporal load
+    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 __device__ __forceinline__ void split8(const float* x, half8_t& hi, half8_t& lo) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(256) void reduce_ln_kernel(ReduceLnArgs p) {
 template <bool CROSS>
 __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     const int lane = threadIdx.x & 63;
-    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (pair >= p.nb * p.heads) return;
     const int b = pair / p.heads, hd = pair - b * p.heads;
     const int c = lane & 15, g = lane >> 4;
@@ -441,11 +447,19 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
             bv = *reinterpret_cast<const float4*>(p.bias + p.voff + hd * 64 + 4 * c);
         }
     }
+    // cross-attention K / V: 2 * S_enc * M * 4 B per row and layer, read once per step and never again before the next
+    // step has streamed all weights and caches (more than the memory-side cache holds): non-temporal loads
     float4 kreg[16], vreg[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const float4*>(kc + (int64_t)min(4 * i + g, last) * p.cache_ld);
+    for (int i = 0; i < 16; ++i) {
+        const float* a = kc + (int64_t)min(4 * i + g, last) * p.cache_ld;
+        kreg[i] = CROSS ? nt_load4(a) : *reinterpret_cast<const float4*>(a);
+    }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) vreg[i] = *reinterpret_cast<const float4*>(vc + (int64_t)min(4 * i + g, last) * p.cache_ld);
+    for (int i = 0; i < 16; ++i) {
+        const float* a = vc + (int64_t)min(4 * i + g, last) * p.cache_ld;
+        vreg[i] = CROSS ? nt_load4(a) : *reinterpret_cast<const float4*>(a);
+    }
     __builtin_amdgcn_sched_barrier(0);  // every load above is issued before the first of them is waited for
 
     float4 q4 = zero, kn = zero, vn = zero;
@@ -689,8 +703,11 @@ void launch_dattn(const DAttnArgs& a, bool cross, hipStream_t s) {
     const int pairs = a.nb * a.heads;
     // KV bytes are data dependent (position / encoder lengths): the profiler gets the capacity-independent part
     prof::Scope scope(cross ? "dattn_cross" : "dattn_self", 0.0, 0.0, s);
-    if (cross) hipLaunchKernelGGL((dattn_kernel<true>), dim3(cdiv(pairs, 4)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((dattn_kernel<false>), dim3(cdiv(pairs, 4)), dim3(256), 0, s, a);
+    // (row, head) pairs per workgroup: a CU pulls ~45 GB/s of cold K / V whatever its workgroup looks like
+    // (profiles/r3_micro_percu.txt), so the pairs are spread over at least 256 workgroups before they are stacked
+    const int ppw = std::max(1, std::min(4, pairs / 256));
+    if (cross) hipLaunchKernelGGL((dattn_kernel<true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+    else hipLaunchKernelGGL((dattn_kernel<false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
     SC_LAUNCH_CHECK();
 }
 

@@ -1,0 +1,793 @@
+// Decoder-step kernels, third generation (round 3).
+//
+// What round 2's chain measured (profiles/r2_dstep_trace_rows64.txt, profiles/r3_micro_percu.txt): a step is ~265
+// DEPENDENT launches; a launch costs 1.6 us of boundary + 0.5 .. 2 us for input that the previous launch wrote on other
+// XCDs (it comes back through the memory-side cache, at 50 - 80 GB/s per workgroup) + whatever ONE workgroup has to
+// pull before it can start: a 256-thread workgroup pulls ~32 KB per round trip (30 - 35 GB/s), a 1024-thread one
+// 50 - 85 GB/s.  A persistent kernel with device-wide barriers is 10 x worse than a launch boundary
+// (profiles/r3_micro_persist_chain.txt).  So the step gets faster by (1) fewer launches, (2) fewer bytes per WORKGROUP
+// of freshly written input, (3) every byte a workgroup needs in flight at once.  Hence:
+//   * gemv3_kernel: the workgroup owns 32 (or 64) output features x a ROW GROUP of <= 32 (64) batch rows x the WHOLE K
+//     range (16 waves x 4 k-steps, or a K slice for the 8192-wide FFN-out): no split-K partial sums and no separate
+//     reduce launch for the N = 1024 products, input bytes per workgroup = weights of the tile (64 KB, cold but
+//     independent of the chain) + rows x K x 4 B of activations (16 rows: 64 KB).  Because the workgroup sees complete
+//     rows it applies the LayerNorm that precedes the product ITSELF (statistics across its 16 waves through LDS, two
+//     pass), and because it owns complete outputs it adds bias + residual itself: the launches
+//     "reduce + residual + LayerNorm" of generation 2 disappear (11 -> 9 launches per layer).
+//   * the residual stream lives in HBM as fp32 in k-group-major order X[k / 8][row slot][8] (a row group's slice of
+//     a k-group is one contiguous run), attention outputs / the FFN inner activation as split fp16 planes (as before).
+//   * vocab3_kernel: the vocabulary projection (0.52 GB of weights) with the activation planes of 32 rows staged ONCE
+//     per workgroup in LDS (128 KB) and each wave streaming whole 32-feature tiles through a two-deep register
+//     pipeline - generation 2 re-read 256 KB of planes from L2 for every tile (2 GB per step through the L1s).  The
+//     two row halves of a tile group run on the same XCD (block ids b, b + 8): the second read of a tile is an L2 hit.
+// Numerics are those of generation 2: fp16 weights x (hi + lo) fp16 halves of the fp32 activation on
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation, fixed summation order (independent of the k-chunk rotation below).
+//
+// Reference semantics: ggml/examples/unity/fairseq2.cpp:979-1094 (StandardTransformerDecoderLayer, pre-LN),
+// src/seamless_communication/models/unity/model.py:233-260 (decode / project).
+#include "kernels.h"
+
+namespace sc {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr uint32_t OOB = 0x80000000u;  // >= num_records of every buffer used here (all below 2 GB): reads as zero
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc3(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void split8v(const float* x, half8_t& hi, half8_t& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 h = (_Float16)x[e];
+        hi[e] = h;
+        lo[e] = (_Float16)(x[e] - (float)h);
+    }
+}
+
+// --------------------------------------------------------------------------------------------- //
+// gemv3_kernel<NT, MT, WAVES, KSW, IN, EPI>
+//   grid (ceil(tiles / NT), row groups, k splits); WAVES waves; the workgroup owns NT consecutive 32-feature tiles, the
+//   rows [r0, r0 + rg) (rg <= 32 * MT) and the k-steps [split * WAVES * KSW, + WAVES * KSW); wave w takes the chunk of KSW
+//   k-steps number (w + blockIdx.x) % WAVES (rotated: the workgroups of one row group read the same activations and
+//   would otherwise hit the same L2 channel at the same time, profiles/r3_micro_percu.txt "in order" vs "rotated").
+// --------------------------------------------------------------------------------------------- //
+template <int NT, int MT, int WAVES, int KSW, int IN, int EPI>
+__global__ __launch_bounds__(64 * WAVES) void gemv3_kernel(Gemv3Args p) {
+    constexpr int T = 64 * WAVES;
+    constexpr int NJ = NT * MT;
+    __shared__ float red[WAVES][NJ][32 * 33];
+    __shared__ float gb[IN == IN3_LN ? 2 : 1][IN == IN3_LN ? 1024 : 1];
+    __shared__ float stat[2][WAVES][32 * MT];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31;  // batch row inside a row tile (MFMA column)
+    const int h = lane >> 5;  // k half of the fragment
+    const int nt0 = blockIdx.x * NT;
+    const int r0 = blockIdx.y * p.rg;
+    const int rot = blockIdx.x % WAVES;
+    const int chunk = (wave + rot) % WAVES;
+    const int ks_w0 = (blockIdx.z * WAVES + chunk) * KSW;
+
+    const __amdgpu_buffer_rsrc_t rw = rsrc3(p.Wp, p.w_bytes);
+    const uint32_t w_voff = (uint32_t)lane * 16u;
+
+    // ---- every global load of the workgroup is issued here, before the first use ---------------------------------
+    u32x4_t w[NT][KSW];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        const uint32_t tkill = (nt0 + jt < p.NT_total) ? 0u : OOB;
+        const uint32_t w_tile = (uint32_t)(nt0 + jt) * (uint32_t)p.KS * 1024u;  // packed weights stay below 4 GB
+#pragma unroll
+        for (int j = 0; j < KSW; ++j) {
+            const uint32_t kk = (ks_w0 + j < p.KS) ? 0u : OOB;
+            // a tile's weights are read once per row group: streaming hint only when there is a single group
+            w[jt][j] = gridDim.y == 1 ? __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff | tkill | kk, w_tile + (uint32_t)(ks_w0 + j) * 1024u, 2 /*nt*/)
+                                      : __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff | tkill | kk, w_tile + (uint32_t)(ks_w0 + j) * 1024u, 0);
+        }
+    }
+    bool rvalid[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rvalid[i] = (32 * i + n < p.rg) && (r0 + 32 * i + n < p.M);
+
+    u32x4_t ah[IN == IN3_PLANES ? MT : 1][KSW], al[IN == IN3_PLANES ? MT : 1][KSW];
+    float xr[IN == IN3_LN ? MT : 1][KSW][8];
+    if (IN == IN3_PLANES) {
+        const __amdgpu_buffer_rsrc_t rah = rsrc3(p.Ah, p.a_bytes);
+        const __amdgpu_buffer_rsrc_t ral = rsrc3(p.Al, p.a_bytes);
+        const uint32_t a_kstep = (uint32_t)(2 * p.RB * 16);  // bytes per k-step in a plane
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const uint32_t voff = rvalid[i] ? (uint32_t)((h * p.RB + r0 + 32 * i + n) * 16) : OOB;
+#pragma unroll
+            for (int j = 0; j < KSW; ++j) {
+                const uint32_t kk = (ks_w0 + j < p.KS) ? 0u : OOB;
+                const uint32_t so = (uint32_t)(ks_w0 + j) * a_kstep;
+                ah[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rah, voff | kk, so, 0);
+                al[i][j] = __builtin_amdgcn_raw_buffer_load_b128(ral, voff | kk, so, 0);
+            }
+        }
+    } else {
+        const __amdgpu_buffer_rsrc_t rx = rsrc3(p.xg, p.a_bytes);
+        const uint32_t x_kstep = (uint32_t)(2 * p.RB * 32);  // bytes per k-step of the fp32 stream
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const uint32_t voff = rvalid[i] ? (uint32_t)((h * p.RB + r0 + 32 * i + n) * 32) : OOB;
+#pragma unroll
+            for (int j = 0; j < KSW; ++j) {
+                const uint32_t kk = (ks_w0 + j < p.KS) ? 0u : OOB;
+                const uint32_t so = (uint32_t)(ks_w0 + j) * x_kstep;
+                // (bit-cast the whole vector: __builtin_bit_cast(float, v[e]) on a u32 vector element reads element 0 for every e
+                //  with this compiler - ROCm 7.2 hipcc, found by the op tests)
+                const f32x4_t v0 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, voff | kk, so, 0));
+                const f32x4_t v1 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, voff | kk, so + 16u, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xr[i][j][e] = v0[e];
+                    xr[i][j][4 + e] = v1[e];
+                }
+            }
+        }
+    }
+    // LayerNorm parameters of the whole row (<= 1024 columns) into LDS: thread t brings columns t, t + T, ...
+    float gv[IN == IN3_LN ? (1024 / T > 0 ? 1024 / T : 1) : 1], bv[IN == IN3_LN ? (1024 / T > 0 ? 1024 / T : 1) : 1];
+    if (IN == IN3_LN) {
+#pragma unroll
+        for (int u = 0; u < 1024 / T; ++u) {
+            const int col = tid + u * T;
+            gv[u] = col < p.K ? p.gamma[col] : 0.f;
+            bv[u] = col < p.K ? p.beta[col] : 0.f;
+        }
+    }
+    // epilogue operands: bias of this thread's feature(s), residual values
+    constexpr int ITER = (NJ * 1024) / T;          // (tile, row tile, row, feature) elements per thread
+    constexpr int PITER = (NJ * 128 + T - 1) / T;  // EPI3_PLANES: (tile, row tile, row, 8 features) elements per thread
+    float bias_f[EPI == EPI3_PLANES ? 1 : ITER], res_f[EPI == EPI3_RESID ? ITER : 1];
+    float bias8[EPI == EPI3_PLANES ? PITER : 1][8];
+    if (EPI == EPI3_ROWS || EPI == EPI3_RESID) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int u = tid + it * T;
+            const int jj = u >> 10, jt = jj / MT, i = jj % MT, rn = (u >> 5) & 31, f = u & 31;
+            const int feat = (nt0 + jt) * 32 + f, row = r0 + 32 * i + rn;
+            const bool ok = feat < p.N && 32 * i + rn < p.rg && row < p.M;
+            bias_f[it] = (p.bias && ok) ? p.bias[feat] : 0.f;
+            if (EPI == EPI3_RESID) res_f[it] = ok ? p.xres[((int64_t)(feat >> 3) * p.XRB + row) * 8 + (feat & 7)] : 0.f;
+        }
+    }
+    if (EPI == EPI3_PLANES) {
+#pragma unroll
+        for (int it = 0; it < PITER; ++it) {
+            const int u = tid + it * T;
+            const int jj = u >> 7, jt = jj / MT, g = (u >> 5) & 3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int feat = (nt0 + jt) * 32 + 8 * g + e;
+                bias8[it][e] = (p.bias && u < NJ * 128 && feat < p.N) ? p.bias[feat] : 0.f;
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- LayerNorm of the row group (IN3_LN): statistics across the waves, two pass ----------------------------
+    float mean[MT], rstd[MT];
+    if (IN == IN3_LN) {
+#pragma unroll
+        for (int u = 0; u < 1024 / T; ++u) {
+            gb[0][tid + u * T] = gv[u];
+            gb[1][tid + u * T] = bv[u];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < KSW; ++j)  // columns behind K were read as zeros
+                s += ((xr[i][j][0] + xr[i][j][1]) + (xr[i][j][2] + xr[i][j][3])) + ((xr[i][j][4] + xr[i][j][5]) + (xr[i][j][6] + xr[i][j][7]));
+            s += __shfl_xor(s, 32);
+            if (h == 0) stat[0][chunk][32 * i + n] = s;  // indexed by chunk: the sum below does not depend on the rotation
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < WAVES; ++c) s += stat[0][c][32 * i + n];
+            mean[i] = s / (float)p.K;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < KSW; ++j) {
+                if (ks_w0 + j < p.KS) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float d = xr[i][j][e] - mean[i];
+                        q = fmaf(d, d, q);
+                    }
+                }
+            }
+            q += __shfl_xor(q, 32);
+            if (h == 0) stat[1][chunk][32 * i + n] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < WAVES; ++c) q += stat[1][c][32 * i + n];
+            rstd[i] = 1.0f / sqrtf(q / (float)p.K + 1e-5f);
+        }
+    }
+
+    // ---- products ------------------------------------------------------------------------------------------
+    float16_t acc[NT][MT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[jt][i][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+        half8_t bh[MT], bl[MT];
+        if (IN == IN3_PLANES) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                bh[i] = __builtin_bit_cast(half8_t, ah[i][j]);
+                bl[i] = __builtin_bit_cast(half8_t, al[i][j]);
+            }
+        } else {
+            const int k0 = min((ks_w0 + j) * 16 + h * 8, 1024 - 8);  // columns behind K: zero weights, any finite activation
+            const float4 g0 = *reinterpret_cast<const float4*>(&gb[0][k0]), g1 = *reinterpret_cast<const float4*>(&gb[0][k0 + 4]);
+            const float4 b0 = *reinterpret_cast<const float4*>(&gb[1][k0]), b1 = *reinterpret_cast<const float4*>(&gb[1][k0 + 4]);
+            const float g8[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (xr[i][j][e] - mean[i]) * rstd[i] * g8[e] + b8[e];
+                split8v(y, bh[i], bl[i]);
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            const half8_t wf = __builtin_bit_cast(half8_t, w[jt][j]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[jt][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, bh[i], acc[jt][i], 0, 0, 0);
+                acc[jt][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, bl[i], acc[jt][i], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- cross-wave sum through LDS: red[chunk][tile, row tile][row * 33 + feature] ---------------------------
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = (r & 3) + 8 * (r >> 2) + 4 * h;
+                red[chunk][jt * MT + i][n * 33 + f] = acc[jt][i][r];
+            }
+    __syncthreads();
+
+    if (EPI == EPI3_PLANES) {
+        // out = act(sum + bias) as split planes for the next product: thread -> (row, 8 consecutive features)
+#pragma unroll
+        for (int it = 0; it < PITER; ++it) {
+            const int u = tid + it * T;
+            if (u >= NJ * 128) break;
+            const int jj = u >> 7, jt = jj / MT, i = jj % MT, rn = u & 31, g = (u >> 5) & 3;
+            const int row = r0 + 32 * i + rn;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int o = rn * 33 + 8 * g + e;
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < WAVES; ++c) s += red[c][jj][o];
+                s += bias8[it][e];
+                if (p.act == ACT_RELU) s = s > 0.f ? s : 0.f;
+                if ((nt0 + jt) * 32 + 8 * g + e >= p.N) s = 0.f;
+                v[e] = s;
+            }
+            if (32 * i + rn < p.rg && row < p.M && ((nt0 + jt) * 4 + g) * 8 < p.N) {
+                half8_t hi, lo;
+                split8v(v, hi, lo);
+                const int64_t off = ((int64_t)((nt0 + jt) * 4 + g) * p.ORB + row) * 8;
+                *reinterpret_cast<half8_t*>(p.Oh + off) = hi;
+                *reinterpret_cast<half8_t*>(p.Ol + off) = lo;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int u = tid + it * T;
+            const int jj = u >> 10, jt = jj / MT, i = jj % MT, rn = (u >> 5) & 31, f = u & 31;
+            const int feat = (nt0 + jt) * 32 + f, row = r0 + 32 * i + rn;
+            const int o = rn * 33 + f;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < WAVES; ++c) s += red[c][jj][o];
+            if (feat < p.N && 32 * i + rn < p.rg && row < p.M) {
+                if (EPI == EPI3_PARTIAL) {
+                    p.out[((int64_t)blockIdx.z * p.M + row) * p.N + feat] = s;
+                } else if (EPI == EPI3_ROWS) {
+                    p.out[(int64_t)row * p.ldo + feat] = s + bias_f[it];
+                } else {  // EPI3_RESID: x += product + bias
+                    p.xres[((int64_t)(feat >> 3) * p.XRB + row) * 8 + (feat & 7)] = (s + bias_f[it]) + res_f[it];
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------- //
+// reduce3_kernel<LN>: x[row] += bias + sum_s partial[s][row] on the k-group-major residual stream; LN: additionally
+// h = LayerNorm(x[row]) as split planes / fp32 rows (the decoder output after the last layer).  One workgroup per row,
+// thread t owns columns 4t .. 4t+3; every global load is issued before the first use.
+// --------------------------------------------------------------------------------------------- //
+template <bool LN>
+__global__ __launch_bounds__(256) void reduce3_kernel(Reduce3Args p) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int nv = p.C >> 2;
+    const bool on = tid < nv;
+    const int t = on ? tid : 0;  // idle lanes read element 0 and discard it
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* xp = reinterpret_cast<float4*>(p.xg + ((int64_t)(t >> 1) * p.XRB + row) * 8 + (t & 1) * 4);
+    float4 a = zero;
+    float4 pv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        pv[u] = reinterpret_cast<const float4*>(p.partial + ((int64_t)min(u, p.S - 1) * p.rows + row) * p.C)[t];
+    const float4 bb = p.bias ? reinterpret_cast<const float4*>(p.bias)[t] : zero;
+    const float4 r = *xp;
+    float4 g = zero, be = zero;
+    if (LN) {
+        g = reinterpret_cast<const float4*>(p.gamma)[t];
+        be = reinterpret_cast<const float4*>(p.beta)[t];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if (u < p.S) {
+            a.x += pv[u].x;
+            a.y += pv[u].y;
+            a.z += pv[u].z;
+            a.w += pv[u].w;
+        }
+    for (int s0 = 16; s0 < p.S; ++s0) {
+        const float4 v = reinterpret_cast<const float4*>(p.partial + ((int64_t)s0 * p.rows + row) * p.C)[t];
+        a.x += v.x;
+        a.y += v.y;
+        a.z += v.z;
+        a.w += v.w;
+    }
+    a.x = (a.x + bb.x) + r.x;
+    a.y = (a.y + bb.y) + r.y;
+    a.z = (a.z + bb.z) + r.z;
+    a.w = (a.w + bb.w) + r.w;
+    if (on) *xp = a;
+    if (!LN) return;
+    float s = on ? (a.x + a.y) + (a.z + a.w) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)p.C;
+    float q = 0.f;
+    if (on) {
+        const float d0 = a.x - mean, d1 = a.y - mean, d2 = a.z - mean, d3 = a.w - mean;
+        q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)p.C + 1e-5f);
+    if (!on) return;
+    float o4[4];
+    o4[0] = (a.x - mean) * rstd * g.x + be.x;
+    o4[1] = (a.y - mean) * rstd * g.y + be.y;
+    o4[2] = (a.z - mean) * rstd * g.z + be.z;
+    o4[3] = (a.w - mean) * rstd * g.w + be.w;
+    if (p.Hh) {
+        half4_t hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const _Float16 hh = (_Float16)o4[e];
+            hi[e] = hh;
+            lo[e] = (_Float16)(o4[e] - (float)hh);
+        }
+        const int64_t off = ((int64_t)(tid >> 1) * p.RB + row) * 8 + (tid & 1) * 4;
+        *reinterpret_cast<half4_t*>(p.Hh + off) = hi;
+        *reinterpret_cast<half4_t*>(p.Hl + off) = lo;
+    }
+    if (p.hfix) reinterpret_cast<float4*>(p.hfix + (int64_t)row * p.C)[tid] = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    if (p.hrow) {
+        const int pos = p.d_pos ? *p.d_pos : 0;
+        if (pos < p.hrow_rows)
+            reinterpret_cast<float4*>(p.hrow + (int64_t)row * p.hrow_bs + (int64_t)pos * p.C)[tid] = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
+}
+
+// h = LayerNorm(x[row]) of the k-group-major residual stream as split planes (the first layer's QKV input)
+__global__ __launch_bounds__(256) void ln3_kernel(const float* __restrict__ xg, int XRB, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, __half* __restrict__ Hh, __half* __restrict__ Hl, int RB,
+                                                  int C) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const bool on = tid < (C >> 2);
+    const int t = on ? tid : 0;
+    const float4 a = *reinterpret_cast<const float4*>(xg + ((int64_t)(t >> 1) * XRB + row) * 8 + (t & 1) * 4);
+    const float4 g = reinterpret_cast<const float4*>(gamma)[t];
+    const float4 be = reinterpret_cast<const float4*>(beta)[t];
+    float s = on ? (a.x + a.y) + (a.z + a.w) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)C;
+    float q = 0.f;
+    if (on) {
+        const float d0 = a.x - mean, d1 = a.y - mean, d2 = a.z - mean, d3 = a.w - mean;
+        q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)C + 1e-5f);
+    if (!on) return;
+    const float o4[4] = {(a.x - mean) * rstd * g.x + be.x, (a.y - mean) * rstd * g.y + be.y, (a.z - mean) * rstd * g.z + be.z,
+                         (a.w - mean) * rstd * g.w + be.w};
+    half4_t hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 hh = (_Float16)o4[e];
+        hi[e] = hh;
+        lo[e] = (_Float16)(o4[e] - (float)hh);
+    }
+    const int64_t off = ((int64_t)(tid >> 1) * RB + row) * 8 + (tid & 1) * 4;
+    *reinterpret_cast<half4_t*>(Hh + off) = hi;
+    *reinterpret_cast<half4_t*>(Hl + off) = lo;
+}
+
+// x[row] = embed[tok[row]] * scale + pos_table[*d_pos] on the k-group-major residual stream (the first LayerNorm is the
+// QKV product's own)
+__global__ __launch_bounds__(256) void embed3_kernel(const int* __restrict__ tok, const __half* __restrict__ embed, float scale,
+                                                     const float* __restrict__ pos_table, const int* __restrict__ d_pos,
+                                                     float* __restrict__ xg, int XRB, int C) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if (tid >= (C >> 2)) return;
+    const int pos = d_pos ? *d_pos : 0;
+    const int token = tok[row];
+    const half4_t e = *reinterpret_cast<const half4_t*>(embed + (int64_t)token * C + 4 * tid);
+    const float4 pe = *reinterpret_cast<const float4*>(pos_table + (int64_t)pos * C + 4 * tid);
+    float4 a;
+    a.x = (float)e[0] * scale + pe.x;
+    a.y = (float)e[1] * scale + pe.y;
+    a.z = (float)e[2] * scale + pe.z;
+    a.w = (float)e[3] * scale + pe.w;
+    *reinterpret_cast<float4*>(xg + ((int64_t)(tid >> 1) * XRB + row) * 8 + (tid & 1) * 4) = a;
+}
+
+// k-group-major fp32 <-> rows (tests)
+__global__ __launch_bounds__(256) void rows_to_kgm_kernel(const float* __restrict__ x, int64_t ldx, int rows, int C, int XRB,
+                                                          float* __restrict__ xg) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C) return;
+    const int row = idx / C, k = idx - row * C;
+    xg[((int64_t)(k >> 3) * XRB + row) * 8 + (k & 7)] = x[(int64_t)row * ldx + k];
+}
+__global__ __launch_bounds__(256) void kgm_to_rows_kernel(const float* __restrict__ xg, int XRB, float* __restrict__ out, int64_t ldo,
+                                                          int rows, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C) return;
+    const int row = idx / C, k = idx - row * C;
+    out[(int64_t)row * ldo + k] = xg[((int64_t)(k >> 3) * XRB + row) * 8 + (k & 7)];
+}
+
+// --------------------------------------------------------------------------------------------- //
+// vocab3_kernel<WAVES>: vocabulary projection + generation rules + arg-max / log-sum-exp, no logits in HBM.
+//   grid = tile groups x row halves; the workgroup stages the split planes of its 32 rows in LDS (K <= 1024: 2 x 64 KB,
+//   fragment order: k-step ks, lane l at byte (ks * 64 + l) * 16), then wave w takes the tiles t_lo + w, + WAVES, ... of the
+//   group: a tile's 64 weight fragments stream through two 16-fragment register buffers (the next chunk, of the next tile
+//   if need be, is in flight while the current one is multiplied), B operands come from LDS.  One record per
+//   (tile group, row) {best tweaked logit, its index, max, sum exp}; launch_argmax_finalize combines them.
+// --------------------------------------------------------------------------------------------- //
+// FULLK: K == 1024 (no per-k-step range checks in the weight stream); HALVES2: two row halves per tile group - the second
+// reader of a tile must find it in the XCD's L2, so the weight loads carry no streaming hint then
+template <int WAVES, bool FULLK, bool HALVES2>
+__global__ __launch_bounds__(64 * WAVES) void vocab3_kernel(Vocab3Args p) {
+    constexpr int T = 64 * WAVES;
+    __shared__ __attribute__((aligned(16))) unsigned char act_lds[2 * 65536];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+    int grp, half_idx;
+    if (HALVES2) {  // the two row halves of a tile group on the same XCD (block ids b and b + 8)
+        grp = (b >> 4) * 8 + (b & 7);
+        half_idx = (b >> 3) & 1;
+    } else {
+        grp = b;
+        half_idx = 0;
+    }
+    const int r0 = 32 * half_idx;
+    const int t_lo = grp * p.tpg, t_hi = min(p.NT_total, t_lo + p.tpg);
+
+    const __amdgpu_buffer_rsrc_t rw = rsrc3(p.Wp, p.w_bytes);
+    const uint32_t w_voff = (uint32_t)lane * 16u;
+    u32x4_t wb[2][16];
+#define V3_LOADW(B, TILE, C)                                                                                          \
+    {                                                                                                                 \
+        const uint32_t kill_ = ((TILE) < t_hi) ? 0u : OOB;                                                            \
+        const uint32_t base_ = (uint32_t)(TILE) * (uint32_t)p.KS * 1024u;                                             \
+        _Pragma("unroll") for (int j_ = 0; j_ < 16; ++j_) {                                                           \
+            const uint32_t kk_ = (FULLK || 16 * (C) + j_ < p.KS) ? 0u : OOB;                                          \
+            wb[B][j_] = HALVES2 ? __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff | kill_ | kk_, base_ + (uint32_t)(16 * (C) + j_) * 1024u, 0) \
+                                : __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff | kill_ | kk_, base_ + (uint32_t)(16 * (C) + j_) * 1024u, 2); \
+        }                                                                                                             \
+    }
+    int t = t_lo + wave;
+    V3_LOADW(0, t, 0);  // the first chunk of weights travels while the planes are staged
+
+    // ---- stage the planes: piece (plane, k-group kg, row n) -> LDS piece plane * 4096 + kg * 32 + n -----------------
+    {
+        const int KG = p.K >> 3;
+        for (int idx = tid; idx < 2 * 4096; idx += T) {
+            const int plane = idx >> 12, rem = idx & 4095, kg = rem >> 5, rn = rem & 31;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (kg < KG && r0 + rn < p.M)
+                v = *reinterpret_cast<const u32x4_t*>((plane ? p.Al : p.Ah) + ((int64_t)kg * p.RB + r0 + rn) * 8);
+            *reinterpret_cast<u32x4_t*>(act_lds + (size_t)idx * 16) = v;
+        }
+    }
+    const int am_step = p.am_pos ? *p.am_pos : 0;
+    const bool am_force = (p.am_force_eos_step >= 0 && am_step == p.am_force_eos_step);
+    const bool am_no_eos = am_step < p.am_min_step_for_eos;
+    float best = -INFINITY, mm = -INFINITY, ss = 0.f;
+    int bidx = 0x7fffffff;
+    const int m = r0 + n;
+    __syncthreads();
+
+    while (t < t_hi) {
+        float16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < 3) {
+                V3_LOADW((c + 1) & 1, t, c + 1);
+            } else {
+                V3_LOADW(0, t + WAVES, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int ks = 16 * c + j;
+                const half8_t bh = *reinterpret_cast<const half8_t*>(act_lds + (size_t)(ks * 64 + lane) * 16);
+                const half8_t bl = *reinterpret_cast<const half8_t*>(act_lds + 65536 + (size_t)(ks * 64 + lane) * 16);
+                const half8_t wf = __builtin_bit_cast(half8_t, wb[c & 1][j]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, bl, acc, 0, 0, 0);
+                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // B operands are fetched four fragments ahead, not sixteen
+            }
+        }
+        // generation step rules on the 16 logits this lane holds for row m (argmax_rows_kernel / gemvp EPI_ARGMAX)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int feat = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (feat < p.N) {
+                float v = acc[r];
+                if (p.bias) v += p.bias[feat];
+                if (feat == p.am_eos_idx && m < p.M) p.am_eos_logit[m] = v;
+                if (v > mm) {
+                    ss = ss * expf(mm - v) + 1.f;
+                    mm = v;
+                } else {
+                    ss += expf(v - mm);
+                }
+                float tv = v;
+                if (feat == p.am_unk_idx) tv -= p.am_unk_penalty;
+                if (feat == p.am_pad_idx) tv = -INFINITY;
+                if (am_no_eos && feat == p.am_eos_idx) tv = -INFINITY;
+                if (am_force && feat != p.am_eos_idx) tv = -INFINITY;
+                if (tv > best || (tv == best && feat < bidx)) {
+                    best = tv;
+                    bidx = feat;
+                }
+            }
+        }
+        t += WAVES;
+    }
+#undef V3_LOADW
+    // the two k halves of a lane pair hold different features of the same row: combine, then across the waves
+    {
+        const float ob = __shfl_xor(best, 32);
+        const int oi = __shfl_xor(bidx, 32);
+        if (ob > best || (ob == best && oi < bidx)) {
+            best = ob;
+            bidx = oi;
+        }
+        const float om = __shfl_xor(mm, 32);
+        const float os = __shfl_xor(ss, 32);
+        const float nm = fmaxf(mm, om);
+        const float a = (mm == -INFINITY) ? 0.f : ss * expf(mm - nm);
+        const float c2 = (om == -INFINITY) ? 0.f : os * expf(om - nm);
+        ss = a + c2;
+        mm = nm;
+    }
+    __syncthreads();  // every wave is done with the planes
+    float4* rec = reinterpret_cast<float4*>(act_lds);
+    if (h == 0) rec[wave * 32 + n] = make_float4(best, __int_as_float(bidx), mm, ss);
+    __syncthreads();
+    if (tid < 32 && m < p.M) {
+        float4 r = rec[tid];
+#pragma unroll
+        for (int w2 = 1; w2 < WAVES; ++w2) {
+            const float4 o = rec[w2 * 32 + tid];
+            const int oi = __float_as_int(o.y), ri = __float_as_int(r.y);
+            if (o.x > r.x || (o.x == r.x && oi < ri)) {
+                r.x = o.x;
+                r.y = o.y;
+            }
+            const float nm = fmaxf(r.z, o.z);
+            const float a = (r.z == -INFINITY) ? 0.f : r.w * expf(r.z - nm);
+            const float c2 = (o.z == -INFINITY) ? 0.f : o.w * expf(o.z - nm);
+            r.w = a + c2;
+            r.z = nm;
+        }
+        p.am_part[(int64_t)grp * p.M + m] = r;
+    }
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------------- //
+// host side
+// --------------------------------------------------------------------------------------------- //
+bool gemv3_supported(int M, int N, int K, int in_mode) {
+    if (M < 1 || M > 64 || K % 16 != 0 || N % 8 != 0 || packed_weight_halfs(N, K) * 2 >= (1ll << 32)) return false;
+    if (in_mode == IN3_LN) return K <= 1024;  // the whole row inside one workgroup: 16 waves x 4 k-steps
+    return true;
+}
+
+// Workgroup shapes (Gemv3Args::shape).  What one workgroup pulls decides the launch's time (~45 - 80 GB/s per CU,
+// profiles/r3_micro_percu.txt), so the shape is chosen per product:
+//   G3_T1   1 tile  x 16 waves x 4 k-steps (whole K <= 1024): the N = 1024 products, 64 KB of weights + rg x K x 4 B
+//   G3_T2K8 2 tiles x  8 waves x 8 k-steps (whole K <= 1024): FFN-in - the row group's activations are pulled once for
+//           64 features (128 KB of weights + 128 KB of rows per workgroup at 32 rows: the minimum per CU for 256 tiles x 64 rows)
+//   G3_T2K4 2 tiles x  8 waves x 4 k-steps (512-wide K slices): FFN-out, 64 KB of weights + rows x 512 x 4 B
+static int shape_ksteps(int shape) { return shape == G3_T1 ? 64 : (shape == G3_T2K8 ? 64 : 32); }
+
+int gemv3_splits(int K, int shape) { return cdiv(K / 16, shape_ksteps(shape)); }
+
+template <int NT, int MT, int WAVES, int KSW>
+static void gemv3_dispatch(const Gemv3Args& a, dim3 grid, hipStream_t s) {
+#define G3_CASE(I, E)                                                                                              \
+    if (a.in_mode == I && a.epi == E) {                                                                            \
+        hipLaunchKernelGGL((gemv3_kernel<NT, MT, WAVES, KSW, I, E>), grid, dim3(64 * WAVES), 0, s, a);             \
+        return;                                                                                                    \
+    }
+    if (MT == 1) {
+        G3_CASE(IN3_LN, EPI3_ROWS)
+        G3_CASE(IN3_LN, EPI3_PLANES)
+        G3_CASE(IN3_PLANES, EPI3_RESID)
+        G3_CASE(IN3_PLANES, EPI3_ROWS)
+    }
+    G3_CASE(IN3_PLANES, EPI3_PARTIAL)
+#undef G3_CASE
+    SC_CHECK(false, "gemv3: no kernel for input mode %d with epilogue %d (row tiles %d)", a.in_mode, a.epi, MT);
+}
+
+void launch_gemv3(const Gemv3Args& a0, hipStream_t s) {
+    Gemv3Args a = a0;
+    SC_CHECK(gemv3_supported(a.M, a.N, a.K, a.in_mode), "gemv3: M=%d N=%d K=%d mode %d unsupported", a.M, a.N, a.K, a.in_mode);
+    SC_CHECK(a.RB >= 32 && a.RB % 32 == 0 && a.RB >= a.M, "gemv3: RB=%d for M=%d", a.RB, a.M);
+    SC_CHECK(a.shape == G3_T1 || a.shape == G3_T2K8 || a.shape == G3_T2K4, "gemv3: shape %d", a.shape);
+    a.KS = a.K / 16;
+    a.NT_total = cdiv(a.N, 32);
+    a.w_bytes = (uint32_t)(packed_weight_halfs(a.N, a.K) * 2);
+    a.a_bytes = (uint32_t)((int64_t)(a.K / 8) * a.RB * (a.in_mode == IN3_LN ? 32 : 16));
+    const int splits = gemv3_splits(a.K, a.shape);
+    SC_CHECK(a.epi == EPI3_PARTIAL || splits == 1, "gemv3: a fused epilogue needs the whole K range in one workgroup (K=%d, shape %d)", a.K,
+             a.shape);
+    const bool two = a.mt2 && a.M > 32;  // 33..64 rows in ONE row group (two MFMA row tiles): K-slice products only
+    const int rg_cap = two ? 64 : 32;
+    if (a.rg < 1 || a.rg > rg_cap) a.rg = rg_cap;
+    const int groups = cdiv(a.M, a.rg);
+    const int nt = a.shape == G3_T1 ? 1 : 2;
+    dim3 grid(cdiv(a.NT_total, nt), groups, splits);
+    prof::Scope scope(a.in_mode == IN3_LN ? "gemv3_ln" : "gemv3_planes", 2.0 * a.M * (double)a.N * a.K,
+                      2.0 * a.N * (double)a.K + 4.0 * a.M * ((double)a.K + (double)a.N * splits), s);
+    if (a.shape == G3_T1) {
+        if (two) gemv3_dispatch<1, 2, 16, 4>(a, grid, s);
+        else gemv3_dispatch<1, 1, 16, 4>(a, grid, s);
+    } else if (a.shape == G3_T2K8) {
+        SC_CHECK(!two, "gemv3: shape G3_T2K8 takes row groups of at most 32 rows");
+        gemv3_dispatch<2, 1, 8, 8>(a, grid, s);
+    } else {
+        if (two) gemv3_dispatch<2, 2, 8, 4>(a, grid, s);
+        else gemv3_dispatch<2, 1, 8, 4>(a, grid, s);
+    }
+    SC_LAUNCH_CHECK();
+}
+
+void launch_reduce3(const Reduce3Args& p, hipStream_t s) {
+    SC_CHECK(p.C % 8 == 0 && p.C <= 1024, "reduce3: C=%d unsupported", p.C);
+    SC_CHECK(p.S >= 1 && p.partial, "reduce3: need at least one partial");
+    if (p.rows <= 0) return;
+    prof::Scope scope("reduce3", 0.0, 4.0 * p.rows * (double)p.C * (p.S + 3), s);
+    if (p.gamma) hipLaunchKernelGGL((reduce3_kernel<true>), dim3(p.rows), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((reduce3_kernel<false>), dim3(p.rows), dim3(256), 0, s, p);
+    SC_LAUNCH_CHECK();
+}
+
+void launch_embed3(const int* tok, const __half* embed, float scale, const float* pos_table, const int* d_pos, float* xg, int XRB,
+                   int rows, int C, hipStream_t s) {
+    SC_CHECK(C % 8 == 0 && C <= 1024, "embed3: C=%d unsupported", C);
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(embed3_kernel, dim3(rows), dim3(256), 0, s, tok, embed, scale, pos_table, d_pos, xg, XRB, C);
+    SC_LAUNCH_CHECK();
+}
+
+void launch_ln3(const float* xg, int XRB, const float* gamma, const float* beta, __half* Hh, __half* Hl, int RB, int rows, int C,
+                hipStream_t s) {
+    SC_CHECK(C % 8 == 0 && C <= 1024, "ln3: C=%d unsupported", C);
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(ln3_kernel, dim3(rows), dim3(256), 0, s, xg, XRB, gamma, beta, Hh, Hl, RB, C);
+    SC_LAUNCH_CHECK();
+}
+
+void launch_rows_to_kgm(const float* x, int64_t ldx, int rows, int C, int XRB, float* xg, hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(rows_to_kgm_kernel, dim3(cdiv(rows * C, 256)), dim3(256), 0, s, x, ldx, rows, C, XRB, xg);
+    SC_LAUNCH_CHECK();
+}
+
+void launch_kgm_to_rows(const float* xg, int XRB, float* out, int64_t ldo, int rows, int C, hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(kgm_to_rows_kernel, dim3(cdiv(rows * C, 256)), dim3(256), 0, s, xg, XRB, out, ldo, rows, C);
+    SC_LAUNCH_CHECK();
+}
+
+// tile groups of the vocabulary projection: one record per (group, row); 128 groups x 2 row halves above 32 rows
+int vocab3_groups(int M) { return M > 32 ? 128 : 256; }
+
+bool vocab3_supported(int M, int N, int K) {
+    return M >= 1 && M <= 64 && K % 16 == 0 && K <= 1024 && packed_weight_halfs(N, K) * 2 < (1ll << 32);
+}
+
+void launch_vocab3(const Vocab3Args& a0, hipStream_t s) {
+    Vocab3Args a = a0;
+    SC_CHECK(vocab3_supported(a.M, a.N, a.K), "vocab3: M=%d N=%d K=%d unsupported", a.M, a.N, a.K);
+    SC_CHECK(a.RB >= 32 && a.RB % 32 == 0 && a.RB >= a.M, "vocab3: RB=%d for M=%d", a.RB, a.M);
+    a.KS = a.K / 16;
+    a.NT_total = cdiv(a.N, 32);
+    a.w_bytes = (uint32_t)(packed_weight_halfs(a.N, a.K) * 2);
+    const int groups = vocab3_groups(a.M);
+    a.halves = a.M > 32 ? 2 : 1;
+    a.tpg = cdiv(a.NT_total, groups);
+    SC_CHECK(a.am_tiles_cap >= groups, "vocab3: arg-max partial buffer holds %d groups, need %d", a.am_tiles_cap, groups);
+    prof::Scope scope(a.M <= 32 ? "vocab3_m32" : "vocab3_m64", 2.0 * a.M * (double)a.N * a.K, 2.0 * a.N * (double)a.K, s);
+    const dim3 grid(groups * a.halves);
+    if (a.K == 1024 && a.halves == 2) hipLaunchKernelGGL((vocab3_kernel<8, true, true>), grid, dim3(512), 0, s, a);
+    else if (a.K == 1024) hipLaunchKernelGGL((vocab3_kernel<8, true, false>), grid, dim3(512), 0, s, a);
+    else if (a.halves == 2) hipLaunchKernelGGL((vocab3_kernel<8, false, true>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((vocab3_kernel<8, false, false>), grid, dim3(512), 0, s, a);
+    SC_LAUNCH_CHECK();
+}
+
+}  // namespace sc

@@ -240,6 +240,98 @@ struct TouchArgs {
 void launch_touch(const TouchArgs& a, int workgroups, hipStream_t s);
 void launch_rows_to_planes(const float* x, int64_t ldx, int rows, int C, int RB, __half* Hh, __half* Hl, hipStream_t s);
 
+// ---- decoder step, third generation (k_dstep3.hip) ----------------------------------------------------------------
+// Row-group GEMV: a workgroup owns 32 output features x a group of <= 32 (64) batch rows x the whole K range (or a
+// 1024-wide K slice), applies the LayerNorm in front of the product itself (IN3_LN: input = the fp32 residual stream in
+// k-group-major order X[K/8][RB][8]) and finishes the output itself (bias, residual, ReLU + split planes).
+enum In3 { IN3_PLANES = 0, IN3_LN = 1 };
+enum Epi3 {
+    EPI3_ROWS = 0,     // out[row * ldo + feature] = product + bias                    (q / k / v rows)
+    EPI3_RESID = 1,    // xres (k-group-major fp32 [N/8][XRB][8]) += product + bias    (out-projections)
+    EPI3_PLANES = 2,   // act(product + bias) as split fp16 planes [N/8][ORB][8]       (FFN inner activation)
+    EPI3_PARTIAL = 3,  // out[(split * M + row) * N + feature] = partial product       (K > 1024: FFN-out)
+};
+struct Gemv3Args {
+    const __half* Wp = nullptr;  // packed fragments (launch_pack_weight)
+    int M = 0, N = 0, K = 0;
+    int in_mode = IN3_PLANES;
+    const float* xg = nullptr;  // IN3_LN: residual stream, k-group-major fp32 [K/8][RB][8]
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    const __half* Ah = nullptr;  // IN3_PLANES: activation planes [K/8][RB][8]
+    const __half* Al = nullptr;
+    int RB = 32;   // row slots of the input buffers
+    int rg = 0;    // rows per row group (<= 32; <= 64 with mt2); 0 = as many as the shape allows
+    int mt2 = 0;   // 33..64 rows as ONE row group (two MFMA row tiles per workgroup)
+    int shape = 0; // G3_T1 / G3_T2K8 / G3_T2K4: tiles per workgroup x waves x k-steps per wave (k_dstep3.hip)
+    int epi = EPI3_ROWS;
+    const float* bias = nullptr;
+    float* out = nullptr;
+    int64_t ldo = 0;
+    float* xres = nullptr;
+    int XRB = 32;
+    __half* Oh = nullptr;
+    __half* Ol = nullptr;
+    int ORB = 32;
+    int act = ACT_NONE;
+    // filled by the launcher
+    int KS = 0, NT_total = 0;
+    uint32_t w_bytes = 0, a_bytes = 0;
+};
+enum Gemv3Shape { G3_T1 = 0, G3_T2K8 = 1, G3_T2K4 = 2 };
+bool gemv3_supported(int M, int N, int K, int in_mode);
+int gemv3_splits(int K, int shape);  // K ranges (EPI3_PARTIAL slabs) launch_gemv3 uses for this K and workgroup shape
+void launch_gemv3(const Gemv3Args& a, hipStream_t s);
+// x[row] += bias + sum_s partial[s][row] on the k-group-major residual stream; gamma != null: h = LayerNorm(x[row]) ->
+// planes Hh / Hl, fp32 rows hfix [rows][C], captured rows hrow (see launch_reduce_ln)
+struct Reduce3Args {
+    const float* partial = nullptr;  // [S][rows][C]
+    int S = 0;
+    const float* bias = nullptr;
+    float* xg = nullptr;
+    int XRB = 32;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    __half* Hh = nullptr;
+    __half* Hl = nullptr;
+    int RB = 32;
+    float* hrow = nullptr;
+    int64_t hrow_bs = 0;
+    int hrow_rows = 0;
+    const int* d_pos = nullptr;
+    float* hfix = nullptr;
+    int rows = 0, C = 0;
+};
+void launch_reduce3(const Reduce3Args& a, hipStream_t s);
+void launch_embed3(const int* tok, const __half* embed, float scale, const float* pos_table, const int* d_pos, float* xg, int XRB,
+                   int rows, int C, hipStream_t s);
+void launch_ln3(const float* xg, int XRB, const float* gamma, const float* beta, __half* Hh, __half* Hl, int RB, int rows, int C,
+                hipStream_t s);
+void launch_rows_to_kgm(const float* x, int64_t ldx, int rows, int C, int XRB, float* xg, hipStream_t s);
+void launch_kgm_to_rows(const float* xg, int XRB, float* out, int64_t ldo, int rows, int C, hipStream_t s);
+// vocabulary projection with the generation rules fused (record format of GemvPArgs' EPI_ARGMAX)
+struct Vocab3Args {
+    const __half* Wp = nullptr;
+    const __half* Ah = nullptr;
+    const __half* Al = nullptr;
+    int RB = 32;
+    int M = 0, N = 0, K = 0;
+    const float* bias = nullptr;
+    float4* am_part = nullptr;  // [vocab3_groups(M)][M]
+    int am_tiles_cap = 0;
+    float* am_eos_logit = nullptr;
+    const int* am_pos = nullptr;
+    int am_min_step_for_eos = 0, am_force_eos_step = -1;
+    int am_pad_idx = -1, am_eos_idx = -1, am_unk_idx = -1;
+    float am_unk_penalty = 0.f;
+    // filled by the launcher
+    int KS = 0, NT_total = 0, tpg = 0, halves = 1;
+    uint32_t w_bytes = 0;
+};
+bool vocab3_supported(int M, int N, int K);
+int vocab3_groups(int M);
+void launch_vocab3(const Vocab3Args& a, hipStream_t s);
+
 // y = act(LayerNorm(x) * gamma + beta); rows masked to zero when t >= lens[n] (optional).
 void launch_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
                       int64_t ldy, int rows, int C, int act, const int* lens, int t_per_batch,

@@ -66,6 +66,13 @@ struct StepCtx {
     __half *wideH = nullptr, *wideL = nullptr;  // FFN inner activation [ffn/8][rb][8]
     Buf<__half> planes;                       // backing store of the six planes
     int touch_ahead = 0;  // > 0: the weight toucher runs this many layers ahead on Model::touch_stream (SC_DSTEP_TOUCH)
+    // third-generation step (k_dstep3.hip): fp32 residual stream in k-group-major order, complete q / k / v rows
+    bool gen3 = false;
+    float* xg = nullptr;    // [M/8][rb][8]
+    float* qkvr = nullptr;  // [nb][M]: the cross-attention query rows
+    int rg_small = 16, rg_ffn = 32;  // rows per row group of the N = M products / FFN-in (tuning knobs, SC_D3_*)
+    int ffn_in_mode = 1;   // 0: partials + reduce/LN launch + packed product; 1 / 2: LayerNorm inside the product (2 tiles / 1 tile)
+    int ffn_out_mode = 1;  // 0: gemvp, 8 K ranges; 1: gemv3 2 tiles x 512-wide K slices; 2: gemv3 1 tile x 1024-wide
 };
 
 DecStack unity_stack(const Model& m) {
@@ -485,12 +492,154 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
     launch_add_i32(c.d_pos, 1, m.stream);
 }
 
+// ---- third-generation step (k_dstep3.hip) ---------------------------------------------------------------------
+// 9 launches per layer: QKV (packed product, K-range partials) | self-attention | out-proj (+bias +residual inside) |
+// q (LayerNorm inside) | cross-attention | out-proj (+bias +residual inside) | FFN-in (LayerNorm inside, ReLU, planes) |
+// FFN-out (K-slice partials) | reduce + bias + residual + the NEXT LayerNorm as planes (after the last layer: the decoder output).
+bool step3_eligible(const Model& m, const DecStack& W, int nb) {
+    static const bool off = getenv("SC_DECODER_GEN2") != nullptr;  // A/B switch: the second-generation chain
+    if (off || !step2_eligible(m, W, nb)) return false;
+    const int M = m.cfg.model_dim;
+    return gemv3_supported(nb, 3 * M, M, IN3_LN) && gemv3_supported(nb, M, W.ffn_dim, IN3_PLANES) && M % 8 == 0;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
+    const sc_config& cfg = m.cfg;
+    const int M = cfg.model_dim, nb = c.nb, H = cfg.num_heads;
+    const std::vector<DecoderLayer>& layers = *W.layers;
+    const int n_layers = (int)layers.size();
+    launch_embed3(c.d_tok, W.embed, sqrtf((float)M), W.pos, c.d_pos, c.xg, c.rb, nb, M, m.stream);
+    launch_ln3(c.xg, c.rb, layers[0].self_ln.g, layers[0].self_ln.b, c.hH, c.hL, c.rb, nb, M, m.stream);
+    auto out_resid = [&](const Linear& L) {  // x += att . W^T + b, finished inside the product
+        Gemv3Args a;
+        a.Wp = L.wp, a.M = nb, a.N = L.out, a.K = L.in;
+        a.in_mode = IN3_PLANES, a.Ah = c.attH, a.Al = c.attL, a.RB = c.rb, a.rg = c.rg_small;
+        a.epi = EPI3_RESID, a.bias = L.b, a.xres = c.xg, a.XRB = c.rb;
+        launch_gemv3(a, m.stream);
+    };
+    // x += bias + partials; h = LayerNorm(x) as planes: the K-slice products' closing launch
+    auto reduce_ln3 = [&](int S, const float* bias, const LNorm& ln, bool decoder_output) {
+        Reduce3Args r;
+        r.partial = c.partial, r.S = S, r.bias = bias, r.xg = c.xg, r.XRB = c.rb, r.rows = nb, r.C = M;
+        r.gamma = ln.g, r.beta = ln.b, r.Hh = c.hH, r.Hl = c.hL, r.RB = c.rb;
+        if (decoder_output) {  // also fp32 rows (c.hN) and the per-position capture (the reference's teacher-forced pass)
+            r.hrow = c.dec_hidden, r.hrow_bs = (int64_t)(c.cap - 1) * M, r.hrow_rows = c.dec_hidden ? c.cap - 1 : 0, r.d_pos = c.d_pos;
+            r.hfix = c.hN;
+        }
+        launch_reduce3(r, m.stream);
+    };
+    for (int li = 0; li < n_layers; ++li) {
+        const DecoderLayer& l = layers[li];
+        const bool last = li + 1 == n_layers;
+        int sp = 1;
+        // self attention: q | k | v as K-range partials of the packed product (summed by the attention kernel)
+        gemv2(m, c, c.hH, c.hL, l.qkv, 2, &sp);
+        DAttnArgs a;
+        a.q = c.partial;
+        a.ldq = 3 * M;
+        a.sstride = (int64_t)nb * 3 * M;
+        a.S = sp;
+        a.koff = M;
+        a.voff = 2 * M;
+        a.bias = l.qkv.b;
+        a.kcache = c.kcache[li];
+        a.vcache = c.vcache[li];
+        a.cache_ld = M;
+        a.cache_bs = (int64_t)c.cap * M;
+        a.cap = c.cap;
+        a.d_pos = c.d_pos;
+        a.Oh = c.attH;
+        a.Ol = c.attL;
+        a.ORB = c.rb;
+        a.nb = nb;
+        a.heads = H;
+        launch_dattn(a, /*cross=*/false, m.stream);
+        out_resid(l.self_out);
+        // encoder-decoder attention: the query projection applies its LayerNorm itself
+        {
+            Gemv3Args q;
+            q.Wp = l.cross_q.wp, q.M = nb, q.N = M, q.K = M;
+            q.in_mode = IN3_LN, q.xg = c.xg, q.gamma = l.cross_ln.g, q.beta = l.cross_ln.b, q.RB = c.rb, q.rg = c.rg_small;
+            q.epi = EPI3_ROWS, q.bias = l.cross_q.b, q.out = c.qkvr, q.ldo = M;
+            launch_gemv3(q, m.stream);
+        }
+        DAttnArgs x;
+        x.q = c.qkvr;
+        x.ldq = M;
+        x.sstride = 0;
+        x.S = 1;
+        x.bias = nullptr;  // added by the projection
+        x.kcache = c.cross_kv[li];
+        x.vcache = c.cross_kv[li] + M;
+        x.cache_ld = 2 * M;
+        x.cache_bs = (int64_t)c.s_enc * 2 * M;
+        x.cap = c.s_enc;
+        x.kv_lens = c.d_enc_lens;
+        x.Oh = c.attH;
+        x.Ol = c.attL;
+        x.ORB = c.rb;
+        x.nb = nb;
+        x.heads = H;
+        launch_dattn(x, /*cross=*/true, m.stream);
+        // feed-forward network: the inner activation stays in split planes
+        if (c.ffn_in_mode == 0) {  // K-range partials + reduce / LayerNorm launch, then the packed product on planes
+            gemv2(m, c, c.attH, c.attL, l.cross_out, 4, &sp);
+            reduce_ln3(sp, l.cross_out.b, l.ffn_ln, false);
+            GemvPArgs f;
+            f.Wp = l.ffn_in.wp, f.Ah = c.hH, f.Al = c.hL, f.RB = c.rb, f.M = nb, f.N = W.ffn_dim, f.K = M;
+            f.splits = 1, f.epi = EPI_PLANES, f.bias = l.ffn_in.b, f.act = ACT_RELU;
+            f.Oh = c.wideH, f.Ol = c.wideL, f.ORB = c.rb;
+            launch_gemvp(f, m.stream);
+        } else {  // the out-projection finishes x itself, FFN-in applies the LayerNorm itself
+            out_resid(l.cross_out);
+            Gemv3Args f;
+            f.Wp = l.ffn_in.wp, f.M = nb, f.N = W.ffn_dim, f.K = M;
+            f.in_mode = IN3_LN, f.xg = c.xg, f.gamma = l.ffn_ln.g, f.beta = l.ffn_ln.b, f.RB = c.rb, f.rg = c.rg_ffn;
+            f.shape = c.ffn_in_mode == 1 ? G3_T2K8 : G3_T1;
+            f.epi = EPI3_PLANES, f.bias = l.ffn_in.b, f.act = ACT_RELU, f.Oh = c.wideH, f.Ol = c.wideL, f.ORB = c.rb;
+            launch_gemv3(f, m.stream);
+        }
+        if (c.ffn_out_mode == 0) {
+            gemv2(m, c, c.wideH, c.wideL, l.ffn_out, 8, &sp);
+        } else {
+            Gemv3Args o;
+            o.Wp = l.ffn_out.wp, o.M = nb, o.N = M, o.K = W.ffn_dim;
+            o.in_mode = IN3_PLANES, o.Ah = c.wideH, o.Al = c.wideL, o.RB = c.rb, o.mt2 = 1;
+            o.shape = c.ffn_out_mode == 1 ? G3_T2K4 : G3_T1;
+            o.epi = EPI3_PARTIAL, o.out = c.partial;
+            launch_gemv3(o, m.stream);
+            sp = gemv3_splits(W.ffn_dim, o.shape);
+        }
+        reduce_ln3(sp, l.ffn_out.b, last ? *W.final_ln : layers[li + 1].self_ln, last);
+    }
+    if (project) {
+        Vocab3Args v;
+        v.Wp = W.embed_p, v.Ah = c.hH, v.Al = c.hL, v.RB = c.rb, v.M = nb, v.N = W.vocab, v.K = M;
+        v.am_part = c.am_part, v.am_tiles_cap = c.am_tiles, v.am_eos_logit = c.am_eos_logit, v.am_pos = c.d_pos;
+        v.am_min_step_for_eos = c.min_seq_len, v.am_force_eos_step = c.force_eos_step;
+        v.am_pad_idx = W.pad_idx, v.am_eos_idx = W.eos_idx, v.am_unk_idx = W.unk_idx, v.am_unk_penalty = c.unk_penalty;
+        launch_vocab3(v, m.stream);
+        launch_argmax_finalize(c.am_part, vocab3_groups(nb), nb, c.am_eos_logit, c.d_pos, c.force_eos_step, W.pad_idx, W.eos_idx,
+                               c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len, c.d_score, m.stream);
+    }
+    launch_add_i32(c.d_pos, 1, m.stream);
+}
+
 // One decoder step for all batch rows: feeds d_tok at position *d_pos.
 void decoder_step(Model& m, StepCtx& c, bool project) {
     const sc_config& cfg = m.cfg;
     const int M = cfg.model_dim, nb = c.nb;
     const DecStack own = unity_stack(m);
     const DecStack& W = c.stack ? *c.stack : own;
+    if (c.gen3) {
+        decoder_step3(m, c, project, W);
+        return;
+    }
     if (c.rb > 0) {
         decoder_step2(m, c, project, W);
         return;
@@ -833,7 +982,7 @@ struct DecodeSession {
     float unk_penalty = 0.f;
     StepCtx c;
     Buf<int> ints;
-    Buf<float> fl, x, h, wide, att, hN, logits, partial, am_eos, hidden;
+    Buf<float> fl, x, h, wide, att, hN, logits, partial, am_eos, hidden, xg, qkvr;
     Buf<float4> am_part;
     std::vector<Buf<float>> caches;
     hipGraph_t graph = nullptr;
@@ -885,10 +1034,23 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
     // worst case: K/256 ranges of an [n][M] out-projection, or M/256 ranges of the [n][3M] q/k/v projection
     S.partial = Buf<float>(&m.pool, (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * n * 3 * M);
     c.partial = S.partial;
+    const bool gen3 = gen2 && step3_eligible(m, W, n) && (forced || (fused_argmax && W.embed_p && vocab3_supported(n, W.vocab, M)));
     if (gen2) {
         alloc_step2(m, c, cfg.dec_ffn_dim);
         c.am_ntl = 4;
         c.am_tiles = fused_argmax ? gemvp_argmax_tiles(cfg.text_vocab_size, c.am_ntl) : 0;
+        if (gen3) {
+            c.gen3 = true;
+            S.xg = Buf<float>(&m.pool, (size_t)M * c.rb);
+            S.qkvr = Buf<float>(&m.pool, (size_t)n * M);
+            c.xg = S.xg;
+            c.qkvr = S.qkvr;
+            c.am_tiles = std::max(c.am_tiles, vocab3_groups(n));
+            c.rg_small = env_int("SC_D3_RG_SMALL", 16);
+            c.rg_ffn = env_int("SC_D3_RG_FFN", 32);
+            c.ffn_in_mode = env_int("SC_D3_FFN_IN", 1);
+            c.ffn_out_mode = env_int("SC_D3_FFN_OUT", 1);
+        }
         if (touch_setting() > 0 && !forced) {  // greedy generation only: the session owns the captured step
             prepare_touch(m, cfg.dec_layers);
             c.touch_ahead = touch_setting();
