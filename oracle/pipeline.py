@@ -61,15 +61,17 @@ class OracleS2ST:
     def s2tt(self, fbank: Tensor, lens: Tensor, tgt_lang: str, soft_max_seq_len=(1, 200),
              hard_max_seq_len: int = 1024, beam_size: int = 1):
         enc, enc_lens = self.encode_speech(fbank, lens)
-        # the generator is called with the fbank sequences: their padded length feeds the soft length rule
-        return self._text_from_encoder(enc, enc_lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size, int(fbank.shape[1]))
+        # the generator is called with the fbank sequences and their padding mask: the longest sequence feeds the soft
+        # length rule (fairseq2 0.2: int(padding_mask.seq_lens.max()), the padded width only without a mask; restated from
+        # the source text, not under /root/reference)
+        return self._text_from_encoder(enc, enc_lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size, int(lens.max()))
 
     @torch.inference_mode()
     def t2tt(self, tokens: Tensor, lens: Tensor, tgt_lang: str, soft_max_seq_len=(1, 200),
              hard_max_seq_len: int = 1024, beam_size: int = 1):
         """Text input (UnitYModel.encode_text, models/unity/model.py:138-151) -> the same generation."""
         enc = ou.encode_text(self.P, self.cfg, tokens, lens, self.pos_table)
-        return self._text_from_encoder(enc, lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size, int(tokens.shape[1]))
+        return self._text_from_encoder(enc, lens, tgt_lang, soft_max_seq_len, hard_max_seq_len, beam_size, int(lens.max()))
 
     def _text_from_encoder(self, enc: Tensor, enc_lens: Tensor, tgt_lang: str, soft_max_seq_len, hard_max_seq_len: int,
                            beam_size: int, source_len: int = 0):

@@ -463,13 +463,14 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
         SC_LAUNCH_CHECK();
     }
     if (project) {
+        SC_CHECK(W.embed_p, "decoder_step2: the fused vocabulary projection needs the packed embedding of this decoder stack");
         GemvPArgs v;
         v.Wp = W.embed_p;
         v.Ah = c.hH;
         v.Al = c.hL;
         v.RB = c.rb;
         v.M = nb;
-        v.N = cfg.text_vocab_size;
+        v.N = W.vocab;
         v.K = M;
         v.splits = 1;
         v.ntl = c.am_ntl;
@@ -480,13 +481,13 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
         v.am_pos = c.d_pos;
         v.am_min_step_for_eos = c.min_seq_len;
         v.am_force_eos_step = c.force_eos_step;
-        v.am_pad_idx = cfg.pad_idx;
-        v.am_eos_idx = cfg.eos_idx;
-        v.am_unk_idx = cfg.unk_idx;
+        v.am_pad_idx = W.pad_idx;
+        v.am_eos_idx = W.eos_idx;
+        v.am_unk_idx = W.unk_idx;
         v.am_unk_penalty = c.unk_penalty;
         launch_gemvp(v, m.stream);
-        launch_argmax_finalize(c.am_part, gemvp_argmax_tiles(cfg.text_vocab_size, c.am_ntl), nb, c.am_eos_logit, c.d_pos,
-                               c.force_eos_step, cfg.pad_idx, cfg.eos_idx, c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len,
+        launch_argmax_finalize(c.am_part, gemvp_argmax_tiles(W.vocab, c.am_ntl), nb, c.am_eos_logit, c.d_pos,
+                               c.force_eos_step, W.pad_idx, W.eos_idx, c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len,
                                c.d_score, m.stream);
     }
     launch_add_i32(c.d_pos, 1, m.stream);
@@ -1021,7 +1022,8 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
     c.d_lprob = S.fl;
     c.d_score = S.fl.get() + n;
     const DecStack W = unity_stack(m);
-    const bool gen2 = step2_eligible(m, W, n);
+    // the packed step projects through the packed embedding (a failed pack leaves it null: first-generation step then)
+    const bool gen2 = step2_eligible(m, W, n) && (forced || W.embed_p != nullptr);
     const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
     const bool fused_argmax = !forced && n <= 64 && M % 64 == 0;
     S.fused_argmax = fused_argmax;
@@ -1131,8 +1133,11 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
                          cur->unk_penalty == o.unk_penalty && cur->has_hidden == (int)want_hidden;
         if (!hit) {
             m.dec_session.reset();  // the old buffers go back to the pool first
-            m.dec_session = std::unique_ptr<DecodeSession, void (*)(DecodeSession*)>(new DecodeSession(), delete_decode_session);
-            setup_session(m, *m.dec_session, n, max_len, s_enc, forced, want_hidden, o);
+            // built aside and installed only when complete: an allocation that throws half way must not leave a session
+            // whose key matches the next call but whose buffers are missing
+            std::unique_ptr<DecodeSession, void (*)(DecodeSession*)> fresh(new DecodeSession(), delete_decode_session);
+            setup_session(m, *fresh, n, max_len, s_enc, forced, want_hidden, o);
+            m.dec_session = std::move(fresh);
         }
         S = m.dec_session.get();
     }

@@ -335,21 +335,30 @@ class Translator:
     def _speech_from_ar_units(self, units: np.ndarray, pad: int, tgt_lang: str, spkr: Optional[int], sample_rate: int,
                               t_start: float) -> BatchedSpeechOutput:
         """translator.py:385-428 for the autoregressive T2U of the v1 models: the language token is already removed
-        (``units[:, 1:]``), the vocoder predicts the durations (``dur_prediction=True``).  The reference concatenates the
-        expanded items of a batch (codehifigan.py:85-88), which only works when they expand to the same length, i.e. in
-        practice for one utterance; here every item is synthesised on its own units."""
+        (``units[:, 1:]``), the vocoder predicts the durations (``dur_prediction=True``).
+
+        One utterance (what the reference's own callers pass on this path): exactly the reference - the WHOLE row goes
+        through the vocoder, the trailing EOS-turned-pad unit included, and ``int(T_wav * len(speech_units) / len(row))``
+        samples are kept (translator.py:407-419).  Several utterances: the reference concatenates the expanded items
+        (codehifigan.py:85-88), which fails unless every item expands to the same length; here each item is then
+        synthesised on its own pad-free units and returned whole - a documented extension, not reference behaviour."""
         speech_units = [[int(u) for u in units[i] if u != pad] for i in range(units.shape[0])]
         audio_wavs: List[Tensor] = []
         if self.has_vocoder:
             lang_map = self.lang_spkr_idx_map
             lang_idx = [lang_map["multilingual"][tgt_lang]]
             spkr_idx = [lang_map["multispkr"][tgt_lang][0] if spkr in (None, -1) else spkr]
-            for i in range(units.shape[0]):
-                row = np.asarray(speech_units[i], dtype=np.int64)[None, :]
-                if row.shape[1] == 0:
-                    audio_wavs.append(torch.zeros(1, 1, 0, device=self.model.device))
-                    continue
-                audio_wavs.append(self.model.vocode(row, lang_idx, spkr_idx, dur_prediction=True))
+            if units.shape[0] == 1 and units.shape[1] > 0:
+                wav = self.model.vocode(np.asarray(units, dtype=np.int64), lang_idx, spkr_idx, dur_prediction=True)
+                keep = int(wav.size(-1) * len(speech_units[0]) / units.shape[1])
+                audio_wavs.append(wav[0, :, :keep].unsqueeze(0))
+            else:
+                for i in range(units.shape[0]):
+                    row = np.asarray(speech_units[i], dtype=np.int64)[None, :]
+                    if row.shape[1] == 0:
+                        audio_wavs.append(torch.zeros(1, 1, 0, device=self.model.device))
+                        continue
+                    audio_wavs.append(self.model.vocode(row, lang_idx, spkr_idx, dur_prediction=True))
             self.last_stage_ms["vocoder"] = (time.perf_counter() - t_start) * 1e3
         return BatchedSpeechOutput(units=speech_units, audio_wavs=audio_wavs, sample_rate=sample_rate)
 
@@ -418,7 +427,8 @@ class Translator:
             want_hidden=want_speech,
             # fairseq2 applies int(a * source_len + b) to the sequences the generator is called with: the fbank frames
             # (speech) or the source tokens (text), generator.py:261-263 -- not to the adaptor's 8x shorter output
-            source_len=int(seqs.shape[1]),
+            # (fairseq2 0.2 takes the longest sequence of the padding mask when there is one, the padded width otherwise)
+            source_len=int(max(src_lens)) if padding_mask is not None else int(seqs.shape[1]),
         )
         t2 = time.perf_counter()
         text_ids = [ids[b, : out_lens[b]].tolist() for b in range(ids.shape[0])]
@@ -431,8 +441,13 @@ class Translator:
         if unit_tokenizer is None:
             raise ValueError("the model was loaded with output_modality=TEXT; speech output is unavailable")
         # generator.py:281-291: pad_seqs + trim the last column; PaddingMask.trim(1)
-        text_seqs = ids[:, :-1]
+        # (pad_seqs pads to the longest hypothesis, not to the generator's length limit: the T2U stage - and the length
+        #  rule of the v1 unit search, int(25 * s_text) + 50 - sees max(text_lens) columns)
         text_lens = (out_lens - 1).tolist()
+        s_text = max(1, int(max(text_lens)))
+        text_seqs = np.ascontiguousarray(ids[:, :s_text])
+        if hidden is not None and hidden.shape[1] != s_text:
+            hidden = hidden[:, :s_text].contiguous()
         t3 = time.perf_counter()
         if getattr(model, "t2u_variant", 0) == 1:
             # generator.py:316-336: UnitYT2UModel + BeamSearchSeq2SeqGenerator from the unit tokenizer's prompt [eos, lang]

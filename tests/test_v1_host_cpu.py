@@ -115,6 +115,7 @@ def v1_translator():
 
         def vocode(self, units, lang_idx, spkr_idx, unit_lens=None, dur_prediction=False):
             self.calls.append(dict(vocode_rows=int(np.asarray(units).shape[0]), dur_prediction=dur_prediction))
+            self.last_vocoded_units = np.asarray(units).astype(np.int64).copy()
             return ov.vocode(self.orc.vocoder_sd, self.cfg.vocoder, torch.as_tensor(np.asarray(units).astype(np.int64)),
                              list(lang_idx), list(spkr_idx), dur_prediction=dur_prediction)
 
@@ -165,16 +166,17 @@ def test_translator_v1_tail_units_and_waveform(v1_translator):
     assert useq[:2] == [cfg.unit_eos_idx, lang_tok] and useq[-1] == cfg.unit_eos_idx
     body = [t - 4 for t in useq[2:-1]]  # unit_tokenizer.py:180-216: eos column dropped, EOS -> pad, units = token - 4
     assert speech.units == [[u for u in body if u != cfg.unit_pad_idx]] and len(speech.units[0]) >= 1
-    # waveform: one duration-predicting vocoder call per utterance on the filtered units
+    # waveform, one utterance = the reference to the letter (translator.py:385-419): ONE duration-predicting vocoder call
+    # on the whole unit row - the language token removed, the EOS-turned-pad column still there - then
+    # int(T_wav * len(speech_units) / len(row)) samples are kept
     voc_calls = [c for c in tr.model.calls if "vocode_rows" in c]
     assert voc_calls == [dict(vocode_rows=1, dur_prediction=True)]
-    units = np.asarray(speech.units[0], dtype=np.int64)[None, :]
-    if units.shape[1]:
-        lang_idx, spkr_idx = ov.resolve_lang_spkr(tr.lang_spkr_idx_map, ["fra"], [-1])
-        ref = ov.vocode(orc.vocoder_sd, cfg.vocoder, torch.from_numpy(units), lang_idx, spkr_idx, dur_prediction=True)
-        assert torch.equal(speech.audio_wavs[0], ref)
-        dur = ov.vocoder_durations(orc.vocoder_sd, cfg.vocoder, torch.from_numpy(units))
-        assert ref.shape == (1, 1, int(dur.sum()) * cfg.vocoder.hop)
+    row = tr.model.last_vocoded_units
+    assert row.shape == (1, len(body) + 1) and row[0, :-1].tolist() == body and row[0, -1] == cfg.unit_pad_idx
+    lang_idx, spkr_idx = ov.resolve_lang_spkr(tr.lang_spkr_idx_map, ["fra"], [-1])
+    ref = ov.vocode(orc.vocoder_sd, cfg.vocoder, torch.from_numpy(row), lang_idx, spkr_idx, dur_prediction=True)
+    keep = int(ref.shape[-1] * len(speech.units[0]) / row.shape[1])
+    assert speech.audio_wavs[0].shape == (1, 1, keep) and torch.equal(speech.audio_wavs[0], ref[:, :, :keep])
     assert speech.sample_rate == 16000 and "t2u" in tr.last_stage_ms and "vocoder" in tr.last_stage_ms
 
 
