@@ -70,6 +70,9 @@ def parse_args():
     ap.add_argument("--free-run", action="store_true",
                     help="let the micro-batch slices free-run over the K steps (joined once) instead of joining them after "
                          "every step; measured no faster on MI355X (profiles/r1_microbatch_schedule.txt), kept for experiments")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the secondary lines reported under `extra` (S2TT-only, beam 5, streaming p50)")
+    ap.add_argument("--extra-timeout", type=int, default=240, help="limit of the streaming child process, seconds")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch check only: every rank joins a gloo group on the CPU, rank 0 prints the rank count it saw "
                          "(tests/test_bench_launch_cpu.py); no device, no model")
@@ -89,7 +92,7 @@ def prof_report(lib):
     return fams
 
 
-def roofline_of(fams):
+def roofline_of(fams, step_bytes=None):
     if not fams:
         return None, {}
     name = max(fams, key=lambda k: fams[k]["ms"])
@@ -97,7 +100,19 @@ def roofline_of(fams):
     sec = f["ms"] * 1e-3
     avg_us = 1e3 * f["ms"] / max(1, f["launches"])
     base = name.split(":")[-1]
-    if base.startswith(("gemv", "skinny", "step_graph", "resblock_pair_c16", "resblock_pair_c32")):
+    if base == "step_graph" and step_bytes:
+        # one replayed decoder step.  `achieved` follows SURVEY.md section 8(d): 866.7 M parameters = 1.733 GB of fp16 weights
+        # per generated token, whatever the batch; the fp32 K / V rows the attention kernels also stream (self: positions so
+        # far, cross: every encoder position, per batch row) are reported separately, not counted as algorithmic
+        ach = step_bytes["survey_weight_bytes"] / (sec / max(1, f["launches"])) / 1e9
+        all_bytes = f["bytes"] / sec / 1e9
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": step_bytes["survey_weight_bytes"],
+                "kv_cache_bytes_per_launch": f["bytes"] / max(1, f["launches"]) - step_bytes["streamed_weight_bytes"],
+                "weight_bytes_streamed_per_launch": step_bytes["streamed_weight_bytes"],
+                "achieved_incl_kv_cache": all_bytes, "frac_incl_kv_cache": all_bytes / HBM_PEAK_GBS,
+                "rows_per_launch": step_bytes["rows"]}
+    elif base.startswith(("gemv", "skinny", "step_graph", "vocab3", "resblock_pair_c16", "resblock_pair_c32")):
         # weight streaming (decoder step) / narrow vocoder stages: HBM-bound kernels
         ach = f["bytes"] / sec / 1e9
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
@@ -110,8 +125,8 @@ def roofline_of(fams):
                 "mfma_issue_frac": 2.0 * ach / MFMA_F16_PEAK_TFLOPS}
     traffic, traffic_from = pmc_traffic(name)
     roof.update({"traffic": traffic, "traffic_from": traffic_from, "kernel": name, "launches": f["launches"], "avg_launch_us": avg_us,
-                 "algorithmic_flops_per_launch": f["flops"] / max(1, f["launches"]),
-                 "algorithmic_bytes_per_launch": f["bytes"] / max(1, f["launches"])})
+                 "algorithmic_flops_per_launch": f["flops"] / max(1, f["launches"])})
+    roof.setdefault("algorithmic_bytes_per_launch", f["bytes"] / max(1, f["launches"]))
     total = sum(v["ms"] for v in fams.values())
     shares = {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
@@ -121,44 +136,67 @@ def roofline_of(fams):
     return roof, shares
 
 
+def csrc_sha() -> str:
+    """Digest of the kernel sources of this tree (scripts/pmc_summary.py stamps the same digest into a capture)."""
+    import hashlib
+
+    root = ROOT / "seamless_communication_amd" / "csrc"
+    h = hashlib.sha256()
+    for f in sorted(list(root.glob("*.hip")) + list(root.glob("*.h")) + list(root.glob("*.cpp"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(family: str):
-    """(HBM bytes per launch, source file) of the kernel family from the newest committed rocprofv3 PMC summary under
-    profiles/ (FETCH_SIZE / WRITE_SIZE collected in separate passes of this command line, FETCH_SIZE doubled per the
-    gfx950 correction of MI355X_MICROARCH.md; scripts/pmc_summary.py).  bench.py cannot run the PMC passes on itself:
-    the number is NOT measured in this run, `traffic_from` names the file; (None, None) when there is none."""
+    """(HBM bytes per launch, source) of the kernel family from the newest committed rocprofv3 PMC summary under profiles/
+    (FETCH_SIZE / WRITE_SIZE collected in separate passes of this command line by `scripts/gpu.sh TAG pmc`, FETCH_SIZE
+    doubled per the gfx950 correction of MI355X_MICROARCH.md; scripts/pmc_summary.py).  bench.py cannot run the PMC passes
+    on itself: the number is NOT measured in this run.  A capture carries the digest of the kernel sources it was made
+    with; when that differs from the tree bench.py runs from the capture is STALE: (None, "stale ...")."""
     import csv
     import glob
 
-    keys = {"gemm_128x128_presplit": ("gemm_ps_kernel<128, 128>",), "gemm_128x128_fast_split": ("gemm_fast", "<128, 128, 2, 2, false"),
+    fam = family.split(":")[-1]
+    keys = {"gemm_128x128_presplit": ("gemm_ps_kernel<128, 128",), "gemm_256x256_presplit": ("gemm_ps_kernel<256, 256",),
+            "gemm_128x128_fast_split": ("gemm_fast", "<128, 128, 2, 2, false"),
             "gemm_128x128_vecA_split": ("gemm_kernel<128, 128, 2, 2, 1, true>",), "skinny_m32": ("skinny_kernel<1, 1",),
-            "skinny_m64": ("skinny_kernel<2, 1",), "gemvp_m32": ("gemvp_kernel<1,",), "gemvp_m64": ("gemvp_kernel<2,",)}.get(family.split(":")[-1])
-    files = sorted(glob.glob(str(ROOT / "profiles" / "r2*pmc_hbm_traffic*.csv")))
-    if family.split(":")[-1] == "step_graph" and files:
-        # one replayed decoder step = all launches between two position increments: sum the step's kernels of the PMC run
-        # (which launches them eagerly, --no-graph) and divide by the number of steps (= add_i32 launches)
-        step_kernels = ("gemvp_kernel<", "reduce_ln_kernel", "dattn_kernel<", "argmax_finalize_kernel", "add_i32_kernel")
-        try:
-            total, steps = 0.0, 0
-            with open(files[-1], newline="") as fh:
-                for row in csv.DictReader(fh):
-                    if any(k in row["kernel"] for k in step_kernels):
-                        total += float(row["hbm_bytes_per_launch_corrected"]) * int(row["launches"])
-                        if "add_i32_kernel" in row["kernel"]:
-                            steps = int(row["launches"])
-            if steps > 0 and total > 0:
-                return total / steps, "profiles/" + Path(files[-1]).name + " (sum over the kernels of a step / steps)"
-        except Exception:
-            return None, None
+            "skinny_m64": ("skinny_kernel<2, 1",), "gemvp_m32": ("gemvp_kernel<1,",), "gemvp_m64": ("gemvp_kernel<2,",),
+            "glu_dwconv_ln": ("glu_dwconv_ln_kernel",), "attention_shaw": ("attn_mfma16_kernel<1>",)}.get(fam)
+    files = sorted(glob.glob(str(ROOT / "profiles" / "r[0-9]*pmc_hbm_traffic*.csv")),
+                   key=lambda f: (int(Path(f).name[1:].split("_")[0]) if Path(f).name[1:].split("_")[0].isdigit() else 0, f))
+    if not files:
         return None, None
-    if not keys or not files:
-        return None, None
+    newest = files[-1]
+    name = "profiles/" + Path(newest).name
     try:
-        with open(files[-1], newline="") as fh:
-            for row in csv.DictReader(fh):
-                if all(k in row["kernel"] for k in keys):
-                    return float(row["hbm_bytes_per_launch_corrected"]), "profiles/" + Path(files[-1]).name
+        with open(newest) as fh:
+            first = fh.readline().strip()
+        stamp = first.split("=", 1)[1] if first.startswith("# csrc_sha=") else None
+        if stamp != csrc_sha():
+            return None, f"stale: {name} was captured with kernel sources {stamp or 'unknown'}, this tree is {csrc_sha()} (bash scripts/gpu.sh TAG pmc)"
+        rows = [r for r in csv.DictReader(l for l in open(newest, newline="") if not l.startswith("#"))]
     except Exception:
         return None, None
+    if fam == "step_graph":
+        # one replayed decoder step = all launches between two position increments: sum the step's kernels of the PMC run
+        # (which launches them eagerly, --no-graph) and divide by the number of steps (= add_i32 launches)
+        step_kernels = ("gemvp_kernel<", "gemv3_kernel<", "vocab3_kernel<", "reduce3_kernel<", "reduce_ln_kernel", "dattn_kernel<",
+                        "ln3_kernel", "embed3_kernel", "argmax_finalize_kernel", "add_i32_kernel")
+        total, steps = 0.0, 0
+        for row in rows:
+            if any(k in row["kernel"] for k in step_kernels):
+                total += float(row["hbm_bytes_per_launch_corrected"]) * int(row["launches"])
+                if "add_i32_kernel" in row["kernel"]:
+                    steps = int(row["launches"])
+        if steps > 0 and total > 0:
+            return total / steps, name + " (sum over the kernels of a step / steps)"
+        return None, None
+    if not keys:
+        return None, None
+    for row in rows:
+        if all(k in row["kernel"] for k in keys):
+            return float(row["hbm_bytes_per_launch_corrected"]), name
     return None, None
 
 
@@ -432,6 +470,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage_snapshot = dict(stage_ms)
+    # per-slice T2U data of the LAST TIMED pass (later runs - profiled pass, latency, extras - overwrite the views' copies)
+    t2u_snapshot = [getattr(v, "last_t2u", None) for v in batcher.views]
+    timed_text_ids = [list(t) for t in last["text_ids"]]
     # unit rows the NAR decoder / vocoder really computed in the last timed pass (length buckets) over the useful ones
     pads = [v.model.last_padding() for v in batcher.views]
     useful = sum(len(u) for u in last["units"])
@@ -485,7 +526,14 @@ def main():
         fams = prof_report(lib)
         log("profiled step done")
         if rank == 0:
-            roof, shares = roofline_of(fams)
+            M_, F_, L_, V_ = cfg.model_dim, cfg.dec_ffn_dim, cfg.dec_layers, cfg.text_vocab_size
+            step_bytes = {  # self q/k/v/out + cross q/k/v/out + FFN per layer + the tied projection
+                "survey_weight_bytes": 2.0 * (L_ * (8.0 * M_ * M_ + 2.0 * M_ * F_) + float(V_) * M_),
+                # what a step really streams: the cross-attention k / v projections run once per utterance, not per token
+                "streamed_weight_bytes": 2.0 * (L_ * (6.0 * M_ * M_ + 2.0 * M_ * F_) + float(V_) * M_),
+                "rows": B // batcher.groups,
+            }
+            roof, shares = roofline_of(fams, step_bytes)
             if roof is not None:
                 roof["profiled_pass"] = ("one slice, one stream" if (args.profile_single_stream or batcher.groups == 1) else
                                          f"the {batcher.groups} slices of the timed passes run one after the other (un-overlapped launch durations)")
@@ -512,12 +560,16 @@ def main():
         result["latency_batch1"] = {"seconds": lat, "rtf": lat / AUDIO_SECONDS,
                                     "stage_ms": {k: round(v, 3) for k, v in translator.last_stage_ms.items()}}
 
+    # ---- secondary lines (not the headline): S2TT only (BASELINE cfg 2), beam 5 (the API default), streaming p50 (cfg 5) ----
+    if rank == 0 and world == 1 and not args.no_extra:
+        result["extra"] = extra_lines(args, batcher, translator, wav_dev, ns, B, opts)
+
     if world > 1:
         dist.barrier()
 
     if rank == 0:
         # every utterance of the timed batch against the oracle's committed ids (tests/golden/fullsize_ref.json)
-        result["parity"] = parity_from_goldens(args, batcher, last, B)
+        result["parity"] = parity_from_goldens(args, batcher, {"text_ids": timed_text_ids}, B, t2u_snapshot)
         if world == 1 and not args.no_cpu_baseline:
             log("CPU baseline (oracle: warm-up + 3 passes) in a child process ...")
             base = cpu_baseline(args)
@@ -536,7 +588,56 @@ def main():
         dist.destroy_process_group()
 
 
-def parity_from_goldens(args, batcher, last, B):
+def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
+    """Secondary measurements kept in the same JSON line so that the driver records them; none of them is `value`.
+    Each is a short timed loop bracketed by device synchronisation; failures are reported, not raised."""
+    import subprocess
+
+    from seamless_communication_amd.inference import SequenceGeneratorOptions
+
+    out = {}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    try:  # BASELINE configs[1]: S2TT (Conformer encoder + NLLB text decoder only), same batch and schedule
+        dt = timed(lambda: batcher.predict(wav_dev, ns, "S2TT", "fra", text_generation_opts=opts), 3)
+        out["s2tt"] = {"metric": "S2TT utterances/s, 10 s audio, greedy, same batch / schedule as the headline", "value": B / dt,
+                       "ms_per_step": 1e3 * dt, "rtf": dt / (B * AUDIO_SECONDS)}
+    except Exception as e:  # noqa: BLE001
+        out["s2tt"] = {"error": repr(e)[:300]}
+    try:  # beam_size 5 = the default of Translator.predict (translator.py:311-313): 12 utterances x 5 beams = 60 decoder rows
+        nb5 = min(12, B)
+        o5 = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(1, 200), hard_max_seq_len=args.text_len)
+        fb, frames = translator.model.fbank(wav_dev[:nb5].contiguous(), ns[:nb5], standardize=True, pad_to_multiple=2)
+        src = {"seqs": fb, "seq_lens": torch.from_numpy(frames.astype(np.int64)), "is_ragged": False}
+        dt = timed(lambda: translator.predict(src, "S2ST", "fra", text_generation_opts=o5), 2)
+        out["s2st_beam5"] = {"metric": "S2ST utterances/s with beam_size 5 text search (device-side beam search), one stream",
+                             "value": nb5 / dt, "batch": nb5, "ms_per_step": 1e3 * dt,
+                             "stage_ms": {k: round(v, 3) for k, v in translator.last_stage_ms.items()}}
+    except Exception as e:  # noqa: BLE001
+        out["s2st_beam5"] = {"error": repr(e)[:300]}
+    try:  # BASELINE configs[4]: streaming chain, p50 wall time per 320 ms segment (child process: its own model + monotonic decoder)
+        r = subprocess.run([sys.executable, str(ROOT / "scripts" / "stream_latency.py"), "--arch", args.arch], capture_output=True,
+                           text=True, timeout=args.extra_timeout)
+        lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        if lines:
+            out["streaming"] = [{k: l.get(k) for k in ("metric", "decision_method", "segments", "p50_ms", "p90_ms", "max_ms", "rtf",
+                                                       "text_tokens_written")} for l in lines]
+        else:
+            out["streaming"] = {"error": (r.stderr or "no output")[-300:]}
+    except Exception as e:  # noqa: BLE001
+        out["streaming"] = {"error": repr(e)[:300]}
+    return out
+
+
+def parity_from_goldens(args, batcher, last, B, t2u_views):
     """Ids of the TIMED batch (last timed pass: micro-batch slices, graph replay) against the CPU oracle's ids of the same
     64 utterances, minted once by tests/golden/make_fullsize_goldens.py (oracle/pipeline.py, fp32): text ids / char ids /
     durations / unit ids of every utterance, match rates, and for every mismatching unit position the oracle's own arg-max
@@ -559,7 +660,7 @@ def parity_from_goldens(args, batcher, last, B):
     for i in range(n):
         kw = dict(text_ids=last["text_ids"][i])
         s = next(k for k, (lo, hi) in enumerate(spans) if lo <= i < hi)
-        t2u = getattr(batcher.views[s], "last_t2u", None)
+        t2u = t2u_views[s] if s < len(t2u_views) else None
         b = i - spans[s][0]
         if t2u is not None and len(t2u["unit_lens"]) == spans[s][1] - spans[s][0]:
             ncs, nu = int(t2u["char_seq_lens"][b]), int(t2u["unit_lens"][b])

@@ -369,6 +369,14 @@ int sc_op_attention(const float* d_q, const float* d_k, const float* d_v, float*
                     int32_t rel_right);
 int sc_op_glu_dwconv(const float* d_x, const float* d_w, float* d_y, int32_t nb, int32_t T, int32_t C, int32_t k,
                      const int32_t* d_lens);
+/* Fused element-wise passes of the Conformer stack (k_norm.hip); fused = 0 runs the separate launches they replace, the
+ * results must be bit-identical.  sc_op_glu_dwconv_ln: x [nb*T][2C] -> split fp16 planes [nb*T][C] of
+ * act(LayerNorm(causal_dwconv_k(GLU(x)))) (k = 31, C % 64 == 0, C <= 1024).  sc_op_layernorm2: y = LN_a(x) [rows][C] fp32
+ * and the planes of LN_b(y). */
+int sc_op_glu_dwconv_ln(const float* d_x, const float* d_w, const float* d_gamma, const float* d_beta, int32_t act, void* d_yh_f16,
+                        void* d_yl_f16, int32_t nb, int32_t T, int32_t C, int32_t k, const int32_t* d_lens, int32_t fused);
+int sc_op_layernorm2(const float* d_x, const float* d_ga, const float* d_ba, const float* d_gb, const float* d_bb, float* d_y,
+                     void* d_yh_f16, void* d_yl_f16, int32_t rows, int32_t C, int32_t fused);
 int sc_op_argmax(const float* d_logits, int32_t rows, int32_t V, int32_t* d_idx, float* d_lprob);
 
 #ifdef __cplusplus

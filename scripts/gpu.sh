@@ -12,6 +12,8 @@
 #   dtouch       the same with the weight toucher at several settings (SC_DSTEP_TOUCH), ids compared with the default run
 #   chain        scripts/chain_bench.py (each decoder-step kernel as a dependent chain in a replayed graph)
 #   micro        every scripts/micro/*.hip compiled with hipcc and run
+#   sqpmc        SQ / TCP counters of the encoder GEMM (three --pmc passes of scripts/gemm_bench.py) -> TAG_gemm_pmc_sq.txt
+#   pyt          pytest on $PYT (files / -k expressions)
 #   pstest       GEMM op tests (bit identity of the kernel variants)       gemmab   scripts/gemm_bench.py at SC_PS_TILE=128 / 256
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -19,7 +21,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; shift
 O=gpurun_out/$TAG
 BENCH_ARGS=${BENCH_ARGS:---steps 5 --warmup 2}
-PROF_ARGS=${PROF_ARGS:---steps 3 --warmup 1 --no-cpu-baseline --no-latency}
+PROF_ARGS=${PROF_ARGS:---steps 3 --warmup 1 --no-cpu-baseline --no-latency --no-extra}
 
 line() { python - "$1" <<'PY'
 import json, sys
@@ -55,7 +57,7 @@ for task in "$@"; do
     bench)
       ( timeout 900 python bench.py $BENCH_ARGS > ${O}_bench.json 2> ${O}_bench.err; echo "exit $?" >> ${O}_bench.err ); tail -3 ${O}_bench.err | cut -c1-300; line ${O}_bench.json ;;
     benchfast)
-      ( timeout 600 python bench.py $BENCH_ARGS --no-cpu-baseline --no-latency > ${O}_benchfast.json 2> ${O}_benchfast.err; echo "exit $?" >> ${O}_benchfast.err ); tail -2 ${O}_benchfast.err | cut -c1-300; line ${O}_benchfast.json ;;
+      ( timeout 600 python bench.py $BENCH_ARGS --no-cpu-baseline --no-latency --no-extra > ${O}_benchfast.json 2> ${O}_benchfast.err; echo "exit $?" >> ${O}_benchfast.err ); tail -2 ${O}_benchfast.err | cut -c1-300; line ${O}_benchfast.json ;;
     rocprof)
       rm -rf gpurun_out/${TAG}_prof
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -o bench -- python $R/bench.py $PROF_ARGS > $R/${O}_rocprof.log 2>&1; echo "exit $?" >> $R/${O}_rocprof.log )
@@ -64,12 +66,22 @@ for task in "$@"; do
       grep -E "^\{" ${O}_rocprof.log | tail -1 > ${O}_rocprof_bench.json; line ${O}_rocprof_bench.json ;;
     pmc)
       rm -rf gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write
-      PMC_ARGS=${PMC_ARGS:---steps 1 --warmup 0 --no-cpu-baseline --no-profile-step --no-latency --no-graph}
+      PMC_ARGS=${PMC_ARGS:---steps 1 --warmup 0 --no-cpu-baseline --no-profile-step --no-latency --no-graph --no-extra}
       ( cd /tmp && timeout 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -o bench -- python $R/bench.py $PMC_ARGS > $R/${O}_pmc_fetch.log 2>&1; echo "exit $?" >> $R/${O}_pmc_fetch.log )
       ( cd /tmp && timeout 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -o bench -- python $R/bench.py $PMC_ARGS > $R/${O}_pmc_write.log 2>&1; echo "exit $?" >> $R/${O}_pmc_write.log )
       python scripts/pmc_summary.py gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write > ${O}_pmc_hbm_traffic.csv 2> ${O}_pmc_summary.err
       find gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write -name "*.csv" -size +2M -delete 2>/dev/null
       head -8 ${O}_pmc_hbm_traffic.csv | cut -c1-200 ;;
+    sqpmc)
+      # matrix-pipe / wait / LDS counters of the encoder GEMM (gemm_ps_kernel<256,256>) on the shapes of scripts/gemm_bench.py:
+      # three --pmc passes (8 SQ slots each, no tracing flags), summarised per (kernel, grid) by scripts/pmc_sq_summary.py
+      rm -rf gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 gpurun_out/${TAG}_sq3
+      ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 --output-format csv -d $R/gpurun_out/${TAG}_sq1 -o g -- python $R/scripts/gemm_bench.py --quick --presplit-only > $R/${O}_sq1.log 2>&1; echo "exit $?" >> $R/${O}_sq1.log )
+      ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM --output-format csv -d $R/gpurun_out/${TAG}_sq2 -o g -- python $R/scripts/gemm_bench.py --quick --presplit-only > $R/${O}_sq2.log 2>&1; echo "exit $?" >> $R/${O}_sq2.log )
+      ( cd /tmp && timeout 300 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_sq3 -o g -- python $R/scripts/gemm_bench.py --quick --presplit-only > $R/${O}_sq3.log 2>&1; echo "exit $?" >> $R/${O}_sq3.log )
+      python scripts/pmc_sq_summary.py gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 gpurun_out/${TAG}_sq3 --filter gemm_ps > ${O}_gemm_pmc_sq.txt 2>&1
+      tail -3 ${O}_sq1.log ${O}_sq3.log | cut -c1-200; head -12 ${O}_gemm_pmc_sq.txt | cut -c1-400
+      find gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 gpurun_out/${TAG}_sq3 -name "*.csv" -size +2M -delete 2>/dev/null ;;
     dstep)
       ( timeout 300 python scripts/dstep_bench.py $DSTEP_ARGS > ${O}_dstep.txt 2>&1; echo "exit $?" >> ${O}_dstep.txt ); grep -v amdgpu ${O}_dstep.txt | tail -40 | cut -c1-200 ;;
     dtouch)

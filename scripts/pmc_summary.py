@@ -19,7 +19,22 @@ def load(d):
     return acc
 
 
+def csrc_sha() -> str:
+    """Digest of the kernel sources the capture was made with: bench.py compares it with the tree it runs from and reports
+    `traffic: null, traffic_from: "stale ..."` when a kernel source changed since the capture."""
+    import hashlib
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1] / "seamless_communication_amd" / "csrc"
+    h = hashlib.sha256()
+    for f in sorted(list(root.glob("*.hip")) + list(root.glob("*.h")) + list(root.glob("*.cpp"))):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def main():
+    print(f"# csrc_sha={csrc_sha()}")
     merged = defaultdict(dict)
     for d in sys.argv[1:]:
         for k, cs in load(d).items():

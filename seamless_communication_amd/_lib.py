@@ -125,6 +125,8 @@ SIGNATURES = {
     "sc_op_dstep_res_ln": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i]),
     "sc_op_dstep_linear_planes": (C.c_int, [_P, _P, _P, _P, _i, _i, _i, _i]),
     "sc_op_dstep_argmax": (C.c_int, [_P, _P, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _P, _P]),
+    "sc_op_glu_dwconv_ln": (C.c_int, [_P, _P, _P, _P, _i, _P, _P, _i, _i, _i, _i, _P, _i]),
+    "sc_op_layernorm2": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i]),
     "sc_op_dstep3_gemv": (C.c_int, [_i, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i]),
     "sc_op_dstep3_argmax": (C.c_int, [_P, _P, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, _P, _P]),
     "sc_op_chain_bench": (C.c_int, [_i, _i, _i, _i, _P]),

@@ -1068,6 +1068,41 @@ int sc_op_glu_dwconv(const float* d_x, const float* d_w, float* d_y, int32_t nb,
     SC_API_END
 }
 
+int sc_op_glu_dwconv_ln(const float* d_x, const float* d_w, const float* d_gamma, const float* d_beta, int32_t act, void* d_yh_f16,
+                        void* d_yl_f16, int32_t nb, int32_t T, int32_t C, int32_t k, const int32_t* d_lens, int32_t fused) {
+    SC_API_BEGIN
+    SC_CHECK(d_x && d_w && d_gamma && d_beta && d_yh_f16 && d_yl_f16, "sc_op_glu_dwconv_ln: null argument");
+    __half* yh = static_cast<__half*>(d_yh_f16);
+    __half* yl = static_cast<__half*>(d_yl_f16);
+    if (fused) {
+        launch_glu_dwconv_ln(d_x, 2 * C, d_w, d_gamma, d_beta, act, yh, yl, C, nb, T, C, k, d_lens, g_op_stream);
+    } else {
+        OpScratch scratch;
+        float* mid = scratch.get<float>((size_t)nb * T * C);
+        launch_glu_dwconv(d_x, 2 * C, d_w, mid, C, nb, T, C, k, d_lens, g_op_stream);
+        launch_layernorm_split(mid, C, d_gamma, d_beta, yh, yl, C, nb * T, C, act, nullptr, 1, g_op_stream);
+        SC_HIP(hipStreamSynchronize(g_op_stream));
+    }
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
+int sc_op_layernorm2(const float* d_x, const float* d_ga, const float* d_ba, const float* d_gb, const float* d_bb, float* d_y,
+                     void* d_yh_f16, void* d_yl_f16, int32_t rows, int32_t C, int32_t fused) {
+    SC_API_BEGIN
+    SC_CHECK(d_x && d_ga && d_ba && d_gb && d_bb && d_y && d_yh_f16 && d_yl_f16, "sc_op_layernorm2: null argument");
+    __half* yh = static_cast<__half*>(d_yh_f16);
+    __half* yl = static_cast<__half*>(d_yl_f16);
+    if (fused) {
+        launch_layernorm2_split(d_x, C, d_ga, d_ba, d_y, C, d_gb, d_bb, yh, yl, C, rows, C, g_op_stream);
+    } else {
+        launch_layernorm(d_x, C, d_ga, d_ba, d_y, C, rows, C, ACT_NONE, nullptr, 1, g_op_stream);
+        launch_layernorm_split(d_y, C, d_gb, d_bb, yh, yl, C, rows, C, ACT_NONE, nullptr, 1, g_op_stream);
+    }
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
 int sc_op_argmax(const float* d_logits, int32_t rows, int32_t V, int32_t* d_idx, float* d_lprob) {
     SC_API_BEGIN
     launch_argmax_rows(d_logits, V, rows, V, nullptr, -1, -1, -1, -1, -1, 0.f, d_idx, d_lprob, g_op_stream);

@@ -101,6 +101,91 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Two LayerNorms back to back on a row held in registers: y = LN_a(x) (fp32 rows, may alias x) and the split planes of
+// LN_b(y).  The Conformer stack ends every layer with `layer_norm` and opens the next one with `ffn1_layer_norm` on the
+// same rows (conformer_shaw/builder.py; fairseq2.cpp:733-756): one read of x instead of two.  Same expressions and
+// summation order as two layernorm_kernel<4> launches (bit-identical).
+__global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ ga,
+                                                         const float* __restrict__ ba, float* __restrict__ y, int64_t ldy,
+                                                         const float* __restrict__ gb2, const float* __restrict__ bb2,
+                                                         __half* __restrict__ yh, __half* __restrict__ yl, int64_t ldh, int rows, int C) {
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = C >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * ldx);
+    float4* yr = reinterpret_cast<float4*>(y + (int64_t)row * ldy);
+    h4_t* yhr = reinterpret_cast<h4_t*>(yh + (int64_t)row * ldh);
+    h4_t* ylr = reinterpret_cast<h4_t*>(yl + (int64_t)row * ldh);
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        v[i] = idx < nv ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + 1e-5f);
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float4 g = reinterpret_cast<const float4*>(ga)[idx], b = reinterpret_cast<const float4*>(ba)[idx];
+            v[i].x = (v[i].x - mean) * rstd * g.x + b.x;
+            v[i].y = (v[i].y - mean) * rstd * g.y + b.y;
+            v[i].z = (v[i].z - mean) * rstd * g.z + b.z;
+            v[i].w = (v[i].w - mean) * rstd * g.w + b.w;
+            yr[idx] = v[i];
+        }
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    mean = wave_sum(s) / (float)C;
+    q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float4 g = reinterpret_cast<const float4*>(gb2)[idx], b = reinterpret_cast<const float4*>(bb2)[idx];
+            const f4_t of = {(v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y, (v[i].z - mean) * rstd * g.z + b.z,
+                             (v[i].w - mean) * rstd * g.w + b.w};
+            const h4_t hi = __builtin_convertvector(of, h4_t);
+            const f4_t back = __builtin_convertvector(hi, f4_t);
+            yhr[idx] = hi;
+            ylr[idx] = __builtin_convertvector(of - back, h4_t);
+        }
+    }
+}
+
+void launch_layernorm2_split(const float* x, int64_t ldx, const float* ga, const float* ba, float* y, int64_t ldy, const float* gb2,
+                             const float* bb2, __half* yh, __half* yl, int64_t ldh, int rows, int C, hipStream_t s) {
+    SC_CHECK(C % 4 == 0 && C <= 1024 && ldx % 4 == 0 && ldy % 4 == 0 && ldh % 4 == 0 && y && yh && yl, "layernorm2_split: C=%d", C);
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(layernorm2_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, ga, ba, y, ldy, gb2, bb2, yh, yl, ldh, rows, C);
+    SC_LAUNCH_CHECK();
+}
+
 void launch_layernorm_split(const float* x, int64_t ldx, const float* gamma, const float* beta, __half* yh, __half* yl,
                             int64_t ldh, int rows, int C, int act, const int* lens, int t_per_batch, hipStream_t s) {
     SC_CHECK(C % 4 == 0 && ldx % 4 == 0 && ldh % 4 == 0 && C <= 4096 && yh && yl, "layernorm_split: C=%d ldx=%lld ldh=%lld", C,
@@ -285,6 +370,150 @@ __global__ void relpos_table_kernel(int S, int M, float* __restrict__ out) {
 
 void launch_relpos_table(int S, int M, float* out, hipStream_t s) {
     hipLaunchKernelGGL(relpos_table_kernel, dim3(cdiv((2 * S - 1) * (M / 2), 256)), dim3(256), 0, s, S, M, out);
+    SC_LAUNCH_CHECK();
+}
+
+// --------------------------------------------------------------------------------------------- //
+// glu_dwconv_ln_kernel<K, TT>: the whole middle of the Conformer convolution module in ONE pass -
+//   GLU -> causal depthwise conv (K taps) -> LayerNorm over the channels -> activation -> split fp16 planes
+// (conformer_shaw/builder.py:148-156; fairseq2 ConformerConvolution with causal_depthwise_conv, norm_type "layer_norm").
+// The unfused pair moved 428 MB + 130 MB per launch pair at full size against 196 MB of algorithmic traffic
+// (profiles/r2_bench_b64_pmc_hbm_traffic.csv): a 16-row output tile re-read a 30-row halo, the convolution's output went
+// to HBM and came back for the LayerNorm.  Here a workgroup (one thread per channel, all C channels) WALKS a time range
+// of one item: the GLU'd window lives in registers and slides by TT rows per trip (the 30-row halo is read once per time
+// range, not once per tile), the TT x C convolution outputs go to LDS, and one wave per row normalises them there and
+// writes the planes.  Bit-identical to glu_dwconv_kernel + layernorm_kernel (same expressions, same summation order).
+// --------------------------------------------------------------------------------------------- //
+template <int K, int TT>
+__global__ __launch_bounds__(1024) void glu_dwconv_ln_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ w,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                             __half* __restrict__ yh, __half* __restrict__ yl, int64_t ldh, int T, int C,
+                                                             const int* __restrict__ lens, int range) {
+    __shared__ float tile[2][TT][1024];
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const int c = threadIdx.x;  // channel (blockDim.x == C)
+    const int lane = c & 63, wv = c >> 6, waves = C >> 6;
+    const int n = blockIdx.y;
+    const int t_begin = blockIdx.x * range, t_end = min(T, t_begin + range);
+    if (t_begin >= t_end) return;
+    const int len = lens ? min(lens[n], T) : T;
+    const float* xn = x + (int64_t)n * T * ldx;
+    float wr[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) wr[j] = w[c * K + j];
+    float g[TT + K - 1];  // g[i] = GLU(x)[tc - (K - 1) + i], zero outside [0, len)
+#pragma unroll
+    for (int i = 0; i < K - 1; ++i) {
+        const int t = t_begin - (K - 1) + i;
+        float v = 0.f;
+        if (t >= 0 && t < len) {
+            const float a = xn[(int64_t)t * ldx + c];
+            const float b = xn[(int64_t)t * ldx + C + c];
+            v = a / (1.f + expf(-b));
+        }
+        g[i] = v;
+    }
+    float ra[TT], rb[TT];  // raw rows of the chunk about to be convolved (prefetched one chunk ahead)
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        const int t = t_begin + i;
+        const bool ok = t < t_end && t < len;
+        ra[i] = ok ? xn[(int64_t)t * ldx + c] : 0.f;
+        rb[i] = ok ? xn[(int64_t)t * ldx + C + c] : 0.f;
+    }
+    const int nv = C >> 2;
+    int buf = 0;
+    for (int tc = t_begin; tc < t_end; tc += TT) {
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            const int t = tc + i;
+            g[K - 1 + i] = (t < t_end && t < len) ? ra[i] / (1.f + expf(-rb[i])) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {  // next chunk's rows travel during the convolution and the LayerNorm phase
+            const int t = tc + TT + i;
+            const bool ok = t < t_end && t < len;
+            ra[i] = ok ? xn[(int64_t)t * ldx + c] : 0.f;
+            rb[i] = ok ? xn[(int64_t)t * ldx + C + c] : 0.f;
+        }
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc = fmaf(wr[j], g[tt + j], acc);
+            tile[buf][tt][c] = acc;
+        }
+        __syncthreads();
+        // LayerNorm + activation + split of the chunk's rows: one wave per row (the body of layernorm_kernel<4>)
+        for (int r = wv; r < TT && tc + r < t_end; r += waves) {
+            const float4* xr = reinterpret_cast<const float4*>(&tile[buf][r][0]);
+            const int64_t row = (int64_t)n * T + tc + r;
+            h4_t* yhr = reinterpret_cast<h4_t*>(yh + row * ldh);
+            h4_t* ylr = reinterpret_cast<h4_t*>(yl + row * ldh);
+            // (the row is re-read from LDS in each of the three passes instead of being held in 16 registers: the thread's
+            //  sliding window, taps and prefetched rows already fill the 128-register budget of a 1024-thread workgroup)
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = lane + 64 * i;
+                const float4 vv = idx < nv ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                s += (vv.x + vv.y) + (vv.z + vv.w);
+            }
+            const float mean = wave_sum(s) / (float)C;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = lane + 64 * i;
+                if (idx < nv) {
+                    const float4 vv = xr[idx];
+                    const float a = vv.x - mean, b = vv.y - mean, cc = vv.z - mean, d = vv.w - mean;
+                    q += (a * a + b * b) + (cc * cc + d * d);
+                }
+            }
+            const float var = wave_sum(q) / (float)C;
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+            const float4* g4 = reinterpret_cast<const float4*>(gamma);
+            const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = lane + 64 * i;
+                if (idx < nv) {
+                    const float4 gg = g4[idx], bb = b4[idx], vv = xr[idx];
+                    float4 o;
+                    o.x = act_f((vv.x - mean) * rstd * gg.x + bb.x, act);
+                    o.y = act_f((vv.y - mean) * rstd * gg.y + bb.y, act);
+                    o.z = act_f((vv.z - mean) * rstd * gg.z + bb.z, act);
+                    o.w = act_f((vv.w - mean) * rstd * gg.w + bb.w, act);
+                    const f4_t of = {o.x, o.y, o.z, o.w};
+                    const h4_t hi = __builtin_convertvector(of, h4_t);
+                    const f4_t back = __builtin_convertvector(hi, f4_t);
+                    yhr[idx] = hi;
+                    ylr[idx] = __builtin_convertvector(of - back, h4_t);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) g[i] = g[i + TT];  // slide the window
+        buf ^= 1;  // the next chunk's outputs go to the other tile: one barrier per chunk is enough
+    }
+}
+
+bool glu_dwconv_ln_supported(int C, int ksize) { return ksize == 31 && C % 64 == 0 && C >= 64 && C <= 1024; }
+
+void launch_glu_dwconv_ln(const float* x, int64_t ldx, const float* w, const float* gamma, const float* beta, int act, __half* yh,
+                          __half* yl, int64_t ldh, int nb, int T, int C, int ksize, const int* lens, hipStream_t s) {
+    SC_CHECK(glu_dwconv_ln_supported(C, ksize) && ldh % 4 == 0, "glu_dwconv_ln: C=%d k=%d ldh=%lld unsupported", C, ksize, (long long)ldh);
+    if (nb <= 0 || T <= 0) return;
+    constexpr int TT = 8;
+    // time ranges per item: enough workgroups for the chip, ranges of at least 32 rows (a range re-reads a 30-row halo)
+    int ranges = std::max(1, std::min(cdiv(256, nb), cdiv(T, 32)));
+    const int range = cdiv(cdiv(T, ranges), TT) * TT;
+    ranges = cdiv(T, range);
+    const double rows = (double)nb * T;
+    prof::Scope scope("glu_dwconv_ln", 2.0 * rows * C * ksize, rows * C * (8.0 + 4.0), s);
+    hipLaunchKernelGGL((glu_dwconv_ln_kernel<31, TT>), dim3(ranges, nb), dim3(C), 0, s, x, ldx, w, gamma, beta, act, yh, yl, ldh, T, C, lens,
+                       range);
     SC_LAUNCH_CHECK();
 }
 

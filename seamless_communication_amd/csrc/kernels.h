@@ -340,6 +340,10 @@ void launch_layernorm(const float* x, int64_t ldx, const float* gamma, const flo
 // same, result written as two fp16 planes hi = fp16(y), lo = fp16(y - hi) (the A operand of launch_gemm_presplit)
 void launch_layernorm_split(const float* x, int64_t ldx, const float* gamma, const float* beta, __half* yh, __half* yl,
                             int64_t ldh, int rows, int C, int act, const int* lens, int t_per_batch, hipStream_t s);
+// y = LN_a(x) as fp32 rows (may alias x) and the split planes of LN_b(y) in one pass (C <= 1024): bit-identical to
+// launch_layernorm followed by launch_layernorm_split
+void launch_layernorm2_split(const float* x, int64_t ldx, const float* ga, const float* ba, float* y, int64_t ldy, const float* gb2,
+                             const float* bb2, __half* yh, __half* yl, int64_t ldh, int rows, int C, hipStream_t s);
 // fp32 rows AND planes in one pass; the length mask zeroes the planes only
 void launch_layernorm_both(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy, __half* yh,
                            __half* yl, int64_t ldh, int rows, int C, int act, const int* lens, int t_per_batch, hipStream_t s);
@@ -349,6 +353,11 @@ void launch_split_f32(const float* x, __half* hi, __half* lo, int64_t n, hipStre
 // y[r][c] = x[r][c] * sigmoid(x[r][C + c])
 void launch_glu(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int C, hipStream_t s);
 
+// The same followed by LayerNorm over the channels + activation, written as split planes, in one pass (k = 31, C % 64 == 0,
+// C <= 1024): bit-identical to launch_glu_dwconv + launch_layernorm_split
+bool glu_dwconv_ln_supported(int C, int ksize);
+void launch_glu_dwconv_ln(const float* x, int64_t ldx, const float* w, const float* gamma, const float* beta, int act, __half* yh,
+                          __half* yl, int64_t ldh, int nb, int T, int C, int ksize, const int* lens, hipStream_t s);
 // Conformer conv middle: g = GLU(x) (masked by lens), y = causal depthwise conv_k(g)
 void launch_glu_dwconv(const float* x, int64_t ldx, const float* w, float* y, int64_t ldy, int nb, int T,
                        int C, int ksize, const int* lens, hipStream_t s, int left = -1, const float* bn_scale = nullptr,

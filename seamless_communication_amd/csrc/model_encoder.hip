@@ -151,11 +151,17 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
         launch_gemm_presplit(a, m.stream);
     };
 
+    // fused element-wise passes (SC_ENC_FUSE=0: the separate launches, same bits): GLU + depthwise conv + LayerNorm + SiLU
+    // in one kernel; a layer's closing LayerNorm together with the next layer's first one
+    static const bool fuse = !(getenv("SC_ENC_FUSE") && atoi(getenv("SC_ENC_FUSE")) == 0);
+    const bool fuse_conv = fuse && glu_dwconv_ln_supported(M, c.depthwise_conv_kernel_size);
+    const bool fuse_ln = fuse && M <= 1024;
+    bool ffn1_planes_ready = false;  // the previous layer's closing launch already wrote LN_ffn1(x) as planes
     for (int li = 0; li < c.enc_layers; ++li) {
         const ConformerLayer& l = m.enc[li];
         if (ps_ok) {
             // x += 0.5 * FFN1(LN(x))
-            ln_split(x, l.ffn1_ln, ACT_NONE);
+            if (!ffn1_planes_ready) ln_split(x, l.ffn1_ln, ACT_NONE);
             ps(hs_hi, hs_lo, l.ffn1_in, ACT_SILU, 1.f, nullptr, nullptr, ws_hi, ws_lo);
             ps(ws_hi, ws_lo, l.ffn1_out, ACT_NONE, 0.5f, x, x, nullptr, nullptr);
             // x += MHA_shaw(LN(x))
@@ -185,14 +191,26 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
             // x += Conv(LN(x))
             ln_split(x, l.conv_ln, ACT_NONE);
             ps(hs_hi, hs_lo, l.pw1, ACT_NONE, 1.f, nullptr, wide, nullptr, nullptr);
-            launch_glu_dwconv(wide, 2 * M, l.dw, att, M, n, S, M, c.depthwise_conv_kernel_size, d_lens, m.stream);
-            ln_split(att, l.conv_inner_ln, ACT_SILU);
+            if (fuse_conv) {
+                launch_glu_dwconv_ln(wide, 2 * M, l.dw, l.conv_inner_ln.g, l.conv_inner_ln.b, ACT_SILU, hs_hi, hs_lo, M, n, S, M,
+                                     c.depthwise_conv_kernel_size, d_lens, m.stream);
+            } else {
+                launch_glu_dwconv(wide, 2 * M, l.dw, att, M, n, S, M, c.depthwise_conv_kernel_size, d_lens, m.stream);
+                ln_split(att, l.conv_inner_ln, ACT_SILU);
+            }
             ps(hs_hi, hs_lo, l.pw2, ACT_NONE, 1.f, x, x, nullptr, nullptr);
             // x += 0.5 * FFN2(LN(x)); x = LN(x)
             ln_split(x, l.ffn2_ln, ACT_NONE);
             ps(hs_hi, hs_lo, l.ffn2_in, ACT_SILU, 1.f, nullptr, nullptr, ws_hi, ws_lo);
             ps(ws_hi, ws_lo, l.ffn2_out, ACT_NONE, 0.5f, x, x, nullptr, nullptr);
-            layernorm(m, x, l.final_ln, x, rows);
+            if (fuse_ln && li + 1 < c.enc_layers) {  // x = LN_final(x) and the next layer's LN_ffn1(x) planes from one read of x
+                const LNorm& nx = m.enc[li + 1].ffn1_ln;
+                launch_layernorm2_split(x, M, l.final_ln.g, l.final_ln.b, x, M, nx.g, nx.b, hs_hi, hs_lo, M, rows, M, m.stream);
+                ffn1_planes_ready = true;
+            } else {
+                layernorm(m, x, l.final_ln, x, rows);
+                ffn1_planes_ready = false;
+            }
             continue;
         }
         // x += 0.5 * FFN1(LN(x))
