@@ -172,6 +172,198 @@ __global__ __launch_bounds__(256) void row_token_lprob_kernel(const float* __res
     if (threadIdx.x == 0) out[blockIdx.x] = row[token] - (mx + logf(sm));
 }
 
+// --------------------------------------------------------------------------------------------- //
+// Chunked candidate search for large vocabularies (round 3).  beam_candidates_kernel walks beams x V logits with ONE
+// workgroup per utterance and one 4-byte load in flight per thread: at V = 256 102 that is ~1000 dependent round trips per
+// pass, 11 ms per search step at full size (the decoder step itself takes 1.5 ms).  Here every (row, chunk of V / 32) gets
+// its own workgroup with eight loads in flight per thread:
+//   beam_lse_partial_kernel   chunk max and sum exp(x - max) of a logit row;
+//   (the n-gram processor's -inf writes happen between the two, as before: the log-sum-exp is that of the unblocked row)
+//   beam_topk_partial_kernel  log-softmax from the combined chunk statistics, step rules, + the beam's cumulative score,
+//                             best K of the chunk (same expressions, same tie rule as beam_candidates_kernel);
+//   beam_merge_kernel         best K of an utterance's beams x 32 x K partial candidates.
+// --------------------------------------------------------------------------------------------- //
+constexpr int BEAM_CH = 32;
+
+// K rounds of block-wide arg-best over the heads of the threads' sorted lists (tv / ti, best first)
+__device__ __forceinline__ void block_topk(const float (&tv)[BEAM_MAX_K], const int (&ti)[BEAM_MAX_K], int K, float* s_val, int* s_idx,
+                                           int* s_winner, float* out_val, int* out_idx) {
+    const int tid = threadIdx.x;
+    int head = 0;
+    for (int r = 0; r < K; ++r) {
+        float hv = -INFINITY;
+        int hi = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < BEAM_MAX_K; ++q)
+            if (q == head) {
+                hv = tv[q];
+                hi = ti[q];
+            }
+        s_val[tid] = hv;
+        s_idx[tid] = hi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o && better(s_val[tid + o], s_idx[tid + o], s_val[tid], s_idx[tid])) {
+                s_val[tid] = s_val[tid + o];
+                s_idx[tid] = s_idx[tid + o];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            out_val[r] = s_val[0];
+            out_idx[r] = s_idx[0];
+            *s_winner = s_idx[0];
+        }
+        __syncthreads();
+        if (hi == *s_winner && hi != 0x7fffffff) ++head;  // flattened indices are unique: exactly one list advances
+        __syncthreads();
+    }
+}
+
+// insertion of (v, idx) into a thread's sorted best-K list; wv / wi = the list's current K-th entry
+__device__ __forceinline__ void list_insert(float (&tv)[BEAM_MAX_K], int (&ti)[BEAM_MAX_K], int K, float v, int idx, float& wv, int& wi) {
+    if (!better(v, idx, wv, wi)) return;
+    float cv = v;
+    int ci = idx;
+#pragma unroll
+    for (int q = 0; q < BEAM_MAX_K; ++q) {
+        if (q < K && better(cv, ci, tv[q], ti[q])) {
+            const float ov = tv[q];
+            const int oi = ti[q];
+            tv[q] = cv;
+            ti[q] = ci;
+            cv = ov;
+            ci = oi;
+        }
+        if (q == K - 1) {
+            wv = tv[q];
+            wi = ti[q];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void beam_lse_partial_kernel(const float* __restrict__ logits, int64_t ld, int V, int clen,
+                                                               float2* __restrict__ part) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+    const int start = c * clen, end = min(V, start + clen);
+    const float* row = logits + (int64_t)r * ld;
+    float mx = -INFINITY;
+    for (int i = start + tid; i < end; i += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (i + 256 * u < end) ? row[i + 256 * u] : -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mx = fmaxf(mx, v[u]);
+    }
+    mx = block_reduce_max(mx, red);
+    float sm = 0.f;
+    if (mx > -INFINITY) {
+        for (int i = start + tid; i < end; i += 256 * 8) {  // the chunk (32 KB) is cache resident now
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (i + 256 * u < end) ? row[i + 256 * u] : -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sm += expf(v[u] - mx);  // exp(-inf) = 0 for the slots behind the chunk
+        }
+    }
+    sm = block_reduce_sum(sm, red);
+    if (tid == 0) part[(int64_t)r * BEAM_CH + c] = make_float2(mx, sm);
+}
+
+// the n-gram processor alone (see beam_candidates_kernel): one workgroup per row
+__global__ __launch_bounds__(256) void ngram_block_kernel(float* logits, int64_t ld, int V, const int* __restrict__ seqs, int seq_ld, int S,
+                                                          int G) {
+    float* row = logits + (int64_t)blockIdx.x * ld;
+    const int* seq = seqs + (int64_t)blockIdx.x * seq_ld;
+    const int* tail = seq + S - (G - 1);
+    for (int j = threadIdx.x; j + G <= S; j += 256) {
+        bool same = true;
+        for (int e = 0; e + 1 < G; ++e) same = same && (seq[j + e] == tail[e]);
+        const int t = seq[j + G - 1];
+        if (same && t >= 0 && t < V) row[t] = -INFINITY;
+    }
+}
+
+__global__ __launch_bounds__(256) void beam_topk_partial_kernel(const float* __restrict__ logits, int64_t ld, int beams, int V, int clen,
+                                                                const float* __restrict__ cum, int first_step, int no_eos, int force_eos,
+                                                                int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K,
+                                                                const float2* __restrict__ part, float* __restrict__ pval,
+                                                                int* __restrict__ pidx) {
+    __shared__ float s_val[256];
+    __shared__ int s_idx[256];
+    __shared__ int s_winner;
+    const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+    const int b = r % beams;
+    float* out_val = pval + ((int64_t)r * BEAM_CH + c) * K;
+    int* out_idx = pidx + ((int64_t)r * BEAM_CH + c) * K;
+    const int start = c * clen, end = min(V, start + clen);
+    if ((first_step && b != 0) || start >= end) {  // first step: beam 0 only
+        if (tid < K) {
+            out_val[tid] = -INFINITY;
+            out_idx[tid] = 0x7fffffff;
+        }
+        return;
+    }
+    // log-sum-exp of the row from its chunk statistics (every thread the same sequence of operations)
+    float m = -INFINITY;
+    for (int q = 0; q < BEAM_CH; ++q) m = fmaxf(m, part[(int64_t)r * BEAM_CH + q].x);
+    float sm = 0.f;
+    for (int q = 0; q < BEAM_CH; ++q) {
+        const float2 p = part[(int64_t)r * BEAM_CH + q];
+        if (p.x > -INFINITY) sm += p.y * expf(p.x - m);
+    }
+    const float l = m + logf(sm);
+    const float base = cum[r];
+    const float* row = logits + (int64_t)r * ld;
+    float tv[BEAM_MAX_K];
+    int ti[BEAM_MAX_K];
+#pragma unroll
+    for (int q = 0; q < BEAM_MAX_K; ++q) {
+        tv[q] = -INFINITY;
+        ti[q] = 0x7fffffff;
+    }
+    float wv = -INFINITY;
+    int wi = 0x7fffffff;
+    for (int i = start + tid; i < end; i += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (i + 256 * u < end) ? row[i + 256 * u] : -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = i + 256 * u;
+            if (t < end) {
+                float lp = v[u] - l;
+                if (no_eos && t == eos_idx) lp = -INFINITY;
+                if (force_eos && t != eos_idx) lp = -INFINITY;
+                if (t == pad_idx) lp = -INFINITY;
+                if (t == unk_idx) lp -= unk_penalty;
+                list_insert(tv, ti, K, lp + base, b * V + t, wv, wi);
+            }
+        }
+    }
+    block_topk(tv, ti, K, s_val, s_idx, &s_winner, out_val, out_idx);
+}
+
+__global__ __launch_bounds__(256) void beam_merge_kernel(const float* __restrict__ pval, const int* __restrict__ pidx, int entries, int K,
+                                                         float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+    __shared__ float s_val[256];
+    __shared__ int s_idx[256];
+    __shared__ int s_winner;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float tv[BEAM_MAX_K];
+    int ti[BEAM_MAX_K];
+#pragma unroll
+    for (int q = 0; q < BEAM_MAX_K; ++q) {
+        tv[q] = -INFINITY;
+        ti[q] = 0x7fffffff;
+    }
+    float wv = -INFINITY;
+    int wi = 0x7fffffff;
+    for (int e = tid; e < entries; e += 256) list_insert(tv, ti, K, pval[(int64_t)n * entries + e], pidx[(int64_t)n * entries + e], wv, wi);
+    block_topk(tv, ti, K, s_val, s_idx, &s_winner, cand_val + (int64_t)n * K, cand_idx + (int64_t)n * K);
+}
+
 // beam_select_kernel: the candidate walk of one search step, one workgroup per utterance (the loop the host ran in
 // round 1: fairseq2.cpp:1463-1594 with fairseq2's EOS rule, see model_decoder.hip).  Thread 0 walks the K = 2 * beam
 // candidates (best first): an EOS candidate among the first `beam` ranks becomes a finished hypothesis (score
@@ -268,6 +460,29 @@ void launch_beam_candidates(float* logits, int64_t ld, int n_utt, int beams, int
     SC_CHECK((int64_t)beams * V < (1ll << 31) - 1, "beam search: beam * vocabulary overflows the candidate index");
     hipLaunchKernelGGL(beam_candidates_kernel, dim3(n_utt), dim3(256), 0, s, logits, ld, beams, V, cum, first_step, no_eos, force_eos,
                        pad_idx, eos_idx, unk_idx, unk_penalty, K, cand_val, cand_idx, seqs, seq_ld, S, G);
+    SC_LAUNCH_CHECK();
+}
+
+// workspace of the chunked search: floats = rows * 32 * 2 (chunk statistics) + rows * 32 * K (values), ints = rows * 32 * K
+bool beam_chunked(int V) { return V >= 32768; }
+size_t beam_ws_floats(int rows, int K) { return (size_t)rows * BEAM_CH * (2 + K); }
+size_t beam_ws_ints(int rows, int K) { return (size_t)rows * BEAM_CH * K; }
+
+void launch_beam_candidates_chunked(float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step, int no_eos,
+                                    int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K, float* cand_val,
+                                    int* cand_idx, const int* seqs, int seq_ld, int S, int G, float* ws_f, int* ws_i, hipStream_t s) {
+    SC_CHECK(K >= 1 && K <= BEAM_MAX_K && beams >= 1 && beams <= BEAM_MAX_K, "beam search: beam_size %d / K %d out of range (max %d candidates)",
+             beams, K, BEAM_MAX_K);
+    SC_CHECK((int64_t)beams * V < (1ll << 31) - 1, "beam search: beam * vocabulary overflows the candidate index");
+    const int rows = n_utt * beams;
+    const int clen = (int)align_up(cdiv(V, BEAM_CH), 4);
+    float2* part = reinterpret_cast<float2*>(ws_f);
+    float* pval = ws_f + (size_t)rows * BEAM_CH * 2;
+    hipLaunchKernelGGL(beam_lse_partial_kernel, dim3(BEAM_CH, rows), dim3(256), 0, s, logits, ld, V, clen, part);
+    if (seqs && G > 0 && G < S) hipLaunchKernelGGL(ngram_block_kernel, dim3(rows), dim3(256), 0, s, logits, ld, V, seqs, seq_ld, S, G);
+    hipLaunchKernelGGL(beam_topk_partial_kernel, dim3(BEAM_CH, rows), dim3(256), 0, s, logits, ld, beams, V, clen, cum, first_step, no_eos,
+                       force_eos, pad_idx, eos_idx, unk_idx, unk_penalty, K, part, pval, ws_i);
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(n_utt), dim3(256), 0, s, pval, ws_i, beams * BEAM_CH * K, K, cand_val, cand_idx);
     SC_LAUNCH_CHECK();
 }
 

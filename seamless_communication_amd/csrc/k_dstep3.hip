@@ -507,7 +507,8 @@ __global__ __launch_bounds__(256) void kgm_to_rows_kernel(const float* __restric
 // --------------------------------------------------------------------------------------------- //
 // FULLK: K == 1024 (no per-k-step range checks in the weight stream); HALVES2: two row halves per tile group - the second
 // reader of a tile must find it in the XCD's L2, so the weight loads carry no streaming hint then
-template <int WAVES, bool FULLK, bool HALVES2>
+// LOGITS: the raw logits go to HBM ([rows][ldl] fp32: what the beam search's candidate kernel reads) instead of the fused rules
+template <int WAVES, bool FULLK, bool HALVES2, bool LOGITS>
 __global__ __launch_bounds__(64 * WAVES) void vocab3_kernel(Vocab3Args p) {
     constexpr int T = 64 * WAVES;
     __shared__ __attribute__((aligned(16))) unsigned char act_lds[2 * 65536];
@@ -585,6 +586,26 @@ __global__ __launch_bounds__(64 * WAVES) void vocab3_kernel(Vocab3Args p) {
                 if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // B operands are fetched four fragments ahead, not sixteen
             }
         }
+        if (LOGITS) {  // accumulator registers 4q .. 4q+3 are four consecutive features: one 16-byte store each
+            if (m < p.M) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int feat = t * 32 + 8 * q4 + 4 * h;
+                    float* dst = p.logits + (int64_t)m * p.ldl + feat;
+                    if (feat + 3 < p.N && (p.ldl & 3) == 0) {
+                        f32x4_t v = {acc[4 * q4], acc[4 * q4 + 1], acc[4 * q4 + 2], acc[4 * q4 + 3]};
+                        if (p.bias) v += f32x4_t{p.bias[feat], p.bias[feat + 1], p.bias[feat + 2], p.bias[feat + 3]};
+                        *reinterpret_cast<f32x4_t*>(dst) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (feat + e < p.N) dst[e] = acc[4 * q4 + e] + (p.bias ? p.bias[feat + e] : 0.f);
+                    }
+                }
+            }
+            t += WAVES;
+            continue;
+        }
         // generation step rules on the 16 logits this lane holds for row m (argmax_rows_kernel / gemvp EPI_ARGMAX)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -613,6 +634,7 @@ __global__ __launch_bounds__(64 * WAVES) void vocab3_kernel(Vocab3Args p) {
         t += WAVES;
     }
 #undef V3_LOADW
+    if (LOGITS) return;
     // the two k halves of a lane pair hold different features of the same row: combine, then across the waves
     {
         const float ob = __shfl_xor(best, 32);
@@ -780,13 +802,21 @@ void launch_vocab3(const Vocab3Args& a0, hipStream_t s) {
     const int groups = vocab3_groups(a.M);
     a.halves = a.M > 32 ? 2 : 1;
     a.tpg = cdiv(a.NT_total, groups);
-    SC_CHECK(a.am_tiles_cap >= groups, "vocab3: arg-max partial buffer holds %d groups, need %d", a.am_tiles_cap, groups);
-    prof::Scope scope(a.M <= 32 ? "vocab3_m32" : "vocab3_m64", 2.0 * a.M * (double)a.N * a.K, 2.0 * a.N * (double)a.K, s);
+    SC_CHECK(a.logits || a.am_tiles_cap >= groups, "vocab3: arg-max partial buffer holds %d groups, need %d", a.am_tiles_cap, groups);
+    SC_CHECK(!a.logits || a.ldl >= a.N, "vocab3: logits row stride %lld < N=%d", (long long)a.ldl, a.N);
+    prof::Scope scope(a.M <= 32 ? "vocab3_m32" : "vocab3_m64", 2.0 * a.M * (double)a.N * a.K,
+                      2.0 * a.N * (double)a.K + (a.logits ? 4.0 * a.M * (double)a.N : 0.0), s);
     const dim3 grid(groups * a.halves);
-    if (a.K == 1024 && a.halves == 2) hipLaunchKernelGGL((vocab3_kernel<8, true, true>), grid, dim3(512), 0, s, a);
-    else if (a.K == 1024) hipLaunchKernelGGL((vocab3_kernel<8, true, false>), grid, dim3(512), 0, s, a);
-    else if (a.halves == 2) hipLaunchKernelGGL((vocab3_kernel<8, false, true>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((vocab3_kernel<8, false, false>), grid, dim3(512), 0, s, a);
+#define V3_LAUNCH(FK, H2)                                                                                          \
+    {                                                                                                              \
+        if (a.logits) hipLaunchKernelGGL((vocab3_kernel<8, FK, H2, true>), grid, dim3(512), 0, s, a);              \
+        else hipLaunchKernelGGL((vocab3_kernel<8, FK, H2, false>), grid, dim3(512), 0, s, a);                      \
+    }
+    if (a.K == 1024 && a.halves == 2) V3_LAUNCH(true, true)
+    else if (a.K == 1024) V3_LAUNCH(true, false)
+    else if (a.halves == 2) V3_LAUNCH(false, true)
+    else V3_LAUNCH(false, false)
+#undef V3_LAUNCH
     SC_LAUNCH_CHECK();
 }
 

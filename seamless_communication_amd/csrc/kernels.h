@@ -317,6 +317,8 @@ struct Vocab3Args {
     int RB = 32;
     int M = 0, N = 0, K = 0;
     const float* bias = nullptr;
+    float* logits = nullptr;    // != null: raw logits [M][ldl] fp32 go to HBM and the fused rules are skipped (beam search)
+    int64_t ldl = 0;
     float4* am_part = nullptr;  // [vocab3_groups(M)][M]
     int am_tiles_cap = 0;
     float* am_eos_logit = nullptr;
@@ -412,6 +414,14 @@ void launch_decode_attention(const float* q, int64_t ldq, const float* k_new, co
 void launch_beam_candidates(float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step,
                             int no_eos, int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K,
                             float* cand_val, int* cand_idx, const int* seqs, int seq_ld, int S, int G, hipStream_t s);
+// the same search for large vocabularies: every (row, 1/32 of V) on its own workgroup, then a merge per utterance;
+// ws_f / ws_i: workspaces of beam_ws_floats / beam_ws_ints elements
+bool beam_chunked(int V);
+size_t beam_ws_floats(int rows, int K);
+size_t beam_ws_ints(int rows, int K);
+void launch_beam_candidates_chunked(float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step, int no_eos,
+                                    int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K, float* cand_val,
+                                    int* cand_idx, const int* seqs, int seq_ld, int S, int G, float* ws_f, int* ws_i, hipStream_t s);
 // device-resident beam-search state of one sc_generate_text call (k_beam.hip: beam_select_kernel)
 struct BeamSelectArgs {
     const float* cand_val = nullptr;  // [n][K] best first

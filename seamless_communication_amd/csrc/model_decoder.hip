@@ -1348,7 +1348,7 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     int* d_src_row = c.d_enc_lens + nb;
     const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
     Buf<float> x(&m.pool, (size_t)nb * M), h(&m.pool, (size_t)nb * M), wide(&m.pool, (size_t)nb * wideN), att(&m.pool, (size_t)nb * M),
-        hN(&m.pool, (size_t)nb * M), logits(&m.pool, (size_t)nb * V);
+        hN(&m.pool, (size_t)nb * M), logits(&m.pool, (size_t)nb * (V + 3));
     Buf<float> partial(&m.pool, (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * nb * 3 * M);
     Buf<float> d_cum(&m.pool, (size_t)nb), d_cand_val(&m.pool, (size_t)n * K), d_pref(&m.pool, (size_t)n);
     Buf<int> d_cand_idx(&m.pool, (size_t)n * K);
@@ -1359,9 +1359,25 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     c.att = att;
     c.hN = hN;
     c.logits = logits;
-    {
-        if (step2_eligible(m, W, nb)) alloc_step2(m, c, cfg.dec_ffn_dim);  // second-generation step kernels (<= 64 live rows)
+    Buf<float> xg3(&m.pool, 4), qkvr3(&m.pool, 4);
+    if (step2_eligible(m, W, nb)) {  // packed-weight step kernels (<= 64 live rows)
+        alloc_step2(m, c, cfg.dec_ffn_dim);
+        if (step3_eligible(m, W, nb)) {  // third-generation chain (the step runs without its projection here)
+            c.gen3 = true;
+            xg3 = Buf<float>(&m.pool, (size_t)M * c.rb);
+            qkvr3 = Buf<float>(&m.pool, (size_t)nb * M);
+            c.xg = xg3;
+            c.qkvr = qkvr3;
+            c.rg_small = env_int("SC_D3_RG_SMALL", 16);
+            c.rg_ffn = env_int("SC_D3_RG_FFN", 32);
+            c.ffn_in_mode = env_int("SC_D3_FFN_IN", 1);
+            c.ffn_out_mode = env_int("SC_D3_FFN_OUT", 1);
+        }
     }
+    // vocabulary projection of the live rows: the LDS-staged streaming kernel on the packed embedding when the step left
+    // the decoder output as split planes (<= 64 rows: at 60 rows the tiled GEMM needed ~10 ms per step, this one ~0.12)
+    const bool proj_v3 = c.rb > 0 && W.embed_p != nullptr && vocab3_supported(nb, V, M);
+    const int64_t ldl = proj_v3 ? (int64_t)align_up(V, 4) : V;  // logits row stride: 16-byte aligned rows for the streaming kernel
     // self-attention K/V caches of all layers in one allocation, twice (re-ordered from one into the other)
     const int64_t layer_stride = (int64_t)nb * max_len * M;
     Buf<float> kv_a(&m.pool, (size_t)2 * L * layer_stride), kv_b(&m.pool, (size_t)2 * L * layer_stride);
@@ -1389,6 +1405,20 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     proj.kpad = M;
     proj.in = M;
     proj.out = V;
+
+    const bool chunked = beam_chunked(V);  // large vocabulary: candidate search spread over (row, chunk) workgroups
+    Buf<float> ws_f(&m.pool, chunked ? beam_ws_floats(nb, K) : 4);
+    Buf<int> ws_i(&m.pool, chunked ? beam_ws_ints(nb, K) : 4);
+    auto project_rows = [&]() {
+        if (proj_v3) {
+            Vocab3Args v;
+            v.Wp = W.embed_p, v.Ah = c.hH, v.Al = c.hL, v.RB = c.rb, v.M = nb, v.N = V, v.K = M;
+            v.logits = c.logits, v.ldl = ldl;
+            launch_vocab3(v, m.stream);
+        } else {
+            linear(m, c.hN, M, proj, nullptr, 0, c.logits, V, nb, ACT_NONE, 1.f);
+        }
+    };
 
     // ---- search state: device resident (sequences, cumulative scores, finished hypotheses, counters) ----------
     std::vector<int32_t> seqs((size_t)nb * max_len, cfg.pad_idx), init(8 + 5 * nb, 0), tok(nb);
@@ -1421,8 +1451,8 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     // ---- prompt echo: feed prefix[:-1]; cum = sum_j lprob(prefix[j] | prefix[<j]) (the same for every beam row) ----
     for (int t = 0; t + 1 < prefix_len; ++t) {
         decoder_step(m, c, /*project=*/false);
-        linear(m, c.hN, M, proj, nullptr, 0, c.logits, V, nb, ACT_NONE, 1.f);
-        launch_row_token_lprob(c.logits, V, n, V, B, h_prefix[t + 1], d_pref, m.stream);
+        project_rows();
+        launch_row_token_lprob(c.logits, ldl, n, V, B, h_prefix[t + 1], d_pref, m.stream);
         for (int r = 0; r < nb; ++r) tok[r] = h_prefix[t + 1];
         SC_HIP(hipMemcpyAsync(pref.data(), d_pref.get(), (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
         SC_HIP(hipMemcpyAsync(c.d_tok, tok.data(), (size_t)nb * 4, hipMemcpyHostToDevice, m.stream));
@@ -1436,12 +1466,18 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     int remaining = n;
     for (int step = start; step <= max_len - 2 && remaining > 0; ++step) {
         decoder_step(m, c, /*project=*/false);  // feeds d_tok at position `step`, advances *d_pos
-        linear(m, c.hN, M, proj, nullptr, 0, c.logits, V, nb, ACT_NONE, 1.f);
+        project_rows();
         // n-gram processor: not on the forced-EOS step (blocking EOS there would leave no hypothesis)
         const bool ban = G > 0 && step != max_len - 2;
-        launch_beam_candidates(c.logits, V, n, B, V, d_cum, step == start, step < o.min_seq_len, step == max_len - 2, cfg.pad_idx,
-                               cfg.eos_idx, cfg.unk_idx, o.unk_penalty, K, d_cand_val, d_cand_idx, ban ? d_seqs_cur : nullptr, max_len,
-                               step + 1, G, m.stream);
+        if (chunked) {
+            launch_beam_candidates_chunked(c.logits, ldl, n, B, V, d_cum, step == start, step < o.min_seq_len, step == max_len - 2,
+                                           cfg.pad_idx, cfg.eos_idx, cfg.unk_idx, o.unk_penalty, K, d_cand_val, d_cand_idx,
+                                           ban ? d_seqs_cur : nullptr, max_len, step + 1, G, ws_f, ws_i, m.stream);
+        } else {
+            launch_beam_candidates(c.logits, ldl, n, B, V, d_cum, step == start, step < o.min_seq_len, step == max_len - 2, cfg.pad_idx,
+                                   cfg.eos_idx, cfg.unk_idx, o.unk_penalty, K, d_cand_val, d_cand_idx, ban ? d_seqs_cur : nullptr, max_len,
+                                   step + 1, G, m.stream);
+        }
         BeamSelectArgs a;
         a.cand_val = d_cand_val;
         a.cand_idx = d_cand_idx;
