@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 5
+#define SC_ABI_VERSION 6
 #define SC_MAX_UPSAMPLES 8
 #define SC_MAX_RESBLOCK_KERNELS 4
 #define SC_MAX_RESBLOCK_DILATIONS 4
@@ -357,6 +357,10 @@ int sc_op_linear_presplit(const float* d_x, const void* d_w_f16, const float* d_
 int sc_op_conv1d_presplit(const float* d_x, const void* d_w_f16_packed, const float* d_bias, const float* d_res, float* d_y,
                           void* d_yh_f16, void* d_yl_f16, int32_t nb, int32_t t, int32_t cin, int32_t cout, int32_t k, int32_t pad,
                           int32_t dil, const unsigned char* d_row_valid, int32_t act);
+/* The same dilation pair as the wide vocoder stages (C >= 128, C % 32 == 0, odd k) run it: LeakyReLU(x) as split fp16 planes,
+ * both convolutions on the DMA-fed GEMM in implicit-convolution mode (weights packed by sc_op_pack_conv_weight). */
+int sc_op_resblock_pair_ps(const float* d_x, const void* d_w1_packed, const float* d_b1, const void* d_w2_packed, const float* d_b2,
+                           float* d_out, int32_t nb, int32_t T, int32_t C, int32_t k, int32_t dil);
 /* One HiFi-GAN ResBlock dilation pair (hifigan.py:114-121) fused in one kernel for C in {16, 32, 64}:
  * out = x + conv2_{k,1}(lrelu(conv1_{k,dil}(lrelu(x)) + b1)) + b2, weights packed by sc_op_pack_conv_weight
  * (rows padded to a multiple of 32); with d_avg_a/d_avg_b: out = ((a + b) + that) / 3. */

@@ -11,7 +11,7 @@ from typing import Optional
 
 LIB_PATH = Path(__file__).resolve().parent / "libseamless_hip.so"
 
-SC_ABI_VERSION = 5
+SC_ABI_VERSION = 6
 SC_MAX_UPSAMPLES = 8
 SC_MAX_RESBLOCK_KERNELS = 4
 SC_MAX_RESBLOCK_DILATIONS = 4
@@ -125,6 +125,7 @@ SIGNATURES = {
     "sc_op_dstep_res_ln": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i]),
     "sc_op_dstep_linear_planes": (C.c_int, [_P, _P, _P, _P, _i, _i, _i, _i]),
     "sc_op_dstep_argmax": (C.c_int, [_P, _P, _i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_float, _i, _P, _P]),
+    "sc_op_resblock_pair_ps": (C.c_int, [_P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _i]),
     "sc_op_glu_dwconv_ln": (C.c_int, [_P, _P, _P, _P, _i, _P, _P, _i, _i, _i, _i, _P, _i]),
     "sc_op_layernorm2": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i]),
     "sc_op_dstep3_gemv": (C.c_int, [_i, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i]),

@@ -1007,6 +1007,30 @@ int sc_op_conv1d_presplit(const float* d_x, const void* d_w_f16_packed, const fl
     SC_API_END
 }
 
+/* One HiFi-GAN dilation pair  out = x + conv2_{k,1}(lrelu(conv1_{k,dil}(lrelu(x)) + b1)) + b2  the way the wide vocoder
+ * stages (C >= 128) run it: LeakyReLU(x) split into fp16 planes, both convolutions on the DMA-fed GEMM in implicit-convolution
+ * mode, the first one's epilogue writing the LeakyReLU'd planes the second one reads (model_t2u.hip: vocode_batch). */
+int sc_op_resblock_pair_ps(const float* d_x, const void* d_w1_packed, const float* d_b1, const void* d_w2_packed, const float* d_b2,
+                           float* d_out, int32_t nb, int32_t T, int32_t C, int32_t k, int32_t dil) {
+    SC_API_BEGIN
+    SC_CHECK(d_x && d_w1_packed && d_w2_packed && d_out && C % 32 == 0 && (k & 1), "sc_op_resblock_pair_ps: bad argument");
+    OpScratch scratch;
+    const size_t n = (size_t)nb * T * C;
+    __half* xh = scratch.get<__half>(n);
+    __half* xl = scratch.get<__half>(n);
+    __half* th = scratch.get<__half>(n);
+    __half* tl = scratch.get<__half>(n);
+    launch_lrelu_split_f32(d_x, 0.1f, xh, xl, (int64_t)n, g_op_stream);
+    Model tmp;
+    Conv c1, c2;
+    c1.w = static_cast<const __half*>(d_w1_packed), c1.b = d_b1, c1.cin = c1.cout = C, c1.k = k, c1.kpad = C * k;
+    c2.w = static_cast<const __half*>(d_w2_packed), c2.b = d_b2, c2.cin = c2.cout = C, c2.k = k, c2.kpad = C * k;
+    conv1d_presplit(tmp, xh, xl, c1, nullptr, nullptr, th, tl, nb, T, (k * dil - dil) / 2, dil, nullptr, ACT_NONE, 0, nullptr, 0.1f);
+    conv1d_presplit(tmp, th, tl, c2, d_x, d_out, nullptr, nullptr, nb, T, (k - 1) / 2, 1, nullptr, ACT_NONE, 0, nullptr, 0.1f);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
 int sc_op_resblock_pair(const float* d_x, const void* d_w1_packed, const float* d_b1, const void* d_w2_packed,
                         const float* d_b2, float* d_out, int32_t nb, int32_t T, int32_t C, int32_t k, int32_t dil,
                         float slope, const float* d_avg_a, const float* d_avg_b) {

@@ -93,6 +93,10 @@ __device__ __forceinline__ void ps_epilogue(const GemmPsArgs& p, const float* ep
             if (p.res && !dead) v += *reinterpret_cast<const f4_t*>(p.res + m * p.ldr + col);
             if (p.C) *reinterpret_cast<f4_t*>(p.C + m * p.ldc + col) = v;
             if (p.Ch) {
+                if (p.plane_neg_slope != 1.0f) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f) + p.plane_neg_slope * fminf(v[e], 0.f);
+                }
                 const h4_t hi = __builtin_convertvector(v, h4_t);
                 *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(p.Ch) + m * p.ldcs + col) = hi;
                 *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(p.Cl) + m * p.ldcs + col) =
@@ -106,6 +110,7 @@ __device__ __forceinline__ void ps_epilogue(const GemmPsArgs& p, const float* ep
                 if (p.res && !dead) x += p.res[m * p.ldr + col + e];
                 if (p.C) p.C[m * p.ldc + col + e] = x;
                 if (p.Ch) {
+                    if (p.plane_neg_slope != 1.0f) x = fmaxf(x, 0.f) + p.plane_neg_slope * fminf(x, 0.f);
                     const _Float16 h = (_Float16)x;
                     reinterpret_cast<_Float16*>(p.Ch)[m * p.ldcs + col + e] = h;
                     reinterpret_cast<_Float16*>(p.Cl)[m * p.ldcs + col + e] = (_Float16)(x - (float)h);
@@ -442,7 +447,8 @@ void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s) {
     static const int max_tile = getenv("SC_PS_TILE") ? atoi(getenv("SC_PS_TILE")) : 256;
     const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
     const int64_t tiles256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
-    if (max_tile >= 256 && tiles256 >= 224) launch_ps_cfg<256, 256, 4, 2>(a, s);
+    // (N <= 128: a 256-wide tile would idle half its columns - the 128-channel vocoder stage)
+    if (max_tile >= 256 && tiles256 >= 224 && a.N > 128) launch_ps_cfg<256, 256, 4, 2>(a, s);
     else if (tiles128 >= 256) launch_ps_cfg<128, 128, 2, 2>(a, s);
     else launch_ps_cfg<64, 64, 2, 2>(a, s);
     SC_LAUNCH_CHECK();

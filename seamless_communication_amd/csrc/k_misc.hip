@@ -385,6 +385,26 @@ void launch_split_f32(const float* x, __half* hi, __half* lo, int64_t n, hipStre
     SC_LAUNCH_CHECK();
 }
 
+__global__ void lrelu_split_f32_kernel(const float* __restrict__ x, float neg_slope, __half* __restrict__ hi, __half* __restrict__ lo,
+                                       int64_t n4) {
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f4_t v = reinterpret_cast<const f4_t*>(x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f) + neg_slope * fminf(v[e], 0.f);  // the expression of k_gemm2.hip's in_act
+        const h4_t h = __builtin_convertvector(v, h4_t);
+        reinterpret_cast<h4_t*>(hi)[i] = h;
+        reinterpret_cast<h4_t*>(lo)[i] = __builtin_convertvector(v - __builtin_convertvector(h, f4_t), h4_t);
+    }
+}
+void launch_lrelu_split_f32(const float* x, float neg_slope, __half* hi, __half* lo, int64_t n, hipStream_t s) {
+    SC_CHECK(n % 4 == 0, "lrelu_split_f32: n must be a multiple of 4");
+    if (n <= 0) return;
+    hipLaunchKernelGGL(lrelu_split_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, neg_slope, hi, lo, n / 4);
+    SC_LAUNCH_CHECK();
+}
+
 void launch_avg3(const float* a, const float* b, const float* c, float* out, int64_t n, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(avg3_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, c, out, n);

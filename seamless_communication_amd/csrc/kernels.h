@@ -77,6 +77,9 @@ struct GemmPsArgs {
     int act = ACT_NONE;
     float alpha = 1.0f;
     int split = 1;  // 0: only the hi plane is multiplied (A rounded to fp16 once) - precision study, never the default
+    // the planes Ch / Cl hold max(v, 0) + plane_neg_slope * min(v, 0) of the value v that goes to C (1: v itself): the next
+    // convolution's LeakyReLU input of the HiFi-GAN ResBlocks, while C keeps the un-activated residual stream
+    float plane_neg_slope = 1.0f;
     // implicit 1-D convolution over the rows of the planes (stride 1): the planes hold [items][rows_per_item][conv_cin]
     // (lda = row stride), K = conv_taps * conv_cin in tap-major order (the packed Conv1d weight layout), output row (i, t)
     // reads input rows t + tap * conv_dil - conv_pad of item i, rows outside [0, rows_per_item) as zeros.  conv_taps = 0:
@@ -349,6 +352,8 @@ void launch_layernorm2_split(const float* x, int64_t ldx, const float* ga, const
 // fp32 rows AND planes in one pass; the length mask zeroes the planes only
 void launch_layernorm_both(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy, __half* yh,
                            __half* yl, int64_t ldh, int rows, int C, int act, const int* lens, int t_per_batch, hipStream_t s);
+// the same of max(x, 0) + neg_slope * min(x, 0) (LeakyReLU): the first convolution of a HiFi-GAN ResBlock on the DMA GEMM
+void launch_lrelu_split_f32(const float* x, float neg_slope, __half* hi, __half* lo, int64_t n, hipStream_t s);
 // hi = fp16(x), lo = fp16(x - hi), elementwise over n values (n % 4 == 0)
 void launch_split_f32(const float* x, __half* hi, __half* lo, int64_t n, hipStream_t s);
 

@@ -517,6 +517,51 @@ void vocode_batch(Model& m, const int* d_units, const int* d_lang, const int* d_
         // the third ResBlock also applies the average over the three ResBlocks (k_resblock.hip)
         bool fused_avg = false;
         x = Buf<float>(&m.pool, sz);
+        // wide stages (C >= 128, C % 32 == 0): the ResBlock convolutions on the DMA-fed GEMM in implicit-convolution mode
+        // (k_gemm_ps.hip).  Its activation operand is a pair of fp16 planes: LeakyReLU(y) is split once for the three
+        // ResBlocks, every convolution's epilogue writes the LeakyReLU'd planes the next one reads (plane_neg_slope) next to
+        // the fp32 residual stream.  SC_VOC_PS=0: the register-staged kernel (k_gemm2.hip) as before.
+        static const bool voc_ps = !(getenv("SC_VOC_PS") && atoi(getenv("SC_VOC_PS")) == 0);
+        bool wide_ps = voc_ps && g_force_general_gemm.load(std::memory_order_relaxed) == 0 && ch >= 128 && ch % 32 == 0 &&
+                       (int64_t)n * t2 * ch * 2 < (1ll << 31);
+        for (int j = 0; j < nk && wide_ps; ++j) {
+            const ResBlock& r = m.voc_res[i * nk + j];
+            for (size_t d = 0; d < r.dil.size(); ++d)
+                wide_ps = wide_ps && r.convs1[d].cin == ch && r.convs1[d].cout == ch && r.convs2[d].cin == ch && r.convs2[d].cout == ch &&
+                          r.convs1[d].kpad == ch * r.convs1[d].k && r.convs2[d].kpad == ch * r.convs2[d].k && (r.convs1[d].k & 1) &&
+                          (r.convs2[d].k & 1);
+        }
+        if (wide_ps) {
+            Buf<__half> planes(&m.pool, 6 * sz);
+            __half* py_h = planes.get();  // LeakyReLU(y): the input of every ResBlock's first convolution
+            __half* py_l = py_h + sz;
+            __half* pt_h = py_l + sz;     // LeakyReLU(conv1 + b1)
+            __half* pt_l = pt_h + sz;
+            __half* pn_h = pt_l + sz;     // LeakyReLU(pair output): the next pair's input
+            __half* pn_l = pn_h + sz;
+            launch_lrelu_split_f32(y, 0.1f, py_h, py_l, (int64_t)sz, m.stream);
+            for (int j = 0; j < nk; ++j) {
+                const ResBlock& r = m.voc_res[i * nk + j];
+                const float* cur = y;
+                const __half *ch_ = py_h, *cl_ = py_l;
+                const int nd = (int)r.dil.size();
+                for (int d = 0; d < nd; ++d) {
+                    const int k = r.convs1[d].k, k2 = r.convs2[d].k;
+                    const bool last = d == nd - 1;
+                    float* dst = last ? rout[j].get() : ((d & 1) ? rb.get() : ra.get());
+                    conv1d_presplit(m, ch_, cl_, r.convs1[d], nullptr, nullptr, pt_h, pt_l, n, t2, (k * r.dil[d] - r.dil[d]) / 2, r.dil[d], nullptr,
+                                    ACT_NONE, 0, nullptr, 0.1f);
+                    conv1d_presplit(m, pt_h, pt_l, r.convs2[d], cur, dst, last ? nullptr : pn_h, last ? nullptr : pn_l, n, t2, (k2 - 1) / 2, 1,
+                                    nullptr, ACT_NONE, 0, nullptr, 0.1f);
+                    cur = dst;
+                    ch_ = pn_h;
+                    cl_ = pn_l;
+                }
+            }
+            launch_avg3(rout[0], rout[1], rout[2], x, (int64_t)sz, m.stream);
+            t = t2;
+            continue;
+        }
         for (int j = 0; j < nk; ++j) {
             const ResBlock& r = m.voc_res[i * nk + j];
             const float* cur = y;

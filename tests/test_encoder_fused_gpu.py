@@ -66,3 +66,47 @@ def test_layernorm2_fused_equals_two_launches(lib, report_dir, rows, C_):
     err_z = float((outs[0][1].double() + outs[0][2].double() - z_ref).abs().max())
     _log(report_dir, "layernorm2_fused", rows=rows, C=C_, err_y=err_y, err_z=err_z)
     assert err_y < 2e-5 and err_z < 2e-5
+
+
+@pytest.mark.parametrize("nb,T,C_,k,dil", [(2, 2500, 256, 3, 1), (2, 2500, 256, 11, 5), (1, 10000, 128, 7, 3), (3, 333, 128, 11, 1), (1, 40, 256, 7, 5),
+                                           (32, 2500, 256, 7, 1)])
+def test_resblock_pair_on_dma_gemm(lib, report_dir, nb, T, C_, k, dil):
+    """One HiFi-GAN dilation pair the way the wide vocoder stages (C >= 128) run it since round 3 - LeakyReLU'd split planes,
+    both convolutions on the DMA-fed GEMM in implicit-convolution mode (hifigan.py:130-196) - against the two
+    register-staged implicit-GEMM launches it replaces and against F.conv1d in float64."""
+    import math
+
+    import numpy as np  # noqa: F401
+
+    from tests.test_ops_gpu import rel_err
+
+    g = torch.Generator().manual_seed(T * 13 + C_ * 5 + k + dil)
+    x = torch.randn(nb, T, C_, generator=g)
+    w1 = (torch.randn(C_, C_, k, generator=g) / math.sqrt(C_ * k)).half()
+    w2 = (torch.randn(C_, C_, k, generator=g) / math.sqrt(C_ * k)).half()
+    b1, b2 = torch.randn(C_, generator=g) * 0.1, torch.randn(C_, generator=g) * 0.1
+    kpad = C_ * k
+    wp1 = torch.zeros(C_, kpad, dtype=torch.float16, device="cuda")
+    wp2 = torch.zeros(C_, kpad, dtype=torch.float16, device="cuda")
+    check(lib, lib.sc_op_pack_conv_weight(P(dev(w1)), P(wp1), C_, C_, k))
+    check(lib, lib.sc_op_pack_conv_weight(P(dev(w2)), P(wp2), C_, C_, k))
+    dx, db1, db2 = dev(x), dev(b1), dev(b2)
+    tmp = torch.full((nb, T, C_), float("nan"), device="cuda")
+    two = torch.full((nb, T, C_), float("nan"), device="cuda")
+    check(lib, lib.sc_op_conv1d(P(dx), P(wp1), P(db1), None, P(tmp), nb, T, C_, C_, k, 1, dil * (k - 1) // 2, dil, None, 1, 0))
+    check(lib, lib.sc_op_conv1d(P(tmp), P(wp2), P(db2), P(dx), P(two), nb, T, C_, C_, k, 1, (k - 1) // 2, 1, None, 1, 0))
+    got = torch.full((nb, T, C_), float("nan"), device="cuda")
+    check(lib, lib.sc_op_resblock_pair_ps(P(dx), P(wp1), P(db1), P(wp2), P(db2), P(got), nb, T, C_, k, dil))
+    got, want = got.cpu(), two.cpu()
+    assert not torch.isnan(got).any()
+    same = bool(torch.equal(got, want))
+    err = None
+    if nb * T * C_ <= 2 * 2500 * 256 * 2:
+        xt = F.leaky_relu(x, 0.1).transpose(1, 2).double()
+        h = F.conv1d(xt, w1.double(), b1.double(), padding=dil * (k - 1) // 2, dilation=dil)
+        ref = F.conv1d(F.leaky_relu(h, 0.1), w2.double(), b2.double(), padding=(k - 1) // 2).transpose(1, 2) + x.double()
+        err = rel_err(got, ref)
+        assert err < 3e-6, err
+    dmax = float((got - want).abs().max())
+    _log(report_dir, "resblock_pair_ps", nb=nb, T=T, C=C_, k=k, dil=dil, err=err, bit_identical_to_two_convs=same, max_abs_diff=dmax)
+    assert dmax < 2e-5
