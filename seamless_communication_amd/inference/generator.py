@@ -67,9 +67,10 @@ class SequenceGeneratorOptions:
 
 
 def remove_consecutive_repeated_ngrams(sequence: List[int], min_size: int = 1, max_size: int = 40) -> List[int]:
-    """Unit post-filter of the autoregressive T2U (reference: inference/generator.py:39-56, used at :355-362 when
-    ``unit_generation_ngram_filtering`` is set, batch size 1 only): scanning from the left, an n-gram (longest first)
-    that is immediately followed by a copy of itself loses its first copy."""
+    """Unit post-filter of the autoregressive T2U, TRANSLITERATED from the reference's function of the same name
+    (inference/generator.py:39-56, used at :355-362 when ``unit_generation_ngram_filtering`` is set, batch size 1 only;
+    host integer logic, same control flow): scanning from the left, an n-gram (longest first) that is immediately followed
+    by a copy of itself loses its first copy."""
     assert 1 <= min_size <= max_size
     drop = set()
     start = 0

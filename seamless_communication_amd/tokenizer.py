@@ -1,7 +1,10 @@
 """Host-side tokenizers of the S2ST path (integer / string logic only).
 
-* :class:`UnitTokenizer` mirrors
-  src/seamless_communication/models/unity/unit_tokenizer.py:15-243.
+* :class:`UnitTokenizer` / :class:`UnitTokenEncoder` / :class:`UnitTokenDecoder` are TRANSLITERATED from
+  src/seamless_communication/models/unity/unit_tokenizer.py:15-243 (torch -> numpy, comments dropped): same class and
+  attribute names (the ``lang_symbol_repititions`` spelling included), same error strings, same index arithmetic.  They
+  are the drop-in surface of row a17 and their behaviour is the contract, so they follow the reference line by line
+  rather than being redesigned; pinned against the executed reference class (tests/golden/unit_tokenizer_ref.npz).
 * :class:`NllbTextTokenizer` exposes what the hot path needs from fairseq2's
   ``NllbTokenizer``: vocabulary info, ``index_to_token`` (used by
   nar_decoder_frontend.py:130-141), the target-mode prefix ``[</s>, __lang__]``
