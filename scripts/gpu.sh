@@ -99,6 +99,13 @@ for task in "$@"; do
       f=$(find gpurun_out/${TAG}_dtrace -name "*kernel_trace.csv" | head -1)
       [ -n "$f" ] && python scripts/trace_gaps.py $f --last ${DTRACE_LAST:-10000} > ${O}_dtrace_summary.txt 2>&1; cat ${O}_dtrace_summary.txt | cut -c1-130
       find gpurun_out/${TAG}_dtrace -name "*.csv" -size +20M -delete 2>/dev/null ;;
+    btrace)
+      # kernel trace of the beam-search bench (scripts/beam_bench.py): where a search step's time goes
+      rm -rf gpurun_out/${TAG}_btrace
+      ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_btrace -o d -- python $R/scripts/beam_bench.py ${BTRACE_ARGS:---batches 64 --reps 1 --task S2TT} > $R/${O}_btrace.log 2>&1; echo "exit $?" >> $R/${O}_btrace.log )
+      f=$(find gpurun_out/${TAG}_btrace -name "*kernel_trace.csv" | head -1)
+      [ -n "$f" ] && python scripts/trace_gaps.py $f --last ${BTRACE_LAST:-20000} > ${O}_btrace_summary.txt 2>&1; head -32 ${O}_btrace_summary.txt | cut -c1-130
+      find gpurun_out/${TAG}_btrace -name "*.csv" -size +20M -delete 2>/dev/null ;;
     chain)
       ( timeout 200 python scripts/chain_bench.py > ${O}_chain.txt 2>&1 ); grep -v amdgpu ${O}_chain.txt | head -40 ;;
     micro)

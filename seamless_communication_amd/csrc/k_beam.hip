@@ -180,67 +180,12 @@ __global__ __launch_bounds__(256) void row_token_lprob_kernel(const float* __res
 //   beam_lse_partial_kernel   chunk max and sum exp(x - max) of a logit row;
 //   (the n-gram processor's -inf writes happen between the two, as before: the log-sum-exp is that of the unblocked row)
 //   beam_topk_partial_kernel  log-softmax from the combined chunk statistics, step rules, + the beam's cumulative score,
-//                             best K of the chunk (same expressions, same tie rule as beam_candidates_kernel);
+//                             best K of the chunk (same expressions, same total order as beam_candidates_kernel): the chunk's
+//                             <= 32 values per thread stay in registers, K rounds of a block-wide arg-best with a "taken" mask
+//                             (a per-thread sorted K-list needed 256 registers: one workgroup per CU, 2.4 ms per step);
 //   beam_merge_kernel         best K of an utterance's beams x 32 x K partial candidates.
 // --------------------------------------------------------------------------------------------- //
 constexpr int BEAM_CH = 32;
-
-// K rounds of block-wide arg-best over the heads of the threads' sorted lists (tv / ti, best first)
-__device__ __forceinline__ void block_topk(const float (&tv)[BEAM_MAX_K], const int (&ti)[BEAM_MAX_K], int K, float* s_val, int* s_idx,
-                                           int* s_winner, float* out_val, int* out_idx) {
-    const int tid = threadIdx.x;
-    int head = 0;
-    for (int r = 0; r < K; ++r) {
-        float hv = -INFINITY;
-        int hi = 0x7fffffff;
-#pragma unroll
-        for (int q = 0; q < BEAM_MAX_K; ++q)
-            if (q == head) {
-                hv = tv[q];
-                hi = ti[q];
-            }
-        s_val[tid] = hv;
-        s_idx[tid] = hi;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o && better(s_val[tid + o], s_idx[tid + o], s_val[tid], s_idx[tid])) {
-                s_val[tid] = s_val[tid + o];
-                s_idx[tid] = s_idx[tid + o];
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            out_val[r] = s_val[0];
-            out_idx[r] = s_idx[0];
-            *s_winner = s_idx[0];
-        }
-        __syncthreads();
-        if (hi == *s_winner && hi != 0x7fffffff) ++head;  // flattened indices are unique: exactly one list advances
-        __syncthreads();
-    }
-}
-
-// insertion of (v, idx) into a thread's sorted best-K list; wv / wi = the list's current K-th entry
-__device__ __forceinline__ void list_insert(float (&tv)[BEAM_MAX_K], int (&ti)[BEAM_MAX_K], int K, float v, int idx, float& wv, int& wi) {
-    if (!better(v, idx, wv, wi)) return;
-    float cv = v;
-    int ci = idx;
-#pragma unroll
-    for (int q = 0; q < BEAM_MAX_K; ++q) {
-        if (q < K && better(cv, ci, tv[q], ti[q])) {
-            const float ov = tv[q];
-            const int oi = ti[q];
-            tv[q] = cv;
-            ti[q] = ci;
-            cv = ov;
-            ci = oi;
-        }
-        if (q == K - 1) {
-            wv = tv[q];
-            wi = ti[q];
-        }
-    }
-}
 
 __global__ __launch_bounds__(256) void beam_lse_partial_kernel(const float* __restrict__ logits, int64_t ld, int V, int clen,
                                                                float2* __restrict__ part) {
@@ -285,14 +230,67 @@ __global__ __launch_bounds__(256) void ngram_block_kernel(float* logits, int64_t
     }
 }
 
+// block-wide arg-best of one (value, flattened index) per thread; every thread returns the winner
+__device__ __forceinline__ void block_argbest(float& v, int& i, float* s_val, int* s_idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(i, o);
+        if (better(ov, oi, v, i)) {
+            v = ov;
+            i = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_val[threadIdx.x >> 6] = v;
+        s_idx[threadIdx.x >> 6] = i;
+    }
+    __syncthreads();
+    v = s_val[0];
+    i = s_idx[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (better(s_val[w], s_idx[w], v, i)) {
+            v = s_val[w];
+            i = s_idx[w];
+        }
+    __syncthreads();  // the next round overwrites s_val / s_idx
+}
+
+// K rounds of "every thread offers the best of its not yet taken elements, the block picks one" over EPT elements per
+// thread held in registers (val / idx).  Same order as the sorted-list search of beam_candidates_kernel: value first, ties
+// to the lower flattened index, -inf entries with a real index are candidates too (they fill the list on a forced-EOS step).
+template <int EPT>
+__device__ __forceinline__ void block_select_k(const float (&val)[EPT], const int (&idx)[EPT], unsigned taken, int K, float* s_val, int* s_idx,
+                                               float* out_val, int* out_idx) {
+    for (int r = 0; r < K; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff, be = -1;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+            if (!((taken >> e) & 1u) && better(val[e], idx[e], bv, bi)) {
+                bv = val[e];
+                bi = idx[e];
+                be = e;
+            }
+        const int mine = bi;
+        block_argbest(bv, bi, s_val, s_idx);
+        if (threadIdx.x == 0) {
+            out_val[r] = bv;
+            out_idx[r] = bi;
+        }
+        if (mine == bi && be >= 0) taken |= 1u << be;  // flattened indices are unique: exactly one thread owns the winner
+    }
+}
+
 __global__ __launch_bounds__(256) void beam_topk_partial_kernel(const float* __restrict__ logits, int64_t ld, int beams, int V, int clen,
                                                                 const float* __restrict__ cum, int first_step, int no_eos, int force_eos,
                                                                 int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K,
                                                                 const float2* __restrict__ part, float* __restrict__ pval,
                                                                 int* __restrict__ pidx) {
-    __shared__ float s_val[256];
-    __shared__ int s_idx[256];
-    __shared__ int s_winner;
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    constexpr int EPT = 32;  // elements per thread: chunks of at most 8192 logits
     const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
     const int b = r % beams;
     float* out_val = pval + ((int64_t)r * BEAM_CH + c) * K;
@@ -316,52 +314,47 @@ __global__ __launch_bounds__(256) void beam_topk_partial_kernel(const float* __r
     const float l = m + logf(sm);
     const float base = cum[r];
     const float* row = logits + (int64_t)r * ld;
-    float tv[BEAM_MAX_K];
-    int ti[BEAM_MAX_K];
+    float val[EPT];
+    int idx[EPT];
+    unsigned taken = 0;
 #pragma unroll
-    for (int q = 0; q < BEAM_MAX_K; ++q) {
-        tv[q] = -INFINITY;
-        ti[q] = 0x7fffffff;
+    for (int e = 0; e < EPT; ++e) {
+        const int t = start + tid + 256 * e;
+        val[e] = (t < end) ? row[t] : -INFINITY;
+        idx[e] = b * V + t;
+        if (t >= end) taken |= 1u << e;
     }
-    float wv = -INFINITY;
-    int wi = 0x7fffffff;
-    for (int i = start + tid; i < end; i += 256 * 8) {
-        float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (i + 256 * u < end) ? row[i + 256 * u] : -INFINITY;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int t = i + 256 * u;
-            if (t < end) {
-                float lp = v[u] - l;
-                if (no_eos && t == eos_idx) lp = -INFINITY;
-                if (force_eos && t != eos_idx) lp = -INFINITY;
-                if (t == pad_idx) lp = -INFINITY;
-                if (t == unk_idx) lp -= unk_penalty;
-                list_insert(tv, ti, K, lp + base, b * V + t, wv, wi);
-            }
-        }
+    for (int e = 0; e < EPT; ++e) {
+        const int t = start + tid + 256 * e;
+        float lp = val[e] - l;
+        if (no_eos && t == eos_idx) lp = -INFINITY;
+        if (force_eos && t != eos_idx) lp = -INFINITY;
+        if (t == pad_idx) lp = -INFINITY;
+        if (t == unk_idx) lp -= unk_penalty;
+        val[e] = lp + base;
     }
-    block_topk(tv, ti, K, s_val, s_idx, &s_winner, out_val, out_idx);
+    block_select_k<EPT>(val, idx, taken, K, s_val, s_idx, out_val, out_idx);
 }
 
 __global__ __launch_bounds__(256) void beam_merge_kernel(const float* __restrict__ pval, const int* __restrict__ pidx, int entries, int K,
                                                          float* __restrict__ cand_val, int* __restrict__ cand_idx) {
-    __shared__ float s_val[256];
-    __shared__ int s_idx[256];
-    __shared__ int s_winner;
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    constexpr int EPT = 16;  // beams x 32 chunks x K <= 16 x 32 x 16 = 8192 entries... the launcher checks entries <= 256 * EPT
     const int n = blockIdx.x, tid = threadIdx.x;
-    float tv[BEAM_MAX_K];
-    int ti[BEAM_MAX_K];
+    float val[EPT];
+    int idx[EPT];
+    unsigned taken = 0;
 #pragma unroll
-    for (int q = 0; q < BEAM_MAX_K; ++q) {
-        tv[q] = -INFINITY;
-        ti[q] = 0x7fffffff;
+    for (int e = 0; e < EPT; ++e) {
+        const int q = tid + 256 * e;
+        const bool ok = q < entries;
+        val[e] = ok ? pval[(int64_t)n * entries + q] : -INFINITY;
+        idx[e] = ok ? pidx[(int64_t)n * entries + q] : 0x7fffffff;
+        if (!ok || idx[e] == 0x7fffffff) taken |= 1u << e;  // empty slots (first step: beams > 0) are not candidates
     }
-    float wv = -INFINITY;
-    int wi = 0x7fffffff;
-    for (int e = tid; e < entries; e += 256) list_insert(tv, ti, K, pval[(int64_t)n * entries + e], pidx[(int64_t)n * entries + e], wv, wi);
-    block_topk(tv, ti, K, s_val, s_idx, &s_winner, cand_val + (int64_t)n * K, cand_idx + (int64_t)n * K);
+    block_select_k<EPT>(val, idx, taken, K, s_val, s_idx, cand_val + (int64_t)n * K, cand_idx + (int64_t)n * K);
 }
 
 // beam_select_kernel: the candidate walk of one search step, one workgroup per utterance (the loop the host ran in
@@ -476,6 +469,8 @@ void launch_beam_candidates_chunked(float* logits, int64_t ld, int n_utt, int be
     SC_CHECK((int64_t)beams * V < (1ll << 31) - 1, "beam search: beam * vocabulary overflows the candidate index");
     const int rows = n_utt * beams;
     const int clen = (int)align_up(cdiv(V, BEAM_CH), 4);
+    SC_CHECK(clen <= 8192 && beams * BEAM_CH * K <= 4096, "beam search: vocabulary %d / %d x %d candidates exceed the chunked search's registers", V,
+             beams, K);
     float2* part = reinterpret_cast<float2*>(ws_f);
     float* pval = ws_f + (size_t)rows * BEAM_CH * 2;
     hipLaunchKernelGGL(beam_lse_partial_kernel, dim3(BEAM_CH, rows), dim3(256), 0, s, logits, ld, V, clen, part);

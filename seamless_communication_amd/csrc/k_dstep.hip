@@ -422,8 +422,9 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     // the projected encoder K/V is initialised (finite), so the addresses do not have to wait for kv_lens[b]; keys behind
     // the length are masked below.  Self-attention rows behind `pos` are uninitialised memory and are never touched.
     const int last = CROSS ? p.cap - 1 : kv_len - 1;
-    const float* kc = p.kcache + (int64_t)b * p.cache_bs + hd * 64 + 4 * c;
-    const float* vc = p.vcache + (int64_t)b * p.cache_bs + hd * 64 + 4 * c;
+    const int crow = CROSS ? b / p.kv_row_div : b;  // beam search: the beams of an utterance share its encoder K / V
+    const float* kc = p.kcache + (int64_t)crow * p.cache_bs + hd * 64 + 4 * c;
+    const float* vc = p.vcache + (int64_t)crow * p.cache_bs + hd * 64 + 4 * c;
 
     // the projections' partial sums first (up to 4 K ranges, surplus slots re-read the last one and are discarded),
     // then the first trip of keys / values: 12 + 32 loads in flight before the first wait
@@ -699,7 +700,8 @@ void launch_embed_ln(const int* tok, const __half* embed, float scale, const flo
 }
 
 void launch_dattn(const DAttnArgs& a, bool cross, hipStream_t s) {
-    SC_CHECK(a.nb > 0 && a.heads > 0 && a.S >= 1 && a.S <= 4, "dattn: nb=%d heads=%d S=%d (1..4 K ranges)", a.nb, a.heads, a.S);
+    SC_CHECK(a.nb > 0 && a.heads > 0 && a.S >= 1 && a.S <= 4 && a.kv_row_div >= 1, "dattn: nb=%d heads=%d S=%d (1..4 K ranges)", a.nb,
+             a.heads, a.S);
     const int pairs = a.nb * a.heads;
     // KV bytes are data dependent (position / encoder lengths): the profiler gets the capacity-independent part
     prof::Scope scope(cross ? "dattn_cross" : "dattn_self", 0.0, 0.0, s);

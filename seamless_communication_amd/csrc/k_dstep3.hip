@@ -518,9 +518,9 @@ __global__ __launch_bounds__(64 * WAVES) void vocab3_kernel(Vocab3Args p) {
     const int n = lane & 31, h = lane >> 5;
     const int b = blockIdx.x;
     int grp, half_idx;
-    if (HALVES2) {  // the two row halves of a tile group on the same XCD (block ids b and b + 8)
-        grp = (b >> 4) * 8 + (b & 7);
-        half_idx = (b >> 3) & 1;
+    if (HALVES2) {  // the p.halves 32-row groups of a tile group on the same XCD (block ids b, b + 8, b + 16, ...)
+        grp = (b / (8 * p.halves)) * 8 + (b & 7);
+        half_idx = (b >> 3) % p.halves;
     } else {
         grp = b;
         half_idx = 0;
@@ -681,7 +681,8 @@ __global__ __launch_bounds__(64 * WAVES) void vocab3_kernel(Vocab3Args p) {
 // host side
 // --------------------------------------------------------------------------------------------- //
 bool gemv3_supported(int M, int N, int K, int in_mode) {
-    if (M < 1 || M > 64 || K % 16 != 0 || N % 8 != 0 || packed_weight_halfs(N, K) * 2 >= (1ll << 32)) return false;
+    // up to 512 rows: the rows are cut into row groups (grid.y), a group's weights come from L2 after the first reader
+    if (M < 1 || M > 512 || K % 16 != 0 || N % 8 != 0 || packed_weight_halfs(N, K) * 2 >= (1ll << 32)) return false;
     if (in_mode == IN3_LN) return K <= 1024;  // the whole row inside one workgroup: 16 waves x 4 k-steps
     return true;
 }
@@ -785,11 +786,11 @@ void launch_kgm_to_rows(const float* xg, int XRB, float* out, int64_t ldo, int r
     SC_LAUNCH_CHECK();
 }
 
-// tile groups of the vocabulary projection: one record per (group, row); 128 groups x 2 row halves above 32 rows
+// tile groups of the vocabulary projection: one record per (group, row); 128 groups x ceil(M / 32) row groups above 32 rows
 int vocab3_groups(int M) { return M > 32 ? 128 : 256; }
 
 bool vocab3_supported(int M, int N, int K) {
-    return M >= 1 && M <= 64 && K % 16 == 0 && K <= 1024 && packed_weight_halfs(N, K) * 2 < (1ll << 32);
+    return M >= 1 && M <= 512 && K % 16 == 0 && K <= 1024 && packed_weight_halfs(N, K) * 2 < (1ll << 32);
 }
 
 void launch_vocab3(const Vocab3Args& a0, hipStream_t s) {
@@ -800,7 +801,8 @@ void launch_vocab3(const Vocab3Args& a0, hipStream_t s) {
     a.NT_total = cdiv(a.N, 32);
     a.w_bytes = (uint32_t)(packed_weight_halfs(a.N, a.K) * 2);
     const int groups = vocab3_groups(a.M);
-    a.halves = a.M > 32 ? 2 : 1;
+    a.halves = cdiv(a.M, 32);  // 32-row groups per tile group (the arg-max epilogue is used up to 64 rows, the logits mode beyond)
+    SC_CHECK(a.logits || a.M <= 64, "vocab3: the fused arg-max epilogue takes at most 64 rows (M=%d)", a.M);
     a.tpg = cdiv(a.NT_total, groups);
     SC_CHECK(a.logits || a.am_tiles_cap >= groups, "vocab3: arg-max partial buffer holds %d groups, need %d", a.am_tiles_cap, groups);
     SC_CHECK(!a.logits || a.ldl >= a.N, "vocab3: logits row stride %lld < N=%d", (long long)a.ldl, a.N);
@@ -812,9 +814,9 @@ void launch_vocab3(const Vocab3Args& a0, hipStream_t s) {
         if (a.logits) hipLaunchKernelGGL((vocab3_kernel<8, FK, H2, true>), grid, dim3(512), 0, s, a);              \
         else hipLaunchKernelGGL((vocab3_kernel<8, FK, H2, false>), grid, dim3(512), 0, s, a);                      \
     }
-    if (a.K == 1024 && a.halves == 2) V3_LAUNCH(true, true)
+    if (a.K == 1024 && a.halves >= 2) V3_LAUNCH(true, true)
     else if (a.K == 1024) V3_LAUNCH(true, false)
-    else if (a.halves == 2) V3_LAUNCH(false, true)
+    else if (a.halves >= 2) V3_LAUNCH(false, true)
     else V3_LAUNCH(false, false)
 #undef V3_LAUNCH
     SC_LAUNCH_CHECK();

@@ -223,6 +223,7 @@ struct DAttnArgs {
     int cap = 0;
     const int* d_pos = nullptr;    // self: position of the new row, kv_len = *d_pos + 1
     const int* kv_lens = nullptr;  // cross: valid keys per batch row
+    int kv_row_div = 1;            // cross: batch row b reads cache row b / kv_row_div (the beams of an utterance share its K / V)
     __half* Oh = nullptr;          // output planes [heads*8][ORB][8]
     __half* Ol = nullptr;
     int ORB = 32;

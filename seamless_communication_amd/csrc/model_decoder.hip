@@ -73,6 +73,8 @@ struct StepCtx {
     int rg_small = 16, rg_ffn = 32;  // rows per row group of the N = M products / FFN-in (tuning knobs, SC_D3_*)
     int ffn_in_mode = 1;   // 0: partials + reduce/LN launch + packed product; 1 / 2: LayerNorm inside the product (2 tiles / 1 tile)
     int ffn_out_mode = 1;  // 0: gemvp, 8 K ranges; 1: gemv3 2 tiles x 512-wide K slices; 2: gemv3 1 tile x 1024-wide
+    int cross_row_div = 1;  // beam search: live row r reads the encoder K / V of cache row r / cross_row_div (one per utterance)
+    float* qkv3 = nullptr;  // [nb][3M] complete q | k | v rows: the wide step (> 64 live rows) projects them on gemv3
 };
 
 DecStack unity_stack(const Model& m) {
@@ -269,7 +271,7 @@ bool step2_eligible(const Model& m, const DecStack& W, int nb) {
 // plane buffers of one decoder-step context (rows beyond nb are never read: their lanes load out of range)
 void alloc_step2(Model& m, StepCtx& c, int ffn_dim) {
     const int M = m.cfg.model_dim;
-    c.rb = c.nb <= 32 ? 32 : 64;
+    c.rb = (int)align_up(c.nb, 32);  // 32 / 64 up to 64 rows; more for the wide step of the beam search
     const size_t pm = (size_t)M * c.rb, pf = (size_t)ffn_dim * c.rb;
     c.planes = Buf<__half>(&m.pool, 4 * pm + 2 * pf);
     c.hH = c.planes.get();
@@ -405,6 +407,7 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
         x.cache_bs = (int64_t)c.s_enc * 2 * M;
         x.cap = c.s_enc;
         x.kv_lens = c.d_enc_lens;
+        x.kv_row_div = c.cross_row_div;
         x.Oh = c.attH;
         x.Ol = c.attL;
         x.ORB = c.rb;
@@ -504,6 +507,17 @@ bool step3_eligible(const Model& m, const DecStack& W, int nb) {
     return gemv3_supported(nb, 3 * M, M, IN3_LN) && gemv3_supported(nb, M, W.ffn_dim, IN3_PLANES) && M % 8 == 0;
 }
 
+// > 64 live rows (beam search at the benchmark batch: 64 utterances x 5 beams): the same chain, every product cut into row
+// groups, q | k | v on the row-group kernel too (the packed split-K product stops at 64 rows)
+bool step3_wide_eligible(const Model& m, const DecStack& W, int nb) {
+    static const bool off = getenv("SC_DECODER_GEN2") != nullptr || getenv("SC_DECODER_GEN1") != nullptr;
+    const int M = m.cfg.model_dim;
+    if (off || nb <= 64 || nb > 512 || M % 64 != 0 || M > 1024 || W.ffn_dim % 64 != 0 || M != m.cfg.num_heads * 64) return false;
+    for (const DecoderLayer& l : *W.layers)
+        if (!l.qkv.wp || !l.self_out.wp || !l.cross_q.wp || !l.cross_out.wp || !l.ffn_in.wp || !l.ffn_out.wp) return false;
+    return gemv3_supported(nb, 3 * M, M, IN3_PLANES) && gemv3_supported(nb, M, W.ffn_dim, IN3_PLANES);
+}
+
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -538,16 +552,28 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         const DecoderLayer& l = layers[li];
         const bool last = li + 1 == n_layers;
         int sp = 1;
-        // self attention: q | k | v as K-range partials of the packed product (summed by the attention kernel)
-        gemv2(m, c, c.hH, c.hL, l.qkv, 2, &sp);
         DAttnArgs a;
-        a.q = c.partial;
+        if (nb <= 64) {
+            // self attention: q | k | v as K-range partials of the packed product (summed by the attention kernel)
+            gemv2(m, c, c.hH, c.hL, l.qkv, 2, &sp);
+            a.q = c.partial;
+            a.sstride = (int64_t)nb * 3 * M;
+            a.S = sp;
+            a.bias = l.qkv.b;
+        } else {  // wide step: complete rows from the row-group kernel
+            Gemv3Args q;
+            q.Wp = l.qkv.wp, q.M = nb, q.N = 3 * M, q.K = M;
+            q.in_mode = IN3_PLANES, q.Ah = c.hH, q.Al = c.hL, q.RB = c.rb, q.rg = 32;
+            q.epi = EPI3_ROWS, q.bias = l.qkv.b, q.out = c.qkv3, q.ldo = 3 * M;
+            launch_gemv3(q, m.stream);
+            a.q = c.qkv3;
+            a.sstride = 0;
+            a.S = 1;
+            a.bias = nullptr;
+        }
         a.ldq = 3 * M;
-        a.sstride = (int64_t)nb * 3 * M;
-        a.S = sp;
         a.koff = M;
         a.voff = 2 * M;
-        a.bias = l.qkv.b;
         a.kcache = c.kcache[li];
         a.vcache = c.vcache[li];
         a.cache_ld = M;
@@ -581,6 +607,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         x.cache_bs = (int64_t)c.s_enc * 2 * M;
         x.cap = c.s_enc;
         x.kv_lens = c.d_enc_lens;
+        x.kv_row_div = c.cross_row_div;
         x.Oh = c.attH;
         x.Ol = c.attL;
         x.ORB = c.rb;
@@ -588,7 +615,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         x.heads = H;
         launch_dattn(x, /*cross=*/true, m.stream);
         // feed-forward network: the inner activation stays in split planes
-        if (c.ffn_in_mode == 0) {  // K-range partials + reduce / LayerNorm launch, then the packed product on planes
+        if (c.ffn_in_mode == 0 && nb <= 64) {  // K-range partials + reduce / LayerNorm launch, then the packed product on planes
             gemv2(m, c, c.attH, c.attL, l.cross_out, 4, &sp);
             reduce_ln3(sp, l.cross_out.b, l.ffn_ln, false);
             GemvPArgs f;
@@ -605,7 +632,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
             f.epi = EPI3_PLANES, f.bias = l.ffn_in.b, f.act = ACT_RELU, f.Oh = c.wideH, f.Ol = c.wideL, f.ORB = c.rb;
             launch_gemv3(f, m.stream);
         }
-        if (c.ffn_out_mode == 0) {
+        if (c.ffn_out_mode == 0 && nb <= 64) {
             gemv2(m, c, c.wideH, c.wideL, l.ffn_out, 8, &sp);
         } else {
             Gemv3Args o;
@@ -1165,12 +1192,46 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
 
     // ---- feed the known tokens (prompt echo / teacher forcing) ---------------------
     // positions 0 .. feed_len-2 are fed without projection; the next input is read from hist.
+    // teacher forcing over more than a few positions (the re-pass behind a beam search: ~40 steps of ~220 launches): the
+    // step is captured once and replayed, like the generation step below
+    hipGraph_t fgraph = nullptr;
+    hipGraphExec_t fexec = nullptr;
+    struct FGuard {
+        hipGraph_t& g;
+        hipGraphExec_t& e;
+        ~FGuard() {
+            if (e) (void)hipGraphExecDestroy(e);
+            if (g) (void)hipGraphDestroy(g);
+        }
+    } fguard{fgraph, fexec};
+    const bool forced_graph = forced && o.use_graph != 0 && c.rb > 0 && feed_len >= 8;
+    auto fed_step = [&]() {
+        if (!forced_graph) {
+            decoder_step(m, c, /*project=*/false);
+            return;
+        }
+        if (!fexec) {
+            std::lock_guard<std::mutex> lock(g_capture_mutex);
+            SC_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeThreadLocal));
+            try {
+                decoder_step(m, c, /*project=*/false);
+            } catch (...) {
+                hipGraph_t dead = nullptr;
+                (void)hipStreamEndCapture(m.stream, &dead);
+                if (dead) (void)hipGraphDestroy(dead);
+                throw;
+            }
+            SC_HIP(hipStreamEndCapture(m.stream, &fgraph));
+            SC_HIP(hipGraphInstantiate(&fexec, fgraph, nullptr, nullptr, 0));
+        }
+        SC_HIP(hipGraphLaunch(fexec, m.stream));
+    };
     for (int t = 0; t + 1 < feed_len; ++t) {
-        decoder_step(m, c, /*project=*/false);
+        fed_step();
         SC_HIP(hipMemcpy2DAsync(c.d_tok, 4, c.d_hist + t + 1, (size_t)max_len * 4, 4, n, hipMemcpyDeviceToDevice, m.stream));
     }
     if (forced) {
-        decoder_step(m, c, false);  // last forced position
+        fed_step();  // last forced position
         if (want_hidden)
             SC_HIP(hipMemcpyAsync(d_dec_hidden, c.dec_hidden, (size_t)n * (max_len - 1) * M * 4, hipMemcpyDeviceToDevice, m.stream));
         SC_HIP(hipStreamSynchronize(m.stream));
@@ -1319,9 +1380,12 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     const float len_penalty = o.len_penalty;
     const bool normalize = o.normalize_scores != 0;
 
+    // the packed-weight step kernels read the encoder K / V of live row r from cache row r / beams: one projection per
+    // utterance instead of one per beam (5 x fewer bytes to project, to keep and to stream per step)
+    const bool packed_step = step2_eligible(m, W, nb) || step3_wide_eligible(m, W, nb);
     // ---- fan the encoder output out to the beams (fairseq2.cpp `_fan_out_encoder_output`) ----------
-    Buf<float> enc_rep(&m.pool, (size_t)nb * s_enc * M);
-    {
+    Buf<float> enc_rep(&m.pool, packed_step ? 4 : (size_t)nb * s_enc * M);
+    if (!packed_step) {
         std::vector<int32_t> idx((size_t)nb * s_enc);
         for (int r = 0; r < nb; ++r)
             for (int t = 0; t < s_enc; ++t) idx[(size_t)r * s_enc + t] = (r / B) * s_enc + t;
@@ -1359,15 +1423,19 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     c.att = att;
     c.hN = hN;
     c.logits = logits;
-    Buf<float> xg3(&m.pool, 4), qkvr3(&m.pool, 4);
-    if (step2_eligible(m, W, nb)) {  // packed-weight step kernels (<= 64 live rows)
+    Buf<float> xg3(&m.pool, 4), qkvr3(&m.pool, 4), qkv3w(&m.pool, 4);
+    if (packed_step) {  // packed-weight step kernels (<= 64 live rows; the wide third-generation chain up to 512)
         alloc_step2(m, c, cfg.dec_ffn_dim);
-        if (step3_eligible(m, W, nb)) {  // third-generation chain (the step runs without its projection here)
+        if (step3_eligible(m, W, nb) || nb > 64) {  // third-generation chain (the step runs without its projection here)
             c.gen3 = true;
             xg3 = Buf<float>(&m.pool, (size_t)M * c.rb);
             qkvr3 = Buf<float>(&m.pool, (size_t)nb * M);
             c.xg = xg3;
             c.qkvr = qkvr3;
+            if (nb > 64) {
+                qkv3w = Buf<float>(&m.pool, (size_t)nb * 3 * M);
+                c.qkv3 = qkv3w;
+            }
             c.rg_small = env_int("SC_D3_RG_SMALL", 16);
             c.rg_ffn = env_int("SC_D3_RG_FFN", 32);
             c.ffn_in_mode = env_int("SC_D3_FFN_IN", 1);
@@ -1394,10 +1462,13 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     bind_caches(kv_cur);
     std::vector<Buf<float>> cross;
     cross.reserve(L);
+    const int cross_rows = packed_step ? n : nb;
+    c.cross_row_div = packed_step ? B : 1;
     for (int li = 0; li < L; ++li) {
-        cross.emplace_back(&m.pool, (size_t)nb * s_enc * 2 * M);
+        cross.emplace_back(&m.pool, (size_t)cross_rows * s_enc * 2 * M);
         c.cross_kv.push_back(cross.back());
-        linear(m, enc_rep, M, dec_layers[li].cross_kv, nullptr, 0, c.cross_kv.back(), 2 * M, nb * s_enc, ACT_NONE, 1.f);
+        linear(m, packed_step ? d_enc : enc_rep.get(), M, dec_layers[li].cross_kv, nullptr, 0, c.cross_kv.back(), 2 * M, cross_rows * s_enc,
+               ACT_NONE, 1.f);
     }
     Linear proj;
     proj.w = W.embed;
@@ -1464,8 +1535,42 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     // ---- search: every step is device work only; the host polls the `remaining` counter every 4th step --------
     const int start = prefix_len - 1;
     int remaining = n;
+    // The decoder step of the search is replayed from a captured hipGraph like the greedy one (~220 launches per step: eager
+    // launching alone cost ~2.5 ms per step at 320 rows).  The K/V caches alternate between two allocations (re-ordered from
+    // one into the other after every step), so there are two graphs, one per parity; everything the step reads besides its
+    // baked-in buffer addresses lives in device memory (*d_pos, d_tok).
+    struct StepGraphs {
+        hipGraph_t g[2] = {nullptr, nullptr};
+        hipGraphExec_t e[2] = {nullptr, nullptr};
+        ~StepGraphs() {
+            for (int i = 0; i < 2; ++i) {
+                if (e[i]) (void)hipGraphExecDestroy(e[i]);
+                if (g[i]) (void)hipGraphDestroy(g[i]);
+            }
+        }
+    } graphs;
+    const bool step_graph = o.use_graph != 0 && c.rb > 0;
     for (int step = start; step <= max_len - 2 && remaining > 0; ++step) {
-        decoder_step(m, c, /*project=*/false);  // feeds d_tok at position `step`, advances *d_pos
+        if (step_graph) {
+            const int par = kv_cur == kv_a.get() ? 0 : 1;
+            if (!graphs.e[par]) {
+                std::lock_guard<std::mutex> lock(g_capture_mutex);
+                SC_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeThreadLocal));
+                try {
+                    decoder_step(m, c, /*project=*/false);
+                } catch (...) {
+                    hipGraph_t dead = nullptr;
+                    (void)hipStreamEndCapture(m.stream, &dead);
+                    if (dead) (void)hipGraphDestroy(dead);
+                    throw;
+                }
+                SC_HIP(hipStreamEndCapture(m.stream, &graphs.g[par]));
+                SC_HIP(hipGraphInstantiate(&graphs.e[par], graphs.g[par], nullptr, nullptr, 0));
+            }
+            SC_HIP(hipGraphLaunch(graphs.e[par], m.stream));
+        } else {
+            decoder_step(m, c, /*project=*/false);  // feeds d_tok at position `step`, advances *d_pos
+        }
         project_rows();
         // n-gram processor: not on the forced-EOS step (blocking EOS there would leave no hypothesis)
         const bool ban = G > 0 && step != max_len - 2;

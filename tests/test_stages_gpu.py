@@ -248,6 +248,27 @@ def test_beam_search_ids_match_oracle(env, report_dir, beam, hard_max, min_len):
         assert err < 1e-5, err
 
 
+@pytest.mark.parametrize("n_utt,beam", [(16, 5), (27, 4)])
+def test_beam_search_wide_step_matches_oracle(env, report_dir, n_utt, beam):
+    """More than 64 live rows (the API default beam 5 at the benchmark batch is 64 x 5 = 320): the decoder step cuts every
+    product into row groups, the beams of an utterance share its encoder K / V, the logits come from the LDS-staged
+    projection kernel in row groups.  Ids of every utterance against oracle.beam_search_generate."""
+    from oracle import unity as ou
+
+    cfg, tt, ct, orc, hip = env
+    secs = [0.9 + 0.11 * (i % 9) for i in range(n_utt)]
+    fb, lens = orc.collate_fbank(common.waves(secs))
+    enc, enc_lens = hip.encode_speech(fb.cuda(), lens.tolist())
+    prefix = tt.target_prefix("fra")
+    want = ou.beam_search_generate(orc.P, cfg, enc.cpu(), torch.from_numpy(enc_lens.astype(np.int64)), prefix, beam, hard_max_seq_len=11,
+                                   pos_table=orc.pos_table)
+    ids, out_lens, scores, hidden = hip.generate_text(enc, enc_lens.tolist(), prefix, beam_size=beam, hard_max_seq_len=11)
+    got = [ids[b, : out_lens[b]].tolist() for b in range(n_utt)]
+    bad = [b for b in range(n_utt) if got[b] != want[b]]
+    _log(report_dir, "beam_wide", n_utt=n_utt, beam=beam, rows=n_utt * beam, mismatching=bad)
+    assert not bad, (bad, [got[b] for b in bad], [want[b] for b in bad])
+
+
 def test_beam_size_one_equals_greedy(env):
     from oracle import unity as ou
 
