@@ -28,26 +28,86 @@ DEC_LAST_FFN_GAIN = 64.0
 TEXT_CONTROL_TAIL = [None] * (98 + 3)
 
 
+class _LazyDict(dict):
+    """State dict whose large tensors are drawn on worker threads: a value may be a Future until it is first read (every
+    tensor has its own (seed, key) generator, so the order of drawing does not matter; torch's CPU generators are
+    single-threaded and release the GIL: 2 G parameters take 14 s drawn one after the other, ~2 s on 8+ cores)."""
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if hasattr(v, "result"):
+            v = v.result()
+            dict.__setitem__(self, key, v)
+        return v
+
+    def resolve(self) -> Dict[str, torch.Tensor]:
+        for k in list(dict.keys(self)):
+            self[k]
+        return dict(self)
+
+
+_POOL = None
+
+
+def _pool():
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(16, n)))
+    return _POOL
+
+
 class _Gen:
     def __init__(self, seed: int, dtype: torch.dtype) -> None:
         self.seed = seed
         self.dtype = dtype
-        self.sd: Dict[str, torch.Tensor] = {}
+        self.sd: Dict[str, torch.Tensor] = _LazyDict()
 
     def _g(self, key: str) -> torch.Generator:
         g = torch.Generator(device="cpu")
         g.manual_seed((self.seed * 1000003 + zlib.crc32(key.encode())) % (2**63 - 1))
         return g
 
+    def _draw(self, key: str, shape, fn) -> None:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if n >= (1 << 18):  # large tensors on the worker threads
+            dict.__setitem__(self.sd, key, _pool().submit(fn))
+        else:
+            self.sd[key] = fn()
+
+    def then(self, key: str, fn) -> None:
+        """Applies fn(tensor) -> tensor to an entry once it is drawn, on a worker thread when the entry is still pending
+        (a later task only ever waits for an earlier one: the pool runs them in submission order)."""
+        v = dict.__getitem__(self.sd, key)
+        if hasattr(v, "result"):
+            dict.__setitem__(self.sd, key, _pool().submit(lambda: fn(v.result())))
+        else:
+            self.sd[key] = fn(v)
+
+    def alias(self, new_key: str, key: str) -> None:
+        """Two names for one tensor (tied weights): the pending entry itself is shared, both names resolve to one object."""
+        dict.__setitem__(self.sd, new_key, dict.__getitem__(self.sd, key))
+
     def uniform(self, key: str, shape, bound: float, center: float = 0.0) -> None:
-        t = torch.rand(*shape, generator=self._g(key), dtype=torch.float32)
-        t.mul_(2 * bound).add_(center - bound)
-        self.sd[key] = t.to(self.dtype)
+        def fn():
+            t = torch.rand(*shape, generator=self._g(key), dtype=torch.float32)
+            t.mul_(2 * bound).add_(center - bound)
+            return t.to(self.dtype)
+
+        self._draw(key, shape, fn)
 
     def normal(self, key: str, shape, std: float) -> None:
-        t = torch.randn(*shape, generator=self._g(key), dtype=torch.float32)
-        t.mul_(std)
-        self.sd[key] = t.to(self.dtype)
+        def fn():
+            t = torch.randn(*shape, generator=self._g(key), dtype=torch.float32)
+            t.mul_(std)
+            return t.to(self.dtype)
+
+        self._draw(key, shape, fn)
 
     # ---- module-shaped helpers ------------------------------------------- #
     def linear(self, prefix: str, out_dim: int, in_dim: int, bias: bool = True, gain: float = 1.0) -> None:
@@ -133,13 +193,17 @@ def make_unity_state_dict(
     # std 0.5/sqrt(M): with the full 1/sqrt(M) a random-init decoder with tied
     # input/output embeddings just echoes its input token with a huge margin.
     g.normal("text_decoder_frontend.embed.weight", (cfg.text_vocab_size, M), 0.5 * M ** -0.5)
-    g.sd["text_decoder_frontend.embed.weight"][cfg.pad_idx].zero_()
-    g.sd["final_proj.weight"] = g.sd["text_decoder_frontend.embed.weight"]
     # Control symbols above the sentence pieces (__lang__, <MINED_DATA>, padding rows) are
     # shrunk so that the greedy search of the random model stays on ordinary pieces.
     n_ctrl = len(TEXT_CONTROL_TAIL)
-    g.sd["text_decoder_frontend.embed.weight"][cfg.text_vocab_size - n_ctrl:].mul_(0.1)
-    g.sd["final_proj.weight"] = g.sd["text_decoder_frontend.embed.weight"]
+
+    def _fix_text_embed(t: torch.Tensor) -> torch.Tensor:
+        t[cfg.pad_idx].zero_()
+        t[cfg.text_vocab_size - n_ctrl:].mul_(0.1)
+        return t
+
+    g.then("text_decoder_frontend.embed.weight", _fix_text_embed)
+    g.alias("final_proj.weight", "text_decoder_frontend.embed.weight")
     for i in range(cfg.dec_layers):
         p = f"text_decoder.layers.{i}"
         g.layer_norm(f"{p}.self_attn_layer_norm", M)
@@ -156,12 +220,12 @@ def make_unity_state_dict(
         last = i == cfg.dec_layers - 1
         for q in ("self_attn.output_proj", "encoder_decoder_attn.output_proj", "ffn.output_proj"):
             gain = DEC_LAST_FFN_GAIN if (last and q.startswith("ffn")) else DEC_BRANCH_GAIN
-            g.sd[f"{p}.{q}.weight"] = (g.sd[f"{p}.{q}.weight"].float() * gain).to(dtype)
+            g.then(f"{p}.{q}.weight", lambda t, gain=gain: (t.float() * gain).to(dtype))
     g.layer_norm("text_decoder.layer_norm", M)
 
     if with_text_encoder:
         # NLLB encoder; the embedding frontend is the decoder's (builder.py:443-446, loader.py:150-153)
-        g.sd["text_encoder_frontend.embed.weight"] = g.sd["text_decoder_frontend.embed.weight"]
+        g.alias("text_encoder_frontend.embed.weight", "text_decoder_frontend.embed.weight")
         for i in range(cfg.text_enc_layers):
             p = f"text_encoder.layers.{i}"
             g.layer_norm(f"{p}.self_attn_layer_norm", M)
@@ -171,7 +235,7 @@ def make_unity_state_dict(
         g.layer_norm("text_encoder.layer_norm", M)
 
     if not with_t2u:
-        return g.sd
+        return g.sd.resolve()
 
     # NAR T2U (t2u_builder.py:455-715)
     for i in range(cfg.t2u_enc_layers):
@@ -206,7 +270,7 @@ def make_unity_state_dict(
             g.layer_norm(f"{p}.ffn_layer_norm", M)
             g.ffn(f"{p}.ffn", M, cfg.t2u_ffn_dim)
         g.layer_norm("t2u_model.decoder.layer_norm", M)
-        return g.sd
+        return g.sd.resolve()
     g.normal(f"{f}.embed_char.weight", (cfg.char_vocab_size, M), M ** -0.5)
     g.sd[f"{f}.pos_emb_alpha"] = torch.tensor([0.9], dtype=dtype)
     g.sd[f"{f}.pos_emb_alpha_char"] = torch.tensor([1.1], dtype=dtype)
@@ -229,7 +293,7 @@ def make_unity_state_dict(
         g.conv1d(f"{p}.conv1d.conv2", M, cfg.t2u_conv_inner_dim, cfg.t2u_conv_kernel)
         g.layer_norm(f"{p}.conv1d_layer_norm", M)
     g.layer_norm("t2u_model.decoder.layer_norm", M)
-    return g.sd
+    return g.sd.resolve()
 
 
 def make_monotonic_decoder_state_dict(cfg: S2STConfig, seed: int = DEFAULT_SEED, dtype: torch.dtype = torch.float16) -> Dict[str, torch.Tensor]:
@@ -243,7 +307,7 @@ def make_monotonic_decoder_state_dict(cfg: S2STConfig, seed: int = DEFAULT_SEED,
 
     def put(key: str, make) -> None:
         make("mma/" + key)
-        out[key] = g.sd.pop("mma/" + key)
+        out[key] = g.sd["mma/" + key]
 
     put("text_decoder_frontend.embed.weight", lambda k: g.normal(k, (cfg.text_vocab_size, M), 0.5 * M ** -0.5))
     out["text_decoder_frontend.embed.weight"][cfg.pad_idx].zero_()
@@ -328,7 +392,7 @@ def make_vocoder_state_dict(
         g.layer_norm(f"{d}.ln2", H)
         g.uniform(f"{d}.proj.weight", (1, H), 1.5 * math.sqrt(3.0 / H))
         g.sd[f"{d}.proj.bias"] = torch.tensor([0.9]).to(dtype)
-    return g.sd
+    return g.sd.resolve()
 
 
 def synthetic_waveform(index: int, seconds: float = 10.0, sample_rate: int = 16000) -> torch.Tensor:
