@@ -1114,6 +1114,75 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
 
 }  // namespace
 
+// Teacher-forced decoder pass over KNOWN tokens as ONE batched forward (all positions at once, causal self-attention) - the
+// way the reference runs it (generator.py:294-299: `decode(text_seqs[:, :-1], ...)`) - instead of `s_text` single-position
+// steps of ~220 dependent launches each: n * s_text rows through the tiled GEMMs, the multi-query attention kernel with its
+// causal mask for the self-attention, the encoder K / V projected once.  Used behind the beam search (the decoder outputs of
+// the chosen hypotheses feed the T2U model) and by sc_decode_text; SC_DECODE_STEPWISE=1 keeps the step-by-step pass.
+// Same modules in the same order as decoder_step (fairseq2.cpp:979-1094); results agree with the stepwise pass to fp32
+// re-association (tests/test_stages_gpu.py: test_generated_hidden_equals_teacher_forced_pass, 2e-4).
+void run_decode_text_batched(Model& m, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens, const int32_t* h_tokens, int s_text,
+                             float* d_hidden) {
+    const sc_config& cfg = m.cfg;
+    const int M = cfg.model_dim, rows = n * s_text, erows = n * s_enc;
+    SC_CHECK(s_text <= cfg.text_max_seq_len, "sc_decode_text: %d tokens exceed text_max_seq_len=%d", s_text, cfg.text_max_seq_len);
+    for (int i = 0; i < rows; ++i)
+        SC_CHECK(h_tokens[i] >= 0 && h_tokens[i] < cfg.text_vocab_size, "sc_decode_text: token %d outside the vocabulary", h_tokens[i]);
+    for (int b = 0; b < n; ++b) SC_CHECK(h_enc_lens[b] > 0 && h_enc_lens[b] <= s_enc, "sc_decode_text: enc_lens[%d]=%d out of range", b, h_enc_lens[b]);
+    prof::set_tag("dec");
+    Buf<int> d_tok(&m.pool, rows), d_elens(&m.pool, n);
+    SC_HIP(hipMemcpyAsync(d_tok.get(), h_tokens, (size_t)rows * 4, hipMemcpyHostToDevice, m.stream));
+    SC_HIP(hipMemcpyAsync(d_elens.get(), h_enc_lens, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
+    const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
+    Buf<float> h(&m.pool, (size_t)rows * M), wide(&m.pool, (size_t)rows * wideN), att(&m.pool, (size_t)rows * M),
+        ckv(&m.pool, (size_t)erows * 2 * M);
+    float* x = d_hidden;
+    launch_embed_tokens(d_tok, rows, m.text_embed, M, sqrtf((float)M), m.text_pos, nullptr, s_text, x, M, m.stream);
+    for (const DecoderLayer& l : m.dec) {
+        // causal self-attention
+        layernorm(m, x, l.self_ln, h, rows);
+        linear(m, h, M, l.qkv, nullptr, 0, wide, 3 * M, rows, ACT_NONE, 1.f);
+        AttnArgs a;
+        a.q = wide;
+        a.k = wide.get() + M;
+        a.v = wide.get() + 2 * M;
+        a.out = att;
+        a.ldq = a.ldk = a.ldv = 3 * M;
+        a.ldo = M;
+        a.nb = n;
+        a.heads = cfg.num_heads;
+        a.Sq = a.Skv = s_text;
+        a.causal = 1;
+        launch_attention(a, m.stream);
+        linear(m, att, M, l.self_out, x, M, x, M, rows, ACT_NONE, 1.f);
+        // encoder-decoder attention
+        layernorm(m, x, l.cross_ln, h, rows);
+        linear(m, h, M, l.cross_q, nullptr, 0, wide, M, rows, ACT_NONE, 1.f);
+        linear(m, d_enc, M, l.cross_kv, nullptr, 0, ckv, 2 * M, erows, ACT_NONE, 1.f);
+        AttnArgs c;
+        c.q = wide;
+        c.k = ckv;
+        c.v = ckv.get() + M;
+        c.out = att;
+        c.ldq = M;
+        c.ldk = c.ldv = 2 * M;
+        c.ldo = M;
+        c.nb = n;
+        c.heads = cfg.num_heads;
+        c.Sq = s_text;
+        c.Skv = s_enc;
+        c.kv_lens = d_elens;
+        launch_attention(c, m.stream);
+        linear(m, att, M, l.cross_out, x, M, x, M, rows, ACT_NONE, 1.f);
+        // feed-forward network
+        layernorm(m, x, l.ffn_ln, h, rows);
+        linear(m, h, M, l.ffn_in, nullptr, 0, wide, cfg.dec_ffn_dim, rows, ACT_RELU, 1.f);
+        linear(m, wide, cfg.dec_ffn_dim, l.ffn_out, x, M, x, M, rows, ACT_NONE, 1.f);
+    }
+    layernorm(m, x, m.dec_final_ln, x, rows);
+    SC_HIP(hipStreamSynchronize(m.stream));  // h_tokens / h_enc_lens are the caller's; outputs complete on return
+}
+
 // forced_tokens != null: teacher-forced pass over the given tokens (no arg-max
 // feedback, hidden states only).  Otherwise greedy generation.
 void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens,
@@ -1125,6 +1194,11 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     SC_CHECK(n > 0 && s_enc > 0, "sc_generate_text: empty batch");
     prof::set_tag("dec");
     const bool forced = h_forced_tokens != nullptr;
+    static const bool stepwise_forced = getenv("SC_DECODE_STEPWISE") != nullptr;
+    if (forced && !stepwise_forced && d_dec_hidden) {
+        run_decode_text_batched(m, d_enc, n, s_enc, h_enc_lens, h_forced_tokens, forced_len, d_dec_hidden);
+        return;
+    }
     int max_len;
     if (forced) {
         max_len = forced_len + 1;  // hidden buffer has max_len-1 = forced_len rows
