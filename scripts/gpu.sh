@@ -13,6 +13,7 @@
 #   chain        scripts/chain_bench.py (each decoder-step kernel as a dependent chain in a replayed graph)
 #   micro        every scripts/micro/*.hip compiled with hipcc and run
 #   sqpmc        SQ / TCP counters of the encoder GEMM (three --pmc passes of scripts/gemm_bench.py) -> TAG_gemm_pmc_sq.txt
+#   sqbench      SQ / GRBM counters of every kernel of a bench pass -> TAG_bench_pmc_sq.txt (matrix-pipe busy share per kernel)
 #   pyt          pytest on $PYT (files / -k expressions)
 #   pstest       GEMM op tests (bit identity of the kernel variants)       gemmab   scripts/gemm_bench.py at SC_PS_TILE=128 / 256
 mkdir -p gpurun_out
@@ -82,6 +83,14 @@ for task in "$@"; do
       python scripts/pmc_sq_summary.py gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 gpurun_out/${TAG}_sq3 --filter gemm_ps > ${O}_gemm_pmc_sq.txt 2>&1
       tail -3 ${O}_sq1.log ${O}_sq3.log | cut -c1-200; head -12 ${O}_gemm_pmc_sq.txt | cut -c1-400
       find gpurun_out/${TAG}_sq1 gpurun_out/${TAG}_sq2 gpurun_out/${TAG}_sq3 -name "*.csv" -size +2M -delete 2>/dev/null ;;
+    sqbench)
+      # matrix-pipe utilisation of EVERY kernel of a bench pass (one --pmc pass of SQ / GRBM counters on the PMC command line)
+      rm -rf gpurun_out/${TAG}_sqb
+      PMC_ARGS=${PMC_ARGS:---steps 1 --warmup 0 --no-cpu-baseline --no-profile-step --no-latency --no-graph --no-extra}
+      ( cd /tmp && timeout 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_sqb -o bench -- python $R/bench.py $PMC_ARGS > $R/${O}_sqb.log 2>&1; echo "exit $?" >> $R/${O}_sqb.log )
+      python scripts/pmc_sq_summary.py gpurun_out/${TAG}_sqb --by-kernel > ${O}_bench_pmc_sq.txt 2>&1
+      tail -2 ${O}_sqb.log | cut -c1-200; head -30 ${O}_bench_pmc_sq.txt | cut -c1-220
+      find gpurun_out/${TAG}_sqb -name "*.csv" -size +2M -delete 2>/dev/null ;;
     dstep)
       ( timeout 300 python scripts/dstep_bench.py $DSTEP_ARGS > ${O}_dstep.txt 2>&1; echo "exit $?" >> ${O}_dstep.txt ); grep -v amdgpu ${O}_dstep.txt | tail -40 | cut -c1-200 ;;
     dtouch)

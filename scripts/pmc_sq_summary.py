@@ -10,8 +10,9 @@ from collections import defaultdict
 
 
 def main():
-    dirs = [a for a in sys.argv[1:] if not a.startswith("--")]
     flt = sys.argv[sys.argv.index("--filter") + 1] if "--filter" in sys.argv else ""
+    dirs = [a for a in sys.argv[1:] if not a.startswith("--") and a != flt]
+    by_kernel = "--by-kernel" in sys.argv  # one line per kernel name (all grids together), sorted by total wave cycles
     acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
     for d in dirs:
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -19,11 +20,13 @@ def main():
                 for row in csv.DictReader(fh):
                     if flt and flt not in row["Kernel_Name"]:
                         continue
-                    key = (row["Kernel_Name"][:110], row.get("Grid_Size", "?"))
+                    key = (row["Kernel_Name"][:110], "*" if by_kernel else row.get("Grid_Size", "?"))
                     a = acc[key][row["Counter_Name"]]
                     a[0] += 1
                     a[1] += float(row["Counter_Value"])
-    for (k, grid), cs in sorted(acc.items(), key=lambda kv: -max(v[0] for v in kv[1].values())):
+    # by kernel: largest total GPU time first (sum of GRBM_GUI_ACTIVE over the launches)
+    order = (lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", [0, 0.0])[1]) if by_kernel else (lambda kv: -max(v[0] for v in kv[1].values()))
+    for (k, grid), cs in sorted(acc.items(), key=order):
         m = {c: s / max(n, 1) for c, (n, s) in cs.items()}
         n = max(v[0] for v in cs.values())
         print(f"{k} grid={grid} launches={n}")
