@@ -14,7 +14,7 @@
 #   micro        every scripts/micro/*.hip compiled with hipcc and run
 #   sqpmc        SQ / TCP counters of the encoder GEMM (three --pmc passes of scripts/gemm_bench.py) -> TAG_gemm_pmc_sq.txt
 #   sqbench      SQ / GRBM counters of every kernel of a bench pass -> TAG_bench_pmc_sq.txt (matrix-pipe busy share per kernel)
-#   pyt          pytest on $PYT (files / -k expressions)
+#   pyt          pytest on $PYT (files / -k expressions)           benchsweep  benchfast under each setting of $SWEEP
 #   pstest       GEMM op tests (bit identity of the kernel variants)       gemmab   scripts/gemm_bench.py at SC_PS_TILE=128 / 256
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -59,6 +59,14 @@ for task in "$@"; do
       ( timeout 900 python bench.py $BENCH_ARGS > ${O}_bench.json 2> ${O}_bench.err; echo "exit $?" >> ${O}_bench.err ); tail -3 ${O}_bench.err | cut -c1-300; line ${O}_bench.json ;;
     benchfast)
       ( timeout 600 python bench.py $BENCH_ARGS --no-cpu-baseline --no-latency --no-extra > ${O}_benchfast.json 2> ${O}_benchfast.err; echo "exit $?" >> ${O}_benchfast.err ); tail -2 ${O}_benchfast.err | cut -c1-300; line ${O}_benchfast.json ;;
+    benchsweep)
+      # benchfast once per environment setting of $SWEEP (';'-separated: SWEEP="SC_VOC_STREAMS=1;SC_VOC_STREAMS=3")
+      IFS=';' read -ra SW <<< "$SWEEP"
+      for e in "${SW[@]}"; do
+        n=$(echo "$e" | tr ' =' '__')
+        ( env $e timeout 400 python bench.py $BENCH_ARGS --no-cpu-baseline --no-latency --no-extra > ${O}_sweep_$n.json 2> ${O}_sweep_$n.err; echo "exit $?" >> ${O}_sweep_$n.err )
+        echo "--- $e"; tail -1 ${O}_sweep_$n.err; line ${O}_sweep_$n.json
+      done ;;
     rocprof)
       rm -rf gpurun_out/${TAG}_prof
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof -o bench -- python $R/bench.py $PROF_ARGS > $R/${O}_rocprof.log 2>&1; echo "exit $?" >> $R/${O}_rocprof.log )

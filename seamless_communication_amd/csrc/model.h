@@ -252,6 +252,20 @@ struct Model : ModelData {
     hipStream_t stream = nullptr;
     hipEvent_t order_event = nullptr;  // sc_wait_stream: orders this handle's stream after a producer stream
     DevicePool pool;
+    // Side chains (run_vocode: the length buckets of one call are independent and individually too small to fill the
+    // chip, so they run on a few extra streams).  A side chain owns a stream AND a scratch pool - the pool's "a released
+    // block may be handed out again at once" rule only holds in stream order - and `pp()` is the pool every stage helper
+    // allocates from: the handle's own unless a SideScope has redirected the handle to a side chain.
+    struct SideChain {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        DevicePool pool;
+    };
+    std::vector<std::unique_ptr<SideChain>> side;
+    hipEvent_t side_fork = nullptr;
+    DevicePool* pool_override = nullptr;
+    DevicePool* pp() { return pool_override ? pool_override : &pool; }
+    SideChain& side_chain(int k);  // created on first use
     std::vector<void*> owned;  // weight allocations (empty for a forked handle: the parent owns them)
 
     // results of the last sc_t2u_nar call
@@ -274,6 +288,23 @@ struct Model : ModelData {
     Model(const Model&) = delete;
     Model& operator=(const Model&) = delete;
     ~Model();
+};
+
+// Redirects a handle's stream and scratch pool to one of its side chains for the lifetime of the scope.
+struct SideScope {
+    Model& m;
+    hipStream_t saved;
+    SideScope(Model& mm, int k) : m(mm), saved(mm.stream) {
+        Model::SideChain& c = mm.side_chain(k);
+        m.stream = c.stream;
+        m.pool_override = &c.pool;
+    }
+    ~SideScope() {
+        m.stream = saved;
+        m.pool_override = nullptr;
+    }
+    SideScope(const SideScope&) = delete;
+    SideScope& operator=(const SideScope&) = delete;
 };
 
 // stage implementations (model_*.hip)

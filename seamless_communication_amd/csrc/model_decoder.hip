@@ -273,7 +273,7 @@ void alloc_step2(Model& m, StepCtx& c, int ffn_dim) {
     const int M = m.cfg.model_dim;
     c.rb = (int)align_up(c.nb, 32);  // 32 / 64 up to 64 rows; more for the wide step of the beam search
     const size_t pm = (size_t)M * c.rb, pf = (size_t)ffn_dim * c.rb;
-    c.planes = Buf<__half>(&m.pool, 4 * pm + 2 * pf);
+    c.planes = Buf<__half>(m.pp(), 4 * pm + 2 * pf);
     c.hH = c.planes.get();
     c.hL = c.hH + pm;
     c.attH = c.hL + pm;
@@ -845,12 +845,12 @@ void run_mma_begin(Model& m, const float* d_enc, int s_enc, int max_len) {
         std::unique_ptr<MmaState> st(new MmaState());
         st->cap = max_len;
         st->cap_enc = cap_enc;
-        st->kv = Buf<float>(&m.pool, (size_t)2 * L * max_len * M);
-        st->cross = Buf<float>(&m.pool, (size_t)L * cap_enc * 2 * M);
-        st->kenergy = Buf<float>(&m.pool, (size_t)L * M);
-        st->pchoose = Buf<float>(&m.pool, (size_t)L * H);
-        st->work = Buf<float>(&m.pool, work_n);
-        st->ints = Buf<int>(&m.pool, 16 + 64);
+        st->kv = Buf<float>(m.pp(), (size_t)2 * L * max_len * M);
+        st->cross = Buf<float>(m.pp(), (size_t)L * cap_enc * 2 * M);
+        st->kenergy = Buf<float>(m.pp(), (size_t)L * M);
+        st->pchoose = Buf<float>(m.pp(), (size_t)L * H);
+        st->work = Buf<float>(m.pp(), work_n);
+        st->ints = Buf<int>(m.pp(), 16 + 64);
         m.mma = std::move(st);
     }
     MmaState& st = *m.mma;
@@ -1038,14 +1038,14 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
     c.min_seq_len = o.min_seq_len;
     c.force_eos_step = max_len - 2;
     c.unk_penalty = o.unk_penalty;
-    S.ints = Buf<int>(&m.pool, (size_t)8 + 4 * n + (size_t)n * max_len);
+    S.ints = Buf<int>(m.pp(), (size_t)8 + 4 * n + (size_t)n * max_len);
     c.d_pos = S.ints;
     c.d_tok = S.ints.get() + 8;
     c.d_finished = c.d_tok + n;
     c.d_out_len = c.d_finished + n;
     c.d_enc_lens = c.d_out_len + n;
     c.d_hist = c.d_enc_lens + n;
-    S.fl = Buf<float>(&m.pool, (size_t)2 * n);
+    S.fl = Buf<float>(m.pp(), (size_t)2 * n);
     c.d_lprob = S.fl;
     c.d_score = S.fl.get() + n;
     const DecStack W = unity_stack(m);
@@ -1054,14 +1054,14 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
     const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
     const bool fused_argmax = !forced && n <= 64 && M % 64 == 0;
     S.fused_argmax = fused_argmax;
-    S.x = Buf<float>(&m.pool, (size_t)n * M);
-    S.h = Buf<float>(&m.pool, (size_t)n * M);
-    S.wide = Buf<float>(&m.pool, gen2 ? 4 : (size_t)n * wideN);
-    S.att = Buf<float>(&m.pool, (size_t)n * M);
-    S.hN = Buf<float>(&m.pool, (size_t)n * M);
-    S.logits = Buf<float>(&m.pool, (forced || fused_argmax) ? 4 : (size_t)n * cfg.text_vocab_size);
+    S.x = Buf<float>(m.pp(), (size_t)n * M);
+    S.h = Buf<float>(m.pp(), (size_t)n * M);
+    S.wide = Buf<float>(m.pp(), gen2 ? 4 : (size_t)n * wideN);
+    S.att = Buf<float>(m.pp(), (size_t)n * M);
+    S.hN = Buf<float>(m.pp(), (size_t)n * M);
+    S.logits = Buf<float>(m.pp(), (forced || fused_argmax) ? 4 : (size_t)n * cfg.text_vocab_size);
     // worst case: K/256 ranges of an [n][M] out-projection, or M/256 ranges of the [n][3M] q/k/v projection
-    S.partial = Buf<float>(&m.pool, (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * n * 3 * M);
+    S.partial = Buf<float>(m.pp(), (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * n * 3 * M);
     c.partial = S.partial;
     const bool gen3 = gen2 && step3_eligible(m, W, n) && (forced || (fused_argmax && W.embed_p && vocab3_supported(n, W.vocab, M)));
     if (gen2) {
@@ -1070,8 +1070,8 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
         c.am_tiles = fused_argmax ? gemvp_argmax_tiles(cfg.text_vocab_size, c.am_ntl) : 0;
         if (gen3) {
             c.gen3 = true;
-            S.xg = Buf<float>(&m.pool, (size_t)M * c.rb);
-            S.qkvr = Buf<float>(&m.pool, (size_t)n * M);
+            S.xg = Buf<float>(m.pp(), (size_t)M * c.rb);
+            S.qkvr = Buf<float>(m.pp(), (size_t)n * M);
             c.xg = S.xg;
             c.qkvr = S.qkvr;
             c.am_tiles = std::max(c.am_tiles, vocab3_groups(n));
@@ -1087,8 +1087,8 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
     } else {
         c.am_tiles = fused_argmax ? skinny_argmax_tiles(n, cfg.text_vocab_size) : 0;
     }
-    S.am_part = Buf<float4>(&m.pool, (size_t)std::max(1, c.am_tiles) * n);
-    S.am_eos = Buf<float>(&m.pool, (size_t)n);
+    S.am_part = Buf<float4>(m.pp(), (size_t)std::max(1, c.am_tiles) * n);
+    S.am_eos = Buf<float>(m.pp(), (size_t)n);
     c.am_part = S.am_part;
     c.am_eos_logit = S.am_eos;
     c.x = S.x;
@@ -1098,16 +1098,16 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
     c.hN = S.hN;
     c.logits = S.logits;
     if (want_hidden) {
-        S.hidden = Buf<float>(&m.pool, (size_t)n * (max_len - 1) * M);
+        S.hidden = Buf<float>(m.pp(), (size_t)n * (max_len - 1) * M);
         c.dec_hidden = S.hidden;
     }
     S.caches.reserve(3 * cfg.dec_layers);
     for (int li = 0; li < cfg.dec_layers; ++li) {
-        S.caches.emplace_back(&m.pool, (size_t)n * max_len * M);
+        S.caches.emplace_back(m.pp(), (size_t)n * max_len * M);
         c.kcache.push_back(S.caches.back());
-        S.caches.emplace_back(&m.pool, (size_t)n * max_len * M);
+        S.caches.emplace_back(m.pp(), (size_t)n * max_len * M);
         c.vcache.push_back(S.caches.back());
-        S.caches.emplace_back(&m.pool, (size_t)n * s_enc * 2 * M);
+        S.caches.emplace_back(m.pp(), (size_t)n * s_enc * 2 * M);
         c.cross_kv.push_back(S.caches.back());
     }
 }
@@ -1130,12 +1130,12 @@ void run_decode_text_batched(Model& m, const float* d_enc, int n, int s_enc, con
         SC_CHECK(h_tokens[i] >= 0 && h_tokens[i] < cfg.text_vocab_size, "sc_decode_text: token %d outside the vocabulary", h_tokens[i]);
     for (int b = 0; b < n; ++b) SC_CHECK(h_enc_lens[b] > 0 && h_enc_lens[b] <= s_enc, "sc_decode_text: enc_lens[%d]=%d out of range", b, h_enc_lens[b]);
     prof::set_tag("dec");
-    Buf<int> d_tok(&m.pool, rows), d_elens(&m.pool, n);
+    Buf<int> d_tok(m.pp(), rows), d_elens(m.pp(), n);
     SC_HIP(hipMemcpyAsync(d_tok.get(), h_tokens, (size_t)rows * 4, hipMemcpyHostToDevice, m.stream));
     SC_HIP(hipMemcpyAsync(d_elens.get(), h_enc_lens, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
     const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
-    Buf<float> h(&m.pool, (size_t)rows * M), wide(&m.pool, (size_t)rows * wideN), att(&m.pool, (size_t)rows * M),
-        ckv(&m.pool, (size_t)erows * 2 * M);
+    Buf<float> h(m.pp(), (size_t)rows * M), wide(m.pp(), (size_t)rows * wideN), att(m.pp(), (size_t)rows * M),
+        ckv(m.pp(), (size_t)erows * 2 * M);
     float* x = d_hidden;
     launch_embed_tokens(d_tok, rows, m.text_embed, M, sqrtf((float)M), m.text_pos, nullptr, s_text, x, M, m.stream);
     for (const DecoderLayer& l : m.dec) {
@@ -1416,9 +1416,9 @@ void run_t2u_ar(Model& m, const float* d_dec_hidden, int n, int s_text, const in
     SC_CHECK(n > 0 && s_text > 0, "sc_t2u_ar: empty batch");
     prof::set_tag("t2u");
     const int M = cfg.model_dim;
-    Buf<int> d_tlens(&m.pool, n);
+    Buf<int> d_tlens(m.pp(), n);
     SC_HIP(hipMemcpyAsync(d_tlens.get(), h_text_lens, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
-    Buf<float> enc(&m.pool, (size_t)n * s_text * M);
+    Buf<float> enc(m.pp(), (size_t)n * s_text * M);
     run_t2u_encoder(m, d_dec_hidden, n, s_text, d_tlens, enc);
     const DecStack W = t2u_ar_stack(m);
     // length rule of the unit generator: min(hard, int(a * S_text) + b), prompt included, capped by the position table
@@ -1458,12 +1458,12 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     // utterance instead of one per beam (5 x fewer bytes to project, to keep and to stream per step)
     const bool packed_step = step2_eligible(m, W, nb) || step3_wide_eligible(m, W, nb);
     // ---- fan the encoder output out to the beams (fairseq2.cpp `_fan_out_encoder_output`) ----------
-    Buf<float> enc_rep(&m.pool, packed_step ? 4 : (size_t)nb * s_enc * M);
+    Buf<float> enc_rep(m.pp(), packed_step ? 4 : (size_t)nb * s_enc * M);
     if (!packed_step) {
         std::vector<int32_t> idx((size_t)nb * s_enc);
         for (int r = 0; r < nb; ++r)
             for (int t = 0; t < s_enc; ++t) idx[(size_t)r * s_enc + t] = (r / B) * s_enc + t;
-        Buf<int> d_idx(&m.pool, idx.size());
+        Buf<int> d_idx(m.pp(), idx.size());
         SC_HIP(hipMemcpyAsync(d_idx.get(), idx.data(), idx.size() * 4, hipMemcpyHostToDevice, m.stream));
         launch_gather_rows(d_enc, M, d_idx, enc_rep, M, nb * s_enc, M, m.stream);
         SC_HIP(hipStreamSynchronize(m.stream));  // idx is a host temporary
@@ -1477,7 +1477,7 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     c.min_seq_len = o.min_seq_len;
     c.force_eos_step = max_len - 2;
     c.unk_penalty = o.unk_penalty;
-    Buf<int> ints(&m.pool, (size_t)8 + 5 * nb);
+    Buf<int> ints(m.pp(), (size_t)8 + 5 * nb);
     c.d_pos = ints;
     c.d_tok = ints.get() + 8;
     c.d_finished = c.d_tok + nb;
@@ -1485,11 +1485,11 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     c.d_enc_lens = c.d_out_len + nb;
     int* d_src_row = c.d_enc_lens + nb;
     const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
-    Buf<float> x(&m.pool, (size_t)nb * M), h(&m.pool, (size_t)nb * M), wide(&m.pool, (size_t)nb * wideN), att(&m.pool, (size_t)nb * M),
-        hN(&m.pool, (size_t)nb * M), logits(&m.pool, (size_t)nb * (V + 3));
-    Buf<float> partial(&m.pool, (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * nb * 3 * M);
-    Buf<float> d_cum(&m.pool, (size_t)nb), d_cand_val(&m.pool, (size_t)n * K), d_pref(&m.pool, (size_t)n);
-    Buf<int> d_cand_idx(&m.pool, (size_t)n * K);
+    Buf<float> x(m.pp(), (size_t)nb * M), h(m.pp(), (size_t)nb * M), wide(m.pp(), (size_t)nb * wideN), att(m.pp(), (size_t)nb * M),
+        hN(m.pp(), (size_t)nb * M), logits(m.pp(), (size_t)nb * (V + 3));
+    Buf<float> partial(m.pp(), (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * nb * 3 * M);
+    Buf<float> d_cum(m.pp(), (size_t)nb), d_cand_val(m.pp(), (size_t)n * K), d_pref(m.pp(), (size_t)n);
+    Buf<int> d_cand_idx(m.pp(), (size_t)n * K);
     c.partial = partial;
     c.x = x;
     c.h = h;
@@ -1497,17 +1497,17 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     c.att = att;
     c.hN = hN;
     c.logits = logits;
-    Buf<float> xg3(&m.pool, 4), qkvr3(&m.pool, 4), qkv3w(&m.pool, 4);
+    Buf<float> xg3(m.pp(), 4), qkvr3(m.pp(), 4), qkv3w(m.pp(), 4);
     if (packed_step) {  // packed-weight step kernels (<= 64 live rows; the wide third-generation chain up to 512)
         alloc_step2(m, c, cfg.dec_ffn_dim);
         if (step3_eligible(m, W, nb) || nb > 64) {  // third-generation chain (the step runs without its projection here)
             c.gen3 = true;
-            xg3 = Buf<float>(&m.pool, (size_t)M * c.rb);
-            qkvr3 = Buf<float>(&m.pool, (size_t)nb * M);
+            xg3 = Buf<float>(m.pp(), (size_t)M * c.rb);
+            qkvr3 = Buf<float>(m.pp(), (size_t)nb * M);
             c.xg = xg3;
             c.qkvr = qkvr3;
             if (nb > 64) {
-                qkv3w = Buf<float>(&m.pool, (size_t)nb * 3 * M);
+                qkv3w = Buf<float>(m.pp(), (size_t)nb * 3 * M);
                 c.qkv3 = qkv3w;
             }
             c.rg_small = env_int("SC_D3_RG_SMALL", 16);
@@ -1522,7 +1522,7 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     const int64_t ldl = proj_v3 ? (int64_t)align_up(V, 4) : V;  // logits row stride: 16-byte aligned rows for the streaming kernel
     // self-attention K/V caches of all layers in one allocation, twice (re-ordered from one into the other)
     const int64_t layer_stride = (int64_t)nb * max_len * M;
-    Buf<float> kv_a(&m.pool, (size_t)2 * L * layer_stride), kv_b(&m.pool, (size_t)2 * L * layer_stride);
+    Buf<float> kv_a(m.pp(), (size_t)2 * L * layer_stride), kv_b(m.pp(), (size_t)2 * L * layer_stride);
     float* kv_cur = kv_a;
     float* kv_alt = kv_b;
     auto bind_caches = [&](float* base) {
@@ -1539,7 +1539,7 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     const int cross_rows = packed_step ? n : nb;
     c.cross_row_div = packed_step ? B : 1;
     for (int li = 0; li < L; ++li) {
-        cross.emplace_back(&m.pool, (size_t)cross_rows * s_enc * 2 * M);
+        cross.emplace_back(m.pp(), (size_t)cross_rows * s_enc * 2 * M);
         c.cross_kv.push_back(cross.back());
         linear(m, packed_step ? d_enc : enc_rep.get(), M, dec_layers[li].cross_kv, nullptr, 0, c.cross_kv.back(), 2 * M, cross_rows * s_enc,
                ACT_NONE, 1.f);
@@ -1552,8 +1552,8 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     proj.out = V;
 
     const bool chunked = beam_chunked(V);  // large vocabulary: candidate search spread over (row, chunk) workgroups
-    Buf<float> ws_f(&m.pool, chunked ? beam_ws_floats(nb, K) : 4);
-    Buf<int> ws_i(&m.pool, chunked ? beam_ws_ints(nb, K) : 4);
+    Buf<float> ws_f(m.pp(), chunked ? beam_ws_floats(nb, K) : 4);
+    Buf<int> ws_i(m.pp(), chunked ? beam_ws_ints(nb, K) : 4);
     auto project_rows = [&]() {
         if (proj_v3) {
             Vocab3Args v;
@@ -1574,9 +1574,9 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
         init[8 + 3 * nb + r] = h_enc_lens[r / B];
     }
     SC_HIP(hipMemcpyAsync(ints.get(), init.data(), init.size() * 4, hipMemcpyHostToDevice, m.stream));
-    Buf<int> d_seqs_a(&m.pool, (size_t)nb * max_len), d_seqs_b(&m.pool, (size_t)nb * max_len), d_fin_seq(&m.pool, (size_t)nb * max_len),
-        d_fin_len(&m.pool, (size_t)nb), d_state(&m.pool, (size_t)2 * n + 1);
-    Buf<float> d_fin_score(&m.pool, (size_t)nb);
+    Buf<int> d_seqs_a(m.pp(), (size_t)nb * max_len), d_seqs_b(m.pp(), (size_t)nb * max_len), d_fin_seq(m.pp(), (size_t)nb * max_len),
+        d_fin_len(m.pp(), (size_t)nb), d_state(m.pp(), (size_t)2 * n + 1);
+    Buf<float> d_fin_score(m.pp(), (size_t)nb);
     int* d_seqs_cur = d_seqs_a;
     int* d_seqs_new = d_seqs_b;
     int* d_fin_count = d_state;
@@ -1719,7 +1719,7 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
         std::vector<int32_t> forced((size_t)n * fl, cfg.pad_idx);
         for (int u = 0; u < n; ++u)
             for (int t = 0; t < fl && t < h_out_lens[u]; ++t) forced[(size_t)u * fl + t] = h_out_ids[(size_t)u * max_len + t];
-        Buf<float> hid(&m.pool, (size_t)n * fl * M);
+        Buf<float> hid(m.pp(), (size_t)n * fl * M);
         run_generate_text(m, d_enc, n, s_enc, h_enc_lens, o, nullptr, 0, nullptr, nullptr, nullptr, hid, forced.data(), fl);
         SC_HIP(hipMemsetAsync(d_dec_hidden, 0, (size_t)n * (max_len - 1) * M * 4, m.stream));
         SC_HIP(hipMemcpy2DAsync(d_dec_hidden, (size_t)(max_len - 1) * M * 4, hid.get(), (size_t)fl * M * 4, (size_t)fl * M * 4, n,

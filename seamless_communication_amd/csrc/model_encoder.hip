@@ -28,7 +28,7 @@ void run_fbank(Model& m, const float* d_wav, int n, int64_t wav_stride, const in
                  t_rows);
         if (h_frames) h_frames[i] = frames[i];
     }
-    Buf<int> d_ns(&m.pool, n), d_fr(&m.pool, n);
+    Buf<int> d_ns(m.pp(), n), d_fr(m.pp(), n);
     upload_i32(m, d_ns, h_ns, n);
     upload_i32(m, d_fr, frames.data(), n);
     launch_fbank(d_wav, wav_stride, d_ns, n, d_out, t_rows, m.fbank_consts, 32768.0f, m.stream);
@@ -88,13 +88,13 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
         alens[i] = adaptor_len(c, lens[i]);
         if (h_out_lens) h_out_lens[i] = alens[i];
     }
-    Buf<int> d_lens(&m.pool, n), d_alens(&m.pool, n);
+    Buf<int> d_lens(m.pp(), n), d_alens(m.pp(), n);
     upload_i32(m, d_lens, lens.data(), n);
     upload_i32(m, d_alens, alens.data(), n);
 
     const int F = std::max(std::max(c.enc_ffn_dim, c.adaptor_proj_dim), std::max(3 * M, c.adaptor_ffn_dim));
-    Buf<float> x(&m.pool, (size_t)rows * M), h(&m.pool, (size_t)rows * std::max(M, feat)), wide(&m.pool, (size_t)rows * F),
-        att(&m.pool, (size_t)rows * M);
+    Buf<float> x(m.pp(), (size_t)rows * M), h(m.pp(), (size_t)rows * std::max(M, feat)), wide(m.pp(), (size_t)rows * F),
+        att(m.pp(), (size_t)rows * M);
 
     // frontend: stack fbank_stride frames (a pure reinterpretation of the
     // contiguous [n][t_frames][80] buffer), LayerNorm, Linear
@@ -109,10 +109,10 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
     const bool v1 = c.enc_variant == 1;  // w2v-BERT of the v1 models: fp32-operand path below (not the throughput path)
     const bool ps_ok = !v1 && presplit && M % 32 == 0 && c.enc_ffn_dim % 32 == 0 && (int64_t)rows * std::max(M, c.enc_ffn_dim) * 2 < (1ll << 31);
     // v1: position table [2S-1][M] once per call, its projection r_proj(table) per layer
-    Buf<float> rp_tab(&m.pool, v1 ? (size_t)(2 * S - 1) * M : 0), rp_proj(&m.pool, v1 ? (size_t)(2 * S - 1) * M : 0);
+    Buf<float> rp_tab(m.pp(), v1 ? (size_t)(2 * S - 1) * M : 0), rp_proj(m.pp(), v1 ? (size_t)(2 * S - 1) * M : 0);
     if (v1) launch_relpos_table(S, M, rp_tab, m.stream);
-    Buf<__half> hs(&m.pool, ps_ok ? (size_t)2 * rows * M : 0), ws(&m.pool, ps_ok ? (size_t)2 * rows * c.enc_ffn_dim : 0),
-        as(&m.pool, ps_ok ? (size_t)2 * rows * M : 0);
+    Buf<__half> hs(m.pp(), ps_ok ? (size_t)2 * rows * M : 0), ws(m.pp(), ps_ok ? (size_t)2 * rows * c.enc_ffn_dim : 0),
+        as(m.pp(), ps_ok ? (size_t)2 * rows * M : 0);
     __half* hs_hi = hs.get();
     __half* hs_lo = ps_ok ? hs.get() + (size_t)rows * M : nullptr;
     __half* ws_hi = ws.get();
@@ -270,8 +270,8 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
     const int Sa = encoder_out_len(m, t_frames);
     const int arows = n * Sa;
     const int k = c.adaptor_kernel_size, st = c.adaptor_stride, pad = k / 2;
-    Buf<float> res(&m.pool, (size_t)arows * M), y(&m.pool, (size_t)arows * M), conv(&m.pool, (size_t)arows * 2 * M),
-        aw(&m.pool, (size_t)arows * std::max(3 * M, c.adaptor_ffn_dim)), ah(&m.pool, (size_t)arows * M);
+    Buf<float> res(m.pp(), (size_t)arows * M), y(m.pp(), (size_t)arows * M), conv(m.pp(), (size_t)arows * 2 * M),
+        aw(m.pp(), (size_t)arows * std::max(3 * M, c.adaptor_ffn_dim)), ah(m.pp(), (size_t)arows * M);
     layernorm(m, x, a.res_ln, h, rows);
     conv1d(m, h, a.res_conv, nullptr, conv, n, S, st, pad, 1, nullptr, IN_NONE, ACT_NONE);
     launch_glu(conv, 2 * M, res, M, arows, M, m.stream);

@@ -91,9 +91,30 @@ Model::~Model() {
     if (order_event) (void)hipEventDestroy(order_event);
     for (hipEvent_t e : touch_events) (void)hipEventDestroy(e);
     if (touch_stream) (void)hipStreamDestroy(touch_stream);
+    for (auto& c : side) {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        c->pool.release_all();
+        if (c->done) (void)hipEventDestroy(c->done);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    side.clear();
+    if (side_fork) (void)hipEventDestroy(side_fork);
     pool.release_all();
     for (void* p : owned) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
+}
+
+Model::SideChain& Model::side_chain(int k) {
+    SC_CHECK(k >= 0 && k < 16, "side chain %d", k);
+    while ((int)side.size() <= k) {
+        std::unique_ptr<SideChain> c(new SideChain());
+        SC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        SC_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+        c->pool.set_stream(c->stream);
+        side.push_back(std::move(c));
+    }
+    if (!side_fork) SC_HIP(hipEventCreateWithFlags(&side_fork, hipEventDisableTiming));
+    return *side[k];
 }
 
 // --------------------------------------------------------------------------- //
@@ -243,8 +264,8 @@ struct Loader {
         c.kpad = (int)align_up((int64_t)cin * k, 32);
         const __half* v = f16(p + ".weight_v", {cout, cin, k});
         const __half* g = f16(p + ".weight_g", {cout, 1, 1});
-        Buf<float> folded(&m.pool, (size_t)cout * cin * k);
-        Buf<__half> folded16(&m.pool, (size_t)cout * cin * k);
+        Buf<float> folded(m.pp(), (size_t)cout * cin * k);
+        Buf<__half> folded16(m.pp(), (size_t)cout * cin * k);
         launch_weight_norm_fold(v, g, folded, cout, cin * k, m.stream);
         launch_cvt_f32_f16(folded, folded16, (int64_t)cout * cin * k, m.stream);
         __half* d = static_cast<__half*>(dalloc((size_t)cout * c.kpad * 2));
@@ -267,7 +288,7 @@ struct Loader {
                  p.c_str(), k, stride);
         const __half* v = f16(p + ".weight_v", {cin, cout, k});
         const __half* g = f16(p + ".weight_g", {cin, 1, 1});
-        Buf<float> folded(&m.pool, (size_t)cin * cout * k);
+        Buf<float> folded(m.pp(), (size_t)cin * cout * k);
         launch_weight_norm_fold(v, g, folded, cin, cout * k, m.stream);
         __half* d = static_cast<__half*>(dalloc((size_t)stride * cout * c.kpad * 2));
         launch_pack_convT_weight(folded, d, cin, cout, k, stride, c.kpad, m.stream);

@@ -164,11 +164,11 @@ void run_encode_text(Model& m, const int32_t* h_tokens, int n, int s_text, const
             SC_CHECK(tok >= 0 && tok < c.text_vocab_size, "sc_encode_text: token %d at [%d][%d] outside the vocabulary", tok, b, t);
         }
     }
-    Buf<int> d_tok(&m.pool, rows), d_lens(&m.pool, n);
+    Buf<int> d_tok(m.pp(), rows), d_lens(m.pp(), n);
     SC_HIP(hipMemcpyAsync(d_tok.get(), h_tokens, (size_t)rows * 4, hipMemcpyHostToDevice, m.stream));
     SC_HIP(hipMemcpyAsync(d_lens.get(), h_lens, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
     const int wideN = std::max(3 * M, c.text_enc_ffn_dim);
-    Buf<float> h(&m.pool, (size_t)rows * M), wide(&m.pool, (size_t)rows * wideN), att(&m.pool, (size_t)rows * M);
+    Buf<float> h(m.pp(), (size_t)rows * M), wide(m.pp(), (size_t)rows * wideN), att(m.pp(), (size_t)rows * M);
     float* x = d_out;
     launch_embed_tokens(d_tok, rows, m.text_embed, M, sqrtf((float)M), m.text_pos, nullptr, s_text, x, M, m.stream);
     for (const EncoderLayer& l : m.text_enc) {
@@ -190,7 +190,7 @@ void run_t2u_encoder(Model& m, const float* d_dec_hidden, int n, int s_text, con
     const sc_config& c = m.cfg;
     const int M = c.model_dim, rows = n * s_text;
     const int wideN = std::max(3 * M, c.t2u_ffn_dim);
-    Buf<float> h(&m.pool, (size_t)rows * M), wide(&m.pool, (size_t)rows * wideN), att(&m.pool, (size_t)rows * M);
+    Buf<float> h(m.pp(), (size_t)rows * M), wide(m.pp(), (size_t)rows * wideN), att(m.pp(), (size_t)rows * M);
     SC_HIP(hipMemcpyAsync(x, d_dec_hidden, (size_t)rows * M * 4, hipMemcpyDeviceToDevice, m.stream));
     for (const EncoderLayer& l : m.t2u_enc) {
         layernorm(m, x, l.attn_ln, h, rows);
@@ -213,12 +213,12 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
     prof::set_tag("t2u");
     SC_CHECK(n > 0 && s_text >= 2, "sc_t2u_nar: need at least the 2-token prefix (s_text=%d)", s_text);
     const int rows = n * s_text;
-    Buf<int> d_tlens(&m.pool, n);
+    Buf<int> d_tlens(m.pp(), n);
     SC_HIP(hipMemcpyAsync(d_tlens.get(), h_text_lens, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
 
     // ---- T2U encoder (model.py:404-412) --------------------------------------------
     const int wideN = std::max(3 * M, std::max(c.t2u_ffn_dim, c.t2u_conv_inner_dim));
-    Buf<float> x(&m.pool, (size_t)rows * M);
+    Buf<float> x(m.pp(), (size_t)rows * M);
     run_t2u_encoder(m, d_dec_hidden, n, s_text, d_tlens, x);
 
     // ---- host: characters ---------------------------------------------------------
@@ -244,19 +244,19 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
         SC_CHECK(pos == cseq_lens[b], "sc_t2u_nar: char length bookkeeping mismatch (%d vs %d)", pos, cseq_lens[b]);
         for (int k = 0; k < cseq_lens[b]; ++k) cid_flat[(size_t)b * Sc + k] = cids[b][k];
     }
-    Buf<int> d_gidx(&m.pool, crows), d_cid(&m.pool, crows), d_clens(&m.pool, n), d_dur(&m.pool, crows);
+    Buf<int> d_gidx(m.pp(), crows), d_cid(m.pp(), crows), d_clens(m.pp(), n), d_dur(m.pp(), crows);
     SC_HIP(hipMemcpyAsync(d_gidx.get(), gidx.data(), (size_t)crows * 4, hipMemcpyHostToDevice, m.stream));
     SC_HIP(hipMemcpyAsync(d_cid.get(), cid_flat.data(), (size_t)crows * 4, hipMemcpyHostToDevice, m.stream));
     SC_HIP(hipMemcpyAsync(d_clens.get(), cseq_lens.data(), (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
 
     // ---- character-level upsampling + duration predictor -----------------------------
-    Buf<float> cs(&m.pool, (size_t)crows * M);
+    Buf<float> cs(m.pp(), (size_t)crows * M);
     launch_gather_rows(x, M, d_gidx, cs, M, crows, M, m.stream);
     launch_char_embed_add(cs, M, d_cid, m.char_embed, m.char_pos, Sc, m.pos_alpha_char, sqrtf((float)M), crows, M, m.stream);
     std::vector<int32_t> dur((size_t)crows);
     {
         const int H = c.var_pred_hidden_dim, K = c.var_pred_kernel_size;
-        Buf<float> a(&m.pool, (size_t)crows * H), b(&m.pool, (size_t)crows * H);
+        Buf<float> a(m.pp(), (size_t)crows * H), b(m.pp(), (size_t)crows * H);
         conv1d(m, cs, m.dp_conv1, nullptr, a, n, Sc, 1, K / 2, 1, d_clens, IN_NONE, ACT_RELU);
         layernorm(m, a, m.dp_ln1, b, crows);
         conv1d(m, b, m.dp_conv2, nullptr, a, n, Sc, 1, K / 2, 1, d_clens, IN_NONE, ACT_RELU);
@@ -279,7 +279,7 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
     }
     SC_CHECK(Su > 0, "sc_t2u_nar: zero units predicted");
     const int urows = n * Su;
-    Buf<int> d_ulens(&m.pool, n);
+    Buf<int> d_ulens(m.pp(), n);
     SC_HIP(hipMemcpyAsync(d_ulens.get(), ulens.data(), (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
 
     // ---- FFT decoder: one packed pass over all items (default) or one pass per length bucket ------------------
@@ -339,7 +339,7 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
                         pos2[(size_t)2 * r + 1] = ulens[b];
                     }
             }
-            Buf<int> d_uidx(&m.pool, R), d_row_t(&m.pool, R), d_row_off(&m.pool, n), d_pos2(&m.pool, (size_t)2 * R), d_ids(&m.pool, R);
+            Buf<int> d_uidx(m.pp(), R), d_row_t(m.pp(), R), d_row_off(m.pp(), n), d_pos2(m.pp(), (size_t)2 * R), d_ids(m.pp(), R);
             SC_HIP(hipMemcpyAsync(d_uidx.get(), uidx.data(), (size_t)R * 4, hipMemcpyHostToDevice, m.stream));
             SC_HIP(hipMemcpyAsync(d_row_t.get(), row_t.data(), (size_t)R * 4, hipMemcpyHostToDevice, m.stream));
             SC_HIP(hipMemcpyAsync(d_row_off.get(), row_off.data(), (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
@@ -348,8 +348,8 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
             double pairs = 0;
             for (int b = 0; b < n; ++b) pairs += (double)ulens[b] * ulens[b];
             const int wideN = 3 * M;
-            Buf<float> u(&m.pool, (size_t)R * M), y(&m.pool, (size_t)R * M), wide(&m.pool, (size_t)R * wideN);
-            Buf<__half> planes(&m.pool, (size_t)R * (6 * M + 2 * Ci));
+            Buf<float> u(m.pp(), (size_t)R * M), y(m.pp(), (size_t)R * M), wide(m.pp(), (size_t)R * wideN);
+            Buf<__half> planes(m.pp(), (size_t)R * (6 * M + 2 * Ci));
             __half* up_h = planes.get();
             __half* up_l = up_h + (size_t)R * M;
             __half* yp_h = up_l + (size_t)R * M;
@@ -404,7 +404,7 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
                 launch_layernorm_both(u, M, l.conv_ln.g, l.conv_ln.b, u, M, up_h, up_l, M, R, M, ACT_NONE, nullptr, 1, m.stream);
             }
             launch_layernorm_split(u, M, m.t2u_dec_ln.g, m.t2u_dec_ln.b, up_h, up_l, M, R, M, ACT_NONE, nullptr, 1, m.stream);
-            Buf<float> logits(&m.pool, (size_t)R * c.unit_vocab_size);
+            Buf<float> logits(m.pp(), (size_t)R * c.unit_vocab_size);
             Linear proj;
             proj.w = m.unit_embed;
             proj.ldw = M;
@@ -443,13 +443,13 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
             for (int k = 0; k < Sc; ++k)
                 for (int r = 0; r < dur[(size_t)b * Sc + k]; ++r) uidx[(size_t)gi * Lg + pos++] = b * Sc + k;
         }
-        Buf<int> d_uidx(&m.pool, grows), d_glens(&m.pool, ng);
-        id_bufs.emplace_back(&m.pool, grows);
+        Buf<int> d_uidx(m.pp(), grows), d_glens(m.pp(), ng);
+        id_bufs.emplace_back(m.pp(), grows);
         int* d_ids = id_bufs.back();
         SC_HIP(hipMemcpyAsync(d_uidx.get(), uidx.data(), (size_t)grows * 4, hipMemcpyHostToDevice, m.stream));
         SC_HIP(hipMemcpyAsync(d_glens.get(), glens.data(), (size_t)ng * 4, hipMemcpyHostToDevice, m.stream));
-        Buf<float> u(&m.pool, (size_t)grows * M), y(&m.pool, (size_t)grows * M), att(&m.pool, (size_t)grows * M),
-            wide(&m.pool, (size_t)grows * wideN);
+        Buf<float> u(m.pp(), (size_t)grows * M), y(m.pp(), (size_t)grows * M), att(m.pp(), (size_t)grows * M),
+            wide(m.pp(), (size_t)grows * wideN);
         launch_gather_rows(cs, M, d_uidx, u, M, grows, M, m.stream);
         launch_pos_add(u, M, m.unit_pos, Lg, m.pos_alpha, grows, M, m.stream);
         const int K = c.t2u_conv_kernel;
@@ -464,7 +464,7 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
         }
         layernorm(m, u, m.t2u_dec_ln, u, grows);
         // project + argmax (model.py:438-441, generator.py:346)
-        Buf<float> logits(&m.pool, (size_t)grows * c.unit_vocab_size);
+        Buf<float> logits(m.pp(), (size_t)grows * c.unit_vocab_size);
         Linear proj;
         proj.w = m.unit_embed;
         proj.ldw = M;
@@ -498,9 +498,9 @@ void vocode_batch(Model& m, const int* d_units, const int* d_lang, const int* d_
     int t = T;
     Buf<float> x;
     {
-        Buf<float> in(&m.pool, (size_t)n * T * (E + Lg + Sp));
+        Buf<float> in(m.pp(), (size_t)n * T * (E + Lg + Sp));
         launch_vocoder_embed(d_units, n, T, m.voc_dict, E, m.voc_lang, Lg, d_lang, m.voc_spkr, Sp, d_spkr, in, m.stream);
-        x = Buf<float>(&m.pool, (size_t)n * T * ch);
+        x = Buf<float>(m.pp(), (size_t)n * T * ch);
         conv1d(m, in, m.voc_pre, nullptr, x, n, T, 1, 3, 1, nullptr, IN_NONE, ACT_NONE);
     }
     const int nk = c.voc_num_resblock_kernels;
@@ -510,13 +510,13 @@ void vocode_batch(Model& m, const int* d_units, const int* d_lang, const int* d_
         const int t2 = t * up.stride;
         ch = up.cout;
         const size_t sz = (size_t)n * t2 * ch;
-        Buf<float> y(&m.pool, sz), tmp(&m.pool, sz), ra(&m.pool, sz), rb(&m.pool, sz);
-        Buf<float> rout[3] = {Buf<float>(&m.pool, sz), Buf<float>(&m.pool, sz), Buf<float>(&m.pool, sz)};
+        Buf<float> y(m.pp(), sz), tmp(m.pp(), sz), ra(m.pp(), sz), rb(m.pp(), sz);
+        Buf<float> rout[3] = {Buf<float>(m.pp(), sz), Buf<float>(m.pp(), sz), Buf<float>(m.pp(), sz)};
         conv_transpose1d(m, x, up, y, n, t, IN_LRELU_01);
         // narrow stages: each dilation pair is one kernel with the intermediate in LDS, and the last pair of
         // the third ResBlock also applies the average over the three ResBlocks (k_resblock.hip)
         bool fused_avg = false;
-        x = Buf<float>(&m.pool, sz);
+        x = Buf<float>(m.pp(), sz);
         // wide stages (C >= 128, C % 32 == 0): the ResBlock convolutions on the DMA-fed GEMM in implicit-convolution mode
         // (k_gemm_ps.hip).  Its activation operand is a pair of fp16 planes: LeakyReLU(y) is split once for the three
         // ResBlocks, every convolution's epilogue writes the LeakyReLU'd planes the next one reads (plane_neg_slope) next to
@@ -532,7 +532,7 @@ void vocode_batch(Model& m, const int* d_units, const int* d_lang, const int* d_
                           (r.convs2[d].k & 1);
         }
         if (wide_ps) {
-            Buf<__half> planes(&m.pool, 6 * sz);
+            Buf<__half> planes(m.pp(), 6 * sz);
             __half* py_h = planes.get();  // LeakyReLU(y): the input of every ResBlock's first convolution
             __half* py_l = py_h + sz;
             __half* pt_h = py_l + sz;     // LeakyReLU(conv1 + b1)
@@ -655,9 +655,9 @@ void run_vocoder_durations(Model& m, const int32_t* h_units, int n, int T, int32
     const int rows = n * T;
     for (int i = 0; i < rows; ++i)
         SC_CHECK(h_units[i] >= 0 && h_units[i] < c.voc_num_embeddings, "sc_vocoder_durations: unit %d outside the vocoder dictionary", h_units[i]);
-    Buf<int> d_units(&m.pool, rows), d_dur(&m.pool, rows);
+    Buf<int> d_units(m.pp(), rows), d_dur(m.pp(), rows);
     SC_HIP(hipMemcpyAsync(d_units.get(), h_units, (size_t)rows * 4, hipMemcpyHostToDevice, m.stream));
-    Buf<float> x(&m.pool, (size_t)rows * E), a(&m.pool, (size_t)rows * H), b(&m.pool, (size_t)rows * H);
+    Buf<float> x(m.pp(), (size_t)rows * E), a(m.pp(), (size_t)rows * H), b(m.pp(), (size_t)rows * H);
     hipLaunchKernelGGL(embed_rows_f16_kernel, dim3(rows), dim3(256), 0, m.stream, d_units.get(), m.voc_dict, E, x.get());
     SC_LAUNCH_CHECK();
     conv1d(m, x, m.vdp_conv1, nullptr, a, n, T, 1, K / 2, 1, nullptr, IN_NONE, ACT_RELU);
@@ -688,7 +688,7 @@ void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h
     for (const ConvT& up : m.voc_ups) hop *= up.stride;
     static const int max_groups = getenv("SC_VOC_GROUPS") ? std::max(1, atoi(getenv("SC_VOC_GROUPS"))) : 8;
     if (!h_unit_lens || max_groups == 1) {
-        Buf<int> d_units(&m.pool, (size_t)n * T), d_ls(&m.pool, 2 * n);
+        Buf<int> d_units(m.pp(), (size_t)n * T), d_ls(m.pp(), 2 * n);
         SC_HIP(hipMemcpyAsync(d_units.get(), h_units, (size_t)n * T * 4, hipMemcpyHostToDevice, m.stream));
         SC_HIP(hipMemcpyAsync(d_ls.get(), h_lang, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
         SC_HIP(hipMemcpyAsync(d_ls.get() + n, h_spkr, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
@@ -707,10 +707,24 @@ void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h
     for (int i = 0; i < n; ++i) need[i] = std::min(T, h_unit_lens[i] + halo);
     const std::vector<std::vector<int>> groups = plan_length_groups(need, 250, max_groups);
     SC_HIP(hipMemsetAsync(d_wav, 0, (size_t)n * T * hop * sizeof(float), m.stream));
+    // The buckets are independent chains of ~150 launches each, and a bucket (a few utterances) is too small to fill the
+    // chip in the wide stages (40 - 300 workgroups per product): they go round `chains` side streams, each with its own
+    // scratch pool (model.h: SideChain), forked after the memset and joined before the final synchronisation.
+    // SC_VOC_STREAMS=1: every bucket on the handle's own stream, as before.
+    static const int max_chains = getenv("SC_VOC_STREAMS") ? std::max(1, std::min(8, atoi(getenv("SC_VOC_STREAMS")))) : 3;
+    const int chains = std::min<int>(max_chains, (int)groups.size());
+    if (chains > 1) {
+        m.side_chain(chains - 1);
+        SC_HIP(hipEventRecord(m.side_fork, m.stream));
+        for (int k = 0; k < chains; ++k) SC_HIP(hipStreamWaitEvent(m.side[k]->stream, m.side_fork, 0));
+    }
     std::vector<std::vector<int32_t>> staging;
     staging.reserve(2 * groups.size());
     int64_t rows_done = 0;
-    for (const std::vector<int>& grp : groups) {
+    for (size_t g = 0; g < groups.size(); ++g) {
+        const std::vector<int>& grp = groups[g];
+        std::unique_ptr<SideScope> scope;
+        if (chains > 1) scope.reset(new SideScope(m, (int)(g % chains)));
         const int ng = (int)grp.size();
         int Lg = 0;
         for (int b : grp) Lg = std::max(Lg, need[b]);
@@ -725,14 +739,18 @@ void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h
             gls[gi] = h_lang[b];
             gls[ng + gi] = h_spkr[b];
         }
-        Buf<int> d_units(&m.pool, (size_t)ng * Lg), d_ls(&m.pool, 2 * ng);
+        Buf<int> d_units(m.pp(), (size_t)ng * Lg), d_ls(m.pp(), 2 * ng);
         SC_HIP(hipMemcpyAsync(d_units.get(), gu.data(), (size_t)ng * Lg * 4, hipMemcpyHostToDevice, m.stream));
         SC_HIP(hipMemcpyAsync(d_ls.get(), gls.data(), (size_t)2 * ng * 4, hipMemcpyHostToDevice, m.stream));
-        Buf<float> gw(&m.pool, (size_t)ng * Lg * hop);
+        Buf<float> gw(m.pp(), (size_t)ng * Lg * hop);
         vocode_batch(m, d_units, d_ls, d_ls.get() + ng, ng, Lg, gw);
         for (int gi = 0; gi < ng; ++gi)
             SC_HIP(hipMemcpyAsync(d_wav + (size_t)grp[gi] * T * hop, gw.get() + (size_t)gi * Lg * hop, (size_t)Lg * hop * sizeof(float),
                                   hipMemcpyDeviceToDevice, m.stream));
+    }
+    for (int k = 0; k < chains && chains > 1; ++k) {
+        SC_HIP(hipEventRecord(m.side[k]->done, m.side[k]->stream));
+        SC_HIP(hipStreamWaitEvent(m.stream, m.side[k]->done, 0));
     }
     m.last_vocoder_unit_rows = rows_done;
     SC_HIP(hipStreamSynchronize(m.stream));
