@@ -16,6 +16,7 @@
 #   sqbench      SQ / GRBM counters of every kernel of a bench pass -> TAG_bench_pmc_sq.txt (matrix-pipe busy share per kernel)
 #   pyt          pytest on $PYT (files / -k expressions)           benchsweep  benchfast under each setting of $SWEEP
 #   pstest       GEMM op tests (bit identity of the kernel variants)       gemmab   scripts/gemm_bench.py at SC_PS_TILE=128 / 256
+#   gemmhalf     scripts/gemm_bench.py at SC_PS_HALF=0 / 1 (barrier in front of the slab / mid-slab)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -136,6 +137,9 @@ for task in "$@"; do
     gemmab)
       # pre-split GEMM: round-1 tile choice (128 x 128) against the 8-wave 256 x 256 tile, encoder shapes
       for t in 128 256; do ( SC_PS_TILE=$t timeout 200 python scripts/gemm_bench.py --quick --presplit-only > ${O}_gemm_tile$t.txt 2>&1 ); grep presplit ${O}_gemm_tile$t.txt | cut -c1-170; done ;;
+    gemmhalf)
+      # pre-split GEMM: barrier in front of the slab (SC_PS_HALF=0) against the mid-slab barrier schedule, encoder shapes
+      for t in 0 1; do ( SC_PS_HALF=$t timeout 200 python scripts/gemm_bench.py --quick --presplit-only > ${O}_gemm_half$t.txt 2>&1 ); echo "--- SC_PS_HALF=$t"; grep presplit ${O}_gemm_half$t.txt | cut -c1-170; done ;;
     *) echo "unknown task $task" ;;
   esac
 done

@@ -130,7 +130,16 @@ __device__ __forceinline__ void ps_epilogue(const GemmPsArgs& p, const float* ep
 // 256 x 256 tile (wave tile 64 x 128) halves the barriers per MFMA (32 matrix instructions per slab and wave instead of
 // 16) and takes the fragment reads from 0.75 to 0.5 ds_read_b128 per MFMA at the same 6 DMAs per wave and slab; its
 // three stages fill 144 KB of the 160 KB LDS (one workgroup of 8 waves per CU = the same 2 waves per SIMD).
-template <int BM, int BN, int WGM, int WGN, bool ILV, bool SPLIT, bool CONV = false>
+// HALF (needs ILV and SPLIT): the slab's barrier sits in the MIDDLE of its matrix instructions instead of in front of them.
+// With the barrier in front, all eight waves leave it together, request their 16 fragments together (128 KB of LDS reads per
+// workgroup) and nobody has a matrix instruction to issue until the first ones are back; the hi/lo pairs of the slab's second
+// 16-wide K chunk and the next slab's first-chunk fragments are then fetched under running MFMAs:
+//     step s:  read chunk-1 fragments of slab s | MFMA chunk 0 (fragments carried in registers) + DMAs 3..5 of slab s+2
+//              wait for slab s+1's DMAs, BARRIER | read chunk-0 fragments of slab s+1 | MFMA chunk 1 + DMAs 0..2 of slab s+3
+// After the barrier every wave has matrix work in registers at once.  The barrier of step s also says that every wave is
+// done reading slab s (both chunks: lgkmcnt(0) in front of it), so slab s+3 may land in the same stage from there on.
+// Same instructions and the same accumulation order as the other schedules: bit-identical results.
+template <int BM, int BN, int WGM, int WGN, bool ILV, bool SPLIT, bool CONV = false, bool HALF = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, int tiles_n, int tiles_total, int tiles_per_xcd,
                                                                  uint32_t a_bytes, uint32_t w_bytes) {
     constexpr int NWAVE = WGM * WGN;
@@ -360,12 +369,99 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
     } while (0)
 
     const int nslab = p.K / PBK;
+    if constexpr (HALF) {
+        static_assert(!HALF || (ILV && SPLIT), "the mid-slab barrier schedule is written for the split, interleaved kernel");
+        constexpr int NH = NDMA / 2;  // DMAs of a slab issued in the second half of step s-3; the rest in the first half of step s-2
+        half8_t c_ah[TM], c_al[TM], c_bf[TN];  // chunk-0 fragments of the current slab, carried from the previous step
+#define PS_LDS8(BASE, OFF) (*reinterpret_cast<const half8_t*>(reinterpret_cast<const char*>(BASE) + (OFF)))
+#define PS_READ_C0(AH, AL, BB)                                                                  \
+    do {                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
+            c_ah[i] = PS_LDS8(AH, a_off[i][0]);                                                 \
+            c_al[i] = PS_LDS8(AL, a_off[i][0]);                                                 \
+        }                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) c_bf[j] = PS_LDS8(BB, b_off[j][0]);      \
+    } while (0)
+// C* = stage of slab S (and of S+3), N* = stage of S+1, O* = stage of S+2
+#define PS_HSTEP(S, CAH, CAL, CB, NAH, NAL, NB, OAH, OAL, OB)                                                          \
+    do {                                                                                                               \
+        half8_t ah1[TM], al1[TM], bf1[TN];                                                                             \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                               \
+            ah1[i] = PS_LDS8(CAH, a_off[i][1]);                                                                        \
+            al1[i] = PS_LDS8(CAL, a_off[i][1]);                                                                        \
+        }                                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) bf1[j] = PS_LDS8(CB, b_off[j][1]);                              \
+        const bool iss2_ = (S) + 2 < nslab;                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        int q_ = NH;                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                           \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c_ah[i], c_bf[j], acc[i][j], 0, 0, 0);               \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c_al[i], c_bf[j], acc[i][j], 0, 0, 0);               \
+                if (q_ < NDMA) {                                                                                       \
+                    __builtin_amdgcn_sched_barrier(0);                                                                 \
+                    if (iss2_) PS_DMA_Q(q_, OAH, OAL, OB, ((S) + 2) * (PBK * 2));                                      \
+                    __builtin_amdgcn_sched_barrier(0);                                                                 \
+                }                                                                                                      \
+                ++q_;                                                                                                  \
+            }                                                                                                          \
+        _Pragma("unroll") for (int q2 = NH + TM * TN; q2 < NDMA; ++q2)                                                 \
+            if (iss2_) PS_DMA_Q(q2, OAH, OAL, OB, ((S) + 2) * (PBK * 2));                                              \
+        if ((S) + 1 < nslab) {                                                                                         \
+            if (iss2_) __builtin_amdgcn_s_waitcnt(NDMA == 6 ? 0x0076 : 0x0073); /* vmcnt(6 | 3) lgkmcnt(0) */          \
+            else __builtin_amdgcn_s_waitcnt(0x0070);                            /* vmcnt(0) lgkmcnt(0) */              \
+            __builtin_amdgcn_s_barrier();                                                                              \
+            asm volatile("" ::: "memory");                                                                             \
+            PS_READ_C0(NAH, NAL, NB);                                                                                  \
+        }                                                                                                              \
+        const bool iss3_ = (S) + 3 < nslab;                                                                            \
+        if (iss3_) PS_NEXT_ADDR();                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        q_ = 0;                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                           \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bf1[j], acc[i][j], 0, 0, 0);                 \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[i], bf1[j], acc[i][j], 0, 0, 0);                 \
+                if (q_ < NH) {                                                                                         \
+                    __builtin_amdgcn_sched_barrier(0);                                                                 \
+                    if (iss3_) PS_DMA_Q(q_, CAH, CAL, CB, ((S) + 3) * (PBK * 2));                                      \
+                    __builtin_amdgcn_sched_barrier(0);                                                                 \
+                }                                                                                                      \
+                ++q_;                                                                                                  \
+            }                                                                                                          \
+        asm volatile("" ::: "memory");                                                                                 \
+    } while (0)
+
+        // prologue: slabs 0 and 1 whole, the first NH DMAs of slab 2; slab 0 must have landed before its fragments are read
+        PS_ISSUE(sAh0, sAl0, sB0, 0);
+        if (nslab > 1) PS_ISSUE(sAh1, sAl1, sB1, PBK * 2);
+        if (nslab > 2) {
+            PS_NEXT_ADDR();
+#pragma unroll
+            for (int q = 0; q < NH; ++q) PS_DMA_Q(q, sAh2, sAl2, sB2, 2 * (PBK * 2));
+        }
+        if (nslab > 2) __builtin_amdgcn_s_waitcnt(NDMA == 6 ? 0x0079 : 0x0074);       // vmcnt(NDMA + NH)
+        else if (nslab > 1) __builtin_amdgcn_s_waitcnt(NDMA == 6 ? 0x0076 : 0x0073);  // vmcnt(NDMA)
+        else __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        PS_READ_C0(sAh0, sAl0, sB0);
+        for (int s = 0; s < nslab; s += 3) {
+            PS_HSTEP(s, sAh0, sAl0, sB0, sAh1, sAl1, sB1, sAh2, sAl2, sB2);
+            if (s + 1 < nslab) PS_HSTEP(s + 1, sAh1, sAl1, sB1, sAh2, sAl2, sB2, sAh0, sAl0, sB0);
+            if (s + 2 < nslab) PS_HSTEP(s + 2, sAh2, sAl2, sB2, sAh0, sAl0, sB0, sAh1, sAl1, sB1);
+        }
+#undef PS_HSTEP
+#undef PS_READ_C0
+#undef PS_LDS8
+    } else {
     PS_ISSUE(sAh0, sAl0, sB0, 0);
     if (nslab > 1) PS_ISSUE(sAh1, sAl1, sB1, PBK * 2);
     for (int s = 0; s < nslab; s += 3) {
         PS_STEP(s, sAh0, sAl0, sB0, sAh2, sAl2, sB2);
         if (s + 1 < nslab) PS_STEP(s + 1, sAh1, sAl1, sB1, sAh0, sAl0, sB0);
         if (s + 2 < nslab) PS_STEP(s + 2, sAh2, sAl2, sB2, sAh1, sAl1, sB1);
+    }
     }
 #undef PS_STEP
 #undef PS_COMPUTE
@@ -415,8 +511,11 @@ void launch_ps_cfg(const GemmPsArgs& a, hipStream_t s) {
     static const bool ilv = !(getenv("SC_PS_ILV") && atoi(getenv("SC_PS_ILV")) == 0);  // A/B switch (development)
     const dim3 grid(tiles_per_xcd * 8), block(WGM * WGN * 64);
     const uint32_t ab = (uint32_t)((int64_t)a.M * a.lda * 2), wb = (uint32_t)((int64_t)a.N * a.ldw * 2);
+    static const bool half = !(getenv("SC_PS_HALF") && atoi(getenv("SC_PS_HALF")) == 0);  // mid-slab barrier schedule (A/B switch)
     if (!a.split) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
+    else if (a.conv_taps > 0 && half) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (a.conv_taps > 0) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
+    else if (ilv && half) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, false, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (ilv) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
 }

@@ -705,7 +705,8 @@ void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h
     const int halo = vocoder_halo_units(m);
     std::vector<int> need(n);
     for (int i = 0; i < n; ++i) need[i] = std::min(T, h_unit_lens[i] + halo);
-    const std::vector<std::vector<int>> groups = plan_length_groups(need, 250, max_groups);
+    static const int group_overhead = getenv("SC_VOC_GROUP_OVERHEAD") ? std::max(0, atoi(getenv("SC_VOC_GROUP_OVERHEAD"))) : 250;
+    const std::vector<std::vector<int>> groups = plan_length_groups(need, group_overhead, max_groups);
     SC_HIP(hipMemsetAsync(d_wav, 0, (size_t)n * T * hop * sizeof(float), m.stream));
     // The buckets are independent chains of ~150 launches each, and a bucket (a few utterances) is too small to fill the
     // chip in the wide stages (40 - 300 workgroups per product): they go round `chains` side streams, each with its own
