@@ -131,6 +131,36 @@ __device__ __forceinline__ void stage_weights(const __half* __restrict__ W, int6
     }
 }
 
+// One tap (C x C halfs) of a packed weight matrix in two steps, so that a tap's global loads are in flight WHILE the previous
+// tap is multiplied: tap_load issues them into registers, tap_store (after the matrix instructions) puts them into the other
+// LDS buffer.  With load + store back to back in front of the product every tap paid a full L2 round trip before its first
+// MFMA (counters: waves 65 % in s_waitcnt, matrix pipe 17 % busy).
+template <int C>
+struct TapRegs {
+    static constexpr int N = (C * (C / 8) + 255) / 256;
+    half8_t v[N];
+};
+template <int C>
+__device__ __forceinline__ void tap_load(const __half* __restrict__ W, int64_t ldw, int k0, int tid, TapRegs<C>& r) {
+    constexpr int VPR = C / 8;
+#pragma unroll
+    for (int j = 0; j < TapRegs<C>::N; ++j) {
+        const int i = tid + 256 * j;
+        const int col = i / VPR, v = i - col * VPR;
+        if (i < C * VPR) r.v[j] = *reinterpret_cast<const half8_t*>(W + (int64_t)col * ldw + k0 + v * 8);
+    }
+}
+template <int C>
+__device__ __forceinline__ void tap_store(const TapRegs<C>& r, _Float16* sW, int ldb, int tid) {
+    constexpr int VPR = C / 8;
+#pragma unroll
+    for (int j = 0; j < TapRegs<C>::N; ++j) {
+        const int i = tid + 256 * j;
+        const int col = i / VPR, v = i - col * VPR;
+        if (i < C * VPR) *reinterpret_cast<half8_t*>(sW + col * ldb + v * 8) = r.v[j];
+    }
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int tiles) {
     constexpr int CS = C + 8;          // halfs per LDS row: 16-byte fragment reads of consecutive rows hit distinct banks
@@ -186,9 +216,11 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
         if (PER_TAP) {
-            for (int t = 0; t < k; ++t) {  // tap t from buffer t&1 while tap t+1 is staged into the other one
-                if (t + 1 < k) stage_weights<C>(p.w1, p.ldw1, (t + 1) * C, C, sW + ((t + 1) & 1) * C * ldb, ldb, tid);
+            TapRegs<C> wr;
+            for (int t = 0; t < k; ++t) {  // tap t from buffer t&1 while tap t+1 travels: registers, then the other buffer
+                if (t + 1 < k) tap_load<C>(p.w1, p.ldw1, (t + 1) * C, tid, wr);
                 conv_from_lds_w<C, NF>(xh, xl, 32 * wave, dil, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc);
+                if (t + 1 < k) tap_store<C>(wr, sW + ((t + 1) & 1) * C * ldb, ldb, tid);  // read last at tap t-1: barrier since
                 __syncthreads();
             }
         } else {
@@ -224,10 +256,14 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nf][r] = 0.f;
         if (PER_TAP) {
+            TapRegs<C> wr;
             for (int t = 0; t < k; ++t) {
-                if (t + 1 < k) stage_weights<C>(p.w2, p.ldw2, (t + 1) * C, C, sW + ((t + 1) & 1) * C * ldb, ldb, tid);
+                if (t + 1 < k) tap_load<C>(p.w2, p.ldw2, (t + 1) * C, tid, wr);
                 conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc);
-                if (t + 1 < k) __syncthreads();
+                if (t + 1 < k) {
+                    tap_store<C>(wr, sW + ((t + 1) & 1) * C * ldb, ldb, tid);
+                    __syncthreads();
+                }
             }
         } else {
             conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, 0, k, sW, ldb, lane, acc);
