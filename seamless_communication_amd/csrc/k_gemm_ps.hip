@@ -547,8 +547,10 @@ void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s) {
     const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
     const int64_t tiles256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
     // (N <= 128: a 256-wide tile would idle half its columns - the 128-channel vocoder stage)
-    if (max_tile >= 256 && tiles256 >= 224 && a.N > 128) launch_ps_cfg<256, 256, 4, 2>(a, s);
-    else if (tiles128 >= 256) launch_ps_cfg<128, 128, 2, 2>(a, s);
+    static const int min256 = getenv("SC_PS_MIN256") ? atoi(getenv("SC_PS_MIN256")) : 224;
+    static const int min128 = getenv("SC_PS_MIN128") ? atoi(getenv("SC_PS_MIN128")) : 256;
+    if (max_tile >= 256 && tiles256 >= min256 && a.N > 128) launch_ps_cfg<256, 256, 4, 2>(a, s);
+    else if (tiles128 >= min128) launch_ps_cfg<128, 128, 2, 2>(a, s);
     else launch_ps_cfg<64, 64, 2, 2>(a, s);
     SC_LAUNCH_CHECK();
 }
