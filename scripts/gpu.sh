@@ -17,6 +17,7 @@
 #   pyt          pytest on $PYT (files / -k expressions)           benchsweep  benchfast under each setting of $SWEEP
 #   pstest       GEMM op tests (bit identity of the kernel variants)       gemmab   scripts/gemm_bench.py at SC_PS_TILE=128 / 256
 #   gemmhalf     scripts/gemm_bench.py at SC_PS_HALF=0 / 1 (barrier in front of the slab / mid-slab)
+#   cover        kernel trace of a bench pass -> device-busy share, idle gaps, timeline (scripts/trace_cover.py)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -124,6 +125,14 @@ for task in "$@"; do
       f=$(find gpurun_out/${TAG}_btrace -name "*kernel_trace.csv" | head -1)
       [ -n "$f" ] && python scripts/trace_gaps.py $f --last ${BTRACE_LAST:-20000} > ${O}_btrace_summary.txt 2>&1; head -32 ${O}_btrace_summary.txt | cut -c1-130
       find gpurun_out/${TAG}_btrace -name "*.csv" -size +20M -delete 2>/dev/null ;;
+    cover)
+      # kernel trace of two bench passes: how busy the device is over the last pass (union of kernel intervals, idle gaps, timeline)
+      rm -rf gpurun_out/${TAG}_cover
+      ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_cover -o b -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-extra --no-profile-step > $R/${O}_cover.log 2>&1; echo "exit $?" >> $R/${O}_cover.log )
+      f=$(find gpurun_out/${TAG}_cover -name "*kernel_trace.csv" | head -1)
+      ms=$(python -c "import json,sys; print(json.loads([l for l in open('${O}_cover.log') if l.startswith('{')][-1])['ms_per_step'])" 2>/dev/null || echo 260)
+      [ -n "$f" ] && python scripts/trace_cover.py $f --window-ms $ms --bin-ms ${COVER_BIN:-5} > ${O}_cover.txt 2>&1; head -90 ${O}_cover.txt | cut -c1-200
+      find gpurun_out/${TAG}_cover -name "*.csv" -size +2M -delete 2>/dev/null ;;
     chain)
       ( timeout 200 python scripts/chain_bench.py > ${O}_chain.txt 2>&1 ); grep -v amdgpu ${O}_chain.txt | head -40 ;;
     micro)
