@@ -15,6 +15,7 @@
 #   sqpmc        SQ / TCP counters of the encoder GEMM (three --pmc passes of scripts/gemm_bench.py) -> TAG_gemm_pmc_sq.txt
 #   sqbench      SQ / GRBM counters of every kernel of a bench pass -> TAG_bench_pmc_sq.txt (matrix-pipe busy share per kernel)
 #   pyt          pytest on $PYT (files / -k expressions)           benchsweep  benchfast under each setting of $SWEEP
+#   argsweep     benchfast with each extra argument list of $ARGSWEEP (e.g. "--microbatches 1;--free-run")
 #   pstest       GEMM op tests (bit identity of the kernel variants)       gemmab   scripts/gemm_bench.py at SC_PS_TILE=128 / 256
 #   gemmhalf     scripts/gemm_bench.py at SC_PS_HALF=0 / 1 (barrier in front of the slab / mid-slab)
 #   cover        kernel trace of a bench pass -> device-busy share, idle gaps, timeline (scripts/trace_cover.py)
@@ -61,6 +62,15 @@ for task in "$@"; do
       ( timeout 900 python bench.py $BENCH_ARGS > ${O}_bench.json 2> ${O}_bench.err; echo "exit $?" >> ${O}_bench.err ); tail -3 ${O}_bench.err | cut -c1-300; line ${O}_bench.json ;;
     benchfast)
       ( timeout 600 python bench.py $BENCH_ARGS --no-cpu-baseline --no-latency --no-extra > ${O}_benchfast.json 2> ${O}_benchfast.err; echo "exit $?" >> ${O}_benchfast.err ); tail -2 ${O}_benchfast.err | cut -c1-300; line ${O}_benchfast.json ;;
+    argsweep)
+      # benchfast once per extra argument list of $ARGSWEEP (';'-separated: ARGSWEEP="--microbatches 2;--free-run")
+      IFS=';' read -ra SW <<< "$ARGSWEEP"
+      i=0
+      for e in "${SW[@]}"; do
+        i=$((i+1))
+        ( timeout 400 python bench.py $BENCH_ARGS --no-cpu-baseline --no-latency --no-extra $e > ${O}_argsweep_$i.json 2> ${O}_argsweep_$i.err; echo "exit $?" >> ${O}_argsweep_$i.err )
+        echo "--- $e"; tail -1 ${O}_argsweep_$i.err; line ${O}_argsweep_$i.json
+      done ;;
     benchsweep)
       # benchfast once per environment setting of $SWEEP (';'-separated: SWEEP="SC_VOC_STREAMS=1;SC_VOC_STREAMS=3")
       IFS=';' read -ra SW <<< "$SWEEP"
