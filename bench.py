@@ -447,6 +447,7 @@ def main():
     stagger = args.stagger if args.stagger >= 0 else (warm_s / batcher.groups if args.warmup > 0 else 0.0)
     fence()
     t0 = time.perf_counter()
+    step_marks = [t0]
     if free_run:
         # K passes over the per-GPU batch; the micro-batch slices free-run (joined once), the all-gathers of the K
         # passes follow.  Same work as K lock-step passes, see MicroBatcher.predict_steps.
@@ -462,6 +463,7 @@ def main():
     else:
         for _ in range(args.steps):
             step()
+            step_marks.append(time.perf_counter())  # a pass ends with its ids / waveforms on the host: no extra sync
     fence()
     elapsed = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s; last step {stage_ms}")
@@ -493,6 +495,7 @@ def main():
             "metric": "S2ST utterances/sec (and real-time factor), seamlessM4T_v2_large, 10 s audio",
             "value": utt_per_s, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_each_step": [round(1e3 * (b - a), 1) for a, b in zip(step_marks, step_marks[1:])],
             "dtype": "f32 activations x f16 weights, f32 accumulate", "data": "synthetic",
             "rtf": (elapsed / args.steps) / (B * AUDIO_SECONDS),
             "config": {
