@@ -493,6 +493,10 @@ void launch_vocoder_embed(const int* units, int nb, int T, const __half* dict, i
                           const __half* lang, int Lg, const int* lang_idx, const __half* spkr, int Sp,
                           const int* spkr_idx, float* out /*[nb*T][Lg+E+Sp]*/, hipStream_t s);
 void launch_avg3(const float* a, const float* b, const float* c, float* out, int64_t n, hipStream_t s);
+// Conv1d(cin -> 1, k taps, 'same') with LeakyReLU(in_slope) on the input and `act` on the output (k_misc.hip: the vocoder's conv_post)
+bool conv_to_mono_supported(int cin, int cout, int k, int stride, int pad, int dil, int act);
+void launch_conv_to_mono(const float* x, const __half* w_packed, const float* bias, int nb, int T, int cin, int k, float in_slope, int act,
+                         float* y, hipStream_t s);
 void launch_fill_i32(int* p, int v, int n, hipStream_t s);
 void launch_add_i32(int* p, int v, hipStream_t s);
 

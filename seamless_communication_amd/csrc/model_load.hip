@@ -697,6 +697,13 @@ void conv1d(Model& m, const float* x, const Conv& c, const float* res, float* y,
             int dil, const int* d_in_lens, int in_act, int act) {
     const int t_out = (t_in + 2 * pad - dil * (c.k - 1) - 1) / stride + 1;
     if (nb <= 0 || t_out <= 0) return;
+    // one output channel (the vocoder's conv_post): a direct fp32 kernel instead of an MFMA tile with one live column
+    if (!res && !d_in_lens && g_force_general_gemm.load(std::memory_order_relaxed) == 0 &&
+        conv_to_mono_supported(c.cin, c.cout, c.k, stride, pad, dil, act)) {
+        const float slope = in_act == IN_LRELU_01 ? 0.1f : in_act == IN_LRELU_001 ? 0.01f : 1.0f;
+        launch_conv_to_mono(x, c.w, c.b, nb, t_in, c.cin, c.k, slope, act, y, m.stream);
+        return;
+    }
     GemmArgs a;
     a.A = x;
     a.lda = c.cin;

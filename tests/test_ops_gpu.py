@@ -258,6 +258,34 @@ def test_fast_gemm_bit_identical_to_general_conv(lib, report_dir, case):
     assert torch.equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("nb,T,act", [(1, 4000, 3), (3, 1000, 3), (2, 255, 0), (1, 7, 3), (2, 257, 3)])
+def test_conv_to_one_channel_matches_torch_and_the_gemm_path(lib, report_dir, nb, T, act):
+    """The vocoder's conv_post shape (16 -> 1 channel, k = 7, LeakyReLU(0.01) in front, tanh behind) runs on a direct fp32
+    kernel (k_misc.hip: conv_to_mono_kernel) instead of an MFMA tile with one live column: against a float64 reference, and
+    against the GEMM path (which the general-kernel switch still selects) - two fp32-accurate evaluations of the same sum."""
+    cin, cout, k = 16, 1, 7
+    g = torch.Generator().manual_seed(T + nb)
+    x = torch.randn(nb, T, cin, generator=g) * 1.5
+    w = (torch.randn(cout, cin, k, generator=g) / math.sqrt(cin * k)).half()
+    b = torch.randn(cout, generator=g) * 0.1
+    wp = torch.zeros(cout, 128, dtype=torch.float16, device="cuda")  # packed row, padded to a multiple of 32
+    check(lib, lib.sc_op_pack_conv_weight(P(dev(w)), P(wp), cout, cin, k))
+    ref = F.conv1d(F.leaky_relu(x.double(), 0.01).transpose(1, 2), w.double(), b.double(), padding=3).transpose(1, 2)
+    if act == 3:
+        ref = torch.tanh(ref)
+    out = []
+    for general in (1, 0):
+        check(lib, lib.sc_op_force_general_gemm(general))
+        y = torch.full((nb, T, cout), float("nan"), device="cuda")
+        check(lib, lib.sc_op_conv1d(P(dev(x)), P(wp), P(dev(b)), P(None), P(y), nb, T, cin, cout, k, 1, 3, 1, P(None), 2, act))
+        out.append(y.cpu())
+    check(lib, lib.sc_op_force_general_gemm(0))
+    err = float((out[1].double() - ref).abs().max())
+    err_g = float((out[0].double() - ref).abs().max())
+    _log(report_dir, "conv_to_mono", nb=nb, T=T, act=act, err=err, err_gemm_path=err_g)
+    assert err < 2e-6 and err_g < 2e-6
+
+
 @pytest.mark.parametrize("nb,T,cin,cout,k,s", [(2, 250, 512, 256, 11, 5), (1, 4000, 64, 32, 4, 2), (3, 77, 32, 16, 8, 4)])
 def test_fast_gemm_bit_identical_to_general_conv_transpose(lib, report_dir, nb, T, cin, cout, k, s):
     g = torch.Generator().manual_seed(T + cin + k)

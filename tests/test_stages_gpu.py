@@ -362,6 +362,11 @@ def test_ragged_vocoder_and_bucketed_t2u_match_the_padded_batch(env, report_dir)
     _log(report_dir, "ragged_vocoder", errs=errs, rows_computed=pad["vocoder_rows_computed"], rows_padded=len(lens) * T)
     assert max(errs) == 0.0  # the same kernels on the same window: bit-identical where it is kept
     assert pad["vocoder_rows_computed"] < 0.75 * len(lens) * T
+    # the buckets run on side chains (own stream + scratch pool each, model_t2u.hip: run_vocode): repeated calls must not
+    # differ by a bit - a block handed to two chains at once or a missing join would show up here
+    for _ in range(4):
+        again = hip.vocode(units, lang_idx, spkr_idx, lens)
+        assert all(torch.equal(again[i, :, : l * hop], rag[i, :, : l * hop]) for i, l in enumerate(lens))
     # NAR decoder: ids of a ragged batch equal the ids of each item run alone (one bucket each)
     ws = common.waves((2.0, 0.6, 1.3, 0.4))
     fb, flens = orc.collate_fbank(ws)
