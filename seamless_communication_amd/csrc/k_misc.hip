@@ -110,10 +110,61 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restri
     }
 }
 
+// Arg-max only (no generation rule, no log-probability): the unit projection of the NAR T2U (generator.py:346) - 22 k rows
+// x 10 082 logits per slice.  One wave per row, 8-byte loads, ties -> lowest index like the kernel above; that one spends an
+// exp per element on a log-sum-exp nobody reads here (555 us per call at 1.6 TB/s).
+__global__ __launch_bounds__(256) void argmax_plain_rows_kernel(const float* __restrict__ logits, int64_t ld, int rows, int V,
+                                                                int* __restrict__ out_idx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* lr = logits + (int64_t)row * ld;
+    const float2* l2 = reinterpret_cast<const float2*>(lr);
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    const int nv = V >> 1;
+#pragma unroll 4
+    for (int i = lane; i < nv; i += 64) {
+        const float2 v = l2[i];
+        if (v.x > best || (v.x == best && 2 * i < bidx)) {
+            best = v.x;
+            bidx = 2 * i;
+        }
+        if (v.y > best || (v.y == best && 2 * i + 1 < bidx)) {
+            best = v.y;
+            bidx = 2 * i + 1;
+        }
+    }
+    if ((V & 1) && lane == 0) {
+        const float t = lr[V - 1];
+        if (t > best || (t == best && V - 1 < bidx)) {
+            best = t;
+            bidx = V - 1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bidx, o);
+        if (ob > best || (ob == best && oi < bidx)) {
+            best = ob;
+            bidx = oi;
+        }
+    }
+    if (lane == 0) out_idx[row] = bidx;
+}
+
 void launch_argmax_rows(const float* logits, int64_t ld, int rows, int V, const int* d_pos,
                         int min_step_for_eos, int force_eos_step, int pad_idx, int eos_idx, int unk_idx,
                         float unk_penalty, int* out_idx, float* out_lprob, hipStream_t s) {
     if (rows <= 0) return;
+    const bool plain = !d_pos && !out_lprob && min_step_for_eos <= 0 && force_eos_step < 0 && pad_idx < 0 && unk_idx < 0 && (ld & 1) == 0 &&
+                       (reinterpret_cast<uintptr_t>(logits) & 7) == 0;
+    if (plain) {
+        hipLaunchKernelGGL(argmax_plain_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, logits, ld, rows, V, out_idx);
+        SC_LAUNCH_CHECK();
+        return;
+    }
     hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(1024), 0, s, logits, ld, V, d_pos, min_step_for_eos,
                        force_eos_step, pad_idx, eos_idx, unk_idx, unk_penalty, out_idx, out_lprob);
     SC_LAUNCH_CHECK();

@@ -566,6 +566,27 @@ def test_argmax_lprob(lib, report_dir, rows, V):
     assert err < 1e-5
 
 
+@pytest.mark.parametrize("rows,V", [(1, 256102), (7, 10082), (64, 1200), (5, 1201), (1030, 10082)])
+def test_argmax_without_lprob_takes_the_plain_kernel(lib, rows, V):
+    """No log-probability asked for (the NAR T2U unit projection): one wave per row, 8-byte loads, no exp (k_misc.hip:
+    argmax_plain_rows_kernel; odd V falls back to the general kernel).  Ties -> lowest index; a row of -inf -> index 0."""
+    g = torch.Generator().manual_seed(V + rows)
+    x = torch.randn(rows, V, generator=g) * 3
+    x[0, V - 1] = x[0].max() + 1.0
+    x[0, 9] = x[0, V - 1]  # tie -> lowest index wins
+    if rows > 2:
+        x[2] = float("-inf")
+        x[1, 1::2] = 7.0  # ties across lanes and inside a load
+        x[1, 0::2] = -7.0
+    idx = torch.full((rows,), -5, dtype=torch.int32, device="cuda")
+    check(lib, lib.sc_op_argmax(P(dev(x)), rows, V, P(idx), P(None)))
+    want = x.argmax(-1).tolist()
+    want[0] = 9
+    if rows > 2:
+        want[1], want[2] = 1, 0
+    assert idx.cpu().tolist() == want
+
+
 SKINNY_SHAPES = [
     (1, 1024, 1024), (16, 3072, 1024), (16, 8192, 1024), (16, 1024, 8192), (32, 1024, 1024), (33, 1024, 1024),
     (64, 3072, 1024), (7, 100, 128), (16, 256102, 1024), (5, 1200, 256), (16, 70, 64),
