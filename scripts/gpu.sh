@@ -18,6 +18,7 @@
 #   argsweep     benchfast with each extra argument list of $ARGSWEEP (e.g. "--microbatches 1;--free-run")
 #   pstest       GEMM op tests (bit identity of the kernel variants)       gemmab   scripts/gemm_bench.py at SC_PS_TILE=128 / 256
 #   gemmhalf     scripts/gemm_bench.py at SC_PS_HALF=0 / 1 (barrier in front of the slab / mid-slab)
+#   pyprof       rocprofv3 kernel stats of `python $PYPROF` under each setting of $SWEEP
 #   cover        kernel trace of a bench pass -> device-busy share, idle gaps, timeline (scripts/trace_cover.py)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -135,6 +136,17 @@ for task in "$@"; do
       f=$(find gpurun_out/${TAG}_btrace -name "*kernel_trace.csv" | head -1)
       [ -n "$f" ] && python scripts/trace_gaps.py $f --last ${BTRACE_LAST:-20000} > ${O}_btrace_summary.txt 2>&1; head -32 ${O}_btrace_summary.txt | cut -c1-130
       find gpurun_out/${TAG}_btrace -name "*.csv" -size +20M -delete 2>/dev/null ;;
+    pyprof)
+      # kernel stats of a python script ($PYPROF) under each environment setting of $SWEEP (';'-separated; empty = one run)
+      IFS=';' read -ra SW <<< "${SWEEP:- }"
+      i=0
+      for e in "${SW[@]}"; do
+        i=$((i+1)); rm -rf gpurun_out/${TAG}_pyprof_$i
+        ( cd /tmp && env $e timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_pyprof_$i -o p -- python $R/$PYPROF > $R/${O}_pyprof_$i.log 2>&1 )
+        find gpurun_out/${TAG}_pyprof_$i -name "*kernel_trace*" -delete 2>/dev/null
+        f=$(find gpurun_out/${TAG}_pyprof_$i -name "*kernel_stats.csv" | head -1)
+        echo "--- $e"; [ -n "$f" ] && cp $f ${O}_pyprof_$i.csv && head -8 ${O}_pyprof_$i.csv | cut -c1-200
+      done ;;
     cover)
       # kernel trace of two bench passes: how busy the device is over the last pass (union of kernel intervals, idle gaps, timeline)
       rm -rf gpurun_out/${TAG}_cover
