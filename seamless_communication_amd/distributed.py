@@ -113,9 +113,10 @@ def predict_batch_dp(translator, waveforms: Sequence[torch.Tensor], task_str: st
 class MicroBatcher:
     """Runs ``Translator.predict`` on ``groups`` contiguous slices of a batch concurrently, one host
     thread and one forked handle (own HIP stream) per slice.  Utterances are independent, so the
-    results are those of one big batch; what changes is the schedule on the GPU: the decoder steps of
-    one slice (a chain of ~270 short dependent kernels per token, latency bound) run underneath the
-    GEMM-bound encoder / T2U / vocoder stages of another slice instead of leaving the chip idle."""
+    results are those of one big batch; what changes is the schedule on the GPU: the slices start together and
+    stay in lock step, so every stage of one slice shares the chip with the same stage of the other - which pays
+    most in the decoder phase (a chain of ~220 short dependent kernels per token that leaves more than half of
+    the chip idle on its own; DESIGN.md section 3, profiles/r3_bench_cover_timeline.txt)."""
 
     def __init__(self, translator, groups: int) -> None:
         from concurrent.futures import ThreadPoolExecutor
