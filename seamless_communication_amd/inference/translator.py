@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import logging
 import time
+import warnings
 from pathlib import Path
 from dataclasses import dataclass
 from enum import Enum, auto
@@ -96,10 +97,33 @@ DEFAULT_CARDS: Dict[str, Dict[str, Any]] = {
 }
 
 
+def parse_synthetic_uri(uri: str) -> Tuple[int, Dict[str, str]]:
+    """``synthetic://<seed>[?key=value[&key=value]]`` -> (seed, options).  Options: ``eos_ramp`` (synthetic.EosRamp)."""
+    body = uri[len("synthetic://"):]
+    head, _, query = body.partition("?")
+    opts = dict(kv.split("=", 1) for kv in query.split("&") if "=" in kv)
+    unknown = set(opts) - {"eos_ramp"}
+    if unknown:
+        raise ValueError(f"checkpoint '{uri}': unknown option(s) {sorted(unknown)}")
+    return int(head or _syn.DEFAULT_SEED), opts
+
+
+def _warn_synthetic(name: str, card: Dict[str, Any]) -> None:
+    """A NAMED card that resolves to seeded random weights is not the published model (the reference card points at the
+    released checkpoint, cards/seamlessM4T_v2_large.yaml:10-11): say so loudly instead of translating into noise."""
+    if str(card.get("checkpoint", "")).startswith("synthetic://"):
+        msg = (f"asset card '{name}' resolves to SEEDED RANDOM weights ({card['checkpoint']}): no published checkpoint is reachable "
+               f"offline.  Outputs are noise with the right shapes.  Pass a card dict with checkpoint='file://<converted .pt>' for "
+               f"the real model.")
+        logger.warning(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 def _resolve_card(name_or_card: Union[str, Dict[str, Any]]) -> Dict[str, Any]:
     if isinstance(name_or_card, dict):
         return name_or_card
     if name_or_card in DEFAULT_CARDS:
+        _warn_synthetic(name_or_card, DEFAULT_CARDS[name_or_card])
         return DEFAULT_CARDS[name_or_card]
     raise ValueError(f"unknown asset card '{name_or_card}'; pass a card dict (reference YAML schema) instead")
 
@@ -108,9 +132,10 @@ def _load_state_dict(card: Dict[str, Any], cfg: S2STConfig, kind: str, with_t2u:
                      char_pieces: Optional[List[str]] = None, with_text_encoder: bool = False) -> Dict[str, Tensor]:
     uri = card.get("checkpoint", "")
     if uri.startswith("synthetic://"):
-        seed = int(uri[len("synthetic://"):] or _syn.DEFAULT_SEED)
+        seed, opts = parse_synthetic_uri(uri)
         if kind == "unity":
-            return _syn.make_unity_state_dict(cfg, seed, with_t2u=with_t2u, with_text_encoder=with_text_encoder)
+            return _syn.make_unity_state_dict(cfg, seed, with_t2u=with_t2u, with_text_encoder=with_text_encoder,
+                                              eos_ramp=opts.get("eos_ramp"))
         return _syn.make_vocoder_state_dict(cfg, seed, with_dur_predictor=bool(card.get("dur_predictor", False)))
     if uri.startswith("file://"):
         from ..checkpoint import load_converted_checkpoint

@@ -24,6 +24,34 @@ from .config import S2STConfig
 DEFAULT_SEED = 20240901  # BASELINE.md "weights from seed 20240901"
 DEC_BRANCH_GAIN = 0.25
 DEC_LAST_FFN_GAIN = 64.0
+
+
+class EosRamp:
+    """Knobs of the ``eos_ramp`` weight variant (make_unity_state_dict): ``length`` = reference position of the ramp,
+    ``level`` = ramp height at position length + 2 over the expected winning logit, ``start`` = height at position 0 over
+    the height at length + 2, ``noise`` = scale of the random part of the EOS row (spread of the stopping step).  The
+    URI form is ``synthetic://<seed>?eos_ramp=<length>[,<level>[,<start>[,<noise>]]]``.  BENCH = the setting of the
+    benchmark's ragged workload (base_v2: text lengths of about 3 ... 60 tokens around a mean of about 40, measured with
+    oracle/; the random model's own common-mode logit offsets decide the exact shape)."""
+
+    def __init__(self, length: int, level: float = 1.0, start: float = 0.0, noise: float = 1.0) -> None:
+        self.length, self.level, self.start, self.noise = int(length), float(level), float(start), float(noise)
+        assert self.length > 0 and self.level > 0 and 0 <= self.start < 1 and self.noise > 0
+
+    @classmethod
+    def parse(cls, spec) -> "EosRamp":
+        if isinstance(spec, cls):
+            return spec
+        if isinstance(spec, (int, float)):
+            return cls(int(spec))
+        parts = [x for x in str(spec).split(",") if x]
+        return cls(int(parts[0]), *[float(x) for x in parts[1:4]])
+
+    def __str__(self) -> str:
+        return f"{self.length},{self.level:g},{self.start:g},{self.noise:g}"
+
+
+EOS_RAMP_BENCH = "45,1.52,0.34,2.5"
 # number of rows after the sentence pieces in the NLLB layout: languages + 3 data-source tags
 TEXT_CONTROL_TAIL = [None] * (98 + 3)
 
@@ -135,11 +163,50 @@ class _Gen:
         self.linear(prefix + ".output_proj", dim, inner)
 
 
+def eos_ramp_plan(cfg: S2STConfig, ramp):
+    """Channels and gains of the position-driven EOS logit of the ``eos_ramp`` weight variant (see make_unity_state_dict).
+
+    The sinusoidal position encoder (fairseq2 SinusoidalPositionEncoder, oracle/unity.py: sinusoidal_table) puts
+    ``sin(w_i * p)`` on channel i and ``cos(w_i * p)`` on channel M/2 + i, ``w_i = 1e4 ** (-i / (M/2 - 1))``.
+    ``rise`` = sine channels that still climb over 1.5 * ramp_len positions, ``one`` = cosine channels that stay ~1 there,
+    ``flat`` = the sine channels of the same frequencies (~0; they make the EOS row sum to zero over the clean channels,
+    so that the mean the final LayerNorm subtracts cancels).  With gains (g_rise, g_one) the EOS logit's deterministic part
+    is ``level * top * (start + (1 - start) * S(p) / S(ramp_len + 2))``, S(p) = sum of the rising sines: it starts at
+    ``start`` of its height at position ramp_len + 2, which is ``level`` times ``top``, the expected winning
+    logit of V iid N(0, 0.5) logits; the final residual's standard deviation (what the LayerNorm divides by) is that of
+    the last feed-forward block, sqrt(2 * gain_ffn^2 * F * M) / (M + F)."""
+    ramp = EosRamp.parse(ramp)
+    ramp_len = ramp.length
+    M, F, V = cfg.model_dim, cfg.dec_ffn_dim, cfg.text_vocab_size
+    half = M // 2
+    w = [math.exp(-i * math.log(10000.0) / (half - 1)) for i in range(half)]
+    rise = [i for i in range(half) if w[i] * 1.5 * ramp_len <= math.pi / 2 and w[i] * ramp_len >= 0.2]
+    flat = [i for i in range(half) if w[i] * ramp_len <= 0.02]
+    one = [half + i for i in flat]
+    assert len(rise) >= 4 and len(flat) >= 4, "eos_ramp: model_dim too small for this ramp length"
+    lnv = math.log(V)
+    top = 0.5 * (math.sqrt(2 * lnv) - (math.log(lnv) + math.log(4 * math.pi)) / (2 * math.sqrt(2 * lnv)))
+    sigma_x = math.sqrt(2.0 * DEC_LAST_FFN_GAIN ** 2 * F * M) / (M + F)
+    s_ref = sum(math.sin(w[i] * (ramp_len + 2)) for i in rise)
+    height = ramp.level * top * sigma_x
+    return rise, one, flat, height * (1.0 - ramp.start) / s_ref, height * ramp.start / len(one)
+
+
 def make_unity_state_dict(
     cfg: S2STConfig, seed: int = DEFAULT_SEED, dtype: torch.dtype = torch.float16,
-    with_t2u: bool = True, with_text_encoder: bool = False,
+    with_t2u: bool = True, with_text_encoder: bool = False, eos_ramp=None,
 ) -> Dict[str, torch.Tensor]:
-    """UnitY2 speech-encoder / text-decoder / NAR-T2U weights (+ the NLLB text encoder of the text-input tasks)."""
+    """UnitY2 speech-encoder / text-decoder / NAR-T2U weights (+ the NLLB text encoder of the text-input tasks).
+
+    ``eos_ramp`` (an EosRamp or its string form; checkpoint URI ``synthetic://<seed>?eos_ramp=<n>[,...]``): the same
+    tensors, except that the text decoder emits EOS ON ITS OWN after about ``n`` tokens (spread over the utterances)
+    instead of running into the length limit - what a trained checkpoint does on every batch and what the
+    finished-row logic of a batched greedy search exists for.  Built from the decoder's own modules: a set of
+    position-encoder channels is kept clean through the stack (embedding columns zero, rows of every residual branch's
+    output projection zero, final LayerNorm gain 1 / bias 0 there), so the final hidden state carries ``sin(w_i * p)``
+    of the position on them, and the EOS row of the tied embedding reads exactly those channels (eos_ramp_plan): its
+    logit climbs with the position and overtakes the winner of the pseudo-random logits around position n; the
+    random remainder of the row decides the step per utterance."""
     g = _Gen(seed, dtype)
     M = cfg.model_dim
     feat = cfg.num_fbank_channels * cfg.fbank_stride
@@ -197,9 +264,20 @@ def make_unity_state_dict(
     # shrunk so that the greedy search of the random model stays on ordinary pieces.
     n_ctrl = len(TEXT_CONTROL_TAIL)
 
+    ramp = eos_ramp_plan(cfg, eos_ramp) if eos_ramp else None
+    ramp_noise = EosRamp.parse(eos_ramp).noise if eos_ramp else 1.0
+    clean = sorted(ramp[0] + ramp[1] + ramp[2]) if ramp else []
+
     def _fix_text_embed(t: torch.Tensor) -> torch.Tensor:
         t[cfg.pad_idx].zero_()
         t[cfg.text_vocab_size - n_ctrl:].mul_(0.1)
+        if ramp:
+            rise, one, flat, g_rise, g_one = ramp
+            t[:, clean] = 0
+            t[cfg.eos_idx] *= ramp_noise
+            t[cfg.eos_idx, rise] = g_rise
+            t[cfg.eos_idx, one] = g_one
+            t[cfg.eos_idx, flat] = -(g_rise * len(rise) + g_one * len(one)) / len(flat)
         return t
 
     g.then("text_decoder_frontend.embed.weight", _fix_text_embed)
@@ -221,7 +299,17 @@ def make_unity_state_dict(
         for q in ("self_attn.output_proj", "encoder_decoder_attn.output_proj", "ffn.output_proj"):
             gain = DEC_LAST_FFN_GAIN if (last and q.startswith("ffn")) else DEC_BRANCH_GAIN
             g.then(f"{p}.{q}.weight", lambda t, gain=gain: (t.float() * gain).to(dtype))
+            if ramp:  # no residual branch writes to the clean channels
+                def _zero_rows(t: torch.Tensor) -> torch.Tensor:
+                    t[clean] = 0
+                    return t
+
+                g.then(f"{p}.{q}.weight", _zero_rows)
+                g.sd[f"{p}.{q}.bias"][clean] = 0
     g.layer_norm("text_decoder.layer_norm", M)
+    if ramp:
+        g.sd["text_decoder.layer_norm.weight"][clean] = 1
+        g.sd["text_decoder.layer_norm.bias"][clean] = 0
 
     if with_text_encoder:
         # NLLB encoder; the embedding frontend is the decoder's (builder.py:443-446, loader.py:150-153)

@@ -12,20 +12,29 @@ from seamless_communication_amd.config import S2STConfig, tiny_config
 from seamless_communication_amd.tokenizer import CharTokenizer, NllbTextTokenizer
 
 
-@functools.lru_cache(maxsize=4)
-def tiny_bundle(seed: int = 20240901):
+# eos_ramp settings of the tiny model (synthetic.EosRamp) under which a greedy batch stops on its own (lengths of the eight
+# utterances of tests/test_oracle_eos_cpu.py: AUDIO): EOS_SPREAD rows that finish at 5 different steps (8 ... 12 tokens),
+# EOS_MIXED rows that finish on the second generated token next to rows that run to 16 / 17, EOS_EARLY rows that all finish
+# on the first generated token (before the host's first look at the finished flags)
+EOS_SPREAD = "20,1,0,1"
+EOS_MIXED = "30,1,0,2"
+EOS_EARLY = "10,1.2,0.2,1.5"
+
+
+@functools.lru_cache(maxsize=6)
+def tiny_bundle(seed: int = 20240901, eos_ramp=None):
     cfg = tiny_config()
-    sd = syn.make_unity_state_dict(cfg, seed)
+    sd = syn.make_unity_state_dict(cfg, seed, eos_ramp=eos_ramp)
     vsd = syn.make_vocoder_state_dict(cfg, seed)
     tt = NllbTextTokenizer(cfg.text_vocab_size, cards.TEXT_LANGS)
     ct = CharTokenizer(cfg.char_vocab_size)
     return cfg, sd, vsd, tt, ct
 
 
-def make_oracle(seed: int = 20240901):
+def make_oracle(seed: int = 20240901, eos_ramp=None):
     from oracle.pipeline import OracleS2ST
 
-    cfg, sd, vsd, tt, ct = tiny_bundle(seed)
+    cfg, sd, vsd, tt, ct = tiny_bundle(seed, eos_ramp)
     return OracleS2ST(cfg, sd, vsd, tt, ct, cards.vocoder_lang_spkr_idx_map())
 
 
@@ -54,11 +63,11 @@ def make_hip_text(seed: int = 20240901):
     return m
 
 
-@functools.lru_cache(maxsize=2)
-def make_hip(seed: int = 20240901):
+@functools.lru_cache(maxsize=4)
+def make_hip(seed: int = 20240901, eos_ramp=None):
     from seamless_communication_amd.runtime import HipS2STModel
 
-    cfg, sd, vsd, tt, ct = tiny_bundle(seed)
+    cfg, sd, vsd, tt, ct = tiny_bundle(seed, eos_ramp)
     m = HipS2STModel(cfg, sd, vsd, device=0)
     m.set_nar_tables(tt, ct)
     return m

@@ -1,0 +1,172 @@
+"""Greedy batches whose rows stop ON THEIR OWN at different steps, HIP path (through the C ABI) against the CPU oracle -
+what every trained checkpoint produces on every batch and the finished-row logic exists for (inference/generator.py:
+261-299: pad_seqs of hypotheses of different lengths, the trimmed EOS column, the teacher-forced pass; ggml/examples/unity/
+fairseq2.cpp:1535-1563: finished beams).  Weights: the ``eos_ramp`` variant of the tiny synthetic model (tests/common.py;
+tests/test_oracle_eos_cpu.py pins the oracle's side of these runs against the reference's compiled generator).
+
+Covered: ids / lengths / scores-bearing rows, the decoder outputs captured during generation against the oracle's
+teacher-forced pass, T2U char ids / durations / units, the proportionally trimmed waveform; eager steps and graph replay;
+one slice and two forked slices; rows that finish on the first generated token; a whole batch finished between two looks
+of the host at the finished flags; finished rows riding along with live ones for many steps.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import common
+from tests.test_oracle_eos_cpu import AUDIO
+
+pytestmark = pytest.mark.gpu
+CAP = 24
+
+
+def _log(report_dir, name, **kw):
+    with open(report_dir / "eos_report.txt", "a") as f:
+        f.write(name + " " + " ".join(f"{k}={v}" for k, v in kw.items()) + "\n")
+
+
+def _env(spec):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    cfg, sd, vsd, tt, ct = common.tiny_bundle(eos_ramp=spec)
+    return cfg, tt, common.make_oracle(eos_ramp=spec), common.make_hip(eos_ramp=spec)
+
+
+def _oracle_s2st(orc, seconds, start=0):
+    fb, lens = orc.collate_fbank(common.waves(seconds, start))
+    return (fb, lens) + tuple(orc.s2st(fb, lens, "fra", (1, 200), CAP))
+
+
+@pytest.mark.parametrize("spec", [common.EOS_SPREAD, common.EOS_MIXED, common.EOS_EARLY])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_rows_that_stop_at_different_steps(spec, use_graph, report_dir):
+    from oracle import unity as ou
+
+    cfg, tt, orc, hip = _env(spec)
+    fb, lens = orc.collate_fbank(common.waves(AUDIO))
+    seqs, enc, enc_lens, margins = orc.s2tt(fb, lens, "fra", (1, 200), CAP)
+    want_lens = [len(s) for s in seqs]
+    if spec != common.EOS_EARLY:
+        assert len(set(want_lens)) >= 4, want_lens
+    ids, out_lens, scores, hidden = hip.generate_text(enc.cuda().contiguous(), enc_lens.tolist(), tt.target_prefix("fra"),
+                                                      soft_max_seq_len=(1, 200), hard_max_seq_len=CAP, use_graph=use_graph,
+                                                      source_len=int(lens.max()))
+    got = [ids[b, : out_lens[b]].tolist() for b in range(len(seqs))]
+    _log(report_dir, "eos_greedy", spec=spec, use_graph=use_graph, lens=out_lens.tolist(), want=want_lens,
+         min_margin=min(min(m) for m in margins))
+    assert out_lens.tolist() == want_lens
+    assert got == seqs
+    # beyond its length a row holds padding (fairseq2 pad_seqs, generator.py:281-284)
+    for b, n in enumerate(want_lens):
+        assert (ids[b, n:] == cfg.pad_idx).all()
+    # decoder outputs captured while generating == the reference's teacher-forced pass over text_seqs[:, :-1]
+    L = max(want_lens)
+    text = torch.full((len(seqs), L), cfg.pad_idx, dtype=torch.int64)
+    for i, s in enumerate(seqs):
+        text[i, : len(s)] = torch.tensor(s)
+    tl = torch.tensor(want_lens) - 1
+    ref = ou.decode_text(orc.P, cfg, text[:, :-1], tl, enc, enc_lens, orc.pos_table)
+    errs = [float((hidden[b, : tl[b]].cpu() - ref[b, : tl[b]]).abs().max()) for b in range(len(seqs))]
+    assert max(errs) < 2e-4, errs
+
+
+@pytest.mark.parametrize("spec", [common.EOS_SPREAD, common.EOS_MIXED])
+def test_s2st_chain_on_rows_of_different_lengths(spec, report_dir):
+    """text -> T2U -> vocoder on hypotheses of different lengths: char ids, durations, units exact, waveform 2e-3, and the
+    trimmed length of every utterance (translator.py:407-419)."""
+    from oracle import vocoder as ov
+
+    cfg, tt, orc, hip = _env(spec)
+    fb, lens, seqs, speech_units, wavs, units_ref, aux = _oracle_s2st(orc, AUDIO)
+    enc, enc_lens = aux["enc"], aux["enc_lens"]
+    ids, out_lens, _, hidden = hip.generate_text(enc.cuda().contiguous(), enc_lens.tolist(), tt.target_prefix("fra"),
+                                                 hard_max_seq_len=CAP, source_len=int(lens.max()))
+    assert [ids[b, : out_lens[b]].tolist() for b in range(len(seqs))] == seqs
+    L = int(out_lens.max())
+    units, ulens, dur, cids, clens = hip.t2u_nar(hidden[:, : L - 1].contiguous(), ids[:, : L - 1].copy(), (out_lens - 1).tolist(), 1.0)
+    assert clens.tolist() == aux["char_seq_lens"].tolist()
+    assert cids.tolist() == aux["char_seqs"].tolist()
+    assert dur.tolist() == aux["durations"].tolist()
+    assert ulens.tolist() == aux["unit_lens"].tolist()
+    assert units.tolist() == units_ref.tolist()
+    lang_idx, spkr_idx = ov.resolve_lang_spkr(orc.lang_spkr_idx_map, ["fra"] * len(seqs), [-1] * len(seqs))
+    wav = hip.vocode(np.asarray(units), lang_idx, spkr_idx, ulens)
+    errs = []
+    for b in range(len(seqs)):
+        keep = int(wav.shape[-1] * len(speech_units[b]) / units.shape[1])
+        assert keep == wavs[b].shape[-1]
+        errs.append(float((wav[b, :, :keep].cpu() - wavs[b][0]).abs().max()))
+    _log(report_dir, "eos_s2st", spec=spec, text_lens=out_lens.tolist(), unit_lens=ulens.tolist(), wav_err=max(errs))
+    assert max(errs) < 2e-3
+
+
+def _translator(spec):
+    from seamless_communication_amd.inference import Translator
+    from seamless_communication_amd.inference.translator import DEFAULT_CARDS
+
+    card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch="tiny_v2", checkpoint=f"synthetic://20240901?eos_ramp={spec}")
+    return Translator(card, dict(DEFAULT_CARDS["vocoder_v2"]), device=torch.device("cuda", 0))
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_translator_predict_one_slice_and_two_forked_slices(groups, report_dir):
+    """Translator.predict on the whole batch and on two forked handles in flight (distributed.MicroBatcher): text ids, units,
+    waveform lengths and samples equal the oracle's on the same (sub-)batches - results of a padded item depend on its
+    batch (adaptor_block.py:255-276), so the oracle runs each slice as its own batch."""
+    from seamless_communication_amd.distributed import MicroBatcher, shard_range
+    from seamless_communication_amd.inference import SequenceGeneratorOptions
+
+    spec = common.EOS_MIXED
+    orc = common.make_oracle(eos_ramp=spec)
+    tr = _translator(spec)
+    opts = SequenceGeneratorOptions(beam_size=1, soft_max_seq_len=(1, 200), hard_max_seq_len=CAP)
+    wav, ns = common.pad_waves(common.waves(AUDIO))
+    batcher = MicroBatcher(tr, groups)
+    for use_graph in (True, False):
+        for v in batcher.views:
+            v.use_graph = use_graph
+        texts, units, wavs, text_ids, _ = batcher.predict(torch.from_numpy(wav).cuda(), ns, "S2ST", "fra", text_generation_opts=opts)
+        for g in range(groups):
+            lo, hi = shard_range(len(AUDIO), g, groups)
+            fb, lens, seqs, speech_units, wavs_ref, units_ref, aux = _oracle_s2st(orc, AUDIO[lo:hi], start=lo)
+            assert text_ids[lo:hi] == seqs
+            assert len({len(s) for s in seqs}) >= 2
+            for b in range(hi - lo):
+                assert units[lo + b] == [int(u) for u in speech_units[b]]
+                assert wavs[lo + b].shape[-1] == wavs_ref[b].shape[-1]
+                assert float((wavs[lo + b].cpu() - wavs_ref[b]).abs().max()) < 2e-3
+    batcher.close()
+
+
+def test_finished_rows_ride_along_and_the_loop_ends_early(report_dir):
+    """EOS_EARLY: every row finishes on the first generated token, i.e. before the host first looks at the finished flags
+    (every 4th step): ids are [</s>, lang, </s>], nothing is appended afterwards, and the call does not run to the limit.
+    EOS_MIXED with a far limit: rows finished at step 2 stay finished while others run ~15 more steps."""
+    import time
+
+    cfg, tt, orc, hip = _env(common.EOS_EARLY)
+    fb, lens = orc.collate_fbank(common.waves(AUDIO))
+    seqs, enc, enc_lens, _ = orc.s2tt(fb, lens, "fra", (1, 200), 200)
+    assert all(len(s) == 3 for s in seqs)
+    encd = enc.cuda().contiguous()
+    for use_graph in (True, False):
+        ids, out_lens, _, _ = hip.generate_text(encd, enc_lens.tolist(), tt.target_prefix("fra"), hard_max_seq_len=200, use_graph=use_graph,
+                                                source_len=int(lens.max()))
+        assert out_lens.tolist() == [3] * len(seqs) and [ids[b, :3].tolist() for b in range(len(seqs))] == seqs
+        assert (ids[:, 3:] == cfg.pad_idx).all()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hip.generate_text(encd, enc_lens.tolist(), tt.target_prefix("fra"), hard_max_seq_len=200, source_len=int(lens.max()))
+    early = time.perf_counter() - t0
+    cfg2, tt2, orc2, hip2 = _env(None)  # the same model without the ramp runs all ~200 steps
+    t0 = time.perf_counter()
+    hip2.generate_text(encd, enc_lens.tolist(), tt.target_prefix("fra"), hard_max_seq_len=200, source_len=int(lens.max()))
+    full = time.perf_counter() - t0
+    _log(report_dir, "eos_early_exit", early_ms=round(early * 1e3, 2), full_ms=round(full * 1e3, 2))
+    assert early < 0.5 * full
+    cfg, tt, orc, hip = _env(common.EOS_MIXED)
+    seqs, enc, enc_lens, _ = orc.s2tt(fb, lens, "fra", (1, 200), 200)
+    ids, out_lens, _, _ = hip.generate_text(enc.cuda().contiguous(), enc_lens.tolist(), tt.target_prefix("fra"), hard_max_seq_len=200,
+                                            source_len=int(lens.max()))
+    assert [ids[b, : out_lens[b]].tolist() for b in range(len(seqs))] == seqs
+    assert max(out_lens) - min(out_lens) >= 10
