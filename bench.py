@@ -11,9 +11,14 @@ N > 1 the RCCL all-gather of text/unit ids) over one batch of ``--batch``
 synthetic 10 s / 16 kHz utterances per GPU that are already resident in HBM
 (BASELINE.json configs[2]: S2ST 10 s audio, seamlessM4T_v2_large).  Weights are
 seeded random tensors with the reference's checkpoint schema (no checkpoints
-are reachable offline); such a model never emits EOS, so the text length is
-fixed by ``SequenceGeneratorOptions.hard_max_seq_len`` (``--text-len``,
-default 42 = 40 generated tokens, the length BASELINE.md prices the path at).
+are reachable offline).  Default workload ``--workload ragged``: the ``eos_ramp``
+weight variant (synthetic.py), under which every hypothesis stops ON ITS OWN at
+its own step like a trained model's - text lengths of 8 ... 64 tokens around a
+mean of about 40 (``config.text_tokens_per_utt``), finished rows riding along in
+the batched step, ragged T2U / vocoder lengths; ``hard_max_seq_len`` 64.
+``--workload fixed`` is the workload of rounds 1-3 (plain random weights never
+emit EOS: every hypothesis is cut at ``--text-len`` 42); the default run reports
+it under ``extra.fixed42`` for continuity.
 
 Rank 0 prints ONE JSON line.  ``value`` is utterances/s over all GPUs (weak
 scaling: per-GPU batch fixed).  ``roofline`` describes the kernel family with
@@ -54,7 +59,15 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step (BASELINE configs[3]: 64 per GPU)")
     ap.add_argument("--microbatches", type=int, default=2,
                     help="concurrent slices of the per-GPU batch (one host thread + one HIP stream each)")
-    ap.add_argument("--text-len", type=int, default=42, help="hard_max_seq_len of the greedy text search (prompt included)")
+    ap.add_argument("--workload", default="ragged", choices=["ragged", "fixed"],
+                    help="ragged: eos_ramp weights, hypotheses stop on their own (text lengths ~8..64, mean ~40); fixed: every hypothesis "
+                         "cut at --text-len (the workload of rounds 1-3)")
+    ap.add_argument("--text-len", type=int, default=0,
+                    help="hard_max_seq_len of the greedy text search, prompt included (default: 64 ragged, 42 fixed)")
+    ap.add_argument("--dec-cus", type=int, default=-1,
+                    help="CU partition: greedy decoder steps on this many compute units, everything else on the rest "
+                         "(sc_set_cu_partition); 0 = none; default: SC_BENCH_DEC_CUS or 0")
+    ap.add_argument("--cu-layout", default="low", choices=["low", "xcd"], help="mask layout of --dec-cus (runtime.cu_masks)")
     ap.add_argument("--arch", default="base_v2", choices=["base_v2", "tiny_v2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -136,16 +149,24 @@ def roofline_of(fams, step_bytes=None):
     return roof, shares
 
 
+_CSRC_SHA = None
+
+
 def csrc_sha() -> str:
     """Digest of the kernel sources of this tree (scripts/pmc_summary.py stamps the same digest into a capture)."""
     import hashlib
+
+    global _CSRC_SHA
+    if _CSRC_SHA is not None:
+        return _CSRC_SHA
 
     root = ROOT / "seamless_communication_amd" / "csrc"
     h = hashlib.sha256()
     for f in sorted(list(root.glob("*.hip")) + list(root.glob("*.h")) + list(root.glob("*.cpp"))):
         h.update(f.name.encode())
         h.update(f.read_bytes())
-    return h.hexdigest()[:16]
+    _CSRC_SHA = h.hexdigest()[:16]
+    return _CSRC_SHA
 
 
 def pmc_traffic(family: str):
@@ -200,6 +221,33 @@ def pmc_traffic(family: str):
     return None, None
 
 
+def decoder_row_stats(text_lens, B, groups, stage_ms):
+    """What the ragged text lengths cost the batched greedy step (SURVEY.md section 8e names it as the loss source of the
+    data-parallel path): a slice runs until its longest hypothesis ends (the host looks at the finished flags every 4th
+    step), rows that finished earlier ride along.  useful row-steps = generated tokens; computed row-steps = rows of the
+    slice x steps the slice ran."""
+    from seamless_communication_amd.distributed import shard_range
+
+    useful = computed = 0
+    per_slice = []
+    for g in range(groups):
+        lo, hi = shard_range(B, g, groups)
+        lens = text_lens[lo:hi]
+        gen = [l - 2 for l in lens]          # generated tokens per row (the two prompt tokens are fed, not generated)
+        longest = max(gen)
+        steps = min(-(-longest // 4) * 4, max(gen) + 3)   # the loop ends at the first poll after the last row finished
+        alive = [sum(1 for x in gen if x > t) for t in range(longest)]
+        per_slice.append({"rows": hi - lo, "steps_to_last_eos": longest, "mean_rows_alive": round(float(np.mean(alive)), 2),
+                          "rows_alive_at_quartiles": [alive[int(q * (longest - 1))] for q in (0.0, 0.25, 0.5, 0.75, 1.0)]})
+        useful += sum(gen)
+        computed += (hi - lo) * steps
+    out = {"useful_row_steps": int(useful), "computed_row_steps": int(computed), "row_step_efficiency": round(useful / max(1, computed), 3),
+           "slices": per_slice}
+    if stage_ms.get("text_decoder"):
+        out["slice0_decoder_us_per_useful_row_step"] = round(1e3 * stage_ms["text_decoder"] / max(1, sum(l - 2 for l in text_lens[: shard_range(B, 0, groups)[1]])), 2)
+    return out
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -246,7 +294,8 @@ def cpu_baseline_worker(args):
     cfg = _ARCHS[args.arch]()
     tt = NllbTextTokenizer(cfg.text_vocab_size, cards.TEXT_LANGS)
     ct = CharTokenizer(cfg.char_vocab_size)
-    orc = OracleS2ST(cfg, syn.make_unity_state_dict(cfg, syn.DEFAULT_SEED), syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED),
+    ramp = syn.EOS_RAMP_BENCH if args.workload == "ragged" else None
+    orc = OracleS2ST(cfg, syn.make_unity_state_dict(cfg, syn.DEFAULT_SEED, eos_ramp=ramp), syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED),
                      tt, ct, cards.vocoder_lang_spkr_idx_map())
 
     def one(index):
@@ -292,7 +341,7 @@ def cpu_baseline(args):
 
     threads = args.cpu_threads or usable_cpus()
     cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-worker", "--arch", args.arch, "--text-len",
-           str(args.text_len), "--cpu-threads", str(threads)]
+           str(args.text_len), "--cpu-threads", str(threads), "--workload", args.workload]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_baseline_timeout)
         if r.returncode != 0:
@@ -344,6 +393,10 @@ def dry_run(args):
 
 def main():
     args = parse_args()
+    if args.text_len <= 0:
+        args.text_len = 64 if args.workload == "ragged" else 42
+    if args.dec_cus < 0:
+        args.dec_cus = int(os.environ.get("SC_BENCH_DEC_CUS", "0"))
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -373,7 +426,8 @@ def main():
 
     log(f"rank {rank}/{world}: building weights + loading the model ...")
     t_load = time.perf_counter()
-    card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch=args.arch)
+    checkpoint = f"synthetic://{syn.DEFAULT_SEED}" + (f"?eos_ramp={syn.EOS_RAMP_BENCH}" if args.workload == "ragged" else "")
+    card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch=args.arch, checkpoint=checkpoint)
     # speech input only: like the reference (translator.py:100-102) this skips the NLLB text encoder of T2TT/T2ST
     translator = Translator(card, "vocoder_v2", device=device, input_modality=Modality.SPEECH)
     translator.use_graph = not args.no_graph
@@ -390,7 +444,7 @@ def main():
     opts = SequenceGeneratorOptions(beam_size=1, soft_max_seq_len=(1, 200), hard_max_seq_len=args.text_len)
     stage_ms = {}
 
-    batcher = MicroBatcher(translator, min(args.microbatches, B))
+    batcher = MicroBatcher(translator, min(args.microbatches, B), decoder_cus=args.dec_cus, cu_layout=args.cu_layout)
     last = {}
 
     def step(single_stream: bool = False, sequential_slices: bool = False):
@@ -403,7 +457,7 @@ def main():
             texts, units, wavs, text_ids = [], [], [], []
             for i, view in enumerate(batcher.views):
                 lo, hi = shard_range(B, i, batcher.groups)
-                t, speech, ids, st = batcher._one(view, wav_dev[lo:hi].contiguous(), ns[lo:hi], "S2ST", "fra", {"text_generation_opts": opts})
+                t, speech, ids, st = batcher._one(view, wav_dev[lo:hi], ns[lo:hi], "S2ST", "fra", {"text_generation_opts": opts})
                 texts += t
                 text_ids += ids
                 units += speech.units
@@ -500,10 +554,14 @@ def main():
             "rtf": (elapsed / args.steps) / (B * AUDIO_SECONDS),
             "config": {
                 "workload": "S2ST 10 s 16 kHz audio -> text -> units -> 16 kHz waveform (BASELINE configs[2])",
-                "arch": args.arch, "weights": "synthetic://20240901 (reference state-dict schema, fp16)",
+                "arch": args.arch, "weights": checkpoint + " (reference state-dict schema, fp16)",
+                "text_lengths": ("hypotheses stop on their own (eos_ramp weights), finished rows ride along in the batched step"
+                                 if args.workload == "ragged" else "every hypothesis cut at hard_max_seq_len (plain random weights never emit EOS)"),
                 "batch_per_gpu": B, "global_batch": world * B, "tgt_lang": "fra",
                 "text_search": f"greedy, soft_max_seq_len=(1,200), hard_max_seq_len={args.text_len}",
-                "text_tokens_per_utt": float(np.mean(text_lens)), "units_per_utt": float(np.mean(unit_counts)),
+                "text_tokens_per_utt": {"min": int(min(text_lens)), "mean": float(np.mean(text_lens)), "max": int(max(text_lens))},
+                "units_per_utt": float(np.mean(unit_counts)), "units_per_utt_min_max": [int(min(unit_counts)), int(max(unit_counts))],
+                "decoder_rows": decoder_row_stats(text_lens, B, batcher.groups, stage_snapshot),
                 "out_audio_seconds_per_utt": float(np.mean(wav_secs)),
                 "s_unit_max": int(max(unit_counts)), **padding_info,
                 "parallelism": f"dp{world} (utterances sharded, full replica per GPU, all-gather of ids)",
@@ -511,6 +569,7 @@ def main():
                 "hip_graph_decoder_step": bool(translator.use_graph),
                 "microbatches_in_flight": batcher.groups,
                 "microbatch_schedule": (f"free-running slices, start offsets {stagger * 1e3:.0f} ms" if free_run else "lock-step (join per pass)"),
+                "cu_partition": ({"decoder_cus": args.dec_cus, "layout": args.cu_layout, "device_cus": model.cu_count()} if args.dec_cus > 0 else None),
             },
             "stage_ms_last_step_slice0": {k: round(v, 3) for k, v in stage_snapshot.items()},
             "load_seconds": round(load_s, 1),
@@ -572,7 +631,10 @@ def main():
 
     if rank == 0:
         # every utterance of the timed batch against the oracle's committed ids (tests/golden/fullsize_ref.json)
-        result["parity"] = parity_from_goldens(args, batcher, {"text_ids": timed_text_ids}, B, t2u_snapshot)
+        try:
+            result["parity"] = parity_from_goldens(args, batcher, {"text_ids": timed_text_ids}, B, t2u_snapshot, first_index=rank * B)
+        except Exception as e:  # noqa: BLE001  (a fixture / shape surprise must not lose the measured line)
+            result["parity"] = {"n_checked": 0, "error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             log("CPU baseline (oracle: warm-up + 3 passes) in a child process ...")
             base = cpu_baseline(args)
@@ -626,6 +688,25 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
                              "stage_ms": {k: round(v, 3) for k, v in translator.last_stage_ms.items()}}
     except Exception as e:  # noqa: BLE001
         out["s2st_beam5"] = {"error": repr(e)[:300]}
+    if args.workload == "ragged":
+        try:  # the workload of rounds 1-3 for continuity: plain random weights, every hypothesis cut at 42 tokens, same schedule
+            from seamless_communication_amd import synthetic as syn
+            from seamless_communication_amd.distributed import MicroBatcher
+            from seamless_communication_amd.inference import Translator
+            from seamless_communication_amd.inference.translator import DEFAULT_CARDS, Modality
+
+            card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch=args.arch, checkpoint=f"synthetic://{syn.DEFAULT_SEED}")
+            tr42 = Translator(card, dict(DEFAULT_CARDS["vocoder_v2"]), device=translator.device, input_modality=Modality.SPEECH)
+            tr42.use_graph = translator.use_graph
+            mb42 = MicroBatcher(tr42, batcher.groups, decoder_cus=args.dec_cus, cu_layout=args.cu_layout)
+            o42 = SequenceGeneratorOptions(beam_size=1, soft_max_seq_len=(1, 200), hard_max_seq_len=42)
+            dt = timed(lambda: mb42.predict(wav_dev, ns, "S2ST", "fra", text_generation_opts=o42), 3)
+            out["fixed42"] = {"metric": "S2ST utterances/s, the workload of rounds 1-3 (every hypothesis cut at 42 tokens), same batch / schedule",
+                              "value": B / dt, "ms_per_step": 1e3 * dt, "rtf": dt / (B * AUDIO_SECONDS)}
+            mb42.close()
+            del mb42, tr42
+        except Exception as e:  # noqa: BLE001
+            out["fixed42"] = {"error": repr(e)[:300]}
     try:  # BASELINE configs[4]: streaming chain, p50 wall time per 320 ms segment (child process: its own model + monotonic decoder)
         r = subprocess.run([sys.executable, str(ROOT / "scripts" / "stream_latency.py"), "--arch", args.arch], capture_output=True,
                            text=True, timeout=args.extra_timeout)
@@ -640,7 +721,7 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
     return out
 
 
-def parity_from_goldens(args, batcher, last, B, t2u_views):
+def parity_from_goldens(args, batcher, last, B, t2u_views, first_index=0):
     """Ids of the TIMED batch (last timed pass: micro-batch slices, graph replay) against the CPU oracle's ids of the same
     64 utterances, minted once by tests/golden/make_fullsize_goldens.py (oracle/pipeline.py, fp32): text ids / char ids /
     durations / unit ids of every utterance, match rates, and for every mismatching unit position the oracle's own arg-max
@@ -651,13 +732,24 @@ def parity_from_goldens(args, batcher, last, B, t2u_views):
     from tests.golden import fullsize as fg
 
     try:
-        gold = fg.load()
+        if args.workload == "ragged":
+            from seamless_communication_amd import synthetic as syn
+
+            gold = fg.load(fg.GOLDEN_MORE)
+            if args.arch != "base_v2" or args.text_len != gold["meta"]["eos_text_len"] or gold["meta"]["eos_ramp"] != syn.EOS_RAMP_BENCH:
+                return {"n_checked": 0, "error": "the golden fixture holds arch base_v2 / text length 64 / EOS_RAMP_BENCH only"}
+            section, fixture = gold["b64eos"], "tests/golden/fullsize_more_ref.json: b64eos"
+        else:
+            gold = fg.load()
+            if args.arch != gold["meta"]["arch"] or args.text_len != gold["meta"]["text_len"]:
+                return {"n_checked": 0, "error": "the golden fixture holds arch base_v2 / text length 42 only"}
+            section, fixture = gold["b64"], "tests/golden/fullsize_ref.json: b64"
     except OSError as e:
         return {"n_checked": 0, "error": f"golden fixture missing: {e}"}
-    if args.arch != gold["meta"]["arch"] or args.text_len != gold["meta"]["text_len"]:
-        return {"n_checked": 0, "error": "the golden fixture holds arch base_v2 / text length 42 only"}
-    items = fg.items_by_index(gold["b64"])
-    n = min(B, len(items))
+    items = fg.items_by_index(section)
+    n = min(B, len(items) - first_index)  # this rank's shard holds utterances first_index .. first_index + B - 1
+    if n <= 0:
+        return {"n_checked": 0, "error": f"the golden fixture holds utterances 0..{len(items) - 1} only"}
     reports = []
     spans = [shard_range(B, i, batcher.groups) for i in range(batcher.groups)]
     for i in range(n):
@@ -669,13 +761,13 @@ def parity_from_goldens(args, batcher, last, B, t2u_views):
             ncs, nu = int(t2u["char_seq_lens"][b]), int(t2u["unit_lens"][b])
             kw.update(char_ids=t2u["char_ids"][b, :ncs].tolist(), durations=t2u["durations"][b, :ncs].tolist(),
                       units=t2u["units"][b, :nu].tolist())
-        reports.append(fg.compare(items[i], **kw))
+        reports.append(fg.compare(items[first_index + i], **kw))
     out = fg.summarize(reports)
     out.pop("utterances", None)
-    tm = [m for i in range(n) for m in items[i]["text_margins"]]
-    um = [m for i in range(n) for m in items[i]["unit_margins"]]
+    tm = [m for i in range(n) for m in items[first_index + i]["text_margins"]]
+    um = [m for i in range(n) for m in items[first_index + i]["unit_margins"]]
     out.update({
-        "compared": "timed batch (last timed pass) vs tests/golden/fullsize_ref.json (CPU oracle, all utterances)",
+        "compared": f"timed batch (last timed pass) vs {fixture} (CPU oracle, all utterances)",
         "oracle_pinned": "partial (DESIGN.md section 5)",
         "min_text_margin": min(tm), "min_unit_margin": min(um),
         "text_margin_hist": _margin_hist(tm), "unit_margin_hist": _margin_hist(um),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 6
+#define SC_ABI_VERSION 7
 #define SC_MAX_UPSAMPLES 8
 #define SC_MAX_RESBLOCK_KERNELS 4
 #define SC_MAX_RESBLOCK_DILATIONS 4
@@ -149,6 +149,19 @@ int sc_synchronize(sc_model* m);
  * non-blocking, so a caller that fills device inputs on another stream (PyTorch's current stream in the Python
  * host) calls this before the stage that reads them.  Every stage returns only after its outputs are complete. */
 int sc_wait_stream(sc_model* m, void* producer_stream);
+/* CU partition of a handle (ABI 7; no reference counterpart - the reference has no scheduling layer).
+ * The greedy decoder step is a chain of ~220 short dependent kernels per token that cannot fill the chip, the other stages
+ * are wide GEMM-shaped launches whose workgroups hold a CU for 40-160 us; run from different handles at the same time, the
+ * chain has to wait for CUs to turn over after every launch.  With a partition the step chain of sc_generate_text (greedy)
+ * runs on a stream restricted to the compute units of `decoder_mask` and every other launch of the handle (its own stream,
+ * the vocoder's side chains) on streams restricted to `other_mask` (hipExtStreamCreateWithCUMask; one bit per CU, `words`
+ * 32-bit words each, bit i of word w = CU 32 w + i in the driver's numbering: consecutive bits rotate over the XCDs).
+ * words = 0 removes the partition.  The handle must be idle; cached decode sessions are dropped.  Streams created this
+ * way synchronise with the legacy default stream: a caller that partitions handles must keep its own work off the default
+ * stream while calls are in flight (the Python host gives every worker thread its own stream).  Results do not change. */
+int sc_set_cu_partition(sc_model* m, const uint32_t* decoder_mask, const uint32_t* other_mask, int words);
+/* number of compute units of the handle's device (the width of the masks above, in bits) */
+int sc_device_cu_count(sc_model* m);
 
 /* Per-vocabulary tables for NARDecoderFrontend's string rules
  * (models/unity/nar_decoder_frontend.py:158-259), built once by the host from

@@ -11,7 +11,7 @@ from typing import Optional
 
 LIB_PATH = Path(__file__).resolve().parent / "libseamless_hip.so"
 
-SC_ABI_VERSION = 6
+SC_ABI_VERSION = 7
 SC_MAX_UPSAMPLES = 8
 SC_MAX_RESBLOCK_KERNELS = 4
 SC_MAX_RESBLOCK_DILATIONS = 4
@@ -89,6 +89,8 @@ SIGNATURES = {
     "sc_free": (None, [_P]),
     "sc_synchronize": (C.c_int, [_P]),
     "sc_wait_stream": (C.c_int, [_P, _P]),
+    "sc_set_cu_partition": (C.c_int, [_P, _P, _P, C.c_int]),
+    "sc_device_cu_count": (C.c_int, [_P]),
     "sc_set_nar_tables": (C.c_int, [_P, _i, _P, _P, _P, _P, _P]),
     "sc_fbank": (C.c_int, [_P, _P, _i, C.c_int64, _P, _i, _P, _i, _P]),
     "sc_encoder_out_len": (_i, [_P, _i]),

@@ -57,6 +57,7 @@ sc_model* sc_load(const sc_tensor_desc* tensors, size_t n_tensors, const sc_conf
         h->m.device = device;
         SC_HIP(hipStreamCreateWithFlags(&h->m.stream, hipStreamNonBlocking));
         h->m.pool.set_stream(h->m.stream);
+        h->m.hook_pool(h->m.pool);
         load_model(h->m, tensors, n_tensors);
         return h;
     } catch (const sc::Error&) {
@@ -76,6 +77,7 @@ sc_model* sc_fork(sc_model* parent) {
         static_cast<ModelData&>(h->m) = static_cast<const ModelData&>(parent->m);
         SC_HIP(hipStreamCreateWithFlags(&h->m.stream, hipStreamNonBlocking));
         h->m.pool.set_stream(h->m.stream);
+        h->m.hook_pool(h->m.pool);
         return h;
     } catch (const sc::Error&) {
     } catch (const std::exception& e) {
@@ -97,6 +99,21 @@ int sc_synchronize(sc_model* m) {
     SC_HIP(hipSetDevice(m->m.device));
     SC_HIP(hipStreamSynchronize(m->m.stream));
     SC_API_END
+}
+
+int sc_set_cu_partition(sc_model* m, const uint32_t* decoder_mask, const uint32_t* other_mask, int words) {
+    SC_API_BEGIN
+    SC_CHECK(m, "null handle");
+    SC_HIP(hipSetDevice(m->m.device));
+    m->m.set_cu_partition(decoder_mask, other_mask, words);
+    SC_API_END
+}
+
+int sc_device_cu_count(sc_model* m) {
+    if (!m) return SC_ERR_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, m->m.device) != hipSuccess) return SC_ERR_HIP;
+    return prop.multiProcessorCount;
 }
 
 int sc_wait_stream(sc_model* m, void* producer_stream) {

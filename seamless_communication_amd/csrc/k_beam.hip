@@ -457,7 +457,11 @@ void launch_beam_candidates(float* logits, int64_t ld, int n_utt, int beams, int
 }
 
 // workspace of the chunked search: floats = rows * 32 * 2 (chunk statistics) + rows * 32 * K (values), ints = rows * 32 * K
-bool beam_chunked(int V) { return V >= 32768; }
+// the chunked search holds a chunk's values in registers (cdiv(V, 32) <= 8192) and merges beams * 32 * K candidates through
+// 4096 LDS slots; shapes outside that fall back to the single-workgroup kernel, which takes any vocabulary
+bool beam_chunked(int V, int beams, int K) {
+    return V >= 32768 && align_up(cdiv(V, BEAM_CH), 4) <= 8192 && beams * BEAM_CH * K <= 4096;
+}
 size_t beam_ws_floats(int rows, int K) { return (size_t)rows * BEAM_CH * (2 + K); }
 size_t beam_ws_ints(int rows, int K) { return (size_t)rows * BEAM_CH * K; }
 

@@ -422,7 +422,7 @@ void launch_beam_candidates(float* logits, int64_t ld, int n_utt, int beams, int
                             float* cand_val, int* cand_idx, const int* seqs, int seq_ld, int S, int G, hipStream_t s);
 // the same search for large vocabularies: every (row, 1/32 of V) on its own workgroup, then a merge per utterance;
 // ws_f / ws_i: workspaces of beam_ws_floats / beam_ws_ints elements
-bool beam_chunked(int V);
+bool beam_chunked(int V, int beams, int K);
 size_t beam_ws_floats(int rows, int K);
 size_t beam_ws_ints(int rows, int K);
 void launch_beam_candidates_chunked(float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step, int no_eos,

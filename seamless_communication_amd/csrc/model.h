@@ -2,6 +2,7 @@
 // device allocator for activations, and the per-stage launch sequences.
 #pragma once
 #include <map>
+#include <functional>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -24,8 +25,12 @@ class DevicePool {
     void trim();  // hipFree every cached (not handed out) block
     // the one stream every user of this pool's blocks launches on (the handle's): the SC_DEBUG_FILL fill is ordered on it
     void set_stream(hipStream_t s) { stream_ = s; }
+    // called when hipMalloc fails after this pool's own cache was trimmed: the owner frees what its OTHER pools cache
+    // (a handle's side chains each cache their own copy of the vocoder scratch) before the allocation is retried
+    void set_oom_hook(std::function<void()> f) { oom_hook_ = std::move(f); }
 
    private:
+    std::function<void()> oom_hook_;
     void* debug_filled(void* p, size_t bytes);
     hipStream_t stream_ = nullptr;
     std::multimap<size_t, void*> free_;
@@ -263,6 +268,15 @@ struct Model : ModelData {
     };
     std::vector<std::unique_ptr<SideChain>> side;
     hipEvent_t side_fork = nullptr;
+    // CU partition (sc_set_cu_partition): `other_mask` restricts the handle's own stream and its side chains, `dec_chain`
+    // (stream on the decoder mask + own scratch pool) carries the greedy decoder-step chain.  Empty / null: no partition.
+    std::vector<uint32_t> other_mask;
+    std::unique_ptr<SideChain> dec_chain;
+    hipEvent_t dec_fork = nullptr;
+    hipStream_t make_stream(const std::vector<uint32_t>& mask);  // non-blocking when mask is empty, CU-masked otherwise
+    void set_cu_partition(const uint32_t* decoder_mask, const uint32_t* other, int words);
+    void trim_all_pools();   // every cached block of the handle's pools (own, side chains, decoder chain) back to the driver
+    void hook_pool(DevicePool& p) { p.set_oom_hook([this] { trim_all_pools(); }); }
     DevicePool* pool_override = nullptr;
     DevicePool* pp() { return pool_override ? pool_override : &pool; }
     SideChain& side_chain(int k);  // created on first use
@@ -294,8 +308,8 @@ struct Model : ModelData {
 struct SideScope {
     Model& m;
     hipStream_t saved;
-    SideScope(Model& mm, int k) : m(mm), saved(mm.stream) {
-        Model::SideChain& c = mm.side_chain(k);
+    SideScope(Model& mm, int k) : SideScope(mm, mm.side_chain(k)) {}
+    SideScope(Model& mm, Model::SideChain& c) : m(mm), saved(mm.stream) {
         m.stream = c.stream;
         m.pool_override = &c.pool;
     }

@@ -515,7 +515,8 @@ bool step3_wide_eligible(const Model& m, const DecStack& W, int nb) {
     if (off || nb <= 64 || nb > 512 || M % 64 != 0 || M > 1024 || W.ffn_dim % 64 != 0 || M != m.cfg.num_heads * 64) return false;
     for (const DecoderLayer& l : *W.layers)
         if (!l.qkv.wp || !l.self_out.wp || !l.cross_q.wp || !l.cross_out.wp || !l.ffn_in.wp || !l.ffn_out.wp) return false;
-    return gemv3_supported(nb, 3 * M, M, IN3_PLANES) && gemv3_supported(nb, M, W.ffn_dim, IN3_PLANES);
+    return gemv3_supported(nb, 3 * M, M, IN3_PLANES) && gemv3_supported(nb, M, W.ffn_dim, IN3_PLANES) &&
+           gemv3_supported(nb, M, M, IN3_LN) && gemv3_supported(nb, W.ffn_dim, M, IN3_LN);  // the LayerNorm-fused q / FFN-in launches
 }
 
 static int env_int(const char* name, int dflt) {
@@ -1075,10 +1076,12 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
             c.xg = S.xg;
             c.qkvr = S.qkvr;
             c.am_tiles = std::max(c.am_tiles, vocab3_groups(n));
-            c.rg_small = env_int("SC_D3_RG_SMALL", 16);
-            c.rg_ffn = env_int("SC_D3_RG_FFN", 32);
-            c.ffn_in_mode = env_int("SC_D3_FFN_IN", 1);
-            c.ffn_out_mode = env_int("SC_D3_FFN_OUT", 1);
+            // tuning knobs, read once per session and clamped to what the launches accept (an out-of-range value would
+            // otherwise only surface as a failed check inside a captured step)
+            c.rg_small = std::min(32, std::max(1, env_int("SC_D3_RG_SMALL", 16)));
+            c.rg_ffn = std::min(32, std::max(1, env_int("SC_D3_RG_FFN", 32)));
+            c.ffn_in_mode = std::min(2, std::max(0, env_int("SC_D3_FFN_IN", 1)));
+            c.ffn_out_mode = std::min(2, std::max(0, env_int("SC_D3_FFN_OUT", 1)));
         }
         if (touch_setting() > 0 && !forced) {  // greedy generation only: the session owns the captured step
             prepare_touch(m, cfg.dec_layers);
@@ -1263,6 +1266,17 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     SC_HIP(hipMemcpyAsync(c.d_hist, hist.data(), hist.size() * 4, hipMemcpyHostToDevice, m.stream));
     SC_HIP(hipMemsetAsync(S->fl.get(), 0, (size_t)2 * n * 4, m.stream));
     if (c.dec_hidden) SC_HIP(hipMemsetAsync(c.dec_hidden, 0, (size_t)n * (max_len - 1) * M * 4, m.stream));
+
+    // ---- CU partition (sc_set_cu_partition): from here on the run is the latency-bound step chain - it moves to the
+    // handle's decoder chain (a stream restricted to the decoder's compute units, own scratch pool), ordered behind the
+    // encoder K/V products and the initial copies above; the run ends with that stream drained, so the caller's next
+    // stage (on the handle's own stream again) finds everything complete
+    std::unique_ptr<SideScope> on_dec_chain;
+    if (!forced && m.dec_chain) {
+        SC_HIP(hipEventRecord(m.dec_fork, m.stream));
+        SC_HIP(hipStreamWaitEvent(m.dec_chain->stream, m.dec_fork, 0));
+        on_dec_chain.reset(new SideScope(m, *m.dec_chain));
+    }
 
     // ---- feed the known tokens (prompt echo / teacher forcing) ---------------------
     // positions 0 .. feed_len-2 are fed without projection; the next input is read from hist.
@@ -1510,10 +1524,12 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
                 qkv3w = Buf<float>(m.pp(), (size_t)nb * 3 * M);
                 c.qkv3 = qkv3w;
             }
-            c.rg_small = env_int("SC_D3_RG_SMALL", 16);
-            c.rg_ffn = env_int("SC_D3_RG_FFN", 32);
-            c.ffn_in_mode = env_int("SC_D3_FFN_IN", 1);
-            c.ffn_out_mode = env_int("SC_D3_FFN_OUT", 1);
+            // tuning knobs, read once per session and clamped to what the launches accept (an out-of-range value would
+            // otherwise only surface as a failed check inside a captured step)
+            c.rg_small = std::min(32, std::max(1, env_int("SC_D3_RG_SMALL", 16)));
+            c.rg_ffn = std::min(32, std::max(1, env_int("SC_D3_RG_FFN", 32)));
+            c.ffn_in_mode = std::min(2, std::max(0, env_int("SC_D3_FFN_IN", 1)));
+            c.ffn_out_mode = std::min(2, std::max(0, env_int("SC_D3_FFN_OUT", 1)));
         }
     }
     // vocabulary projection of the live rows: the LDS-staged streaming kernel on the packed embedding when the step left
@@ -1551,7 +1567,7 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     proj.in = M;
     proj.out = V;
 
-    const bool chunked = beam_chunked(V);  // large vocabulary: candidate search spread over (row, chunk) workgroups
+    const bool chunked = beam_chunked(V, B, K);  // large vocabulary: candidate search spread over (row, chunk) workgroups
     Buf<float> ws_f(m.pp(), chunked ? beam_ws_floats(nb, K) : 4);
     Buf<int> ws_i(m.pp(), chunked ? beam_ws_ints(nb, K) : 4);
     auto project_rows = [&]() {

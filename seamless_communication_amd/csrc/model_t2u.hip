@@ -719,6 +719,18 @@ void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h
         SC_HIP(hipEventRecord(m.side_fork, m.stream));
         for (int k = 0; k < chains; ++k) SC_HIP(hipStreamWaitEvent(m.side[k]->stream, m.side_fork, 0));
     }
+    // Whatever ends the loop below - the last bucket or an exception out of a launch / an allocation - the side chains are
+    // joined before this frame unwinds: on the error path by draining them (they must not keep writing into d_wav and into
+    // blocks of their pools while the caller frees its buffers), on the normal path by events behind the handle's stream.
+    struct Join {
+        Model& m;
+        int chains;
+        bool joined = false;
+        ~Join() {
+            if (joined || chains <= 1) return;
+            for (int k = 0; k < chains && k < (int)m.side.size(); ++k) (void)hipStreamSynchronize(m.side[k]->stream);
+        }
+    } join{m, chains};
     std::vector<std::vector<int32_t>> staging;
     staging.reserve(2 * groups.size());
     int64_t rows_done = 0;
@@ -753,6 +765,7 @@ void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h
         SC_HIP(hipEventRecord(m.side[k]->done, m.side[k]->stream));
         SC_HIP(hipStreamWaitEvent(m.stream, m.side[k]->done, 0));
     }
+    join.joined = true;
     m.last_vocoder_unit_rows = rows_done;
     SC_HIP(hipStreamSynchronize(m.stream));
 }

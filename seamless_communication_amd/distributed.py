@@ -118,14 +118,32 @@ class MicroBatcher:
     most in the decoder phase (a chain of ~220 short dependent kernels per token that leaves more than half of
     the chip idle on its own; DESIGN.md section 3, profiles/r3_bench_cover_timeline.txt)."""
 
-    def __init__(self, translator, groups: int) -> None:
+    def __init__(self, translator, groups: int, decoder_cus: int = 0, cu_layout: str = "low") -> None:
         from concurrent.futures import ThreadPoolExecutor
 
         self.groups = max(1, int(groups))
         self.views = [translator] + [translator.fork() for _ in range(self.groups - 1)]
         self.pool = ThreadPoolExecutor(max_workers=self.groups) if self.groups > 1 else None
+        # every slice does its torch-side device work (slices, .contiguous(), output tensors) on its own torch stream: the
+        # library's streams are then never ordered behind the legacy default stream, which CU-masked streams synchronise with
+        self.torch_streams = [torch.cuda.Stream(device=translator.device) for _ in self.views] if translator.device.type == "cuda" else None
+        self.decoder_cus = int(decoder_cus)
+        if self.decoder_cus > 0:
+            for v in self.views:
+                v.model.set_cu_partition(self.decoder_cus, cu_layout)
 
     def _one(self, view, wav_dev: torch.Tensor, num_samples, task_str, tgt_lang, kwargs):
+        ts = self.torch_streams[self.views.index(view)] if self.torch_streams else None
+        if ts is None:
+            return self._one_on_current_stream(view, wav_dev, num_samples, task_str, tgt_lang, kwargs)
+        with torch.cuda.stream(ts):
+            out = self._one_on_current_stream(view, wav_dev, num_samples, task_str, tgt_lang, kwargs)
+        ts.synchronize()  # the outputs are used by the caller's thread / stream next
+        return out
+
+    def _one_on_current_stream(self, view, wav_dev: torch.Tensor, num_samples, task_str, tgt_lang, kwargs):
+        if not wav_dev.is_contiguous():
+            wav_dev = wav_dev.contiguous()
         fb, frames = view.model.fbank(wav_dev, num_samples, standardize=True, pad_to_multiple=2)
         src = {"seqs": fb, "seq_lens": torch.from_numpy(frames.astype(np.int64)), "is_ragged": len(set(frames.tolist())) > 1}
         texts, speech = view.predict(src, task_str, tgt_lang, **kwargs)
@@ -140,7 +158,7 @@ class MicroBatcher:
         if g == 1:
             outs = [self._one(self.views[0], wav_dev, list(num_samples), task_str, tgt_lang, kwargs)]
         else:
-            futs = [self.pool.submit(self._one, self.views[i], wav_dev[lo:hi].contiguous(), list(num_samples[lo:hi]),
+            futs = [self.pool.submit(self._one, self.views[i], wav_dev[lo:hi], list(num_samples[lo:hi]),
                                      task_str, tgt_lang, kwargs) for i, (lo, hi) in enumerate(spans)]
             outs = [f.result() for f in futs]
         texts: List[str] = []
@@ -169,7 +187,7 @@ class MicroBatcher:
         spans = [shard_range(n, i, g) for i in range(g)]
         if g == 1:
             return [self.predict(wav_dev, num_samples, task_str, tgt_lang, **kwargs) for _ in range(steps)]
-        slices = [wav_dev[lo:hi].contiguous() for lo, hi in spans]
+        slices = [wav_dev[lo:hi] for lo, hi in spans]  # row ranges of a contiguous matrix: views, no copy
 
         def worker(i):
             if stagger_s > 0 and i > 0:

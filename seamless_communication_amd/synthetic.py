@@ -51,7 +51,13 @@ class EosRamp:
         return f"{self.length},{self.level:g},{self.start:g},{self.noise:g}"
 
 
-EOS_RAMP_BENCH = "45,1.52,0.34,2.5"
+EOS_RAMP_BENCH = "45,1.27,0.34,2.5"
+# eos_ramp variant: bias of the NAR duration predictor.  The hypotheses of this variant are ordinary token streams (about 4.4
+# characters per piece, the mean of the synthetic vocabulary) instead of the few short pieces the plain random decoder
+# favours (2.3), so the plain value (1.8: ~5 units per character) would give ~19 s of speech per 10 s utterance; 1.3
+# (~2.7 units per character, what 50 units/s over ~175 characters means) keeps the ~460 units per utterance BASELINE.md
+# prices the path at.
+EOS_RAMP_DUR_BIAS = 1.3
 # number of rows after the sentence pieces in the NLLB layout: languages + 3 data-source tags
 TEXT_CONTROL_TAIL = [None] * (98 + 3)
 
@@ -206,7 +212,8 @@ def make_unity_state_dict(
     output projection zero, final LayerNorm gain 1 / bias 0 there), so the final hidden state carries ``sin(w_i * p)``
     of the position on them, and the EOS row of the tied embedding reads exactly those channels (eos_ramp_plan): its
     logit climbs with the position and overtakes the winner of the pseudo-random logits around position n; the
-    random remainder of the row decides the step per utterance."""
+    random remainder of the row decides the step per utterance.  The variant also lowers the bias of the NAR duration
+    predictor (EOS_RAMP_DUR_BIAS) so that its ordinary token streams still give about 50 units per second of input."""
     g = _Gen(seed, dtype)
     M = cfg.model_dim
     feat = cfg.num_fbank_channels * cfg.fbank_stride
@@ -372,7 +379,7 @@ def make_unity_state_dict(
     # characters of a 40-token synthetic hypothesis give the ~500 units (10 s of speech) that
     # BASELINE.md prices the path at.
     g.uniform(f"{d}.proj.weight", (1, H), 0.3 * math.sqrt(3.0 / H))
-    g.sd[f"{d}.proj.bias"] = torch.tensor([1.8], dtype=dtype)
+    g.sd[f"{d}.proj.bias"] = torch.tensor([EOS_RAMP_DUR_BIAS if ramp else 1.8], dtype=dtype)
     for i in range(cfg.t2u_dec_layers):
         p = f"t2u_model.decoder.layers.{i}"
         g.mha(f"{p}.self_attn", M)

@@ -13,12 +13,13 @@ from pathlib import Path
 from typing import Dict, List, Optional, Sequence
 
 GOLDEN = Path(__file__).resolve().parent / "fullsize_ref.json"
+GOLDEN_MORE = Path(__file__).resolve().parent / "fullsize_more_ref.json"  # make_fullsize_more_goldens.py
 UNIT_MARGIN_TOL = 1e-4   # logit units; the oracle's unit logits are O(10)
 TEXT_MARGIN_TOL = 1e-4   # log-probability units
 
 
-def load() -> Dict:
-    return json.loads(GOLDEN.read_text())
+def load(path: Path = GOLDEN) -> Dict:
+    return json.loads(Path(path).read_text())
 
 
 def items_by_index(section: Dict) -> Dict[int, Dict]:

@@ -25,7 +25,7 @@ def test_argument_contract(monkeypatch):
 def test_cpu_baseline_worker_reports_the_oracle_on_one_utterance():
     """1 warm-up + 3 timed passes (median), per-stage split, and the ids / arg-max margins of the checked utterances."""
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-worker", "--arch", "tiny_v2", "--text-len", "10",
-                        "--cpu-threads", "2"], capture_output=True, text=True, timeout=300)
+                        "--cpu-threads", "2", "--workload", "fixed"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-500:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["kind"] == "port" and d["unit"] == "utterances/s" and d["cores"] == 2 and d["value"] > 0
@@ -36,6 +36,23 @@ def test_cpu_baseline_worker_reports_the_oracle_on_one_utterance():
         assert len(c["text_ids"]) == 10 and c["text_ids"][0] == 3 and len(c["units"]) > 0
         assert c["min_text_margin"] >= 0 and c["min_unit_margin"] >= 0
         assert sum(c["text_margin_hist"].values()) == 8 and sum(c["unit_margin_hist"].values()) >= len(c["units"])
+
+
+def test_default_workload_is_the_ragged_one(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse_args()
+    assert a.workload == "ragged" and a.text_len == 0 and a.dec_cus == -1  # resolved in main(): 64 tokens, SC_BENCH_DEC_CUS or 0
+
+
+def test_decoder_row_statistics():
+    """Two slices of 4 rows: useful row-steps = generated tokens, computed = rows x steps up to the first poll after the last EOS."""
+    lens = [10, 6, 3, 12, 8, 8, 8, 8]
+    d = bench.decoder_row_stats(lens, 8, 2, {"text_decoder": 2.0})
+    assert d["useful_row_steps"] == sum(l - 2 for l in lens) == 47
+    assert d["slices"][0]["steps_to_last_eos"] == 10 and d["slices"][1]["steps_to_last_eos"] == 6
+    assert d["computed_row_steps"] == 4 * 12 + 4 * 8
+    assert d["slices"][0]["rows_alive_at_quartiles"][0] == 4 and d["slices"][0]["rows_alive_at_quartiles"][-1] == 1
+    assert d["slice0_decoder_us_per_useful_row_step"] == round(2000.0 / (8 + 4 + 1 + 10), 2)
 
 
 def test_margin_histogram_and_parity_block_without_oracle_output():

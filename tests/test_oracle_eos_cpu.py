@@ -39,7 +39,9 @@ def test_variant_changes_only_the_text_decoder_rows_it_names():
     cfg, sd, *_ = common.tiny_bundle()
     _, sd2, *_ = common.tiny_bundle(eos_ramp=common.EOS_SPREAD)
     changed = sorted(k for k in sd if not torch.equal(sd[k], sd2[k]))
-    assert changed and all(k.startswith(("text_decoder", "final_proj")) for k in changed), changed
+    dur_bias = "t2u_model.decoder_frontend.variance_adaptor.duration_predictor.proj.bias"  # synthetic.EOS_RAMP_DUR_BIAS
+    assert dur_bias in changed and float(sd2[dur_bias]) == pytest.approx(syn.EOS_RAMP_DUR_BIAS, abs=1e-3)
+    assert all(k.startswith(("text_decoder", "final_proj")) or k == dur_bias for k in changed), changed
     assert sd2["final_proj.weight"] is sd2["text_decoder_frontend.embed.weight"]  # still tied
     rise, one, flat, _, _ = syn.eos_ramp_plan(cfg, common.EOS_SPREAD)
     clean = rise + one + flat

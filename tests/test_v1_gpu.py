@@ -175,11 +175,15 @@ def test_translator_v1_card_speech_and_text_outputs():
     assert len(texts) == 1 and speech is not None and len(speech.audio_wavs) == 1
     # translator.py:407-419: the whole unit row (pads included) is vocoded with predicted durations, then
     # int(T_wav * len(speech_units) / len(row)) samples are kept; without pads that is the sum of the durations x hop
-    units = np.asarray(speech.units[0], dtype=np.int64)[None, :]
-    dur = tr.model.vocoder_durations(units)
+    # the decoded row of a single finished hypothesis = its speech units + the EOS the unit decoder turned into a pad
+    # (unit_tokenizer.py:232-243; pads inside the row would have been dropped from speech.units, there are none here)
+    pad = tr.unit_tokenizer.vocab_info.pad_idx
+    row = np.asarray(list(speech.units[0]) + [pad], dtype=np.int64)[None, :]
+    dur = tr.model.vocoder_durations(row)
+    t_wav = int(dur.sum()) * tr.cfg.vocoder.hop
     n_keep = speech.audio_wavs[0].shape[-1]
     assert speech.audio_wavs[0].shape == (1, 1, n_keep) and n_keep > 0
-    assert n_keep <= (int(dur.sum()) + 64) * tr.cfg.vocoder.hop
+    assert n_keep == int(t_wav * len(speech.units[0]) / row.shape[1])
     assert torch.isfinite(speech.audio_wavs[0]).all()
     # text ids: the oracle's beam search on the oracle's v1 encoder output
     cfg, tt, orc, hip = _models()
