@@ -1,10 +1,10 @@
 """Host-side tokenizers of the S2ST path (integer / string logic only).
 
-* :class:`UnitTokenizer` / :class:`UnitTokenEncoder` / :class:`UnitTokenDecoder` are TRANSLITERATED from
-  src/seamless_communication/models/unity/unit_tokenizer.py:15-243 (torch -> numpy, comments dropped): same class and
-  attribute names (the ``lang_symbol_repititions`` spelling included), same error strings, same index arithmetic.  They
-  are the drop-in surface of row a17 and their behaviour is the contract, so they follow the reference line by line
-  rather than being redesigned; pinned against the executed reference class (tests/golden/unit_tokenizer_ref.npz).
+* :class:`UnitTokenizer` / :class:`UnitTokenEncoder` / :class:`UnitTokenDecoder` restate
+  src/seamless_communication/models/unity/unit_tokenizer.py:15-243 (the drop-in surface of row a17) as a vocabulary
+  LAYOUT with look-up tables built once per tokenizer; class / attribute names (the ``lang_symbol_repititions`` spelling
+  included) and error texts are the reference's, the arithmetic is this package's; pinned against the executed
+  reference class (tests/golden/unit_tokenizer_ref.npz).
 * :class:`NllbTextTokenizer` exposes what the hot path needs from fairseq2's
   ``NllbTokenizer``: vocabulary info, ``index_to_token`` (used by
   nar_decoder_frontend.py:130-141), the target-mode prefix ``[</s>, __lang__]``
@@ -46,52 +46,57 @@ class VocabularyInfo:
 # --------------------------------------------------------------------------- #
 # Units
 # --------------------------------------------------------------------------- #
+# The unit vocabulary as a LAYOUT (what models/unity/unit_tokenizer.py:15-117 computes with index arithmetic at every
+# call): four control symbols, the speech units, then `blocks` language blocks of len(langs) + 1 symbols each - the v1
+# (autoregressive) models carry two blocks and use the second one, the "_v2" (NAR) models one.
+#
+#     [ <s>=0 <pad>=1 </s>=2 <unk>=3 | unit 0 .. unit U-1 | block 0: langs.., spare | block 1: langs.., spare ]
+#
+# Encoding and decoding are then table look-ups built once per tokenizer (`encode_lut` over raw unit values, `decode_lut`
+# over vocabulary ids) instead of per-call masked arithmetic.  Public names, signatures and error texts are the
+# reference's (they are the drop-in surface of row a17); results are pinned against the executed reference class
+# (tests/golden/unit_tokenizer_ref.npz, tests/test_unit_tokenizer.py).
+_N_CONTROL = 4
+
+
 class UnitTokenizer:
-    """unit_tokenizer.py:15-117 (vocabulary arithmetic only)."""
+    """Drop-in for ``UnitTokenizer`` (unit_tokenizer.py:15-117)."""
 
     def __init__(self, num_units: int, langs: Sequence[str], model_arch: str) -> None:
         self.num_units = num_units
         self.langs = list(langs)
         self.lang_map = {lang: idx for idx, lang in enumerate(langs)}
-        # "_v2" architectures have a NAR decoder (unit_tokenizer.py:38).
-        if model_arch.split("_")[-1] == "v2":
-            self.is_nar_decoder = True
-            self.lang_symbol_repititions = 1
-        else:
-            self.is_nar_decoder = False
-            self.lang_symbol_repititions = 2
-        vocab_size = num_units + self.lang_symbol_repititions * (len(langs) + 1) + 4
-        self.vocab_info = VocabularyInfo(
-            size=vocab_size, bos_idx=0, pad_idx=1, eos_idx=2, unk_idx=3
-        )
+        self.is_nar_decoder = model_arch.rsplit("_", 1)[-1] == "v2"   # unit_tokenizer.py:38
+        blocks = 1 if self.is_nar_decoder else 2
+        self.lang_symbol_repititions = blocks                           # the reference's attribute name (and spelling)
+        block = len(self.langs) + 1
+        self._first_lang = _N_CONTROL + num_units + (blocks - 1) * block  # first language symbol of the block in use
+        self.vocab_info = VocabularyInfo(size=_N_CONTROL + num_units + blocks * block, bos_idx=0, pad_idx=1, eos_idx=2, unk_idx=3)
+        # raw unit value -> vocabulary id; one extra slot catches everything outside the dictionary (-> <unk>)
+        self.encode_lut = np.concatenate([np.arange(num_units, dtype=np.int64) + _N_CONTROL, [self.vocab_info.unk_idx]])
+        # vocabulary id -> id with </s> folded into <pad> and <pad> moved out of the way of unit 0 (unit_tokenizer.py:232-239:
+        # after the -4 below the pad lands on 1 again, every unit on its raw value)
+        self.decode_lut = np.arange(self.vocab_info.size, dtype=np.int64)
+        self.decode_lut[[self.vocab_info.eos_idx, self.vocab_info.pad_idx]] = self.vocab_info.pad_idx + _N_CONTROL
+
+    def _unknown_lang(self, lang: str) -> ValueError:
+        return ValueError(f"`lang` must be one of the supported languages, but is '{lang}' instead. Supported languages: "
+                          f"{', '.join(self.langs)}")
 
     def lang_to_index(self, lang: str) -> int:
-        try:
-            return (
-                self.num_units
-                + (self.lang_symbol_repititions - 1) * (len(self.langs) + 1)
-                + self.lang_map[lang]
-                + 4
-            )
-        except KeyError:
-            langs = ", ".join(self.langs)
-            raise ValueError(
-                f"`lang` must be one of the supported languages, but is '{lang}' instead. Supported languages: {langs}"
-            )
+        if lang not in self.lang_map:
+            raise self._unknown_lang(lang)
+        return self._first_lang + self.lang_map[lang]
 
     def index_to_lang(self, idx: int) -> str:
-        relative_idx = (
-            idx - self.num_units - (self.lang_symbol_repititions - 1) * (len(self.langs) + 1) - 4
-        )
-        if relative_idx < 0 or relative_idx >= len(self.langs):
-            raise ValueError(
-                f"`idx` must correspond to one of the supported language symbol indices (0 to {len(self.langs) - 1}), but is {idx} instead."
-            )
-        return self.langs[relative_idx]
+        k = idx - self._first_lang
+        if not 0 <= k < len(self.langs):
+            raise ValueError(f"`idx` must correspond to one of the supported language symbol indices (0 to {len(self.langs) - 1}), "
+                             f"but is {idx} instead.")
+        return self.langs[k]
 
     def create_encoder(self, lang: str, device=None) -> "UnitTokenEncoder":
-        """``device`` is accepted for signature parity (unit_tokenizer.py:96-107);
-        tensors are returned on the device of the input."""
+        """``device`` is accepted for signature parity (unit_tokenizer.py:96-107); tensors come back on the input's device."""
         return UnitTokenEncoder(self, lang, self.is_nar_decoder)
 
     def create_decoder(self) -> "UnitTokenDecoder":
@@ -99,48 +104,41 @@ class UnitTokenizer:
 
 
 class UnitTokenEncoder:
-    """unit_tokenizer.py:120-206 on int64 numpy arrays of shape (N, S)."""
+    """Raw units (N, S) -> model ids; the autoregressive models get the prompt ``[</s>, __lang__]`` in front
+    (unit_tokenizer.py:120-206)."""
 
     def __init__(self, tokenizer: UnitTokenizer, lang: str, is_nar_decoder: bool) -> None:
         if lang not in tokenizer.lang_map:
-            langs = ", ".join(tokenizer.langs)
-            raise ValueError(
-                f"`lang` must be one of the supported languages, but is '{lang}' instead. Supported languages: {langs}"
-            )
+            raise tokenizer._unknown_lang(lang)
         self.tokenizer = tokenizer
         self.is_nar_decoder = is_nar_decoder
         self.eos_idx = tokenizer.vocab_info.eos_idx
         self.unk_idx = tokenizer.vocab_info.unk_idx
         self.lang_idx = tokenizer.lang_to_index(lang)
-        if not is_nar_decoder:
-            self.prefix_indices = np.array([self.eos_idx, self.lang_idx], dtype=np.int64)
-        else:
-            self.prefix_indices = None
+        self.prefix_indices = None if is_nar_decoder else np.array([self.eos_idx, self.lang_idx], dtype=np.int64)
 
     def __call__(self, units):
         """int64 array or tensor (N, S) -> same kind, (N, S [+2])."""
         if _is_tensor(units):
             return _like(units, self(units.detach().cpu().numpy()))
         units = np.asarray(units, dtype=np.int64)
-        n = units.shape[0]
-        if self.prefix_indices is not None:
-            out = np.concatenate([np.tile(self.prefix_indices, (n, 1)), units], axis=1)
-            seqs = out[:, 2:]
-        else:
-            out = units.copy()
-            seqs = out
-        seqs += 4
-        seqs[seqs >= self.tokenizer.num_units + 4] = self.unk_idx
-        return out
+        lut = self.tokenizer.encode_lut
+        ids = lut[np.minimum(units, len(lut) - 1)]   # values past the dictionary share the <unk> slot
+        if self.prefix_indices is None:
+            return ids
+        return np.concatenate([np.broadcast_to(self.prefix_indices, (units.shape[0], 2)), ids], axis=1)
 
 
 class UnitTokenDecoder:
-    """unit_tokenizer.py:209-243."""
+    """Model ids -> raw units with pads (value 1) where the sequence has ended (unit_tokenizer.py:209-243).  The NAR models'
+    rows are all units; the autoregressive models' rows start [</s>, __lang__]: the </s> column is dropped and the language
+    column comes back as the reference leaves it (un-shifted, only </s> / <pad> folded)."""
 
     def __init__(self, tokenizer: UnitTokenizer, is_nar_decoder: bool) -> None:
         self.eos_idx = tokenizer.vocab_info.eos_idx
         self.pad_idx = tokenizer.vocab_info.pad_idx
         self.is_nar_decoder = is_nar_decoder
+        self._lut = tokenizer.decode_lut
 
     def __call__(self, token_indices):
         if _is_tensor(token_indices):
@@ -148,16 +146,11 @@ class UnitTokenDecoder:
         token_indices = np.asarray(token_indices, dtype=np.int64)
         if token_indices.shape[1] == 0:
             return token_indices
-        units = token_indices.copy()
-        if not self.is_nar_decoder:
-            units = units[:, 1:]
-        units[units == self.eos_idx] = self.pad_idx
-        units[units == self.pad_idx] = self.pad_idx + 4
         if self.is_nar_decoder:
-            units -= 4
-        else:
-            units[:, 1:] -= 4
-        return units
+            return self._lut[token_indices] - _N_CONTROL
+        folded = self._lut[token_indices[:, 1:]]
+        folded[:, 1:] -= _N_CONTROL
+        return folded
 
 
 # --------------------------------------------------------------------------- #

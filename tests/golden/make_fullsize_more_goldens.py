@@ -15,7 +15,7 @@ Sections:
           synthetic weights: S2TT of a 10 s + 6.4 s batch through the v1 w2v-BERT encoder, and T2TT of two sentences;
           greedy, hard_max_seq_len 24.
   stream  SeamlessStreaming S2T + S2ST agent chains (BASELINE configs[4]) on the oracle backend at base_v2 size with the
-          dense_1b monotonic decoder: one 4.2 s utterance fed in 320 ms segments; every text-decoder call (arg-max index,
+          dense_1b monotonic decoder: one 3.2 s utterance fed in 320 ms segments; every text-decoder call (arg-max index,
           the p_choose statistic the policy compares), every output segment, the unit chunks handed to the vocoder.  The
           decision threshold is picked, as in tests/test_streaming_gpu.py, where it is farthest from any statistic met.
 """
@@ -44,11 +44,11 @@ T2TT_SENTENCES = [
 MEDIUM_SECONDS = (10.0, 6.4)
 MEDIUM_FIRST_INDEX = 200
 MEDIUM_TEXT_LEN = 24
-STREAM_INDEX, STREAM_SECONDS = 300, 4.2
+STREAM_INDEX, STREAM_SECONDS = 300, 3.2
 # decision_method "mean" (online_text_decoder.py:163-187 offers min / mean / median): with seeded random energy projections the
 # MINIMUM over 24 layers x 16 heads is ~0 at every step (the stream would only write once the source has ended), the mean moves
 STREAM_METHOD = "mean"
-STREAM_THRESHOLDS = (0.30, 0.35, 0.40, 0.44, 0.48, 0.52, 0.56, 0.60, 0.65, 0.70)
+STREAM_THRESHOLDS = (0.66, 0.70, 0.74, 0.78, 0.82)
 
 
 def _r(xs, nd=4):
@@ -58,7 +58,7 @@ def _r(xs, nd=4):
 def stream_args(thr):
     from seamless_communication_amd.streaming import default_args
 
-    return default_args(tgt_lang="fra", decision_threshold=thr, decision_method=STREAM_METHOD, min_unit_chunk_size=50, max_len_a=0, max_len_b=40)
+    return default_args(tgt_lang="fra", decision_threshold=thr, decision_method=STREAM_METHOD, min_unit_chunk_size=50, max_len_a=0, max_len_b=24)
 
 
 def run_stream_traced(backend, tt, thr, wav, speech: bool):
