@@ -20,6 +20,15 @@ the batched step, ragged T2U / vocoder lengths; ``hard_max_seq_len`` 64.
 emit EOS: every hypothesis is cut at ``--text-len`` 42); the default run reports
 it under ``extra.fixed42`` for continuity.
 
+Schedule (``--schedule``): by default three whole-batch passes are in flight on
+one GPU, pipelined ACROSS passes (one host thread + forked handle + HIP stream
+each, thread i runs passes i, i+3, ...): the latency-bound decoder chain of one
+pass runs under the GEMM-bound stages of its neighbours.  All K timed passes start
+and finish inside the timed region; the wall time of a single pass is reported as
+``config.pass_latency_ms``.  ``--schedule lockstep`` is the schedule of rounds
+1-3 (two concurrent 32-utterance slices joined after every pass); the default run
+reports it under ``extra.lockstep``.
+
 Rank 0 prints ONE JSON line.  ``value`` is utterances/s over all GPUs (weak
 scaling: per-GPU batch fixed).  ``roofline`` describes the kernel family with
 the largest share of GPU time, from per-launch HIP events recorded on the
@@ -57,8 +66,15 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step (BASELINE configs[3]: 64 per GPU)")
-    ap.add_argument("--microbatches", type=int, default=2,
-                    help="concurrent slices of the per-GPU batch (one host thread + one HIP stream each)")
+    ap.add_argument("--schedule", default="pipeline", choices=["pipeline", "lockstep", "freerun"],
+                    help="pipeline (default): --microbatches whole-batch passes in flight, each worker thread running passes i, i+g, ... "
+                         "over the WHOLE per-GPU batch (one decoder chain of all rows), joined once after the K steps - the decoder chain of "
+                         "one pass runs under the GEMM-bound stages of its neighbours; lockstep: the batch cut into --microbatches slices "
+                         "that run concurrently and are joined after every pass (the schedule of rounds 1-3, reported under extra.lockstep "
+                         "by the default run); freerun: those slices free-running over the K steps")
+    ap.add_argument("--microbatches", type=int, default=0,
+                    help="host threads (one forked handle + HIP stream each): passes in flight (pipeline, default 3) or slices of the "
+                         "batch (lockstep / freerun, default 2)")
     ap.add_argument("--workload", default="ragged", choices=["ragged", "fixed"],
                     help="ragged: eos_ramp weights, hypotheses stop on their own (text lengths ~8..64, mean ~40); fixed: every hypothesis "
                          "cut at --text-len (the workload of rounds 1-3)")
@@ -80,9 +96,9 @@ def parse_args():
                          "(default: the profiled pass runs the slices of the timed passes - same rows per slice, same kernel "
                          "instantiations, graph replay - one after the other, so that per-launch durations do not overlap)")
     ap.add_argument("--no-graph", action="store_true", help="launch decoder steps eagerly instead of hipGraph replay")
-    ap.add_argument("--free-run", action="store_true",
-                    help="let the micro-batch slices free-run over the K steps (joined once) instead of joining them after "
-                         "every step; measured no faster on MI355X (profiles/r1_microbatch_schedule.txt), kept for experiments")
+    ap.add_argument("--free-run", action="store_true", help="same as --schedule freerun")
+    ap.add_argument("--lock-step", action="store_true", help="same as --schedule lockstep")
+    ap.add_argument("--pipeline-passes", action="store_true", help="same as --schedule pipeline")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the secondary lines reported under `extra` (S2TT-only, beam 5, streaming p50)")
     ap.add_argument("--extra-timeout", type=int, default=240, help="limit of the streaming child process, seconds")
@@ -397,6 +413,16 @@ def main():
         args.text_len = 64 if args.workload == "ragged" else 42
     if args.dec_cus < 0:
         args.dec_cus = int(os.environ.get("SC_BENCH_DEC_CUS", "0"))
+    if args.free_run:
+        args.schedule = "freerun"
+    if args.lock_step:
+        args.schedule = "lockstep"
+    if args.pipeline_passes:
+        args.schedule = "pipeline"
+    args.pipeline_passes = args.schedule == "pipeline"
+    args.free_run = args.schedule == "freerun"
+    if args.microbatches <= 0:
+        args.microbatches = 3 if args.pipeline_passes else 2
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -446,6 +472,7 @@ def main():
 
     batcher = MicroBatcher(translator, min(args.microbatches, B), decoder_cus=args.dec_cus, cu_layout=args.cu_layout)
     last = {}
+    gather_s = []  # wall time of every ragged all-gather of ids (N > 1): two collectives + the host packing around them
 
     def step(single_stream: bool = False, sequential_slices: bool = False):
         """One pass of the hot path over the per-GPU batch (fbank included)."""
@@ -480,7 +507,9 @@ def main():
             stage_ms.clear()
             stage_ms.update(st)
         if world > 1:  # the only exchange of the data-parallel path: ids, a few hundred KB
+            tg = time.perf_counter()
             all_text, all_units = all_gather_ragged_lists([text_ids, units], device)
+            gather_s.append(time.perf_counter() - tg)
             assert len(all_text) == len(all_units) == world * B
         last.update(texts=texts, units=units, wavs=wavs, text_ids=text_ids)
 
@@ -493,11 +522,21 @@ def main():
     warm_s = 0.0
     for i in range(args.warmup):
         tw = time.perf_counter()
-        step()
-        torch.cuda.synchronize()
-        warm_s = time.perf_counter() - tw
+        if args.pipeline_passes and batcher.groups > 1:
+            # every worker runs one whole-batch pass (its own decode session, captured graph and scratch pool get warm)
+            outs = batcher.predict_passes(wav_dev, ns, batcher.groups, "S2ST", "fra", text_generation_opts=opts)
+            texts, units, wavs, text_ids, st = outs[-1]
+            stage_ms.clear()
+            stage_ms.update(st)
+            last.update(texts=texts, units=units, wavs=wavs, text_ids=text_ids)
+            torch.cuda.synchronize()
+            warm_s = 2.0 * (time.perf_counter() - tw) / batcher.groups  # ~ one pass alone: the workers start half a pass apart
+        else:
+            step()
+            torch.cuda.synchronize()
+            warm_s = time.perf_counter() - tw
         log(f"warmup step {i}: {stage_ms}")
-    free_run = args.free_run and batcher.groups > 1
+    free_run = (args.free_run or args.pipeline_passes) and batcher.groups > 1
     stagger = args.stagger if args.stagger >= 0 else (warm_s / batcher.groups if args.warmup > 0 else 0.0)
     fence()
     t0 = time.perf_counter()
@@ -505,10 +544,13 @@ def main():
     if free_run:
         # K passes over the per-GPU batch; the micro-batch slices free-run (joined once), the all-gathers of the K
         # passes follow.  Same work as K lock-step passes, see MicroBatcher.predict_steps.
-        outs = batcher.predict_steps(wav_dev, ns, args.steps, "S2ST", "fra", stagger_s=stagger, text_generation_opts=opts)
+        run = batcher.predict_passes if args.pipeline_passes else batcher.predict_steps
+        outs = run(wav_dev, ns, args.steps, "S2ST", "fra", stagger_s=stagger, text_generation_opts=opts)
         for texts, units, wavs, text_ids, st in outs:
             if world > 1:
+                tg = time.perf_counter()
                 all_text, all_units = all_gather_ragged_lists([text_ids, units], device)
+                gather_s.append(time.perf_counter() - tg)
                 assert len(all_text) == len(all_units) == world * B
         texts, units, wavs, text_ids, st = outs[-1]
         stage_ms.clear()
@@ -527,10 +569,14 @@ def main():
         elapsed = float(t.item())
     stage_snapshot = dict(stage_ms)
     # per-slice T2U data of the LAST TIMED pass (later runs - profiled pass, latency, extras - overwrite the views' copies)
-    t2u_snapshot = [getattr(v, "last_t2u", None) for v in batcher.views]
+    # (pipelined passes: the worker that ran the last pass holds the whole batch)
+    whole = args.pipeline_passes and free_run
+    eff_views = [batcher.views[(args.steps - 1) % batcher.groups]] if whole else batcher.views
+    eff_groups = 1 if whole else batcher.groups
+    t2u_snapshot = [getattr(v, "last_t2u", None) for v in eff_views]
     timed_text_ids = [list(t) for t in last["text_ids"]]
     # unit rows the NAR decoder / vocoder really computed in the last timed pass (length buckets) over the useful ones
-    pads = [v.model.last_padding() for v in batcher.views]
+    pads = [v.model.last_padding() for v in eff_views]
     useful = sum(len(u) for u in last["units"])
     padding_info = {
         "padding_ratio_t2u": round(sum(p["t2u_rows_computed"] for p in pads) / max(1, useful), 3),
@@ -561,14 +607,21 @@ def main():
                 "text_search": f"greedy, soft_max_seq_len=(1,200), hard_max_seq_len={args.text_len}",
                 "text_tokens_per_utt": {"min": int(min(text_lens)), "mean": float(np.mean(text_lens)), "max": int(max(text_lens))},
                 "units_per_utt": float(np.mean(unit_counts)), "units_per_utt_min_max": [int(min(unit_counts)), int(max(unit_counts))],
-                "decoder_rows": decoder_row_stats(text_lens, B, batcher.groups, stage_snapshot),
+                "decoder_rows": decoder_row_stats(text_lens, B, eff_groups, stage_snapshot),
                 "out_audio_seconds_per_utt": float(np.mean(wav_secs)),
                 "s_unit_max": int(max(unit_counts)), **padding_info,
                 "parallelism": f"dp{world} (utterances sharded, full replica per GPU, all-gather of ids)",
                 "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                # the ragged all-gather of text + unit ids that ends a pass (host wall time per call on rank 0, timed passes only)
+                "gather_ms": ({"mean": round(1e3 * float(np.mean(gather_s[-args.steps:])), 3), "max": round(1e3 * float(np.max(gather_s[-args.steps:])), 3),
+                               "calls": len(gather_s[-args.steps:])} if gather_s else None),
                 "hip_graph_decoder_step": bool(translator.use_graph),
                 "microbatches_in_flight": batcher.groups,
-                "microbatch_schedule": (f"free-running slices, start offsets {stagger * 1e3:.0f} ms" if free_run else "lock-step (join per pass)"),
+                "pass_latency_ms": (round(1e3 * float(np.mean(batcher.last_pass_seconds)), 1) if args.pipeline_passes and free_run and
+                                    getattr(batcher, "last_pass_seconds", None) else round(ms_per_step, 1)),
+                "microbatch_schedule": ((f"{batcher.groups} whole-batch passes in flight (pipelined across passes), start offsets {stagger * 1e3:.0f} ms"
+                                         if args.pipeline_passes else f"free-running slices, start offsets {stagger * 1e3:.0f} ms")
+                                        if free_run else "lock-step (join per pass)"),
                 "cu_partition": ({"decoder_cus": args.dec_cus, "layout": args.cu_layout, "device_cus": model.cu_count()} if args.dec_cus > 0 else None),
             },
             "stage_ms_last_step_slice0": {k: round(v, 3) for k, v in stage_snapshot.items()},
@@ -582,7 +635,8 @@ def main():
         lib.sc_prof_enable(1)
         # the decoder step stays a replayed graph like in the timed passes: its launches cannot carry events, each
         # replay is one record ("dec:step_graph") with the step's algorithmic bytes
-        step(single_stream=args.profile_single_stream or batcher.groups == 1, sequential_slices=not args.profile_single_stream and batcher.groups > 1)
+        whole_pass = args.profile_single_stream or batcher.groups == 1 or args.pipeline_passes  # the timed passes ARE whole-batch passes
+        step(single_stream=whole_pass, sequential_slices=not whole_pass)
         torch.cuda.synchronize()
         lib.sc_prof_enable(0)
         fams = prof_report(lib)
@@ -593,11 +647,12 @@ def main():
                 "survey_weight_bytes": 2.0 * (L_ * (8.0 * M_ * M_ + 2.0 * M_ * F_) + float(V_) * M_),
                 # what a step really streams: the cross-attention k / v projections run once per utterance, not per token
                 "streamed_weight_bytes": 2.0 * (L_ * (6.0 * M_ * M_ + 2.0 * M_ * F_) + float(V_) * M_),
-                "rows": B // batcher.groups,
+                "rows": B if whole_pass else B // batcher.groups,
             }
             roof, shares = roofline_of(fams, step_bytes)
             if roof is not None:
-                roof["profiled_pass"] = ("one slice, one stream" if (args.profile_single_stream or batcher.groups == 1) else
+                roof["profiled_pass"] = ("one whole-batch pass alone on one stream (the unit of the pipelined schedule; un-overlapped launch durations)"
+                                         if whole_pass else
                                          f"the {batcher.groups} slices of the timed passes run one after the other (un-overlapped launch durations)")
             result["roofline"] = roof
             result["kernel_families_profiled_step"] = shares
@@ -632,7 +687,7 @@ def main():
     if rank == 0:
         # every utterance of the timed batch against the oracle's committed ids (tests/golden/fullsize_ref.json)
         try:
-            result["parity"] = parity_from_goldens(args, batcher, {"text_ids": timed_text_ids}, B, t2u_snapshot, first_index=rank * B)
+            result["parity"] = parity_from_goldens(args, eff_groups, {"text_ids": timed_text_ids}, B, t2u_snapshot, first_index=rank * B)
         except Exception as e:  # noqa: BLE001  (a fixture / shape surprise must not lose the measured line)
             result["parity"] = {"n_checked": 0, "error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
@@ -688,6 +743,21 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
                              "stage_ms": {k: round(v, 3) for k, v in translator.last_stage_ms.items()}}
     except Exception as e:  # noqa: BLE001
         out["s2st_beam5"] = {"error": repr(e)[:300]}
+    if args.pipeline_passes and batcher.groups > 1:
+        try:  # the lock-step schedule of rounds 1-3 on the same workload: two concurrent slices, joined after every pass
+            from seamless_communication_amd.distributed import MicroBatcher
+
+            class _Two(MicroBatcher):  # two of the existing views (no new handles)
+                def __init__(self, parent):
+                    self.groups, self.views, self.pool = 2, parent.views[:2], parent.pool
+                    self.torch_streams, self.decoder_cus = parent.torch_streams[:2], parent.decoder_cus
+
+            two = _Two(batcher)
+            dt = timed(lambda: two.predict(wav_dev, ns, "S2ST", "fra", text_generation_opts=opts), 3)
+            out["lockstep"] = {"metric": "S2ST utterances/s, same workload, lock-step schedule (two 32-utterance slices joined after every pass)",
+                               "value": B / dt, "ms_per_step": 1e3 * dt, "rtf": dt / (B * AUDIO_SECONDS)}
+        except Exception as e:  # noqa: BLE001
+            out["lockstep"] = {"error": repr(e)[:300]}
     if args.workload == "ragged":
         try:  # the workload of rounds 1-3 for continuity: plain random weights, every hypothesis cut at 42 tokens, same schedule
             from seamless_communication_amd import synthetic as syn
@@ -698,11 +768,20 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
             card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch=args.arch, checkpoint=f"synthetic://{syn.DEFAULT_SEED}")
             tr42 = Translator(card, dict(DEFAULT_CARDS["vocoder_v2"]), device=translator.device, input_modality=Modality.SPEECH)
             tr42.use_graph = translator.use_graph
-            mb42 = MicroBatcher(tr42, batcher.groups, decoder_cus=args.dec_cus, cu_layout=args.cu_layout)
+            mb42 = MicroBatcher(tr42, 2, decoder_cus=args.dec_cus, cu_layout=args.cu_layout)
             o42 = SequenceGeneratorOptions(beam_size=1, soft_max_seq_len=(1, 200), hard_max_seq_len=42)
             dt = timed(lambda: mb42.predict(wav_dev, ns, "S2ST", "fra", text_generation_opts=o42), 3)
-            out["fixed42"] = {"metric": "S2ST utterances/s, the workload of rounds 1-3 (every hypothesis cut at 42 tokens), same batch / schedule",
+            out["fixed42"] = {"metric": "S2ST utterances/s, workload AND schedule of rounds 1-3 (every hypothesis cut at 42 tokens, two lock-step slices)",
                               "value": B / dt, "ms_per_step": 1e3 * dt, "rtf": dt / (B * AUDIO_SECONDS)}
+            if args.pipeline_passes and batcher.groups > 1:
+                mbp = MicroBatcher(tr42, batcher.groups)
+
+                def piped():
+                    mbp.predict_passes(wav_dev, ns, 2 * mbp.groups, "S2ST", "fra", stagger_s=0.5 * dt, text_generation_opts=o42)
+
+                dtp = timed(piped, 1) / (2 * mbp.groups)
+                out["fixed42"]["pipelined"] = {"metric": "the same workload under this run's pipelined schedule", "value": B / dtp, "ms_per_step": 1e3 * dtp}
+                mbp.close()
             mb42.close()
             del mb42, tr42
         except Exception as e:  # noqa: BLE001
@@ -721,7 +800,7 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
     return out
 
 
-def parity_from_goldens(args, batcher, last, B, t2u_views, first_index=0):
+def parity_from_goldens(args, groups, last, B, t2u_views, first_index=0):
     """Ids of the TIMED batch (last timed pass: micro-batch slices, graph replay) against the CPU oracle's ids of the same
     64 utterances, minted once by tests/golden/make_fullsize_goldens.py (oracle/pipeline.py, fp32): text ids / char ids /
     durations / unit ids of every utterance, match rates, and for every mismatching unit position the oracle's own arg-max
@@ -751,7 +830,7 @@ def parity_from_goldens(args, batcher, last, B, t2u_views, first_index=0):
     if n <= 0:
         return {"n_checked": 0, "error": f"the golden fixture holds utterances 0..{len(items) - 1} only"}
     reports = []
-    spans = [shard_range(B, i, batcher.groups) for i in range(batcher.groups)]
+    spans = [shard_range(B, i, groups) for i in range(groups)]
     for i in range(n):
         kw = dict(text_ids=last["text_ids"][i])
         s = next(k for k, (lo, hi) in enumerate(spans) if lo <= i < hi)

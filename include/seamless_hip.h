@@ -160,6 +160,12 @@ int sc_wait_stream(sc_model* m, void* producer_stream);
  * way synchronise with the legacy default stream: a caller that partitions handles must keep its own work off the default
  * stream while calls are in flight (the Python host gives every worker thread its own stream).  Results do not change. */
 int sc_set_cu_partition(sc_model* m, const uint32_t* decoder_mask, const uint32_t* other_mask, int words);
+/* Introspection (ABI 7): the kernel family a decoder step of `rows` live rows is dispatched to for `caller` (0 greedy text
+ * generation, 1 beam search over the text decoder, 2 streaming monotonic decoder, 3 beam search over the v1 unit decoder,
+ * 4 teacher-forced stepwise pass): 1 general (split-K skinny products up to 64 rows, tiled GEMMs above), 2 packed-fragment
+ * products, 3 row-group products with fused LayerNorm / residual, 4 the row-group chain cut into row groups (> 64 rows);
+ * negative sc_status when the model has no such decoder.  Decided by the predicates the stages themselves use. */
+int sc_decoder_step_family(sc_model* m, int rows, int caller);
 /* number of compute units of the handle's device (the width of the masks above, in bits) */
 int sc_device_cu_count(sc_model* m);
 

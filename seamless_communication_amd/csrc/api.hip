@@ -109,6 +109,15 @@ int sc_set_cu_partition(sc_model* m, const uint32_t* decoder_mask, const uint32_
     SC_API_END
 }
 
+int sc_decoder_step_family(sc_model* m, int rows, int caller) {
+    if (!m || rows < 1 || caller < 0 || caller > 4) return SC_ERR_INVALID;
+    try {
+        return decoder_step_family(m->m, rows, caller);
+    } catch (...) {
+        return SC_ERR_INTERNAL;
+    }
+}
+
 int sc_device_cu_count(sc_model* m) {
     if (!m) return SC_ERR_INVALID;
     hipDeviceProp_t prop;

@@ -336,6 +336,7 @@ int text_to_char_seqs_host(int vocab, const int32_t* tok_len, const uint8_t* sta
                            int n, int s_text, int32_t* out_char_lens, int32_t* out_char_ids, int cap, int32_t* out_seq_lens);
 void run_encode_text(Model& m, const int32_t* h_tokens, int n, int s_text, const int32_t* h_lens, float* d_out);
 int text_max_len(const Model& m, const sc_gen_opts& o, int s_enc);
+int decoder_step_family(const Model& m, int rows, int caller);
 void ngram_blocked_tokens(const int32_t* seq, int S, int G, std::vector<int32_t>& out);
 void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int32_t* h_enc_lens,
                        const sc_gen_opts& o, const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids,

@@ -77,6 +77,8 @@ struct StepCtx {
     float* qkv3 = nullptr;  // [nb][3M] complete q | k | v rows: the wide step (> 64 live rows) projects them on gemv3
 };
 
+DecStack mma_stack(const Model& m);  // defined with the streaming decoder below
+
 DecStack unity_stack(const Model& m) {
     DecStack w;
     w.embed = m.text_embed;
@@ -659,6 +661,38 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
     launch_add_i32(c.d_pos, 1, m.stream);
 }
 
+}  // namespace
+
+// Which kernel family a decoder step of `rows` live rows runs on, decided by the SAME predicates the callers use (the
+// dispatch matrix in one place; tests/test_dispatch_gpu.py pins it).  caller: 0 greedy text generation (setup_session),
+// 1 beam search over the text decoder, 2 the streaming monotonic decoder's step, 3 beam search over the v1 unit decoder,
+// 4 teacher-forced stepwise pass.  Returns SC_STEP_GENERAL (1: split-K skinny products up to 64 rows, tiled GEMMs above),
+// SC_STEP_PACKED (2: packed-fragment products, k_dstep.hip), SC_STEP_ROWGROUP (3: row-group products with fused LayerNorm /
+// residual, k_dstep3.hip) or SC_STEP_ROWGROUP_WIDE (4: the same chain cut into row groups, > 64 rows).
+int decoder_step_family(const Model& m, int rows, int caller) {
+    const int M = m.cfg.model_dim;
+    if (caller == 2) {
+        if (m.mma_dec.empty()) return SC_ERR_INVALID;
+        return step2_eligible(m, mma_stack(m), 1) ? 2 : 1;
+    }
+    if (caller == 3 && m.t2u_ar_dec.empty()) return SC_ERR_INVALID;
+    const DecStack W = caller == 3 ? t2u_ar_stack(m) : unity_stack(m);
+    if (caller == 0 || caller == 4) {
+        const bool forced = caller == 4;
+        const bool gen2 = step2_eligible(m, W, rows) && (forced || W.embed_p != nullptr);
+        const bool fused_argmax = !forced && rows <= 64 && M % 64 == 0;
+        const bool gen3 = gen2 && step3_eligible(m, W, rows) && (forced || (fused_argmax && W.embed_p && vocab3_supported(rows, W.vocab, M)));
+        return gen3 ? 3 : (gen2 ? 2 : 1);
+    }
+    // beam search (run_generate_beam)
+    const bool packed = step2_eligible(m, W, rows) || step3_wide_eligible(m, W, rows);
+    if (!packed) return 1;
+    if (rows > 64) return 4;
+    return step3_eligible(m, W, rows) ? 3 : 2;
+}
+
+namespace {
+
 // One decoder step for all batch rows: feeds d_tok at position *d_pos.
 void decoder_step(Model& m, StepCtx& c, bool project) {
     const sc_config& cfg = m.cfg;
@@ -728,7 +762,7 @@ void decoder_step(Model& m, StepCtx& c, bool project) {
             a.W = W.embed;
             a.ldw = M;
             a.M = nb;
-            a.N = cfg.text_vocab_size;
+            a.N = W.vocab;
             a.K = M;
             a.am_part = c.am_part;
             a.am_tiles_cap = c.am_tiles;
@@ -736,26 +770,26 @@ void decoder_step(Model& m, StepCtx& c, bool project) {
             a.am_pos = c.d_pos;
             a.am_min_step_for_eos = c.min_seq_len;
             a.am_force_eos_step = c.force_eos_step;
-            a.am_pad_idx = cfg.pad_idx;
-            a.am_eos_idx = cfg.eos_idx;
-            a.am_unk_idx = cfg.unk_idx;
+            a.am_pad_idx = W.pad_idx;
+            a.am_eos_idx = W.eos_idx;
+            a.am_unk_idx = W.unk_idx;
             a.am_unk_penalty = c.unk_penalty;
             launch_skinny(a, m.stream);
-            launch_argmax_finalize(c.am_part, c.am_tiles, nb, c.am_eos_logit, c.d_pos, c.force_eos_step, cfg.pad_idx,
-                                   cfg.eos_idx, c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len, c.d_score, m.stream);
+            launch_argmax_finalize(c.am_part, c.am_tiles, nb, c.am_eos_logit, c.d_pos, c.force_eos_step, W.pad_idx,
+                                   W.eos_idx, c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len, c.d_score, m.stream);
         } else {
             Linear proj;
             proj.w = W.embed;
             proj.ldw = M;
             proj.kpad = M;
             proj.in = M;
-            proj.out = cfg.text_vocab_size;
-            linear(m, c.hN, M, proj, nullptr, 0, c.logits, cfg.text_vocab_size, nb, ACT_NONE, 1.f);
-            launch_argmax_rows(c.logits, cfg.text_vocab_size, nb, cfg.text_vocab_size, c.d_pos, c.min_seq_len,
-                               c.force_eos_step, cfg.pad_idx, cfg.eos_idx, cfg.unk_idx, c.unk_penalty, c.d_tok, c.d_lprob,
+            proj.out = W.vocab;
+            linear(m, c.hN, M, proj, nullptr, 0, c.logits, W.vocab, nb, ACT_NONE, 1.f);
+            launch_argmax_rows(c.logits, W.vocab, nb, W.vocab, c.d_pos, c.min_seq_len,
+                               c.force_eos_step, W.pad_idx, W.eos_idx, W.unk_idx, c.unk_penalty, c.d_tok, c.d_lprob,
                                m.stream);
             launch_step_update(c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len, c.d_lprob, c.d_score, nb, c.d_pos,
-                               cfg.pad_idx, cfg.eos_idx, nullptr, m.stream);
+                               W.pad_idx, W.eos_idx, nullptr, m.stream);
         }
     }
     launch_add_i32(c.d_pos, 1, m.stream);

@@ -210,6 +210,42 @@ class MicroBatcher:
             results.append((texts, units, wavs, text_ids, per_worker[0][k][3]))
         return results
 
+    def predict_passes(self, wav_dev: torch.Tensor, num_samples: Sequence[int], steps: int, task_str: str, tgt_lang: str,
+                       stagger_s: float = 0.0, **kwargs):
+        """``steps`` passes over the same batch, pipelined ACROSS passes: worker i runs passes i, i + groups, ... each over
+        the WHOLE batch (one decoder chain of all rows instead of one per slice), worker i starting ``i * stagger_s`` late,
+        joined once at the end.  In flight at any time: ``groups`` passes in different phases of the path - with a CU
+        partition (``decoder_cus``) the decoder chain of one pass runs on its own compute units under the GEMM-bound
+        stages of its neighbours.  Same total work as ``steps`` lock-step passes; the latency of a single pass grows.
+        Returns one ``predict``-style tuple per pass, in pass order."""
+        import time as _time
+
+        g = self.groups
+        if g == 1:
+            return [self.predict(wav_dev, num_samples, task_str, tgt_lang, **kwargs) for _ in range(steps)]
+        ns = list(num_samples)
+
+        seconds = {}
+
+        def worker(i):
+            if stagger_s > 0 and i > 0:
+                _time.sleep(i * stagger_s)
+            outs = []
+            for k in range(i, steps, g):
+                t0 = _time.perf_counter()
+                outs.append((k, self._one(self.views[i], wav_dev, ns, task_str, tgt_lang, kwargs)))
+                seconds[k] = _time.perf_counter() - t0
+            return outs
+
+        futs = [self.pool.submit(worker, i) for i in range(g)]
+        done = dict(kv for f in futs for kv in f.result())
+        self.last_pass_seconds = [seconds[k] for k in sorted(seconds)]  # wall time of every pass, start to finish
+        results = []
+        for k in range(steps):
+            t, speech, ids, st = done[k]
+            results.append((t, speech.units if speech is not None else [], speech.audio_wavs if speech is not None else [], ids, st))
+        return results
+
     def close(self) -> None:
         if self.pool is not None:
             self.pool.shutdown(wait=True)

@@ -51,3 +51,26 @@ def test_ragged_all_gather_over_rccl_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in results), results
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_over_rccl():
+    """`python bench.py --gpus 2` (self-launching, one rank per GPU): the whole data-parallel path at full size with the RCCL
+    all-gather timed - the first driver record with rccl_ranks = 2 the moment two devices are visible."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one rank per GPU)")
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-latency",
+                        "--no-extra", "--no-profile-step"], capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-800:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["global_batch"] == 128 and d["value"] > 0
+    assert d["config"]["gather_ms"]["calls"] == 2 and d["config"]["gather_ms"]["mean"] > 0
+    assert d["parity"]["text_match"] == "64/64"

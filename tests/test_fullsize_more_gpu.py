@@ -119,7 +119,7 @@ def test_ragged_lengths_two_slices_match_oracle(gold, eos, report_dir):
     tr, vsd, lang_map, opts = eos
     items = fg.items_by_index(gold["b64eos"])
     lens = [len(items[i]["text_ids"]) for i in range(64)]
-    assert len(set(lens)) >= 20 and min(lens) <= 8 and max(lens) >= 56, "fixture lost its spread of stopping steps"
+    assert len(set(lens)) >= 20 and min(lens) <= 10 and max(lens) >= 56, "fixture lost its spread of stopping steps"
     wav = torch.stack(_waves(range(64), [10.0] * 64)).cuda()
     mb = MicroBatcher(tr, 2)
     try:
