@@ -63,8 +63,8 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (no sparsity)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step (BASELINE configs[3]: 64 per GPU)")
     ap.add_argument("--schedule", default="pipeline", choices=["pipeline", "lockstep", "freerun"],
                     help="pipeline (default): --microbatches whole-batch passes in flight, each worker thread running passes i, i+g, ... "
@@ -83,6 +83,8 @@ def parse_args():
     ap.add_argument("--dec-cus", type=int, default=-1,
                     help="CU partition: greedy decoder steps on this many compute units, everything else on the rest "
                          "(sc_set_cu_partition); 0 = none; default: SC_BENCH_DEC_CUS or 0")
+    ap.add_argument("--dec-priority", action="store_true",
+                    help="greedy decoder steps on a highest-priority stream of each handle (sc_set_decoder_priority), no CU mask")
     ap.add_argument("--cu-layout", default="low", choices=["low", "xcd"], help="mask layout of --dec-cus (runtime.cu_masks)")
     ap.add_argument("--arch", default="base_v2", choices=["base_v2", "tiny_v2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -470,7 +472,8 @@ def main():
     opts = SequenceGeneratorOptions(beam_size=1, soft_max_seq_len=(1, 200), hard_max_seq_len=args.text_len)
     stage_ms = {}
 
-    batcher = MicroBatcher(translator, min(args.microbatches, B), decoder_cus=args.dec_cus, cu_layout=args.cu_layout)
+    batcher = MicroBatcher(translator, min(args.microbatches, B), decoder_cus=args.dec_cus, cu_layout=args.cu_layout,
+                           decoder_priority=args.dec_priority)
     last = {}
     gather_s = []  # wall time of every ragged all-gather of ids (N > 1): two collectives + the host packing around them
 
@@ -622,6 +625,7 @@ def main():
                 "microbatch_schedule": ((f"{batcher.groups} whole-batch passes in flight (pipelined across passes), start offsets {stagger * 1e3:.0f} ms"
                                          if args.pipeline_passes else f"free-running slices, start offsets {stagger * 1e3:.0f} ms")
                                         if free_run else "lock-step (join per pass)"),
+                "decoder_stream_priority": "highest" if args.dec_priority and args.dec_cus <= 0 else "default",
                 "cu_partition": ({"decoder_cus": args.dec_cus, "layout": args.cu_layout, "device_cus": model.cu_count()} if args.dec_cus > 0 else None),
             },
             "stage_ms_last_step_slice0": {k: round(v, 3) for k, v in stage_snapshot.items()},

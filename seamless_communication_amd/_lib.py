@@ -91,6 +91,7 @@ SIGNATURES = {
     "sc_wait_stream": (C.c_int, [_P, _P]),
     "sc_set_cu_partition": (C.c_int, [_P, _P, _P, C.c_int]),
     "sc_device_cu_count": (C.c_int, [_P]),
+    "sc_set_decoder_priority": (C.c_int, [_P, C.c_int]),
     "sc_decoder_step_family": (C.c_int, [_P, C.c_int, C.c_int]),
     "sc_set_nar_tables": (C.c_int, [_P, _i, _P, _P, _P, _P, _P]),
     "sc_fbank": (C.c_int, [_P, _P, _i, C.c_int64, _P, _i, _P, _i, _P]),

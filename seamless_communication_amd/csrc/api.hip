@@ -109,6 +109,14 @@ int sc_set_cu_partition(sc_model* m, const uint32_t* decoder_mask, const uint32_
     SC_API_END
 }
 
+int sc_set_decoder_priority(sc_model* m, int high) {
+    SC_API_BEGIN
+    SC_CHECK(m, "null handle");
+    SC_HIP(hipSetDevice(m->m.device));
+    m->m.set_decoder_priority(high != 0);
+    SC_API_END
+}
+
 int sc_decoder_step_family(sc_model* m, int rows, int caller) {
     if (!m || rows < 1 || caller < 0 || caller > 4) return SC_ERR_INVALID;
     try {

@@ -169,6 +169,22 @@ void Model::set_cu_partition(const uint32_t* decoder_mask, const uint32_t* other
     }
 }
 
+void Model::set_decoder_priority(bool high) {
+    if (!other_mask.empty() || dec_chain) set_cu_partition(nullptr, nullptr, 0);  // drops a partition and an earlier chain
+    if (!high) return;
+    SC_HIP(hipStreamSynchronize(stream));
+    dec_session.reset();
+    int least = 0, greatest = 0;
+    SC_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    std::unique_ptr<SideChain> c(new SideChain());
+    SC_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+    SC_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    c->pool.set_stream(c->stream);
+    hook_pool(c->pool);
+    dec_chain = std::move(c);
+    if (!dec_fork) SC_HIP(hipEventCreateWithFlags(&dec_fork, hipEventDisableTiming));
+}
+
 Model::SideChain& Model::side_chain(int k) {
     SC_CHECK(k >= 0 && k < 16, "side chain %d", k);
     while ((int)side.size() <= k) {

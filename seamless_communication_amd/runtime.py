@@ -171,6 +171,10 @@ class HipS2STModel:
         dec, oth = self.cu_masks(self.cu_count(), decoder_cus, layout)
         check(self.lib.sc_set_cu_partition(self.handle, _ptr(dec), _ptr(oth), len(dec)), "sc_set_cu_partition")
 
+    def set_decoder_priority(self, high: bool = True) -> None:
+        """Greedy decoder steps on a highest-priority stream of the handle (sc_set_decoder_priority); False: back on its own."""
+        check(self.lib.sc_set_decoder_priority(self.handle, int(bool(high))), "sc_set_decoder_priority")
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             self.lib.sc_free(self.handle)

@@ -16,7 +16,7 @@ spec.loader.exec_module(bench)
 def test_argument_contract(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse_args()
-    assert (a.gpus, a.steps, a.warmup, a.batch, a.arch) == (1, 3, 1, 64, "base_v2")
+    assert (a.gpus, a.steps, a.warmup, a.batch, a.arch) == (1, 12, 2, 64, "base_v2")  # ~3 s of timed passes: enough to fill the pipeline
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
     a = bench.parse_args()
     assert (a.gpus, a.steps, a.warmup) == (8, 5, 2)
