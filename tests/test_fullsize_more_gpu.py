@@ -143,6 +143,31 @@ def test_ragged_lengths_two_slices_match_oracle(gold, eos, report_dir):
         mb.close()
 
 
+def test_ragged_lengths_pipelined_whole_batch_passes(gold, eos, report_dir):
+    """The default schedule of bench.py: three whole-batch passes in flight on forked handles (MicroBatcher.predict_passes),
+    one 64-row decoder chain per pass.  Every pass of every worker returns the oracle's ids for all 64 utterances."""
+    from seamless_communication_amd.distributed import MicroBatcher
+
+    tr, vsd, lang_map, opts = eos
+    items = fg.items_by_index(gold["b64eos"])
+    wav = torch.stack(_waves(range(64), [10.0] * 64)).cuda()
+    mb = MicroBatcher(tr, 3)
+    try:
+        outs = mb.predict_passes(wav, [wav.shape[1]] * 64, 6, "S2ST", "fra", stagger_s=0.05, text_generation_opts=opts)
+        assert len(outs) == 6 and len(mb.last_pass_seconds) == 6
+        for k, (texts, units, wavs, text_ids, st) in enumerate(outs):
+            assert len(texts) == len(units) == len(wavs) == 64
+            reports = [fg.compare(items[i], text_ids=text_ids[i]) for i in range(64)]
+            assert all(r["text"] for r in reports), (k, [r["index"] for r in reports if not r["text"]])
+            assert all(units[i] == items[i]["speech_units"] for i in range(64)), k
+        for w, view in enumerate(mb.views):  # per-stage data of each worker's last pass: char ids / durations / units
+            _compare_batch(report_dir, f"eos_pipelined_worker{w}", items, list(range(64)), view.last_text_ids, view.last_t2u)
+        by_len = sorted(range(64), key=lambda i: len(items[i]["text_ids"]))
+        _check_waves(report_dir, "eos_pipelined", tr, vsd, lang_map, [by_len[0], by_len[31], by_len[-1]], mb.views[2].last_t2u, outs[5][1], outs[5][2])
+    finally:
+        mb.close()
+
+
 def test_ragged_lengths_one_batch_and_alone(gold, eos, report_dir):
     """40 rows on one stream (the 33..64-row step instantiations) and single utterances: the shortest hypothesis of the
     fixture (it may consist of EOS alone), the longest, and one in between."""
