@@ -419,6 +419,20 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamSelectArgs a) {
             a.fin_score[u * B + sh_fslot[f]] = sh_fscore[f];
         }
     }
+    // K/V ancestor table (DAttnArgs::anc): the new beam b continues beam sh_beam[b], so it inherits that beam's entries for the
+    // positions written so far (0 .. step); a thread owns a position for all beams of the utterance, reads the parents'
+    // entries, then writes - in place.  Entries behind `step` stay what they were initialised to (the row itself).
+    if (a.anc && !sh_done) {
+        for (int t = tid; t <= step && t < a.anc_ld; t += 256) {
+            int v[BEAM_MAX_K];
+#pragma unroll
+            for (int b = 0; b < BEAM_MAX_K; ++b)
+                if (b < B) v[b] = a.anc[(int64_t)(u * B + sh_beam[b]) * a.anc_ld + t];
+#pragma unroll
+            for (int b = 0; b < BEAM_MAX_K; ++b)
+                if (b < B) a.anc[(int64_t)(u * B + b) * a.anc_ld + t] = v[b];
+        }
+    }
     for (int b = 0; b < B; ++b) {
         const int r = u * B + b;
         // a finished utterance keeps running on its own rows (results ignored): token EOS, rows in place

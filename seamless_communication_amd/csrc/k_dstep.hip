@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void reduce_ln_kernel(ReduceLnArgs p) {
 // clamped, masked afterwards), online soft-max across trips.  q (and the new k / v row of self-attention) arrive as
 // split-K partial sums of their projection and are added here, bias last.  The result leaves as split planes.
 // --------------------------------------------------------------------------------------------- //
-template <bool CROSS>
+template <bool CROSS, bool ANC>
 __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     const int lane = threadIdx.x & 63;
     const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -451,15 +451,32 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     // cross-attention K / V: 2 * S_enc * M * 4 B per row and layer, read once per step and never again before the next
     // step has streamed all weights and caches (more than the memory-side cache holds): non-temporal loads
     float4 kreg[16], vreg[16];
+    // beam search (ANC): key j of this row lives in cache row anc[b][j] (the beam it descends from wrote it); the table entries
+    // of a trip are fetched first, then the trip's keys / values as usual.  Addresses as kernel-argument base + a 32-bit byte
+    // offset per load (one register each instead of a 64-bit pointer: 32 loads are in flight), the launcher checks the range.
+    const int* ancb = ANC ? p.anc + (int64_t)b * p.cap : nullptr;
+    const char* kbytes = reinterpret_cast<const char*>(p.kcache);
+    const char* vbytes = reinterpret_cast<const char*>(p.vcache);
+    const unsigned lane_off = (unsigned)(hd * 64 + 4 * c) * 4u, row_bytes = (unsigned)p.cache_bs * 4u, key_bytes = (unsigned)p.cache_ld * 4u;
+    unsigned off[ANC ? 16 : 1];
+    if (ANC) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float* a = kc + (int64_t)min(4 * i + g, last) * p.cache_ld;
-        kreg[i] = CROSS ? nt_load4(a) : *reinterpret_cast<const float4*>(a);
-    }
+        for (int i = 0; i < 16; ++i) off[i] = (unsigned)ancb[min(4 * i + g, last)] * row_bytes + (unsigned)min(4 * i + g, last) * key_bytes + lane_off;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float* a = vc + (int64_t)min(4 * i + g, last) * p.cache_ld;
-        vreg[i] = CROSS ? nt_load4(a) : *reinterpret_cast<const float4*>(a);
+        for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const float4*>(kbytes + off[i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vreg[i] = *reinterpret_cast<const float4*>(vbytes + off[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float* a = kc + (int64_t)min(4 * i + g, last) * p.cache_ld;
+            kreg[i] = CROSS ? nt_load4(a) : *reinterpret_cast<const float4*>(a);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float* a = vc + (int64_t)min(4 * i + g, last) * p.cache_ld;
+            vreg[i] = CROSS ? nt_load4(a) : *reinterpret_cast<const float4*>(a);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);  // every load above is issued before the first of them is waited for
 
@@ -489,10 +506,20 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     int j0 = 0;
     do {  // at least one key: the first trip's loads above are unconditional
         if (j0 > 0) {
+            if (ANC) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const float4*>(kc + (int64_t)min(j0 + 4 * i + g, last) * p.cache_ld);
+                for (int i = 0; i < 16; ++i)
+                    off[i] = (unsigned)ancb[min(j0 + 4 * i + g, last)] * row_bytes + (unsigned)min(j0 + 4 * i + g, last) * key_bytes + lane_off;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) vreg[i] = *reinterpret_cast<const float4*>(vc + (int64_t)min(j0 + 4 * i + g, last) * p.cache_ld);
+                for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const float4*>(kbytes + off[i]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) vreg[i] = *reinterpret_cast<const float4*>(vbytes + off[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) kreg[i] = *reinterpret_cast<const float4*>(kc + (int64_t)min(j0 + 4 * i + g, last) * p.cache_ld);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) vreg[i] = *reinterpret_cast<const float4*>(vc + (int64_t)min(j0 + 4 * i + g, last) * p.cache_ld);
+            }
         }
         float sc[16];
         float mx = -INFINITY;
@@ -708,8 +735,12 @@ void launch_dattn(const DAttnArgs& a, bool cross, hipStream_t s) {
     // (row, head) pairs per workgroup: a CU pulls ~45 GB/s of cold K / V whatever its workgroup looks like
     // (profiles/r3_micro_percu.txt), so the pairs are spread over at least 256 workgroups before they are stacked
     const int ppw = std::max(1, std::min(4, pairs / 256));
-    if (cross) hipLaunchKernelGGL((dattn_kernel<true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
-    else hipLaunchKernelGGL((dattn_kernel<false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+    if (cross) hipLaunchKernelGGL((dattn_kernel<true, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+    else if (a.anc) {
+        SC_CHECK((int64_t)a.nb * a.cache_bs * 4 < (1ll << 32) && a.cache_ld * 4 < (1ll << 31), "dattn: K/V cache too large for the ancestor-table addressing");
+        hipLaunchKernelGGL((dattn_kernel<false, true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+    }
+    else hipLaunchKernelGGL((dattn_kernel<false, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
     SC_LAUNCH_CHECK();
 }
 

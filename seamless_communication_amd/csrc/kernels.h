@@ -224,6 +224,10 @@ struct DAttnArgs {
     const int* d_pos = nullptr;    // self: position of the new row, kv_len = *d_pos + 1
     const int* kv_lens = nullptr;  // cross: valid keys per batch row
     int kv_row_div = 1;            // cross: batch row b reads cache row b / kv_row_div (the beams of an utterance share its K / V)
+    // self (beam search): anc[b * cap + j] = cache row that holds key / value j of batch row b.  Beams that continue another
+    // beam inherit its history through this table instead of having their cache rows copied (k_beam.hip: beam_select_kernel
+    // re-orders the table); a row always appends at its own cache row.  null: row b reads its own cache row.
+    const int* anc = nullptr;
     __half* Oh = nullptr;          // output planes [heads*8][ORB][8]
     __half* Ol = nullptr;
     int ORB = 32;
@@ -443,6 +447,8 @@ struct BeamSelectArgs {
     int* tok = nullptr;          // [n*beams] token fed at the next step
     int* src_row = nullptr;      // [n*beams] row whose K/V cache the beam continues
     float* cum = nullptr;        // [n*beams] cumulative scores
+    int* anc = nullptr;          // [n*beams][anc_ld] ancestor table of the K/V caches (DAttnArgs::anc), re-ordered in place; nullable
+    int anc_ld = 0;
     int beams = 0, K = 0, V = 0, max_len = 0, step = 0;
     int eos_idx = 0, pad_idx = 0, normalize = 1;
     float len_penalty = 1.f;

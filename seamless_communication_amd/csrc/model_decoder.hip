@@ -74,6 +74,7 @@ struct StepCtx {
     int ffn_in_mode = 1;   // 0: partials + reduce/LN launch + packed product; 1 / 2: LayerNorm inside the product (2 tiles / 1 tile)
     int ffn_out_mode = 1;  // 0: gemvp, 8 K ranges; 1: gemv3 2 tiles x 512-wide K slices; 2: gemv3 1 tile x 1024-wide
     int cross_row_div = 1;  // beam search: live row r reads the encoder K / V of cache row r / cross_row_div (one per utterance)
+    const int* anc = nullptr;  // beam search on the packed step kernels: K/V ancestor table [nb][cap] (DAttnArgs::anc)
     float* qkv3 = nullptr;  // [nb][3M] complete q | k | v rows: the wide step (> 64 live rows) projects them on gemv3
 };
 
@@ -389,6 +390,7 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
         a.ORB = c.rb;
         a.nb = nb;
         a.heads = H;
+        a.anc = c.anc;
         launch_dattn(a, /*cross=*/false, m.stream);
         gemv2(m, c, c.attH, c.attL, l.self_out, 4, &sp);
         // monotonic decoder, p_choose step: the normed cross-attention input (monotonic_decoder_layer.py:170-172) of every
@@ -588,6 +590,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         a.ORB = c.rb;
         a.nb = nb;
         a.heads = H;
+        a.anc = c.anc;
         launch_dattn(a, /*cross=*/false, m.stream);
         out_resid(l.self_out);
         // encoder-decoder attention: the query projection applies its LayerNorm itself
@@ -1572,7 +1575,19 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     const int64_t ldl = proj_v3 ? (int64_t)align_up(V, 4) : V;  // logits row stride: 16-byte aligned rows for the streaming kernel
     // self-attention K/V caches of all layers in one allocation, twice (re-ordered from one into the other)
     const int64_t layer_stride = (int64_t)nb * max_len * M;
-    Buf<float> kv_a(m.pp(), (size_t)2 * L * layer_stride), kv_b(m.pp(), (size_t)2 * L * layer_stride);
+    // packed step kernels: ONE allocation + an ancestor table - a beam that continues another beam reads that beam's history
+    // through the table (re-ordered in place by beam_select_kernel), no cache row is ever copied; the general step keeps the
+    // two allocations re-ordered into each other after every step
+    const bool use_anc = packed_step && (int64_t)nb * max_len * M * 4 < (1ll << 32);  // 32-bit byte offsets in dattn_kernel<false, true>
+    Buf<float> kv_a(m.pp(), (size_t)2 * L * layer_stride), kv_b(m.pp(), use_anc ? 4 : (size_t)2 * L * layer_stride);
+    Buf<int> d_anc(m.pp(), use_anc ? (size_t)nb * max_len : 4);
+    if (use_anc) {
+        std::vector<int32_t> ident((size_t)nb * max_len);
+        for (int r = 0; r < nb; ++r) std::fill(ident.begin() + (size_t)r * max_len, ident.begin() + (size_t)(r + 1) * max_len, r);
+        SC_HIP(hipMemcpyAsync(d_anc.get(), ident.data(), ident.size() * 4, hipMemcpyHostToDevice, m.stream));
+        SC_HIP(hipStreamSynchronize(m.stream));  // `ident` is a host temporary
+        c.anc = d_anc;
+    }
     float* kv_cur = kv_a;
     float* kv_alt = kv_b;
     auto bind_caches = [&](float* base) {
@@ -1730,12 +1745,16 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
         a.pad_idx = cfg.pad_idx;
         a.normalize = normalize ? 1 : 0;
         a.len_penalty = len_penalty;
+        a.anc = use_anc ? d_anc.get() : nullptr;
+        a.anc_ld = max_len;
         launch_beam_select(a, n, m.stream);
         std::swap(d_seqs_cur, d_seqs_new);
-        // K/V rows follow their beams (all layers, one launch; rows of finished utterances map onto themselves)
-        launch_gather_cache(kv_cur, kv_alt, d_src_row, nb, step + 1, max_len, M, 2 * L, layer_stride, m.stream);
-        std::swap(kv_cur, kv_alt);
-        bind_caches(kv_cur);
+        if (!use_anc) {
+            // K/V rows follow their beams (all layers, one launch; rows of finished utterances map onto themselves)
+            launch_gather_cache(kv_cur, kv_alt, d_src_row, nb, step + 1, max_len, M, 2 * L, layer_stride, m.stream);
+            std::swap(kv_cur, kv_alt);
+            bind_caches(kv_cur);
+        }
         if (((step - start) & 3) == 3 || step == max_len - 2) {
             SC_HIP(hipMemcpyAsync(&remaining, d_remaining, 4, hipMemcpyDeviceToHost, m.stream));
             SC_HIP(hipStreamSynchronize(m.stream));
