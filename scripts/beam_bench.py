@@ -18,10 +18,13 @@ ap.add_argument("--batches", default="12,32,64")
 ap.add_argument("--beam", type=int, default=5)
 ap.add_argument("--task", default="S2ST")
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--ragged", action="store_true", help="eos_ramp weights (hypotheses stop on their own), hard_max_seq_len 64: bench.py's default workload")
 a = ap.parse_args()
 card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch="base_v2")
+if a.ragged:
+    card["checkpoint"] = f"synthetic://{syn.DEFAULT_SEED}?eos_ramp={syn.EOS_RAMP_BENCH}"
 tr = Translator(card, "vocoder_v2", device="cuda:0", input_modality=Modality.SPEECH)
-opts = SequenceGeneratorOptions(beam_size=a.beam, soft_max_seq_len=(1, 200), hard_max_seq_len=42)
+opts = SequenceGeneratorOptions(beam_size=a.beam, soft_max_seq_len=(1, 200), hard_max_seq_len=64 if a.ragged else 42)
 ref = None
 for nb in [int(x) for x in a.batches.split(",")]:
     wav = torch.stack([syn.synthetic_waveform(i, 10.0) for i in range(nb)]).cuda()

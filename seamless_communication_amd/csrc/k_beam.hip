@@ -48,13 +48,14 @@ __global__ __launch_bounds__(256) void beam_candidates_kernel(float* logits, int
                                                               int force_eos, int pad_idx, int eos_idx, int unk_idx,
                                                               float unk_penalty, int K, float* __restrict__ cand_val,
                                                               int* __restrict__ cand_idx, const int* __restrict__ seqs,
-                                                              int seq_ld, int S, int G) {
+                                                              int seq_ld, int S, int G, const int* __restrict__ d_slots) {
     __shared__ float red[4];
     __shared__ float lse[BEAM_MAX_K];
     __shared__ float s_val[256];
     __shared__ int s_idx[256];
     __shared__ int s_winner;
     const int n = blockIdx.x, tid = threadIdx.x;
+    if (d_slots && n >= *d_slots) return;  // an idle slot (its utterance finished)
     const int nb = first_step ? 1 : beams;
     for (int b = 0; b < nb; ++b) {
         const float* row = logits + ((int64_t)n * beams + b) * ld;
@@ -188,9 +189,10 @@ __global__ __launch_bounds__(256) void row_token_lprob_kernel(const float* __res
 constexpr int BEAM_CH = 32;
 
 __global__ __launch_bounds__(256) void beam_lse_partial_kernel(const float* __restrict__ logits, int64_t ld, int V, int clen,
-                                                               float2* __restrict__ part) {
+                                                               float2* __restrict__ part, const int* __restrict__ d_rows) {
     __shared__ float red[4];
     const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+    if (d_rows && r >= *d_rows) return;  // a row of a finished utterance
     const int start = c * clen, end = min(V, start + clen);
     const float* row = logits + (int64_t)r * ld;
     float mx = -INFINITY;
@@ -218,7 +220,8 @@ __global__ __launch_bounds__(256) void beam_lse_partial_kernel(const float* __re
 
 // the n-gram processor alone (see beam_candidates_kernel): one workgroup per row
 __global__ __launch_bounds__(256) void ngram_block_kernel(float* logits, int64_t ld, int V, const int* __restrict__ seqs, int seq_ld, int S,
-                                                          int G) {
+                                                          int G, const int* __restrict__ d_rows) {
+    if (d_rows && (int)blockIdx.x >= *d_rows) return;
     float* row = logits + (int64_t)blockIdx.x * ld;
     const int* seq = seqs + (int64_t)blockIdx.x * seq_ld;
     const int* tail = seq + S - (G - 1);
@@ -287,11 +290,12 @@ __global__ __launch_bounds__(256) void beam_topk_partial_kernel(const float* __r
                                                                 const float* __restrict__ cum, int first_step, int no_eos, int force_eos,
                                                                 int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K,
                                                                 const float2* __restrict__ part, float* __restrict__ pval,
-                                                                int* __restrict__ pidx) {
+                                                                int* __restrict__ pidx, const int* __restrict__ d_rows) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     constexpr int EPT = 32;  // elements per thread: chunks of at most 8192 logits
     const int c = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+    if (d_rows && r >= *d_rows) return;  // a row of a finished utterance
     const int b = r % beams;
     float* out_val = pval + ((int64_t)r * BEAM_CH + c) * K;
     int* out_idx = pidx + ((int64_t)r * BEAM_CH + c) * K;
@@ -338,11 +342,12 @@ __global__ __launch_bounds__(256) void beam_topk_partial_kernel(const float* __r
 }
 
 __global__ __launch_bounds__(256) void beam_merge_kernel(const float* __restrict__ pval, const int* __restrict__ pidx, int entries, int K,
-                                                         float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+                                                         float* __restrict__ cand_val, int* __restrict__ cand_idx, const int* __restrict__ d_slots) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     constexpr int EPT = 16;  // beams x 32 chunks x K <= 16 x 32 x 16 = 8192 entries... the launcher checks entries <= 256 * EPT
     const int n = blockIdx.x, tid = threadIdx.x;
+    if (d_slots && n >= *d_slots) return;  // an idle slot
     float val[EPT];
     int idx[EPT];
     unsigned taken = 0;
@@ -369,10 +374,12 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamSelectArgs a) {
     __shared__ float sh_sc[BEAM_MAX_K], sh_fscore[BEAM_MAX_K];
     __shared__ int sh_nfin, sh_done;
     const int u = blockIdx.x, tid = threadIdx.x, B = a.beams, K = a.K, step = a.step, L = a.max_len;
+    if (a.d_slots && u >= *a.d_slots) return;  // an idle slot
+    const int ut = a.slot_utt ? a.slot_utt[u] : u;  // the utterance this slot holds: finished hypotheses are stored per utterance
     if (tid == 0) {
-        int done = a.done[u], nfin = 0;
+        int done = a.done[ut], nfin = 0;
         if (!done) {
-            int count = a.fin_count[u], live = 0;
+            int count = a.fin_count[ut], live = 0;
             for (int i = 0; i < K && !done; ++i) {
                 const int cidx = a.cand_idx[(int64_t)u * K + i];
                 const float sc = a.cand_val[(int64_t)u * K + i];
@@ -398,8 +405,8 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamSelectArgs a) {
                 }
                 if (live >= B) break;
             }
-            a.fin_count[u] = count;
-            a.done[u] = done;
+            a.fin_count[ut] = count;
+            a.done[ut] = done;
             for (; live < B; ++live) {  // fewer live candidates than beams: dead copies of the first one
                 sh_beam[live] = live > 0 ? sh_beam[0] : 0;
                 sh_tok[live] = a.pad_idx;
@@ -412,11 +419,11 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamSelectArgs a) {
     __syncthreads();
     for (int f = 0; f < sh_nfin; ++f) {
         const int* src = a.seqs_cur + (int64_t)(u * B + sh_fbeam[f]) * L;
-        int* dst = a.fin_seq + (int64_t)(u * B + sh_fslot[f]) * L;
+        int* dst = a.fin_seq + (int64_t)(ut * B + sh_fslot[f]) * L;
         for (int t = tid; t < L; t += 256) dst[t] = t <= step ? src[t] : (t == step + 1 ? a.eos_idx : a.pad_idx);
         if (tid == 0) {
-            a.fin_len[u * B + sh_fslot[f]] = step + 2;
-            a.fin_score[u * B + sh_fslot[f]] = sh_fscore[f];
+            a.fin_len[ut * B + sh_fslot[f]] = step + 2;
+            a.fin_score[ut * B + sh_fslot[f]] = sh_fscore[f];
         }
     }
     // K/V ancestor table (DAttnArgs::anc): the new beam b continues beam sh_beam[b], so it inherits that beam's entries for the
@@ -448,6 +455,53 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamSelectArgs a) {
     }
 }
 
+// beam_compact_kernel (BeamCompactArgs): one workgroup.  Slots whose utterance is done are dropped, the others keep their
+// order and move to the front; a moved slot's rows are copied to rows with LOWER indices that were vacated (or already moved)
+// earlier in the same sweep, so the sweep is in place.  Nothing moves when no slot was dropped.
+__global__ __launch_bounds__(256) void beam_compact_kernel(BeamCompactArgs a) {
+    __shared__ int s_src[1024];  // new slot -> old slot
+    __shared__ int s_keep;
+    const int tid = threadIdx.x, B = a.beams;
+    const int slots = *a.d_slots;
+    if (tid == 0) {
+        int keep = 0;
+        for (int u = 0; u < slots; ++u)
+            if (!a.done[a.slot_utt[u]]) s_src[keep++] = u;
+        s_keep = keep;
+    }
+    __syncthreads();
+    const int keep = s_keep;
+    if (keep == slots) return;
+    for (int v = 0; v < keep; ++v) {
+        const int u = s_src[v];
+        if (u != v) {
+            for (int b = 0; b < B; ++b) {
+                const int64_t src = (int64_t)u * B + b, dst = (int64_t)v * B + b;
+                for (int t = tid; t < a.seq_len && t < a.max_len; t += 256) a.seqs[dst * a.max_len + t] = a.seqs[src * a.max_len + t];
+                if (a.anc)
+                    for (int t = tid; t < a.anc_len && t < a.anc_ld; t += 256) a.anc[dst * a.anc_ld + t] = a.anc[src * a.anc_ld + t];
+                if (tid == 0) {
+                    a.cum[dst] = a.cum[src];
+                    a.tok[dst] = a.tok[src];
+                    a.enc_lens[dst] = a.enc_lens[src];
+                }
+            }
+        }
+        __syncthreads();  // slot v is complete before a later slot may be copied over what v vacated
+    }
+    // positions whose key / value is not written yet must name the row itself (a row always appends at its own cache row)
+    if (a.anc)
+        for (int r = tid; r < keep * B; r += 256)
+            for (int t = a.anc_len; t < a.anc_ld; ++t) a.anc[(int64_t)r * a.anc_ld + t] = r;
+    __syncthreads();
+    if (tid == 0) {
+        for (int v = 0; v < keep; ++v) s_src[v] = a.slot_utt[s_src[v]];
+        for (int v = 0; v < keep; ++v) a.slot_utt[v] = s_src[v];
+        *a.d_slots = keep;
+        *a.d_rows = keep * B;
+    }
+}
+
 // dst[l][r][t][:] = src[l][src_row[r]][t][:] for t < len; blockIdx = (t, r, l)
 __global__ __launch_bounds__(256) void gather_cache_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                            const int* __restrict__ src_row, int cap, int M, int64_t layer_stride) {
@@ -461,12 +515,12 @@ __global__ __launch_bounds__(256) void gather_cache_kernel(const float* __restri
 
 void launch_beam_candidates(float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step,
                             int no_eos, int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K,
-                            float* cand_val, int* cand_idx, const int* seqs, int seq_ld, int S, int G, hipStream_t s) {
+                            float* cand_val, int* cand_idx, const int* seqs, int seq_ld, int S, int G, hipStream_t s, const int* d_slots) {
     SC_CHECK(K >= 1 && K <= BEAM_MAX_K && beams >= 1 && beams <= BEAM_MAX_K, "beam search: beam_size %d / K %d out of range (max %d candidates)",
              beams, K, BEAM_MAX_K);
     SC_CHECK((int64_t)beams * V < (1ll << 31) - 1, "beam search: beam * vocabulary overflows the candidate index");
     hipLaunchKernelGGL(beam_candidates_kernel, dim3(n_utt), dim3(256), 0, s, logits, ld, beams, V, cum, first_step, no_eos, force_eos,
-                       pad_idx, eos_idx, unk_idx, unk_penalty, K, cand_val, cand_idx, seqs, seq_ld, S, G);
+                       pad_idx, eos_idx, unk_idx, unk_penalty, K, cand_val, cand_idx, seqs, seq_ld, S, G, d_slots);
     SC_LAUNCH_CHECK();
 }
 
@@ -481,7 +535,8 @@ size_t beam_ws_ints(int rows, int K) { return (size_t)rows * BEAM_CH * K; }
 
 void launch_beam_candidates_chunked(float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step, int no_eos,
                                     int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K, float* cand_val,
-                                    int* cand_idx, const int* seqs, int seq_ld, int S, int G, float* ws_f, int* ws_i, hipStream_t s) {
+                                    int* cand_idx, const int* seqs, int seq_ld, int S, int G, float* ws_f, int* ws_i, hipStream_t s,
+                                    const int* d_rows, const int* d_slots) {
     SC_CHECK(K >= 1 && K <= BEAM_MAX_K && beams >= 1 && beams <= BEAM_MAX_K, "beam search: beam_size %d / K %d out of range (max %d candidates)",
              beams, K, BEAM_MAX_K);
     SC_CHECK((int64_t)beams * V < (1ll << 31) - 1, "beam search: beam * vocabulary overflows the candidate index");
@@ -491,17 +546,24 @@ void launch_beam_candidates_chunked(float* logits, int64_t ld, int n_utt, int be
              beams, K);
     float2* part = reinterpret_cast<float2*>(ws_f);
     float* pval = ws_f + (size_t)rows * BEAM_CH * 2;
-    hipLaunchKernelGGL(beam_lse_partial_kernel, dim3(BEAM_CH, rows), dim3(256), 0, s, logits, ld, V, clen, part);
-    if (seqs && G > 0 && G < S) hipLaunchKernelGGL(ngram_block_kernel, dim3(rows), dim3(256), 0, s, logits, ld, V, seqs, seq_ld, S, G);
+    hipLaunchKernelGGL(beam_lse_partial_kernel, dim3(BEAM_CH, rows), dim3(256), 0, s, logits, ld, V, clen, part, d_rows);
+    if (seqs && G > 0 && G < S) hipLaunchKernelGGL(ngram_block_kernel, dim3(rows), dim3(256), 0, s, logits, ld, V, seqs, seq_ld, S, G, d_rows);
     hipLaunchKernelGGL(beam_topk_partial_kernel, dim3(BEAM_CH, rows), dim3(256), 0, s, logits, ld, beams, V, clen, cum, first_step, no_eos,
-                       force_eos, pad_idx, eos_idx, unk_idx, unk_penalty, K, part, pval, ws_i);
-    hipLaunchKernelGGL(beam_merge_kernel, dim3(n_utt), dim3(256), 0, s, pval, ws_i, beams * BEAM_CH * K, K, cand_val, cand_idx);
+                       force_eos, pad_idx, eos_idx, unk_idx, unk_penalty, K, part, pval, ws_i, d_rows);
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(n_utt), dim3(256), 0, s, pval, ws_i, beams * BEAM_CH * K, K, cand_val, cand_idx, d_slots);
     SC_LAUNCH_CHECK();
 }
 
 void launch_beam_select(const BeamSelectArgs& a, int n_utt, hipStream_t s) {
     SC_CHECK(a.beams >= 1 && a.beams <= BEAM_MAX_K && a.K <= BEAM_MAX_K, "beam select: beam_size %d / K %d out of range", a.beams, a.K);
     hipLaunchKernelGGL(beam_select_kernel, dim3(n_utt), dim3(256), 0, s, a);
+    SC_LAUNCH_CHECK();
+}
+
+void launch_beam_compact(const BeamCompactArgs& a, hipStream_t s) {
+    SC_CHECK(a.n >= 1 && a.n <= 1024 && a.beams >= 1 && a.done && a.slot_utt && a.d_slots && a.d_rows && a.seqs && a.cum && a.tok && a.enc_lens,
+             "beam compact: bad arguments (n=%d)", a.n);
+    hipLaunchKernelGGL(beam_compact_kernel, dim3(1), dim3(256), 0, s, a);
     SC_LAUNCH_CHECK();
 }
 

@@ -415,6 +415,7 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (pair >= p.nb * p.heads) return;
     const int b = pair / p.heads, hd = pair - b * p.heads;
+    if (p.d_rows && b >= *p.d_rows) return;  // beam search: a row of a finished utterance
     const int c = lane & 15, g = lane >> 4;
     const int pos = CROSS ? 0 : *p.d_pos;
     const int kv_len = CROSS ? min(p.kv_lens[b], p.cap) : pos + 1;
@@ -422,7 +423,8 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     // the projected encoder K/V is initialised (finite), so the addresses do not have to wait for kv_lens[b]; keys behind
     // the length are masked below.  Self-attention rows behind `pos` are uninitialised memory and are never touched.
     const int last = CROSS ? p.cap - 1 : kv_len - 1;
-    const int crow = CROSS ? b / p.kv_row_div : b;  // beam search: the beams of an utterance share its encoder K / V
+    // beam search: the beams of an utterance share its encoder K / V (projected once per utterance, in utterance order)
+    const int crow = CROSS ? (p.kv_item ? p.kv_item[b / p.kv_row_div] : b / p.kv_row_div) : b;
     const float* kc = p.kcache + (int64_t)crow * p.cache_bs + hd * 64 + 4 * c;
     const float* vc = p.vcache + (int64_t)crow * p.cache_bs + hd * 64 + 4 * c;
 

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv3_kernel(Gemv3Args p) {
     const int h = lane >> 5;  // k half of the fragment
     const int nt0 = blockIdx.x * NT;
     const int r0 = blockIdx.y * p.rg;
+    if (p.d_rows && r0 >= *p.d_rows) return;  // beam search: a row group of finished utterances
     const int rot = blockIdx.x % WAVES;
     const int chunk = (wave + rot) % WAVES;
     const int ks_w0 = (blockIdx.z * WAVES + chunk) * KSW;
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(64 * WAVES) void vocab3_kernel(Vocab3Args p) {
         half_idx = 0;
     }
     const int r0 = 32 * half_idx;
+    if (p.d_rows && r0 >= *p.d_rows) return;  // beam search: a row group of finished utterances
     const int t_lo = grp * p.tpg, t_hi = min(p.NT_total, t_lo + p.tpg);
 
     const __amdgpu_buffer_rsrc_t rw = rsrc3(p.Wp, p.w_bytes);

@@ -228,6 +228,8 @@ struct DAttnArgs {
     // beam inherit its history through this table instead of having their cache rows copied (k_beam.hip: beam_select_kernel
     // re-orders the table); a row always appends at its own cache row.  null: row b reads its own cache row.
     const int* anc = nullptr;
+    const int* kv_item = nullptr;  // cross (beam search): row b reads the encoder K / V of item kv_item[b / kv_row_div] (null: b / kv_row_div)
+    const int* d_rows = nullptr;   // see Gemv3Args::d_rows: (row, head) pairs of rows behind *d_rows return at once
     __half* Oh = nullptr;          // output planes [heads*8][ORB][8]
     __half* Ol = nullptr;
     int ORB = 32;
@@ -282,6 +284,9 @@ struct Gemv3Args {
     __half* Ol = nullptr;
     int ORB = 32;
     int act = ACT_NONE;
+    // beam search: *d_rows = live rows (the rows of utterances still searching, packed to the front); row groups that start
+    // behind it return at once.  null: all M rows.
+    const int* d_rows = nullptr;
     // filled by the launcher
     int KS = 0, NT_total = 0;
     uint32_t w_bytes = 0, a_bytes = 0;
@@ -334,6 +339,7 @@ struct Vocab3Args {
     int am_min_step_for_eos = 0, am_force_eos_step = -1;
     int am_pad_idx = -1, am_eos_idx = -1, am_unk_idx = -1;
     float am_unk_penalty = 0.f;
+    const int* d_rows = nullptr;  // see Gemv3Args::d_rows
     // filled by the launcher
     int KS = 0, NT_total = 0, tpg = 0, halves = 1;
     uint32_t w_bytes = 0;
@@ -423,7 +429,8 @@ void launch_decode_attention(const float* q, int64_t ldq, const float* k_new, co
 // size, 0 = off); logits is modified (blocked tokens)
 void launch_beam_candidates(float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step,
                             int no_eos, int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K,
-                            float* cand_val, int* cand_idx, const int* seqs, int seq_ld, int S, int G, hipStream_t s);
+                            float* cand_val, int* cand_idx, const int* seqs, int seq_ld, int S, int G, hipStream_t s,
+                            const int* d_slots = nullptr);
 // the same search for large vocabularies: every (row, 1/32 of V) on its own workgroup, then a merge per utterance;
 // ws_f / ws_i: workspaces of beam_ws_floats / beam_ws_ints elements
 bool beam_chunked(int V, int beams, int K);
@@ -431,7 +438,8 @@ size_t beam_ws_floats(int rows, int K);
 size_t beam_ws_ints(int rows, int K);
 void launch_beam_candidates_chunked(float* logits, int64_t ld, int n_utt, int beams, int V, const float* cum, int first_step, int no_eos,
                                     int force_eos, int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int K, float* cand_val,
-                                    int* cand_idx, const int* seqs, int seq_ld, int S, int G, float* ws_f, int* ws_i, hipStream_t s);
+                                    int* cand_idx, const int* seqs, int seq_ld, int S, int G, float* ws_f, int* ws_i, hipStream_t s,
+                                    const int* d_rows = nullptr, const int* d_slots = nullptr);
 // device-resident beam-search state of one sc_generate_text call (k_beam.hip: beam_select_kernel)
 struct BeamSelectArgs {
     const float* cand_val = nullptr;  // [n][K] best first
@@ -449,11 +457,32 @@ struct BeamSelectArgs {
     float* cum = nullptr;        // [n*beams] cumulative scores
     int* anc = nullptr;          // [n*beams][anc_ld] ancestor table of the K/V caches (DAttnArgs::anc), re-ordered in place; nullable
     int anc_ld = 0;
+    // live-slot bookkeeping (nullable): slot u of the candidate / sequence arrays holds utterance slot_utt[u]; fin_* / done /
+    // fin_count are indexed by UTTERANCE; slots behind *d_slots are idle (their utterances finished) and are skipped
+    const int* slot_utt = nullptr;
+    const int* d_slots = nullptr;
     int beams = 0, K = 0, V = 0, max_len = 0, step = 0;
     int eos_idx = 0, pad_idx = 0, normalize = 1;
     float len_penalty = 1.f;
 };
 void launch_beam_select(const BeamSelectArgs& a, int n_utt, hipStream_t s);
+// Packs the slots of utterances that are still searching to the front (stable), in place: per-row sequences, cumulative
+// scores, next tokens, encoder lengths and K/V ancestor rows move with their slot; slot_utt follows; *d_slots / *d_rows = the
+// new counts.  One workgroup (the arrays are a few hundred KB).  K/V cache rows do not move: the ancestor table names them.
+struct BeamCompactArgs {
+    const int* done = nullptr;  // [n] by utterance
+    int* slot_utt = nullptr;    // [n]
+    int* d_slots = nullptr;
+    int* d_rows = nullptr;
+    int* seqs = nullptr;        // [n*beams][max_len]
+    float* cum = nullptr;       // [n*beams]
+    int* tok = nullptr;         // [n*beams]
+    int* enc_lens = nullptr;    // [n*beams]
+    int* anc = nullptr;         // [n*beams][anc_ld]
+    int n = 0, beams = 0, max_len = 0, anc_ld = 0;
+    int seq_len = 0, anc_len = 0;  // sequence positions / table positions in use
+};
+void launch_beam_compact(const BeamCompactArgs& a, hipStream_t s);
 void launch_row_token_lprob(const float* logits, int64_t ld, int rows, int V, int row_stride, int token, float* out, hipStream_t s);
 void launch_gather_cache(const float* src, float* dst, const int* src_row, int rows, int len, int cap, int M, int layers,
                          int64_t layer_stride, hipStream_t s);

@@ -75,6 +75,9 @@ struct StepCtx {
     int ffn_out_mode = 1;  // 0: gemvp, 8 K ranges; 1: gemv3 2 tiles x 512-wide K slices; 2: gemv3 1 tile x 1024-wide
     int cross_row_div = 1;  // beam search: live row r reads the encoder K / V of cache row r / cross_row_div (one per utterance)
     const int* anc = nullptr;  // beam search on the packed step kernels: K/V ancestor table [nb][cap] (DAttnArgs::anc)
+    // beam search, row-group chain: live rows packed to the front, *d_rows of them; slot u holds utterance kv_item[u]
+    const int* d_rows = nullptr;
+    const int* kv_item = nullptr;
     float* qkv3 = nullptr;  // [nb][3M] complete q | k | v rows: the wide step (> 64 live rows) projects them on gemv3
 };
 
@@ -391,6 +394,7 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
         a.nb = nb;
         a.heads = H;
         a.anc = c.anc;
+        a.d_rows = c.d_rows;
         launch_dattn(a, /*cross=*/false, m.stream);
         gemv2(m, c, c.attH, c.attL, l.self_out, 4, &sp);
         // monotonic decoder, p_choose step: the normed cross-attention input (monotonic_decoder_layer.py:170-172) of every
@@ -412,6 +416,8 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
         x.cap = c.s_enc;
         x.kv_lens = c.d_enc_lens;
         x.kv_row_div = c.cross_row_div;
+        x.kv_item = c.kv_item;
+        x.d_rows = c.d_rows;
         x.Oh = c.attH;
         x.Ol = c.attL;
         x.ORB = c.rb;
@@ -540,6 +546,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         a.Wp = L.wp, a.M = nb, a.N = L.out, a.K = L.in;
         a.in_mode = IN3_PLANES, a.Ah = c.attH, a.Al = c.attL, a.RB = c.rb, a.rg = c.rg_small;
         a.epi = EPI3_RESID, a.bias = L.b, a.xres = c.xg, a.XRB = c.rb;
+        a.d_rows = c.d_rows;
         launch_gemv3(a, m.stream);
     };
     // x += bias + partials; h = LayerNorm(x) as planes: the K-slice products' closing launch
@@ -570,6 +577,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
             q.Wp = l.qkv.wp, q.M = nb, q.N = 3 * M, q.K = M;
             q.in_mode = IN3_PLANES, q.Ah = c.hH, q.Al = c.hL, q.RB = c.rb, q.rg = 32;
             q.epi = EPI3_ROWS, q.bias = l.qkv.b, q.out = c.qkv3, q.ldo = 3 * M;
+            q.d_rows = c.d_rows;
             launch_gemv3(q, m.stream);
             a.q = c.qkv3;
             a.sstride = 0;
@@ -591,6 +599,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         a.nb = nb;
         a.heads = H;
         a.anc = c.anc;
+        a.d_rows = c.d_rows;
         launch_dattn(a, /*cross=*/false, m.stream);
         out_resid(l.self_out);
         // encoder-decoder attention: the query projection applies its LayerNorm itself
@@ -599,6 +608,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
             q.Wp = l.cross_q.wp, q.M = nb, q.N = M, q.K = M;
             q.in_mode = IN3_LN, q.xg = c.xg, q.gamma = l.cross_ln.g, q.beta = l.cross_ln.b, q.RB = c.rb, q.rg = c.rg_small;
             q.epi = EPI3_ROWS, q.bias = l.cross_q.b, q.out = c.qkvr, q.ldo = M;
+            q.d_rows = c.d_rows;
             launch_gemv3(q, m.stream);
         }
         DAttnArgs x;
@@ -614,6 +624,8 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         x.cap = c.s_enc;
         x.kv_lens = c.d_enc_lens;
         x.kv_row_div = c.cross_row_div;
+        x.kv_item = c.kv_item;
+        x.d_rows = c.d_rows;
         x.Oh = c.attH;
         x.Ol = c.attL;
         x.ORB = c.rb;
@@ -636,6 +648,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
             f.in_mode = IN3_LN, f.xg = c.xg, f.gamma = l.ffn_ln.g, f.beta = l.ffn_ln.b, f.RB = c.rb, f.rg = c.rg_ffn;
             f.shape = c.ffn_in_mode == 1 ? G3_T2K8 : G3_T1;
             f.epi = EPI3_PLANES, f.bias = l.ffn_in.b, f.act = ACT_RELU, f.Oh = c.wideH, f.Ol = c.wideL, f.ORB = c.rb;
+            f.d_rows = c.d_rows;
             launch_gemv3(f, m.stream);
         }
         if (c.ffn_out_mode == 0 && nb <= 64) {
@@ -646,6 +659,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
             o.in_mode = IN3_PLANES, o.Ah = c.wideH, o.Al = c.wideL, o.RB = c.rb, o.mt2 = 1;
             o.shape = c.ffn_out_mode == 1 ? G3_T2K4 : G3_T1;
             o.epi = EPI3_PARTIAL, o.out = c.partial;
+            o.d_rows = c.d_rows;
             launch_gemv3(o, m.stream);
             sp = gemv3_splits(W.ffn_dim, o.shape);
         }
@@ -1624,6 +1638,7 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
             Vocab3Args v;
             v.Wp = W.embed_p, v.Ah = c.hH, v.Al = c.hL, v.RB = c.rb, v.M = nb, v.N = V, v.K = M;
             v.logits = c.logits, v.ldl = ldl;
+            v.d_rows = c.d_rows;
             launch_vocab3(v, m.stream);
         } else {
             linear(m, c.hN, M, proj, nullptr, 0, c.logits, V, nb, ACT_NONE, 1.f);
@@ -1657,6 +1672,27 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     }
     std::vector<float> pref(n);
     const int G = o.no_repeat_ngram_size;
+
+    // ---- live-slot bookkeeping (row-group chain + ancestor table only): the slots of utterances that are still searching are
+    // packed to the front every time the host looks at the counters (every 4th step); kernels skip the rows / slots behind
+    // *d_rows / *d_slots.  Finished hypotheses are stored per UTTERANCE (slot_utt maps a slot to its utterance), so the
+    // results below are read in utterance order whatever moved.  SC_BEAM_COMPACT=0: every slot stays where it is.
+    static const bool compact_env = !(getenv("SC_BEAM_COMPACT") && atoi(getenv("SC_BEAM_COMPACT")) == 0);
+    const bool compact = compact_env && use_anc && c.gen3 && n >= 2 && n <= 1024;
+    Buf<int> d_slot(m.pp(), compact ? (size_t)n + 2 : 4);
+    int* d_slot_utt = d_slot.get();
+    int* d_slots = d_slot.get() + n;
+    int* d_rows_live = d_slot.get() + n + 1;
+    if (compact) {
+        std::vector<int32_t> sl((size_t)n + 2);
+        for (int u = 0; u < n; ++u) sl[u] = u;
+        sl[n] = n;
+        sl[n + 1] = nb;
+        SC_HIP(hipMemcpyAsync(d_slot.get(), sl.data(), sl.size() * 4, hipMemcpyHostToDevice, m.stream));
+        SC_HIP(hipStreamSynchronize(m.stream));  // `sl` is a host temporary
+        c.d_rows = d_rows_live;
+        c.kv_item = d_slot_utt;
+    }
 
     // ---- prompt echo: feed prefix[:-1]; cum = sum_j lprob(prefix[j] | prefix[<j]) (the same for every beam row) ----
     for (int t = 0; t + 1 < prefix_len; ++t) {
@@ -1716,11 +1752,12 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
         if (chunked) {
             launch_beam_candidates_chunked(c.logits, ldl, n, B, V, d_cum, step == start, step < o.min_seq_len, step == max_len - 2,
                                            cfg.pad_idx, cfg.eos_idx, cfg.unk_idx, o.unk_penalty, K, d_cand_val, d_cand_idx,
-                                           ban ? d_seqs_cur : nullptr, max_len, step + 1, G, ws_f, ws_i, m.stream);
+                                           ban ? d_seqs_cur : nullptr, max_len, step + 1, G, ws_f, ws_i, m.stream,
+                                           compact ? d_rows_live : nullptr, compact ? d_slots : nullptr);
         } else {
             launch_beam_candidates(c.logits, ldl, n, B, V, d_cum, step == start, step < o.min_seq_len, step == max_len - 2, cfg.pad_idx,
                                    cfg.eos_idx, cfg.unk_idx, o.unk_penalty, K, d_cand_val, d_cand_idx, ban ? d_seqs_cur : nullptr, max_len,
-                                   step + 1, G, m.stream);
+                                   step + 1, G, m.stream, compact ? d_slots : nullptr);
         }
         BeamSelectArgs a;
         a.cand_val = d_cand_val;
@@ -1747,6 +1784,8 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
         a.len_penalty = len_penalty;
         a.anc = use_anc ? d_anc.get() : nullptr;
         a.anc_ld = max_len;
+        a.slot_utt = compact ? d_slot_utt : nullptr;
+        a.d_slots = compact ? d_slots : nullptr;
         launch_beam_select(a, n, m.stream);
         std::swap(d_seqs_cur, d_seqs_new);
         if (!use_anc) {
@@ -1756,6 +1795,13 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
             bind_caches(kv_cur);
         }
         if (((step - start) & 3) == 3 || step == max_len - 2) {
+            if (compact && step != max_len - 2) {  // utterances that finished since the last look leave the live rows
+                BeamCompactArgs k;
+                k.done = d_done, k.slot_utt = d_slot_utt, k.d_slots = d_slots, k.d_rows = d_rows_live;
+                k.seqs = d_seqs_cur, k.cum = d_cum, k.tok = c.d_tok, k.enc_lens = c.d_enc_lens, k.anc = d_anc;
+                k.n = n, k.beams = B, k.max_len = max_len, k.anc_ld = max_len, k.seq_len = step + 2, k.anc_len = step + 1;
+                launch_beam_compact(k, m.stream);
+            }
             SC_HIP(hipMemcpyAsync(&remaining, d_remaining, 4, hipMemcpyDeviceToHost, m.stream));
             SC_HIP(hipStreamSynchronize(m.stream));
         }

@@ -9,6 +9,9 @@ Sections:
   b64eos  utterances 0..63, 10 s each, greedy, hard_max_seq_len 64, weights synthetic://20240901?eos_ramp=<EOS_RAMP_BENCH>:
           every row stops ON ITS OWN at its own step (the ragged-length workload bench.py times).  Oracle chunks of 4
           equal-length utterances (no item depends on another one).  Text ids / char ids / durations / unit ids + margins.
+  beam5eos  utterances 0..11 as one batch, beam_size 5 (the API default), hard_max_seq_len 64, the same weights: the searches of
+          a batch finish at different steps (the live rows are re-packed as utterances leave).  Text ids / char ids /
+          durations / units.
   t2tt    the same weights + the NLLB text encoder: four English sentences of different lengths as ONE padded batch
           (key padding in the text encoder), T2TT greedy, hard_max_seq_len 64 (translator.py:299-303, model.py:138-151).
   medium  unity arch `medium` = seamlessM4T_medium (models/unity/builder.py:137-162; BASELINE configs[0] names it), default
@@ -89,7 +92,7 @@ def run_stream_traced(backend, tt, thr, wav, speech: bool):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--sections", default="b64eos,t2tt,medium,stream")
+    ap.add_argument("--sections", default="b64eos,beam5eos,t2tt,medium,stream")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--limit", type=int, default=64, help="utterances of section b64eos (debugging)")
     args = ap.parse_args()
@@ -119,7 +122,8 @@ def main():
 
     need_b64 = "b64eos" in want and len(doc.get("b64eos", {}).get("items", [])) < args.limit
     need_t2tt = "t2tt" in want and "t2tt" not in doc
-    if need_b64 or need_t2tt:
+    need_beam = "beam5eos" in want and "beam5eos" not in doc
+    if need_b64 or need_t2tt or need_beam:
         t0 = time.time()
         orc = OracleS2ST(cfg, syn.make_unity_state_dict(cfg, syn.DEFAULT_SEED, with_text_encoder=need_t2tt, eos_ramp=syn.EOS_RAMP_BENCH),
                          None, tt, ct, cards.vocoder_lang_spkr_idx_map())
@@ -134,6 +138,21 @@ def main():
                                      for i in range(len(seqs))]}
             save()
             print(f"t2tt in {time.time() - t1:.0f} s, lengths {[len(s) for s in seqs]}", flush=True)
+        if need_beam:
+            t1 = time.time()
+            idx = list(range(12))
+            fb, lens = orc.collate_fbank([syn.synthetic_waveform(i, 10.0).numpy() for i in idx])
+            seqs, speech_units, _, units, aux = orc.s2st(fb, lens, "fra", (1, 200), EOS_TEXT_LEN, vocode=False, beam_size=5)
+            items = []
+            for j, i in enumerate(idx):
+                nu, ncs = int(aux["unit_lens"][j]), int(aux["char_seq_lens"][j])
+                top2 = torch.topk(aux["logits"][j, :nu], 2, dim=-1).values
+                items.append({"index": int(i), "text_ids": [int(t) for t in seqs[j]], "char_ids": aux["char_seqs"][j, :ncs].tolist(),
+                              "durations": aux["durations"][j, :ncs].tolist(), "unit_len": nu, "units": units[j, :nu].tolist(),
+                              "speech_units": [int(u) for u in speech_units[j]], "unit_margins": _r(top2[:, 0] - top2[:, 1])})
+            doc["beam5eos"] = {"note": f"beam_size 5, hard_max_seq_len {EOS_TEXT_LEN}, utterances 0..11 as one batch, eos_ramp weights", "items": items}
+            save()
+            print(f"beam5eos in {time.time() - t1:.0f} s, text lengths {[len(s) for s in seqs]}", flush=True)
         if need_b64:
             sec = doc.setdefault("b64eos", {"note": f"greedy, hard_max_seq_len {EOS_TEXT_LEN}, 10 s each, eos_ramp weights; oracle chunks of 4",
                                             "items": []})

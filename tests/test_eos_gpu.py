@@ -170,3 +170,39 @@ def test_finished_rows_ride_along_and_the_loop_ends_early(report_dir):
                                             source_len=int(lens.max()))
     assert [ids[b, : out_lens[b]].tolist() for b in range(len(seqs))] == seqs
     assert max(out_lens) - min(out_lens) >= 10
+
+
+@pytest.mark.parametrize("n_utt,beam", [(17, 5), (6, 5), (30, 3)])
+def test_beam_search_with_utterances_that_finish_at_different_steps(n_utt, beam, report_dir):
+    """Beam search (the API default beam 5) on weights that emit EOS on their own: the utterances of a batch finish their
+    searches at different steps (5 ... 11 tokens), finished utterances stay in the batch as idle rows while the others
+    search on.  85 / 90 live rows run the wide row-group step, 30 the 64-row one.  Ids of every utterance and the scores
+    of the winners against oracle.beam_search_generate; the S2ST chain behind it (teacher-forced pass over hypotheses of
+    different lengths, T2U) against the oracle's units."""
+    from oracle import unity as ou
+
+    cfg, tt, orc, hip = _env(common.EOS_MIXED)
+    secs = [0.6 + 0.13 * ((7 * i) % 15) for i in range(n_utt)]
+    fb, lens = orc.collate_fbank(common.waves(secs))
+    enc, enc_lens = hip.encode_speech(fb.cuda(), lens.tolist())
+    el = torch.from_numpy(enc_lens.astype(np.int64))
+    prefix = tt.target_prefix("fra")
+    want, every = ou.beam_search_generate(orc.P, cfg, enc.cpu(), el, prefix, beam, hard_max_seq_len=CAP, pos_table=orc.pos_table,
+                                          return_all=True, source_len=int(lens.max()))
+    ids, out_lens, scores, hidden = hip.generate_text(enc, enc_lens.tolist(), prefix, beam_size=beam, hard_max_seq_len=CAP,
+                                                      source_len=int(lens.max()))
+    got = [ids[b, : out_lens[b]].tolist() for b in range(n_utt)]
+    bad = [b for b in range(n_utt) if got[b] != want[b]]
+    _log(report_dir, "eos_beam", n_utt=n_utt, beam=beam, lens=[len(w) for w in want], mismatching=bad)
+    assert len({len(w) for w in want}) >= 4, [len(w) for w in want]
+    assert not bad, (bad, [got[b] for b in bad], [want[b] for b in bad])
+    for b in range(n_utt):
+        assert abs(float(scores[b]) - every[b][0][0]) < 2e-4
+    # the decoder outputs handed to the T2U model = a teacher-forced pass over the chosen hypotheses (generator.py:281-299)
+    L = int(out_lens.max())
+    toks = np.full((n_utt, L - 1), cfg.pad_idx, dtype=np.int32)
+    for b, s in enumerate(want):
+        toks[b, : len(s) - 1] = s[:-1]
+    forced = hip.decode_text(enc, enc_lens.tolist(), toks)
+    for b, s in enumerate(want):
+        assert float((hidden[b, : len(s) - 1] - forced[b, : len(s) - 1]).abs().max()) < 1e-5

@@ -184,6 +184,22 @@ def test_ragged_lengths_one_batch_and_alone(gold, eos, report_dir):
             _check_waves(report_dir, f"eos_batch1_utt{i}", tr, vsd, lang_map, [0], tr.last_t2u, speech.units, speech.audio_wavs)
 
 
+def test_beam5_with_natural_eos_matches_oracle(gold, eos, report_dir):
+    """beam_size 5 (the API default) on the ragged workload: twelve searches that finish at different steps, the live rows
+    re-packed as utterances leave (k_beam.hip: beam_compact_kernel), K / V history through the ancestor table; the S2ST chain
+    behind it.  Ids of every utterance against the oracle's beam search."""
+    from seamless_communication_amd.inference import SequenceGeneratorOptions
+
+    tr, vsd, lang_map, _ = eos
+    sec = gold["beam5eos"]
+    idx = [r["index"] for r in sec["items"]]
+    lens = [len(r["text_ids"]) for r in sec["items"]]
+    assert len(set(lens)) >= 5, lens
+    opts = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(1, 200), hard_max_seq_len=gold["meta"]["eos_text_len"])
+    texts, speech = tr.predict(_fbank_src(tr, _waves(idx, [10.0] * len(idx))), "S2ST", "fra", text_generation_opts=opts)
+    _compare_batch(report_dir, "eos_beam5", fg.items_by_index(sec), idx, tr.last_text_ids, tr.last_t2u, speech.units)
+
+
 def test_text_input_matches_oracle(gold, eos, report_dir):
     """T2TT at full size: the NLLB text encoder over one padded batch of four sentences, then the same greedy search."""
     tr, _, _, opts = eos
