@@ -206,3 +206,28 @@ def test_beam_search_with_utterances_that_finish_at_different_steps(n_utt, beam,
     forced = hip.decode_text(enc, enc_lens.tolist(), toks)
     for b, s in enumerate(want):
         assert float((hidden[b, : len(s) - 1] - forced[b, : len(s) - 1]).abs().max()) < 1e-5
+
+
+def test_hypotheses_that_consist_of_eos_alone_give_no_units(report_dir):
+    """A hypothesis [</s>, lang, </s>] has no text: after the two prompt tokens are dropped nothing is left for the T2U model
+    (nar_decoder_frontend.py:227-259), the row gets zero units and an empty waveform while its neighbours are synthesised.
+    Six of the eight rows of this batch are such rows (eos_ramp setting "30,1,0,2.5"); units / waveform lengths / samples of
+    every row against the oracle through Translator.predict."""
+    from seamless_communication_amd.inference import SequenceGeneratorOptions
+
+    spec = "30,1,0,2.5"
+    orc = common.make_oracle(eos_ramp=spec)
+    fb, lens, seqs, speech_units, wavs_ref, units_ref, aux = _oracle_s2st(orc, AUDIO)
+    assert sorted({len(s) for s in seqs}) == [3, 4] and aux["unit_lens"].tolist().count(0) >= 4
+    tr = _translator(spec)
+    wav, ns = common.pad_waves(common.waves(AUDIO))
+    fbank, frames = tr.model.fbank(torch.from_numpy(wav).cuda(), ns)
+    src = {"seqs": fbank, "seq_lens": torch.from_numpy(frames.astype(np.int64)), "is_ragged": True}
+    texts, speech = tr.predict(src, "S2ST", "fra", text_generation_opts=SequenceGeneratorOptions(beam_size=1, hard_max_seq_len=CAP))
+    assert tr.last_text_ids == seqs
+    _log(report_dir, "eos_empty_rows", text_lens=[len(s) for s in seqs], units=[len(u) for u in speech.units])
+    for b in range(len(seqs)):
+        assert speech.units[b] == [int(u) for u in speech_units[b]]
+        assert speech.audio_wavs[b].shape[-1] == wavs_ref[b].shape[-1]
+        if wavs_ref[b].shape[-1]:
+            assert float((speech.audio_wavs[b].cpu() - wavs_ref[b]).abs().max()) < 2e-3
