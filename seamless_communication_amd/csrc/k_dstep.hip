@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (pair >= p.nb * p.heads) return;
     const int b = pair / p.heads, hd = pair - b * p.heads;
-    if (p.d_rows && b >= *p.d_rows) return;  // beam search: a row of a finished utterance
+    if (ANC && p.d_rows && b >= *p.d_rows) return;  // beam search: a row of a finished utterance
     const int c = lane & 15, g = lane >> 4;
     const int pos = CROSS ? 0 : *p.d_pos;
     const int kv_len = CROSS ? min(p.kv_lens[b], p.cap) : pos + 1;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     // the length are masked below.  Self-attention rows behind `pos` are uninitialised memory and are never touched.
     const int last = CROSS ? p.cap - 1 : kv_len - 1;
     // beam search: the beams of an utterance share its encoder K / V (projected once per utterance, in utterance order)
-    const int crow = CROSS ? (p.kv_item ? p.kv_item[b / p.kv_row_div] : b / p.kv_row_div) : b;
+    const int crow = CROSS ? ((ANC && p.kv_item) ? p.kv_item[b / p.kv_row_div] : b / p.kv_row_div) : b;
     const float* kc = p.kcache + (int64_t)crow * p.cache_bs + hd * 64 + 4 * c;
     const float* vc = p.vcache + (int64_t)crow * p.cache_bs + hd * 64 + 4 * c;
 
@@ -456,12 +456,13 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     // beam search (ANC): key j of this row lives in cache row anc[b][j] (the beam it descends from wrote it); the table entries
     // of a trip are fetched first, then the trip's keys / values as usual.  Addresses as kernel-argument base + a 32-bit byte
     // offset per load (one register each instead of a 64-bit pointer: 32 loads are in flight), the launcher checks the range.
-    const int* ancb = ANC ? p.anc + (int64_t)b * p.cap : nullptr;
+    constexpr bool TABLE = ANC && !CROSS;  // ANC = "beam search" variant: self attention reads through the table, cross through kv_item
+    const int* ancb = TABLE ? p.anc + (int64_t)b * p.cap : nullptr;
     const char* kbytes = reinterpret_cast<const char*>(p.kcache);
     const char* vbytes = reinterpret_cast<const char*>(p.vcache);
     const unsigned lane_off = (unsigned)(hd * 64 + 4 * c) * 4u, row_bytes = (unsigned)p.cache_bs * 4u, key_bytes = (unsigned)p.cache_ld * 4u;
-    unsigned off[ANC ? 16 : 1];
-    if (ANC) {
+    unsigned off[TABLE ? 16 : 1];
+    if (TABLE) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) off[i] = (unsigned)ancb[min(4 * i + g, last)] * row_bytes + (unsigned)min(4 * i + g, last) * key_bytes + lane_off;
 #pragma unroll
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     int j0 = 0;
     do {  // at least one key: the first trip's loads above are unconditional
         if (j0 > 0) {
-            if (ANC) {
+            if (TABLE) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     off[i] = (unsigned)ancb[min(j0 + 4 * i + g, last)] * row_bytes + (unsigned)min(j0 + 4 * i + g, last) * key_bytes + lane_off;
@@ -737,7 +738,8 @@ void launch_dattn(const DAttnArgs& a, bool cross, hipStream_t s) {
     // (row, head) pairs per workgroup: a CU pulls ~45 GB/s of cold K / V whatever its workgroup looks like
     // (profiles/r3_micro_percu.txt), so the pairs are spread over at least 256 workgroups before they are stacked
     const int ppw = std::max(1, std::min(4, pairs / 256));
-    if (cross) hipLaunchKernelGGL((dattn_kernel<true, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+    if (cross && (a.kv_item || a.d_rows)) hipLaunchKernelGGL((dattn_kernel<true, true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+    else if (cross) hipLaunchKernelGGL((dattn_kernel<true, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
     else if (a.anc) {
         SC_CHECK((int64_t)a.nb * a.cache_bs * 4 < (1ll << 32) && a.cache_ld * 4 < (1ll << 31), "dattn: K/V cache too large for the ancestor-table addressing");
         hipLaunchKernelGGL((dattn_kernel<false, true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
