@@ -2,8 +2,9 @@
 End_Timestamp): the union of the kernel intervals against the wall-clock span, the concurrency profile (time with 0, 1, 2,
 3+ kernels in flight), the idle gaps (count, total, the largest with the kernels either side) and a coarse timeline
 (per bin: busy share, mean concurrency, the kernel family that dominates the bin).
-    python scripts/trace_cover.py <kernel_trace.csv> [--window-ms W] [--bin-ms B]
-W: analyse the last W ms of the trace (default 260: one 64-utterance pass); B: timeline bin (default 5)."""
+    python scripts/trace_cover.py <kernel_trace.csv> [--window-ms W] [--bin-ms B] [--skip-tail-ms S]
+W: analyse W ms of the trace (default 260: one 64-utterance pass) ending S ms before the last kernel (default 0; the pipelined
+schedule drains at the end of a run: S = a few passes puts the window into its steady state); B: timeline bin (default 5)."""
 import csv
 import sys
 from collections import defaultdict
@@ -21,9 +22,9 @@ with open(path, newline="") as fh:
     for r in csv.DictReader(fh):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-t_end = max(e for _, e, _ in rows)
+t_end = max(e for _, e, _ in rows) - int(arg("--skip-tail-ms", 0.0) * 1e6)
 t0 = t_end - window
-rows = [(max(s, t0), e, n) for s, e, n in rows if e > t0]
+rows = [(max(s, t0), min(e, t_end), n) for s, e, n in rows if e > t0 and s < t_end]
 
 
 def short(n):
