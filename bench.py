@@ -83,8 +83,8 @@ def parse_args():
     ap.add_argument("--dec-cus", type=int, default=-1,
                     help="CU partition: greedy decoder steps on this many compute units, everything else on the rest "
                          "(sc_set_cu_partition); 0 = none; default: SC_BENCH_DEC_CUS or 0")
-    ap.add_argument("--dec-priority", action="store_true",
-                    help="greedy decoder steps on a highest-priority stream of each handle (sc_set_decoder_priority), no CU mask")
+    ap.add_argument("--dec-priority", type=int, nargs="?", const=1, default=0,
+                    help="greedy decoder steps on a stream of the highest (1) / lowest (-1) priority of each handle (sc_set_decoder_priority), no CU mask")
     ap.add_argument("--cu-layout", default="low", choices=["low", "xcd"], help="mask layout of --dec-cus (runtime.cu_masks)")
     ap.add_argument("--arch", default="base_v2", choices=["base_v2", "tiny_v2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -625,7 +625,7 @@ def main():
                 "microbatch_schedule": ((f"{batcher.groups} whole-batch passes in flight (pipelined across passes), start offsets {stagger * 1e3:.0f} ms"
                                          if args.pipeline_passes else f"free-running slices, start offsets {stagger * 1e3:.0f} ms")
                                         if free_run else "lock-step (join per pass)"),
-                "decoder_stream_priority": "highest" if args.dec_priority and args.dec_cus <= 0 else "default",
+                "decoder_stream_priority": ("default" if not args.dec_priority or args.dec_cus > 0 else ("highest" if args.dec_priority > 0 else "lowest")),
                 "cu_partition": ({"decoder_cus": args.dec_cus, "layout": args.cu_layout, "device_cus": model.cu_count()} if args.dec_cus > 0 else None),
             },
             "stage_ms_last_step_slice0": {k: round(v, 3) for k, v in stage_snapshot.items()},

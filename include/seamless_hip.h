@@ -160,9 +160,10 @@ int sc_wait_stream(sc_model* m, void* producer_stream);
  * way synchronise with the legacy default stream: a caller that partitions handles must keep its own work off the default
  * stream while calls are in flight (the Python host gives every worker thread its own stream).  Results do not change. */
 int sc_set_cu_partition(sc_model* m, const uint32_t* decoder_mask, const uint32_t* other_mask, int words);
-/* The greedy decoder-step chain of the handle on its own stream of the HIGHEST (high != 0) stream priority, no CU mask
- * (ABI 7): when handles in other phases keep the chip full of GEMM workgroups, the chain's short kernels are served first as
- * compute units turn over instead of taking turns with queued tiles.  high = 0 puts the chain back on the handle's stream.
+/* The greedy decoder-step chain of the handle on its own stream of the HIGHEST (high > 0) or LOWEST (high < 0) stream priority,
+ * no CU mask (ABI 7): when handles in other phases keep the chip full of GEMM workgroups, the chain's short kernels are served
+ * first as compute units turn over (highest) or only fill what the GEMM streams leave (lowest).  high = 0 puts the chain back
+ * on the handle's stream.
  * Replaces a CU partition of the handle (and vice versa).  The handle must be idle.  Results do not change. */
 int sc_set_decoder_priority(sc_model* m, int high);
 /* Introspection (ABI 7): the kernel family a decoder step of `rows` live rows is dispatched to for `caller` (0 greedy text

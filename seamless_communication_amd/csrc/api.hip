@@ -113,7 +113,7 @@ int sc_set_decoder_priority(sc_model* m, int high) {
     SC_API_BEGIN
     SC_CHECK(m, "null handle");
     SC_HIP(hipSetDevice(m->m.device));
-    m->m.set_decoder_priority(high != 0);
+    m->m.set_decoder_priority(high);
     SC_API_END
 }
 

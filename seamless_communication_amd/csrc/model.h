@@ -275,7 +275,7 @@ struct Model : ModelData {
     hipEvent_t dec_fork = nullptr;
     hipStream_t make_stream(const std::vector<uint32_t>& mask);  // non-blocking when mask is empty, CU-masked otherwise
     void set_cu_partition(const uint32_t* decoder_mask, const uint32_t* other, int words);
-    void set_decoder_priority(bool high);  // decoder chain on a highest-priority stream (no mask); false: back on `stream`
+    void set_decoder_priority(int level);  // decoder chain on a stream of the highest (> 0) / lowest (< 0) priority, no mask; 0: back on `stream`
     void trim_all_pools();   // every cached block of the handle's pools (own, side chains, decoder chain) back to the driver
     void hook_pool(DevicePool& p) { p.set_oom_hook([this] { trim_all_pools(); }); }
     DevicePool* pool_override = nullptr;

@@ -169,15 +169,15 @@ void Model::set_cu_partition(const uint32_t* decoder_mask, const uint32_t* other
     }
 }
 
-void Model::set_decoder_priority(bool high) {
+void Model::set_decoder_priority(int level) {
     if (!other_mask.empty() || dec_chain) set_cu_partition(nullptr, nullptr, 0);  // drops a partition and an earlier chain
-    if (!high) return;
+    if (level == 0) return;
     SC_HIP(hipStreamSynchronize(stream));
     dec_session.reset();
     int least = 0, greatest = 0;
     SC_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     std::unique_ptr<SideChain> c(new SideChain());
-    SC_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+    SC_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, level > 0 ? greatest : least));
     SC_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
     c->pool.set_stream(c->stream);
     hook_pool(c->pool);

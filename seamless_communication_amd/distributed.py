@@ -118,7 +118,7 @@ class MicroBatcher:
     most in the decoder phase (a chain of ~220 short dependent kernels per token that leaves more than half of
     the chip idle on its own; DESIGN.md section 3, profiles/r3_bench_cover_timeline.txt)."""
 
-    def __init__(self, translator, groups: int, decoder_cus: int = 0, cu_layout: str = "low", decoder_priority: bool = False) -> None:
+    def __init__(self, translator, groups: int, decoder_cus: int = 0, cu_layout: str = "low", decoder_priority: int = 0) -> None:
         from concurrent.futures import ThreadPoolExecutor
 
         self.groups = max(1, int(groups))
@@ -133,7 +133,7 @@ class MicroBatcher:
                 v.model.set_cu_partition(self.decoder_cus, cu_layout)
         elif decoder_priority:
             for v in self.views:
-                v.model.set_decoder_priority(True)
+                v.model.set_decoder_priority(int(decoder_priority))
 
     def _one(self, view, wav_dev: torch.Tensor, num_samples, task_str, tgt_lang, kwargs):
         ts = self.torch_streams[self.views.index(view)] if self.torch_streams else None

@@ -171,9 +171,10 @@ class HipS2STModel:
         dec, oth = self.cu_masks(self.cu_count(), decoder_cus, layout)
         check(self.lib.sc_set_cu_partition(self.handle, _ptr(dec), _ptr(oth), len(dec)), "sc_set_cu_partition")
 
-    def set_decoder_priority(self, high: bool = True) -> None:
-        """Greedy decoder steps on a highest-priority stream of the handle (sc_set_decoder_priority); False: back on its own."""
-        check(self.lib.sc_set_decoder_priority(self.handle, int(bool(high))), "sc_set_decoder_priority")
+    def set_decoder_priority(self, level: int = 1) -> None:
+        """Greedy decoder steps on a stream of the highest (level > 0) / lowest (level < 0) priority of the handle
+        (sc_set_decoder_priority); 0: back on its own stream."""
+        check(self.lib.sc_set_decoder_priority(self.handle, int(level)), "sc_set_decoder_priority")
 
     def close(self) -> None:
         if getattr(self, "handle", None):
