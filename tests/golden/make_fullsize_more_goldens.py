@@ -17,6 +17,11 @@ Sections:
   medium  unity arch `medium` = seamlessM4T_medium (models/unity/builder.py:137-162; BASELINE configs[0] names it), default
           synthetic weights: S2TT of a 10 s + 6.4 s batch through the v1 w2v-BERT encoder, and T2TT of two sentences;
           greedy, hard_max_seq_len 24.
+  medium_s2st  the v1 SPEECH chain at medium size, one 6.4 s utterance (the reference's v1 speech path is single-utterance:
+          translator.py:385-419): greedy text (24) -> teacher-forced decoder outputs -> autoregressive UnitYT2UModel with the
+          default unit search (beam 5, soft_max_seq_len (25, 50); generator.py:183-191, 316-336) -> UnitTokenDecoder ->
+          language token removed -> `vocoder_36langs` with its duration predictor -> proportional trim.  Unit token ids, the
+          decoded units, the waveform length and its first / last 256 samples.
   stream  SeamlessStreaming S2T + S2ST agent chains (BASELINE configs[4]) on the oracle backend at base_v2 size with the
           dense_1b monotonic decoder: one 3.2 s utterance fed in 320 ms segments; every text-decoder call (arg-max index,
           the p_choose statistic the policy compares), every output segment, the unit chunks handed to the vocoder.  The
@@ -92,7 +97,7 @@ def run_stream_traced(backend, tt, thr, wav, speech: bool):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--sections", default="b64eos,beam5eos,t2tt,medium,stream")
+    ap.add_argument("--sections", default="b64eos,beam5eos,t2tt,medium,medium_s2st,stream")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--limit", type=int, default=64, help="utterances of section b64eos (debugging)")
     args = ap.parse_args()
@@ -198,6 +203,42 @@ def main():
         doc["medium"] = sec
         save()
         print(f"medium in {time.time() - t1:.0f} s", flush=True)
+        del orc
+
+    if "medium_s2st" in want and "medium_s2st" not in doc:
+        from oracle import unity as ou
+        from oracle import vocoder as ov
+        from seamless_communication_amd.tokenizer import UnitTokenizer
+
+        t1 = time.time()
+        mcfg = _ARCHS["medium"]()
+        mtt = NllbTextTokenizer(mcfg.text_vocab_size, cards.TEXT_LANGS)
+        sd = syn.make_unity_state_dict(mcfg, syn.DEFAULT_SEED)
+        vsd = syn.make_vocoder_state_dict(mcfg, syn.DEFAULT_SEED, with_dur_predictor=True)
+        orc = OracleS2ST(mcfg, sd, None, mtt, CharTokenizer(mcfg.char_vocab_size), cards.vocoder_lang_spkr_idx_map())
+        index, seconds = MEDIUM_FIRST_INDEX + 1, MEDIUM_SECONDS[1]
+        fb, lens = orc.collate_fbank([syn.synthetic_waveform(index, seconds).numpy()])
+        seqs, enc, enc_lens, margins = orc.s2tt(fb, lens, "fra", (1, 200), MEDIUM_TEXT_LEN)
+        text = torch.tensor([seqs[0][:-1]], dtype=torch.int64)           # generator.py:281-291: the final EOS column is trimmed
+        tl = torch.tensor([text.shape[1]])
+        dec_out = ou.decode_text(orc.P, mcfg, text, tl, enc, enc_lens, orc.pos_table)
+        utok = UnitTokenizer(cards.NUM_UNITS, cards.UNIT_LANGS, "medium")
+        prefix = utok.create_encoder("fra").prefix_indices.tolist()
+        unit_ids = ou.t2u_ar_generate(orc.P, mcfg, dec_out, tl, prefix, beam_size=5, soft_max_seq_len=(25, 50))[0]
+        row = utok.create_decoder()(np.asarray([unit_ids], dtype=np.int64))[:, 1:]   # translator.py:388: language token removed
+        pad = utok.vocab_info.pad_idx
+        speech_units = [int(u) for u in row[0] if u != pad]
+        lang_idx, spkr_idx = ov.resolve_lang_spkr(cards.vocoder_lang_spkr_idx_map(), ["fra"], [-1])
+        wav = ov.vocode(vsd, mcfg.vocoder, torch.from_numpy(row), lang_idx, spkr_idx, dur_prediction=True)
+        keep = int(wav.shape[-1] * len(speech_units) / row.shape[1])
+        w = wav[0, 0, :keep].double().numpy()
+        doc["medium_s2st"] = {
+            "note": "arch medium, default synthetic weights + vocoder with duration predictor; greedy text 24, unit search beam 5 (25, 50)",
+            "index": index, "seconds": seconds, "text_ids": [int(t) for t in seqs[0]], "text_margins": _r(margins[0]),
+            "unit_token_ids": [int(u) for u in unit_ids], "row": [int(u) for u in row[0]], "speech_units": speech_units,
+            "wav_len": keep, "wav_head": _r(w[:256], 6), "wav_tail": _r(w[-256:], 6), "wav_abs_mean": float(np.abs(w).mean())}
+        save()
+        print(f"medium_s2st in {time.time() - t1:.0f} s: {len(seqs[0])} text tokens, {len(unit_ids)} unit tokens, {keep} samples", flush=True)
         del orc
 
     if "stream" in want and "stream" not in doc:

@@ -9,6 +9,7 @@ fullsize_more_ref.json (minted by tests/golden/make_fullsize_more_goldens.py fro
   (inference/translator.py:299-303, models/unity/model.py:138-151).
 * ``medium`` - seamlessM4T_medium dimensions (models/unity/builder.py:137-162; BASELINE configs[0]): S2TT through the v1
   w2v-BERT encoder and T2TT.
+* ``medium_s2st`` - the v1 speech chain at that size: autoregressive T2U with its unit beam search, duration-predicting vocoder.
 * ``stream`` - the SeamlessStreaming S2T and S2ST agent chains (BASELINE configs[4]; streaming/agents/online_text_decoder.py:
   205-243) on the HIP backend at base_v2 size: every text-decoder call's arg-max index exact and p_choose statistic within
   2e-4, the same segments read / written, the same unit chunks.
@@ -241,6 +242,31 @@ def test_medium_architecture_matches_oracle(gold, report_dir):
     rep = [fg.compare(g, text_ids=tr.last_text_ids[b]) for b, g in enumerate(t["items"])]
     _log(report_dir, "medium_t2tt", ok=[r["text"] for r in rep], margins=[r.get("text_margin_at_diff") for r in rep])
     assert all(r["text"] for r in rep), rep
+    tr.model.close()
+
+
+def test_medium_speech_chain_matches_oracle(gold, report_dir):
+    """The v1 speech chain at seamlessM4T_medium size through Translator.predict: greedy text, the autoregressive T2U's unit
+    beam search (beam 5, the (25, 50) soft limit: 625 unit tokens here), UnitTokenDecoder, the duration-predicting
+    `vocoder_36langs`, the proportional trim (translator.py:385-419; generator.py:183-191, 316-336).  Units exact, the
+    waveform's length exact and its first / last samples within 2e-3."""
+    from seamless_communication_amd.inference import SequenceGeneratorOptions, Translator
+
+    sec = gold["medium_s2st"]
+    tr = Translator(_card("medium", ramp=False), "vocoder_36langs", device="cuda:0")
+    topts = SequenceGeneratorOptions(beam_size=1, soft_max_seq_len=(1, 200), hard_max_seq_len=24)
+    wav = _waves([sec["index"]], [sec["seconds"]])[0]
+    texts, speech = tr.predict(wav, "S2ST", "fra", text_generation_opts=topts)  # unit_generation_opts: the reference's default
+    assert tr.last_text_ids[0] == sec["text_ids"]
+    assert speech.units[0] == sec["speech_units"], (len(speech.units[0]), len(sec["speech_units"]))
+    w = speech.audio_wavs[0][0, 0].double().cpu().numpy()
+    assert len(w) == sec["wav_len"]
+    head = float(np.abs(w[:256] - np.asarray(sec["wav_head"])).max())
+    tail = float(np.abs(w[-256:] - np.asarray(sec["wav_tail"])).max())
+    _log(report_dir, "medium_s2st", unit_tokens=len(sec["unit_token_ids"]), samples=len(w), head_err=head, tail_err=tail,
+         abs_mean=float(np.abs(w).mean()), want_abs_mean=sec["wav_abs_mean"])
+    assert head < WAV_TOL and tail < WAV_TOL
+    assert abs(float(np.abs(w).mean()) - sec["wav_abs_mean"]) < 1e-3
     tr.model.close()
 
 
