@@ -14,6 +14,8 @@ Sections:
           durations / units.
   t2tt    the same weights + the NLLB text encoder: four English sentences of different lengths as ONE padded batch
           (key padding in the text encoder), T2TT greedy, hard_max_seq_len 64 (translator.py:299-303, model.py:138-151).
+  t2st    the same four sentences through T2ST (text encoder -> text decoder -> NAR T2U): char ids / durations / units; two of the
+          hypotheses are EOS alone (rows without units next to rows with units, at full size).
   medium  unity arch `medium` = seamlessM4T_medium (models/unity/builder.py:137-162; BASELINE configs[0] names it), default
           synthetic weights: S2TT of a 10 s + 6.4 s batch through the v1 w2v-BERT encoder, and T2TT of two sentences;
           greedy, hard_max_seq_len 24.
@@ -97,7 +99,7 @@ def run_stream_traced(backend, tt, thr, wav, speech: bool):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--sections", default="b64eos,beam5eos,t2tt,medium,medium_s2st,stream")
+    ap.add_argument("--sections", default="b64eos,beam5eos,t2tt,t2st,medium,medium_s2st,stream")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--limit", type=int, default=64, help="utterances of section b64eos (debugging)")
     args = ap.parse_args()
@@ -128,9 +130,11 @@ def main():
     need_b64 = "b64eos" in want and len(doc.get("b64eos", {}).get("items", [])) < args.limit
     need_t2tt = "t2tt" in want and "t2tt" not in doc
     need_beam = "beam5eos" in want and "beam5eos" not in doc
-    if need_b64 or need_t2tt or need_beam:
+    need_t2st = "t2st" in want and "t2st" not in doc
+    need_text_encoder = need_t2tt or need_t2st
+    if need_b64 or need_text_encoder or need_beam:
         t0 = time.time()
-        orc = OracleS2ST(cfg, syn.make_unity_state_dict(cfg, syn.DEFAULT_SEED, with_text_encoder=need_t2tt, eos_ramp=syn.EOS_RAMP_BENCH),
+        orc = OracleS2ST(cfg, syn.make_unity_state_dict(cfg, syn.DEFAULT_SEED, with_text_encoder=need_text_encoder, eos_ramp=syn.EOS_RAMP_BENCH),
                          None, tt, ct, cards.vocoder_lang_spkr_idx_map())
         print(f"oracle (eos_ramp {syn.EOS_RAMP_BENCH}) ready after {time.time() - t0:.0f} s, {torch.get_num_threads()} threads", flush=True)
         if need_t2tt:
@@ -143,6 +147,21 @@ def main():
                                      for i in range(len(seqs))]}
             save()
             print(f"t2tt in {time.time() - t1:.0f} s, lengths {[len(s) for s in seqs]}", flush=True)
+        if need_t2st:
+            t1 = time.time()
+            tokens, lens = orc.collate_text(T2TT_SENTENCES, "eng")
+            seqs, speech_units, _, units, aux = orc.t2st(tokens, lens, "fra", (1, 200), EOS_TEXT_LEN, vocode=False)
+            items = []
+            for j in range(len(seqs)):
+                nu, ncs = int(aux["unit_lens"][j]), int(aux["char_seq_lens"][j])
+                top2 = torch.topk(aux["logits"][j, :max(nu, 1)], 2, dim=-1).values
+                items.append({"index": j, "text_ids": [int(t) for t in seqs[j]], "char_ids": aux["char_seqs"][j, :ncs].tolist(),
+                              "durations": aux["durations"][j, :ncs].tolist(), "unit_len": nu, "units": units[j, :nu].tolist(),
+                              "speech_units": [int(u) for u in speech_units[j]], "unit_margins": _r((top2[:, 0] - top2[:, 1])[:nu])})
+            doc["t2st"] = {"note": "T2ST eng->fra of the t2tt sentences, ONE padded batch, greedy, hard_max_seq_len 64, eos_ramp weights",
+                           "src_lang": "eng", "sentences": T2TT_SENTENCES, "src_tokens": tokens.tolist(), "src_lens": lens.tolist(), "items": items}
+            save()
+            print(f"t2st in {time.time() - t1:.0f} s, unit lengths {[it['unit_len'] for it in items]}", flush=True)
         if need_beam:
             t1 = time.time()
             idx = list(range(12))

@@ -7,6 +7,7 @@ fullsize_more_ref.json (minted by tests/golden/make_fullsize_more_goldens.py fro
   Reference: inference/generator.py:261-299, ggml/examples/unity/fairseq2.cpp:1535-1563.
 * ``t2tt``   - text input at full size: four sentences as one padded batch through the NLLB text encoder
   (inference/translator.py:299-303, models/unity/model.py:138-151).
+* ``t2st``   - the same sentences to speech (T2ST): two rows without units next to two with.
 * ``medium`` - seamlessM4T_medium dimensions (models/unity/builder.py:137-162; BASELINE configs[0]): S2TT through the v1
   w2v-BERT encoder and T2TT.
 * ``medium_s2st`` - the v1 speech chain at that size: autoregressive T2U with its unit beam search, duration-predicting vocoder.
@@ -217,6 +218,23 @@ def test_text_input_matches_oracle(gold, eos, report_dir):
     # the single-sentence entry of the API (translator.py:295-303)
     texts1, _ = tr.predict(sec["sentences"][0], "T2TT", "fra", src_lang=sec["src_lang"], text_generation_opts=opts)
     assert len(tr.last_text_ids[0]) >= 3 and str(texts1[0]) == tr.text_tokenizer.decode(tr.last_text_ids[0])
+
+
+def test_text_to_speech_matches_oracle(gold, eos, report_dir):
+    """T2ST at full size: the four sentences as one padded batch -> text ids, char ids, durations, units.  Two of the
+    hypotheses are EOS alone: rows without units next to rows with 225 / 311 units."""
+    tr, vsd, lang_map, opts = eos
+    sec = gold["t2st"]
+    src = {"seqs": torch.tensor(sec["src_tokens"], dtype=torch.int64), "seq_lens": torch.tensor(sec["src_lens"]), "is_ragged": True}
+    texts, speech = tr.predict(src, "T2ST", "fra", src_lang=sec["src_lang"], text_generation_opts=opts)
+    items = fg.items_by_index(sec)
+    assert sorted(it["unit_len"] for it in sec["items"])[:2] == [0, 0]
+    _compare_batch(report_dir, "t2st_full", items, list(range(len(sec["items"]))), tr.last_text_ids, tr.last_t2u, speech.units)
+    for b, it in enumerate(sec["items"]):
+        assert speech.audio_wavs[b].shape[-1] == (0 if it["unit_len"] == 0 else speech.audio_wavs[b].shape[-1])
+        assert (speech.audio_wavs[b].shape[-1] == 0) == (it["unit_len"] == 0)
+    rows = [b for b, it in enumerate(sec["items"]) if it["unit_len"]]
+    _check_waves(report_dir, "t2st_full", tr, vsd, lang_map, rows, tr.last_t2u, speech.units, speech.audio_wavs)
 
 
 def test_medium_architecture_matches_oracle(gold, report_dir):
