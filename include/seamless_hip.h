@@ -392,6 +392,13 @@ int sc_op_resblock_pair_ps(const float* d_x, const void* d_w1_packed, const floa
 int sc_op_resblock_pair(const float* d_x, const void* d_w1_packed, const float* d_b1, const void* d_w2_packed,
                         const float* d_b2, float* d_out, int32_t nb, int32_t T, int32_t C, int32_t k, int32_t dil,
                         float slope, const float* d_avg_a, const float* d_avg_b);
+/* The whole multi-receptive-field block of a narrow vocoder stage (hifigan.py:186-191: the average of the three ResBlocks,
+ * kernel sizes k[0..2], three dilation pairs each, dil[3 * block + pair]) fused in one kernel for C in {16, 32}.  The four
+ * pointer tables are HOST arrays of nine device pointers (pair q = 3 * block + pair), weights packed by
+ * sc_op_pack_conv_weight.  Same bits as nine sc_op_resblock_pair calls, the last one averaging. */
+int sc_op_mrf_fused(const float* d_x, const void* const* d_w1_packed, const float* const* d_b1, const void* const* d_w2_packed,
+                    const float* const* d_b2, float* d_out, int32_t nb, int32_t T, int32_t C, const int32_t* k, const int32_t* dil,
+                    float slope);
 int sc_op_attention(const float* d_q, const float* d_k, const float* d_v, float* d_out, int32_t nb, int32_t heads,
                     int32_t sq, int32_t skv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                     const int32_t* d_kv_lens, int32_t causal, const float* d_rel_k, int32_t rel_left,

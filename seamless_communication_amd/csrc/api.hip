@@ -1091,6 +1091,32 @@ int sc_op_resblock_pair(const float* d_x, const void* d_w1_packed, const float* 
     SC_API_END
 }
 
+int sc_op_mrf_fused(const float* d_x, const void* const* d_w1_packed, const float* const* d_b1, const void* const* d_w2_packed,
+                    const float* const* d_b2, float* d_out, int32_t nb, int32_t T, int32_t C, const int32_t* k, const int32_t* dil,
+                    float slope) {
+    SC_API_BEGIN
+    SC_CHECK(d_x && d_w1_packed && d_b1 && d_w2_packed && d_b2 && d_out && k && dil, "sc_op_mrf_fused: null argument");
+    MrfArgs a;
+    a.x = d_x;
+    a.out = d_out;
+    a.nb = nb;
+    a.T = T;
+    a.C = C;
+    a.slope = slope;
+    for (int j = 0; j < 3; ++j) a.k[j] = k[j];
+    for (int q = 0; q < 9; ++q) {
+        a.dil[q] = dil[q];
+        a.w1[q] = static_cast<const __half*>(d_w1_packed[q]);
+        a.w2[q] = static_cast<const __half*>(d_w2_packed[q]);
+        a.ldw1[q] = a.ldw2[q] = align_up((int64_t)C * k[q / 3], 32);
+        a.b1[q] = d_b1[q];
+        a.b2[q] = d_b2[q];
+    }
+    launch_mrf_fused(a, g_op_stream);
+    SC_HIP(hipStreamSynchronize(g_op_stream));
+    SC_API_END
+}
+
 int sc_op_attention(const float* d_q, const float* d_k, const float* d_v, float* d_out, int32_t nb, int32_t heads,
                     int32_t sq, int32_t skv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* d_kv_lens,
                     int32_t causal, const float* d_rel_k, int32_t rel_left, int32_t rel_right) {

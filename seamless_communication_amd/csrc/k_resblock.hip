@@ -21,6 +21,8 @@
 // Arithmetic is the same as the two-launch path op for op: same hi/lo split, the same sequence of
 // v_mfma_f32_32x32x16_f16 per output fragment (16-wide K chunks in tap-major order, hi then lo), the
 // same epilogue expressions, so the results are bit-identical to conv1d + conv1d (tests/test_ops_gpu.py).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace sc {
@@ -302,6 +304,285 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
     }
 }
 
+
+// ---- the whole multi-receptive-field block of a narrow stage in ONE kernel (C = 32 / 16) -------------------------
+//
+//     out = ( RB_{k0}(x) + RB_{k1}(x) + RB_{k2}(x) ) / 3,    RB_k = three chained dilation pairs     (hifigan.py:37-127, 186-191)
+//
+// As nine pair launches the stage moves ~23 tensor passes through HBM (per pair: x + halo in, residual in, out; the two
+// averaging reads) and is bandwidth bound at C <= 32.  Here a workgroup of 16 waves owns MRF_R = 512 consecutive time
+// rows of one item - `halo` rows of context per side, halo = the widest branch's reach, 60 rows at k = 11 - and runs
+// the nine pairs back to back on that tile:
+//   * the fp32 residual stream of a wave's 32 rows never leaves its registers (accumulator layout: lane = column,
+//     16 rows per lane); only its LeakyReLU'd hi/lo fp16 planes are in LDS, where conv1 reads them, the intermediate
+//     of the pair replaces them (as in the pair kernel) and the next pair's input replaces that;
+//   * rows are addressed IN PLACE (tile row j is time t_first + j for every tensor of the chain); each convolution
+//     makes a fringe of (k-1)/2 * dilation more rows per side meaningless.  A convolution is run for the 32-row
+//     fragments that still touch rows a stored output depends on and skipped for the others, so that after six
+//     convolutions exactly the rows [halo, MRF_R - halo) are valid for the widest branch.  MRF_G guard rows of zeros
+//     on both sides of the planes keep the fringe reads inside the allocation;
+//   * rows outside [0, T) are forced to zero after every convolution - the zero padding each separate launch sees;
+//   * both convolutions' packed weights of the running pair sit in LDS; the next pair's are fetched into registers
+//     while the current convolution multiplies and stored once the barrier behind it has retired their predecessor;
+//   * the branch results are summed in registers in the order of the pair kernel's averaging epilogue.
+// HBM traffic: (3 reads of) x with halo - the second and third from L2 - and one write of the stage output.
+// Per output row the arithmetic is the pair kernel's instruction for instruction (same fragments, same chunk order,
+// same epilogue expressions), so the result is bit-identical to the nine-launch chain (tests/test_ops_gpu.py).
+constexpr int MRF_R = 512;
+constexpr int MRF_G = 32;
+constexpr int MRF_THREADS = 1024;
+constexpr int MRF_KMAX = 11;
+
+typedef int mrf_i32x4_t __attribute__((ext_vector_type(4)));
+#define MRF_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// One convolution's packed weights global -> LDS by the buffer unit (`buffer_load_dwordx4 ... lds`: lane p of a wave
+// instruction lands at M0 + 16 p, 1 KB per instruction), no registers and no LDS store instructions in between.  The LDS
+// image is [C][k*C + 8] halfs: the 16-byte slot P of the image is (row P / (vpr + 1), segment P % (vpr + 1)), vpr = k*C/8
+// data segments per row and one pad segment, which - like every slot behind the last row - is fetched from an
+// out-of-range offset and arrives as zeros.  Completion is awaited with an explicit s_waitcnt vmcnt(0) in front of a
+// later barrier (mrf_tile); the compiler's own counts only ever see fewer loads outstanding than there are.
+template <int C>
+__device__ __forceinline__ void mrf_w_dma(const __half* __restrict__ W, int64_t ldw, int k, _Float16* sW, int lane, int wave) {
+    constexpr int NI = (C * (MRF_KMAX * C / 8 + 1) + 64 * (MRF_THREADS / 64) - 1) / (64 * (MRF_THREADS / 64));
+    const int vpr1 = k * C / 8 + 1;
+    const int slots = C * vpr1;
+    const uint64_t base = reinterpret_cast<uint64_t>(W);
+    mrf_i32x4_t rsrc;
+    rsrc[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+    rsrc[1] = __builtin_amdgcn_readfirstlane((int)(uint32_t)((base >> 32) & 0xffff));
+    rsrc[2] = __builtin_amdgcn_readfirstlane((int)(uint32_t)(C * ldw * 2));
+    rsrc[3] = 0x00020000;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int chunk = i * (MRF_THREADS / 64) + wave;  // 1 KB chunk of the image
+        if (chunk * 64 < slots) {
+            const int P = chunk * 64 + lane;
+            const int row = P / vpr1, seg = P - row * vpr1;
+            const uint32_t voff = (row < C && seg < vpr1 - 1) ? (uint32_t)((row * ldw + seg * 8) * 2) : 0x80000000u;
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                         :
+                         : "s"(__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)MRF_LDS_PTR(sW + chunk * 512))), "v"(voff), "s"(rsrc)
+                         : "memory");
+        }
+    }
+}
+
+// conv_from_lds_w for one 32-column fragment with the operands of chunk ch + 1 requested from LDS before the matrix
+// instructions of chunk ch are issued (same chunk order, hi then lo: same bits).  C = 16 fills only half of the 32 output
+// columns: lanes 16-31 multiply the weight rows of columns 0-15 again instead of branching around the read.
+template <int C>
+__device__ __forceinline__ void mrf_conv(const _Float16* __restrict__ ph, const _Float16* __restrict__ pl, int a_row0, int tap_step, int k,
+                                         const _Float16* __restrict__ sW, int ldb, int lane, float16_t& acc) {
+    constexpr int CS = C + 8;
+    constexpr int CPT = C / 16;
+    const int koff = (lane >> 5) * 8;
+    const int a_base = (a_row0 + (lane & 31)) * CS + koff;
+    const int a_step = tap_step * CS;
+    const int b_base = ((lane & 31) % C) * ldb + koff;
+    const int nch = k * CPT;
+    half8_t h0, l0, b0, h1, l1, b1;
+#define MRF_LD(CH, H, L, B)                                                              \
+    do {                                                                                 \
+        const int ao_ = a_base + ((CH) / CPT) * a_step + ((CH) % CPT) * 16;              \
+        H = *reinterpret_cast<const half8_t*>(ph + ao_);                                 \
+        L = *reinterpret_cast<const half8_t*>(pl + ao_);                                 \
+        B = *reinterpret_cast<const half8_t*>(sW + b_base + (CH) * 16);                  \
+    } while (0)
+    MRF_LD(0, h0, l0, b0);
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) MRF_LD(ch + 1, h1, l1, b1);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(l0, b0, acc, 0, 0, 0);
+        h0 = h1, l0 = l1, b0 = b1;
+    }
+#undef MRF_LD
+}
+
+// hi/lo planes of LeakyReLU(v) at plane row `row`
+__device__ __forceinline__ void mrf_put(_Float16* __restrict__ ph, _Float16* __restrict__ pl, int idx, float v, float slope) {
+    v = fmaxf(v, slope * v);  // LeakyReLU for 0 < slope < 1, same bits as v > 0 ? v : slope * v
+    const _Float16 h = (_Float16)v;
+    ph[idx] = h;
+    pl[idx] = (_Float16)(v - (float)h);
+}
+
+// EDGE: the tile reaches outside [0, T) and rows there must read / be forced to zero; interior tiles skip the tests
+template <int C, bool EDGE>
+__device__ __forceinline__ void mrf_tile(const MrfArgs& p, _Float16* __restrict__ ph, _Float16* __restrict__ pl, _Float16* __restrict__ sW1,
+                                         _Float16* __restrict__ sW2, const float* __restrict__ sBias, int n, int t_first, int lane, int wave) {
+    constexpr int CS = C + 8;
+    const int T = p.T, halo = p.halo;
+    const int TT = MRF_R - 2 * halo;
+    const float slope = p.slope;
+    const float* __restrict__ xn = p.x + (int64_t)n * T * C;
+    const int col = lane & 31;
+    const bool colok = col < C;
+    const int jbase = 32 * wave + 4 * (lane >> 5);  // tile row of accumulator register r: jbase + (r & 3) + 8 * (r >> 2)
+    const int w_lo = 32 * wave, w_hi = 32 * wave + 32;
+    const int pbase = (MRF_G + jbase) * CS + col;   // plane index of register 0's element
+    // bit r: register r's row lies inside [0, T)
+    uint32_t inside = 0xffffu;
+    if (EDGE) {
+        inside = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = t_first + jbase + (r & 3) + 8 * (r >> 2);
+            inside |= (t >= 0 && t < T) ? (1u << r) : 0u;
+        }
+    }
+
+    float sum[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum[r] = 0.f;
+
+    for (int br = 0; br < 3; ++br) {
+        const int k = p.k[br], hk = (k - 1) / 2, ldb = k * C + 8;
+        int ext = hk * (p.dil[br * 3 + 0] + p.dil[br * 3 + 1] + p.dil[br * 3 + 2] + 3);  // reach of this branch
+
+        // ---- x (this wave's 32 rows) -> registers (all loads in flight at once); LeakyReLU'd hi/lo planes ------------
+        float xr[16];
+        if (w_hi > halo - ext && w_lo < halo + TT + ext && colok) {
+            if (EDGE) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = min(max(t_first + jbase + (r & 3) + 8 * (r >> 2), 0), T - 1);
+                    xr[r] = xn[(int64_t)t * C + col];
+                }
+            } else {  // one base address, the rows as instruction offsets
+                const float* __restrict__ xb = xn + (int64_t)(t_first + jbase) * C + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xr[r] = xb[((r & 3) + 8 * (r >> 2)) * C];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (EDGE && !((inside >> r) & 1)) xr[r] = 0.f;
+                mrf_put(ph, pl, pbase + ((r & 3) + 8 * (r >> 2)) * CS, xr[r], slope);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xr[r] = 0.f;
+        }
+        __syncthreads();
+
+        for (int d = 0; d < 3; ++d) {
+            const int q = br * 3 + d;
+            const int dil = p.dil[q];
+            const bool more = q + 1 < 9;
+            const int qn = more ? q + 1 : q;
+            const int kn = p.k[qn / 3];
+
+            // ---- conv1 (dilation dil) -> LeakyReLU'd intermediate over the x planes --------------------------------
+            {
+                ext -= hk * dil;
+                const bool act = w_hi > halo - ext && w_lo < halo + TT + ext;
+                float16_t acc[1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+                if (act) mrf_conv<C>(ph, pl, MRF_G + 32 * wave - hk * dil, dil, k, sW1, ldb, lane, acc[0]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this pair's second weights (DMA) have landed
+                __syncthreads();  // every wave is done with the x planes and with this pair's first weights
+                if (more) mrf_w_dma<C>(p.w1[qn], p.ldw1[qn], kn, sW1, lane, wave);
+                if (act && colok) {
+                    const float b = sBias[(2 * q) * C + col];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = (acc[0][r] + b) * 1.0f;
+                        if (EDGE && !((inside >> r) & 1)) v = 0.f;  // conv2 sees zero padding outside [0, T)
+                        mrf_put(ph, pl, pbase + ((r & 3) + 8 * (r >> 2)) * CS, v, slope);
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- conv2 (dilation 1) + residual -> the stream; the next pair's planes --------------------------------
+            {
+                ext -= hk;
+                const bool act = w_hi > halo - ext && w_lo < halo + TT + ext;
+                float16_t acc[1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+                if (act) mrf_conv<C>(ph, pl, MRF_G + 32 * wave - hk, 1, k, sW2, ldb, lane, acc[0]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next pair's first weights (DMA) have landed
+                __syncthreads();  // every wave is done with the intermediate and with this pair's second weights
+                if (more) mrf_w_dma<C>(p.w2[qn], p.ldw2[qn], kn, sW2, lane, wave);
+                if (act && colok) {
+                    const float b = sBias[(2 * q + 1) * C + col];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = (acc[0][r] + b) * 1.0f + xr[r];
+                        if (EDGE && !((inside >> r) & 1)) v = 0.f;
+                        xr[r] = v;
+                        if (d < 2) mrf_put(ph, pl, pbase + ((r & 3) + 8 * (r >> 2)) * CS, v, slope);
+                    }
+                }
+                if (d < 2) __syncthreads();  // after the last pair the next branch's x planes follow (no reader is left)
+            }
+        }
+        // ---- ((a + b) + v) / 3 in the order of the pair kernel's averaging epilogue ----------------------------------
+        if (br < 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum[r] = br == 0 ? xr[r] : sum[r] + xr[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum[r] = (sum[r] + xr[r]) / 3.0f;
+        }
+    }
+
+    if (colok) {
+        float* __restrict__ outb = p.out + (int64_t)n * T * C + (int64_t)(t_first + jbase) * C + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = jbase + (r & 3) + 8 * (r >> 2);
+            if (j >= halo && j < halo + TT && (!EDGE || t_first + j < T)) outb[((r & 3) + 8 * (r >> 2)) * C] = sum[r];
+        }
+    }
+}
+
+template <int C>
+constexpr int mrf_w_halfs() {  // one weight image, rounded up to whole 1 KB DMA chunks
+    return (C * (MRF_KMAX * C / 8 + 1) + 63) / 64 * 512;
+}
+
+template <int C>
+__global__ __launch_bounds__(MRF_THREADS) void mrf_fused_kernel(MrfArgs p, int tiles) {
+    constexpr int CS = C + 8;
+    constexpr int PR = MRF_R + 2 * MRF_G;  // plane rows
+    extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
+    _Float16* const ph = reinterpret_cast<_Float16*>(rb_smem);
+    _Float16* const pl = ph + PR * CS;
+    _Float16* const sW1 = pl + PR * CS;
+    _Float16* const sW2 = sW1 + mrf_w_halfs<C>();
+    float* const sBias = reinterpret_cast<float*>(sW2 + mrf_w_halfs<C>());  // [18][C]: b1, b2 of pair 0, b1, b2 of pair 1, ...
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x / tiles;
+    const int tile = blockIdx.x - n * tiles;
+    const int t_first = tile * (MRF_R - 2 * p.halo) - p.halo;  // time of tile row 0
+
+    // weights of the first pair, every bias, planes start as zeros (the guard rows stay zero)
+    mrf_w_dma<C>(p.w1[0], p.ldw1[0], p.k[0], sW1, lane, wave);
+    mrf_w_dma<C>(p.w2[0], p.ldw2[0], p.k[0], sW2, lane, wave);
+    if (tid < C) {
+        float v[18];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            v[2 * q] = p.b1[q] ? p.b1[q][tid] : 0.f;
+            v[2 * q + 1] = p.b2[q] ? p.b2[q][tid] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 18; ++i) sBias[i * C + tid] = v[i];
+    }
+    {
+        const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = tid; i < 2 * PR * CS / 8; i += MRF_THREADS) reinterpret_cast<half8_t*>(ph)[i] = z;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t_first < 0 || t_first + MRF_R > p.T) mrf_tile<C, true>(p, ph, pl, sW1, sW2, sBias, n, t_first, lane, wave);
+    else mrf_tile<C, false>(p, ph, pl, sW1, sW2, sBias, n, t_first, lane, wave);
+}
+
 }  // namespace
 static size_t weights_lds_bytes(int C, int k) {
     return C > 32 ? (size_t)2 * C * (C + 8) * sizeof(_Float16) : (size_t)C * (k * C + 8) * sizeof(_Float16);
@@ -348,6 +629,67 @@ void launch_resblock_pair(const ResPairArgs& a, hipStream_t s) {
     if (a.C == 16) launch_cfg<16>(a, s);
     else if (a.C == 32) launch_cfg<32>(a, s);
     else launch_cfg<64>(a, s);
+    SC_LAUNCH_CHECK();
+}
+
+static int mrf_halo(const MrfArgs& a) {
+    int halo = 0;
+    for (int j = 0; j < 3; ++j) halo = std::max(halo, (a.k[j] - 1) / 2 * (a.dil[j * 3] + a.dil[j * 3 + 1] + a.dil[j * 3 + 2] + 3));
+    return halo;
+}
+
+bool mrf_fused_supported(int C, const int* k, const int* dil) {
+    if (C != 16 && C != 32) return false;
+    int halo = 0;
+    for (int j = 0; j < 3; ++j) {
+        if (k[j] < 1 || (k[j] & 1) == 0 || k[j] > MRF_KMAX) return false;
+        int sum = 3;
+        for (int d = 0; d < 3; ++d) {
+            if (dil[j * 3 + d] < 1 || (k[j] - 1) / 2 * dil[j * 3 + d] > MRF_G) return false;
+            sum += dil[j * 3 + d];
+        }
+        halo = std::max(halo, (k[j] - 1) / 2 * sum);
+    }
+    return MRF_R - 2 * halo >= 128;
+}
+
+namespace {
+template <int C>
+void launch_mrf_cfg(MrfArgs a, hipStream_t s) {
+    constexpr size_t LDS = ((size_t)2 * (MRF_R + 2 * MRF_G) * (C + 8) + (size_t)2 * mrf_w_halfs<C>()) * sizeof(_Float16) + 18 * C * sizeof(float);
+    static_assert(LDS <= 160 * 1024, "planes + two weight buffers must fit in the CU's LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mrf_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_set = true;
+    }
+    a.halo = mrf_halo(a);
+    const int TT = MRF_R - 2 * a.halo;
+    const int tiles = cdiv(a.T, TT);
+    SC_CHECK((int64_t)a.nb * tiles < (1ll << 31), "mrf: grid too large");
+    char name[48];
+    snprintf(name, sizeof(name), "mrf_fused_c%d", C);
+    const double rows = (double)a.nb * a.T;
+    double flops = 0.0, wbytes = 0.0;
+    for (int j = 0; j < 3; ++j) {
+        flops += 3.0 * 2.0 * 2.0 * rows * C * (double)C * a.k[j];
+        wbytes += 3.0 * 2.0 * 2.0 * C * (double)C * a.k[j];
+    }
+    prof::Scope scope(name, flops, 4.0 * rows * C * 2.0 + wbytes, s);
+    hipLaunchKernelGGL((mrf_fused_kernel<C>), dim3((unsigned)(a.nb * tiles)), dim3(MRF_THREADS), LDS, s, a, tiles);
+}
+}  // namespace
+
+void launch_mrf_fused(const MrfArgs& a, hipStream_t s) {
+    SC_CHECK(mrf_fused_supported(a.C, a.k, a.dil), "mrf: unsupported C=%d k=(%d,%d,%d)", a.C, a.k[0], a.k[1], a.k[2]);
+    SC_CHECK(a.nb > 0 && a.T > 0 && a.x && a.out && a.x != a.out, "mrf: empty problem or in-place call");
+    for (int q = 0; q < 9; ++q) {
+        const int k = a.k[q / 3];
+        SC_CHECK(a.w1[q] && a.w2[q] && a.ldw1[q] % 8 == 0 && a.ldw2[q] % 8 == 0 && a.ldw1[q] >= (int64_t)k * a.C && a.ldw2[q] >= (int64_t)k * a.C,
+                 "mrf: packed weight rows of pair %d missing or too short", q);
+    }
+    if (a.C == 16) launch_mrf_cfg<16>(a, s);
+    else launch_mrf_cfg<32>(a, s);
     SC_LAUNCH_CHECK();
 }
 

@@ -113,6 +113,27 @@ struct ResPairArgs {
 bool resblock_pair_supported(int C, int k, int dil);
 void launch_resblock_pair(const ResPairArgs& a, hipStream_t s);
 
+// k_resblock.hip: the three ResBlocks (kernel sizes k[0..2], three dilation pairs each) of a narrow stage and their
+// average, out = (RB_0(x) + RB_1(x) + RB_2(x)) / 3, in one kernel for C in {16, 32}: bit-identical to nine
+// launch_resblock_pair calls (the last one averaging).  Pair q = 3 * block + pair-in-block.
+struct MrfArgs {
+    const float* x = nullptr;  // [nb][T][C]
+    float* out = nullptr;      // [nb][T][C], not x
+    int nb = 0, T = 0, C = 0;
+    float slope = 0.1f;
+    int halo = 0;              // filled by the launcher: rows of context per side
+    int k[3] = {0, 0, 0};
+    int dil[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
+    const __half* w1[9] = {};
+    const __half* w2[9] = {};
+    int64_t ldw1[9] = {};
+    int64_t ldw2[9] = {};
+    const float* b1[9] = {};
+    const float* b2[9] = {};
+};
+bool mrf_fused_supported(int C, const int* k, const int* dil);
+void launch_mrf_fused(const MrfArgs& a, hipStream_t s);
+
 // out[m][n] = alpha*act(sum_k x[m][k]*W[n][k] + bias[n]) + res[m][n], exact fp32 FMA, M <= 8.
 void launch_gemv(const float* x, int64_t ldx, const __half* W, int64_t ldw, const float* bias,
                  const float* res, int64_t ldr, float* out, int64_t ldo, int M, int N, int K,

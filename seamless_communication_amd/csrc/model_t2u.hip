@@ -562,6 +562,37 @@ void vocode_batch(Model& m, const int* d_units, const int* d_lang, const int* d_
             t = t2;
             continue;
         }
+        // the two narrowest stages (C = 32, 16): the three ResBlocks and their average in one kernel, the residual
+        // stream in registers and every intermediate in LDS (k_resblock.hip: mrf_fused_kernel).  SC_VOC_MRF=0: pair by pair.
+        static const bool voc_mrf = !(getenv("SC_VOC_MRF") && atoi(getenv("SC_VOC_MRF")) == 0);
+        if (voc_mrf && g_force_general_gemm.load(std::memory_order_relaxed) == 0) {
+            MrfArgs a;
+            bool ok = true;
+            for (int j = 0; j < nk && ok; ++j) {
+                const ResBlock& r = m.voc_res[i * nk + j];
+                ok = r.dil.size() == 3;
+                for (int d = 0; d < 3 && ok; ++d) {
+                    const Conv &c1 = r.convs1[d], &c2 = r.convs2[d];
+                    ok = c1.k == r.convs1[0].k && c2.k == c1.k && c1.cin == ch && c1.cout == ch && c2.cin == ch && c2.cout == ch;
+                    const int q = j * 3 + d;
+                    a.dil[q] = r.dil[d];
+                    a.w1[q] = c1.w, a.ldw1[q] = c1.kpad, a.b1[q] = c1.b;
+                    a.w2[q] = c2.w, a.ldw2[q] = c2.kpad, a.b2[q] = c2.b;
+                }
+                if (ok) a.k[j] = r.convs1[0].k;
+            }
+            if (ok && mrf_fused_supported(ch, a.k, a.dil)) {
+                a.x = y.get();
+                a.out = x.get();
+                a.nb = n;
+                a.T = t2;
+                a.C = ch;
+                a.slope = 0.1f;
+                launch_mrf_fused(a, m.stream);
+                t = t2;
+                continue;
+            }
+        }
         for (int j = 0; j < nk; ++j) {
             const ResBlock& r = m.voc_res[i * nk + j];
             const float* cur = y;

@@ -456,6 +456,79 @@ def test_resblock_pair_bit_identical_to_two_convs(lib, report_dir, nb, T, C_, k,
     assert torch.equal(got, want)
 
 
+MRF_CASES = [
+    # nb, T, C, kernel sizes, dilations per block
+    (2, 1000, 32, (3, 7, 11), (1, 3, 5)),
+    (1, 392, 32, (3, 7, 11), (1, 3, 5)),    # exactly one tile
+    (3, 393, 16, (3, 7, 11), (1, 3, 5)),    # one row into the second tile
+    (2, 4100, 16, (3, 7, 11), (1, 3, 5)),
+    (1, 37, 16, (3, 7, 11), (1, 3, 5)),     # shorter than the halo
+    (2, 901, 32, (11, 3, 7), (5, 1, 3)),    # other orders: the halo is the widest block's, whichever it is
+    (1, 650, 16, (5, 5, 9), (2, 1, 4)),
+]
+
+
+@pytest.mark.parametrize("nb,T,C_,ks,dils", MRF_CASES)
+def test_mrf_fused_bit_identical_to_nine_pairs(lib, report_dir, nb, T, C_, ks, dils):
+    """k_resblock.hip: mrf_fused_kernel (three ResBlocks x three dilation pairs + the average in one kernel, residual stream
+    in registers, intermediates in LDS) against the nine pair launches it replaces: identical bits; and against the
+    float64 HiFi-GAN block (hifigan.py:37-127, 186-191)."""
+    import ctypes as C
+
+    g = torch.Generator().manual_seed(T * 7 + C_ * 3 + ks[0])
+    x = torch.randn(nb, T, C_, generator=g)
+    W1, W2, B1, B2, P1, P2, D1, D2 = [], [], [], [], [], [], [], []
+    for k in ks:
+        kpad = (C_ * k + 31) // 32 * 32
+        for _ in dils:
+            w1 = (torch.randn(C_, C_, k, generator=g) / math.sqrt(C_ * k)).half()
+            w2 = (torch.randn(C_, C_, k, generator=g) / math.sqrt(C_ * k)).half()
+            b1, b2 = torch.randn(C_, generator=g) * 0.1, torch.randn(C_, generator=g) * 0.1
+            wp1 = torch.zeros(C_, kpad, dtype=torch.float16, device="cuda")
+            wp2 = torch.zeros(C_, kpad, dtype=torch.float16, device="cuda")
+            check(lib, lib.sc_op_pack_conv_weight(P(dev(w1)), P(wp1), C_, C_, k))
+            check(lib, lib.sc_op_pack_conv_weight(P(dev(w2)), P(wp2), C_, C_, k))
+            W1.append(w1), W2.append(w2), B1.append(b1), B2.append(b2), P1.append(wp1), P2.append(wp2)
+            D1.append(dev(b1)), D2.append(dev(b2))
+    dx = dev(x)
+    # the nine-launch chain
+    outs = []
+    for j, k in enumerate(ks):
+        cur = dx
+        for d, dil in enumerate(dils):
+            q = 3 * j + d
+            last = j == 2 and d == 2
+            nxt = torch.full((nb, T, C_), float("nan"), device="cuda")
+            check(lib, lib.sc_op_resblock_pair(P(cur), P(P1[q]), P(D1[q]), P(P2[q]), P(D2[q]), P(nxt), nb, T, C_, k, dil, 0.1,
+                                               P(outs[0]) if last else None, P(outs[1]) if last else None))
+            cur = nxt
+        outs.append(cur)
+    want = outs[2].cpu()
+    # one launch
+    arr = lambda ts: (C.c_void_p * 9)(*[t.data_ptr() for t in ts])
+    kk = (C.c_int32 * 3)(*ks)
+    dd = (C.c_int32 * 9)(*[dil for _ in ks for dil in dils])
+    got = torch.full((nb, T, C_), float("nan"), device="cuda")
+    check(lib, lib.sc_op_mrf_fused(P(dx), arr(P1), arr(D1), arr(P2), arr(D2), P(got), nb, T, C_, kk, dd, 0.1))
+    got = got.cpu()
+    assert not torch.isnan(got).any()
+    # float64 reference
+    ref = torch.zeros(nb, T, C_, dtype=torch.float64)
+    for j, k in enumerate(ks):
+        cur = x.double().transpose(1, 2)
+        for d, dil in enumerate(dils):
+            q = 3 * j + d
+            h = F.conv1d(F.leaky_relu(cur, 0.1), W1[q].double(), B1[q].double(), padding=dil * (k - 1) // 2, dilation=dil)
+            cur = F.conv1d(F.leaky_relu(h, 0.1), W2[q].double(), B2[q].double(), padding=(k - 1) // 2) + cur
+        ref += cur.transpose(1, 2)
+    ref /= 3.0
+    err = rel_err(got, ref)
+    _log(report_dir, "mrf_fused", nb=nb, T=T, C=C_, ks=list(ks), dils=list(dils), err=err, bit_identical=bool(torch.equal(got, want)),
+         maxdiff=float((got - want).abs().max()))
+    assert err < 5e-6
+    assert torch.equal(got, want)
+
+
 CONVT_CASES = [(2, 25, 64, 32, 11, 5), (1, 100, 32, 16, 8, 4), (2, 77, 16, 8, 4, 2), (1, 13, 512, 256, 11, 5)]
 
 
