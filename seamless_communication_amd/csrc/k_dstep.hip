@@ -94,8 +94,9 @@ __global__ __launch_bounds__(256) void gemvp_kernel(GemvPArgs p) {
     const __amdgpu_buffer_rsrc_t ral = ds_rsrc(p.Al, p.a_bytes);
     const uint32_t w_voff = (uint32_t)lane * 16u;
     uint32_t a_voff[MT];
+    const int live = p.d_rows ? min(*p.d_rows, p.M) : p.M;  // rows behind the live rows are neither read nor written
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a_voff[i] = (32 * i + n < p.M) ? (uint32_t)((h * p.RB + 32 * i + n) * 16) : OOB;
+    for (int i = 0; i < MT; ++i) a_voff[i] = (32 * i + n < live) ? (uint32_t)((h * p.RB + 32 * i + n) * 16) : OOB;
     const uint32_t a_kstep = (uint32_t)(2 * p.RB * 16);  // bytes per k-step in a plane
     uint32_t kill[NCH];                                  // chunks behind the K range read zeros
 #pragma unroll
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void gemvp_kernel(GemvPArgs p) {
                     if (p.act == ACT_RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     if (feat >= p.N) v[e] = 0.f;
                 }
-                if (m < p.M && (nt * 4 + g) * 8 < p.N) {
+                if (m < live && (nt * 4 + g) * 8 < p.N) {
                     half8_t hi, lo;
                     split8(v, hi, lo);
                     const int64_t off = ((int64_t)(nt * 4 + g) * p.ORB + m) * 8;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void gemvp_kernel(GemvPArgs p) {
                     const int m = 32 * i + row;
                     const int o = row * 33 + f;
                     float v = (red[0][i][o] + red[1][i][o]) + (red[2][i][o] + red[3][i][o]);
-                    if (m < p.M && feat < p.N) {
+                    if (m < live && feat < p.N) {
                         if (EPI == EPI_PARTIAL) {
                             p.partial[((int64_t)split * p.M + m) * p.N + feat] = v;
                         } else {  // EPI_ARGMAX: generation step rules on the logit of column `feat` (argmax_rows_kernel)
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void gemvp_kernel(GemvPArgs p) {
                     mm = nm;
                 }
                 const int m = 32 * i + rbase + 8 * q;
-                if (f == 0 && m < p.M) {
+                if (f == 0 && m < live) {
                     float4 rec;
                     rec.x = best;
                     rec.y = __int_as_float(bidx);
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (pair >= p.nb * p.heads) return;
     const int b = pair / p.heads, hd = pair - b * p.heads;
-    if (ANC && p.d_rows && b >= *p.d_rows) return;  // beam search: a row of a finished utterance
+    if (p.d_rows && b >= *p.d_rows) return;  // a row behind the live rows (beam search: finished utterances; greedy: compaction)
     const int c = lane & 15, g = lane >> 4;
     const int pos = CROSS ? 0 : *p.d_pos;
     const int kv_len = CROSS ? min(p.kv_lens[b], p.cap) : pos + 1;
@@ -738,7 +739,7 @@ void launch_dattn(const DAttnArgs& a, bool cross, hipStream_t s) {
     // (row, head) pairs per workgroup: a CU pulls ~45 GB/s of cold K / V whatever its workgroup looks like
     // (profiles/r3_micro_percu.txt), so the pairs are spread over at least 256 workgroups before they are stacked
     const int ppw = std::max(1, std::min(4, pairs / 256));
-    if (cross && (a.kv_item || a.d_rows)) hipLaunchKernelGGL((dattn_kernel<true, true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+    if (cross && a.kv_item) hipLaunchKernelGGL((dattn_kernel<true, true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
     else if (cross) hipLaunchKernelGGL((dattn_kernel<true, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
     else if (a.anc) {
         SC_CHECK((int64_t)a.nb * a.cache_bs * 4 < (1ll << 32) && a.cache_ld * 4 < (1ll << 31), "dattn: K/V cache too large for the ancestor-table addressing");

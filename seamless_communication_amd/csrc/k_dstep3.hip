@@ -74,7 +74,10 @@ __global__ __launch_bounds__(64 * WAVES) void gemv3_kernel(Gemv3Args p) {
     const int h = lane >> 5;  // k half of the fragment
     const int nt0 = blockIdx.x * NT;
     const int r0 = blockIdx.y * p.rg;
-    if (p.d_rows && r0 >= *p.d_rows) return;  // beam search: a row group of finished utterances
+    // rows behind the live rows (beam search: finished utterances; greedy generation: the live-row compaction) are neither
+    // read nor written, a row group that starts behind them returns at once
+    const int live = p.d_rows ? min(*p.d_rows, p.M) : p.M;
+    if (r0 >= live) return;
     const int rot = blockIdx.x % WAVES;
     const int chunk = (wave + rot) % WAVES;
     const int ks_w0 = (blockIdx.z * WAVES + chunk) * KSW;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv3_kernel(Gemv3Args p) {
     }
     bool rvalid[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) rvalid[i] = (32 * i + n < p.rg) && (r0 + 32 * i + n < p.M);
+    for (int i = 0; i < MT; ++i) rvalid[i] = (32 * i + n < p.rg) && (r0 + 32 * i + n < live);
 
     u32x4_t ah[IN == IN3_PLANES ? MT : 1][KSW], al[IN == IN3_PLANES ? MT : 1][KSW];
     float xr[IN == IN3_LN ? MT : 1][KSW][8];
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv3_kernel(Gemv3Args p) {
             const int u = tid + it * T;
             const int jj = u >> 10, jt = jj / MT, i = jj % MT, rn = (u >> 5) & 31, f = u & 31;
             const int feat = (nt0 + jt) * 32 + f, row = r0 + 32 * i + rn;
-            const bool ok = feat < p.N && 32 * i + rn < p.rg && row < p.M;
+            const bool ok = feat < p.N && 32 * i + rn < p.rg && row < live;
             bias_f[it] = (p.bias && ok) ? p.bias[feat] : 0.f;
             if (EPI == EPI3_RESID) res_f[it] = ok ? p.xres[((int64_t)(feat >> 3) * p.XRB + row) * 8 + (feat & 7)] : 0.f;
         }
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv3_kernel(Gemv3Args p) {
                 if ((nt0 + jt) * 32 + 8 * g + e >= p.N) s = 0.f;
                 v[e] = s;
             }
-            if (32 * i + rn < p.rg && row < p.M && ((nt0 + jt) * 4 + g) * 8 < p.N) {
+            if (32 * i + rn < p.rg && row < live && ((nt0 + jt) * 4 + g) * 8 < p.N) {
                 half8_t hi, lo;
                 split8v(v, hi, lo);
                 const int64_t off = ((int64_t)((nt0 + jt) * 4 + g) * p.ORB + row) * 8;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemv3_kernel(Gemv3Args p) {
             float s = 0.f;
 #pragma unroll
             for (int c = 0; c < WAVES; ++c) s += red[c][jj][o];
-            if (feat < p.N && 32 * i + rn < p.rg && row < p.M) {
+            if (feat < p.N && 32 * i + rn < p.rg && row < live) {
                 if (EPI == EPI3_PARTIAL) {
                     p.out[((int64_t)blockIdx.z * p.M + row) * p.N + feat] = s;
                 } else if (EPI == EPI3_ROWS) {
@@ -341,6 +344,7 @@ template <bool LN>
 __global__ __launch_bounds__(256) void reduce3_kernel(Reduce3Args p) {
     __shared__ float red[8];
     const int row = blockIdx.x, tid = threadIdx.x;
+    if (p.d_rows && row >= *p.d_rows) return;  // a row behind the live rows (see Gemv3Args::d_rows)
     const int nv = p.C >> 2;
     const bool on = tid < nv;
     const int t = on ? tid : 0;  // idle lanes read element 0 and discard it

@@ -566,4 +566,58 @@ void launch_step_update(int* next_tok, int* hist, int hist_ld, int* finished, in
     SC_LAUNCH_CHECK();
 }
 
+// Live-row compaction of the greedy step (RowSwapArgs): grid (pairs, 3 * layers + 1).  Block (i, j): j < layers the key
+// cache of layer j, then the value caches, then the encoder K / V (all one-directional, src -> dst), the last block of a
+// pair exchanges the small per-row state and the captured decoder outputs.
+__global__ __launch_bounds__(256) void row_swap_kernel(RowSwapArgs a) {
+    const int i = blockIdx.x, j = blockIdx.y;
+    const int src = a.src[i], dst = a.dst[i];
+    const int tid = threadIdx.x;
+    if (j < 3 * a.layers) {
+        const int kind = j / a.layers, li = j - kind * a.layers;
+        float* base = kind == 0 ? a.k[li] : kind == 1 ? a.v[li] : a.cross[li];
+        const int64_t slot = kind == 2 ? (int64_t)a.s_enc * 2 * a.M : (int64_t)a.cap * a.M;
+        const int64_t n4 = (kind == 2 ? (int64_t)a.s_enc * 2 * a.M : (int64_t)a.filled * a.M) / 4;
+        const float4* s4 = reinterpret_cast<const float4*>(base + src * slot);
+        float4* d4 = reinterpret_cast<float4*>(base + dst * slot);
+        for (int64_t e = tid; e < n4; e += 256) d4[e] = s4[e];
+        return;
+    }
+    if (tid == 0) {
+        int t;
+        t = a.tok[src], a.tok[src] = a.tok[dst], a.tok[dst] = t;
+        t = a.finished[src], a.finished[src] = a.finished[dst], a.finished[dst] = t;
+        t = a.out_len[src], a.out_len[src] = a.out_len[dst], a.out_len[dst] = t;
+        t = a.enc_lens[src], a.enc_lens[src] = a.enc_lens[dst], a.enc_lens[dst] = t;
+        float f;
+        f = a.lprob[src], a.lprob[src] = a.lprob[dst], a.lprob[dst] = f;
+        f = a.score[src], a.score[src] = a.score[dst], a.score[dst] = f;
+    }
+    for (int e = tid; e < a.cap; e += 256) {
+        const int t = a.hist[(int64_t)src * a.cap + e];
+        a.hist[(int64_t)src * a.cap + e] = a.hist[(int64_t)dst * a.cap + e];
+        a.hist[(int64_t)dst * a.cap + e] = t;
+    }
+    if (a.hidden) {
+        const int64_t slot = (int64_t)(a.cap - 1) * a.M;
+        const int64_t n4 = (int64_t)min(a.filled, a.cap - 1) * a.M / 4;
+        float4* s4 = reinterpret_cast<float4*>(a.hidden + src * slot);
+        float4* d4 = reinterpret_cast<float4*>(a.hidden + dst * slot);
+        for (int64_t e = tid; e < n4; e += 256) {
+            const float4 t = s4[e];
+            s4[e] = d4[e];
+            d4[e] = t;
+        }
+    }
+}
+
+void launch_row_swap(const RowSwapArgs& a, hipStream_t s) {
+    if (a.pairs <= 0) return;
+    SC_CHECK(a.layers >= 1 && a.layers <= ROWSWAP_MAX_LAYERS && a.pairs <= ROWSWAP_MAX_PAIRS && a.M % 4 == 0 && a.filled >= 0 && a.filled <= a.cap,
+             "row swap: layers=%d pairs=%d M=%d filled=%d cap=%d", a.layers, a.pairs, a.M, a.filled, a.cap);
+    SC_CHECK(a.tok && a.finished && a.out_len && a.enc_lens && a.lprob && a.score && a.hist, "row swap: null state pointer");
+    hipLaunchKernelGGL(row_swap_kernel, dim3(a.pairs, 3 * a.layers + 1), dim3(256), 0, s, a);
+    SC_LAUNCH_CHECK();
+}
+
 }  // namespace sc

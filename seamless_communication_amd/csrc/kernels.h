@@ -218,6 +218,7 @@ struct GemvPArgs {
     // filled by the launcher
     int KS = 0, NT = 0, ks_per_wg = 0;
     uint32_t w_bytes = 0, a_bytes = 0;
+    const int* d_rows = nullptr;  // rows behind *d_rows are neither read nor written (see Gemv3Args::d_rows)
 };
 bool gemvp_supported(int M, int N, int K);
 int gemvp_splits(int K, int want_splits);  // K ranges launch_gemvp will really use
@@ -335,6 +336,7 @@ struct Reduce3Args {
     const int* d_pos = nullptr;
     float* hfix = nullptr;
     int rows = 0, C = 0;
+    const int* d_rows = nullptr;  // see Gemv3Args::d_rows
 };
 void launch_reduce3(const Reduce3Args& a, hipStream_t s);
 void launch_embed3(const int* tok, const __half* embed, float scale, const float* pos_table, const int* d_pos, float* xg, int XRB,
@@ -555,5 +557,29 @@ void launch_conv_to_mono(const float* x, const __half* w_packed, const float* bi
                          float* y, hipStream_t s);
 void launch_fill_i32(int* p, int v, int n, hipStream_t s);
 void launch_add_i32(int* p, int v, hipStream_t s);
+
+// Greedy generation, live-row compaction (model_decoder.hip: run_generate_text): pair i moves the state of the still
+// generating row src[i] into slot dst[i], whose own hypothesis has finished, and keeps that hypothesis' results in slot
+// src[i]: K / V rows 0 .. filled-1 of every layer and the encoder K / V go src -> dst (the finished row's are dead),
+// tokens, flags, lengths, scores, the sequence and the captured decoder outputs are exchanged.
+constexpr int ROWSWAP_MAX_LAYERS = 32;
+constexpr int ROWSWAP_MAX_PAIRS = 64;
+struct RowSwapArgs {
+    float* k[ROWSWAP_MAX_LAYERS];
+    float* v[ROWSWAP_MAX_LAYERS];
+    float* cross[ROWSWAP_MAX_LAYERS];
+    int layers = 0, pairs = 0;
+    unsigned char src[ROWSWAP_MAX_PAIRS], dst[ROWSWAP_MAX_PAIRS];
+    int M = 0, cap = 0, s_enc = 0, filled = 0;  // K / V row length, rows per cache slot, encoder rows, positions written so far
+    int* tok = nullptr;
+    int* finished = nullptr;
+    int* out_len = nullptr;
+    int* enc_lens = nullptr;
+    float* lprob = nullptr;
+    float* score = nullptr;
+    int* hist = nullptr;      // [rows][cap]
+    float* hidden = nullptr;  // [rows][cap - 1][M] or null
+};
+void launch_row_swap(const RowSwapArgs& a, hipStream_t s);
 
 }  // namespace sc

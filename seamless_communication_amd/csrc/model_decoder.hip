@@ -77,6 +77,7 @@ struct StepCtx {
     const int* anc = nullptr;  // beam search on the packed step kernels: K/V ancestor table [nb][cap] (DAttnArgs::anc)
     // beam search, row-group chain: live rows packed to the front, *d_rows of them; slot u holds utterance kv_item[u]
     const int* d_rows = nullptr;
+    int* d_rows_greedy = nullptr;  // greedy generation: the same counter, written by the live-row compaction (run_generate_text)
     const int* kv_item = nullptr;
     float* qkv3 = nullptr;  // [nb][3M] complete q | k | v rows: the wide step (> 64 live rows) projects them on gemv3
 };
@@ -313,6 +314,7 @@ static void gemv2(Model& m, StepCtx& c, const __half* Ah, const __half* Al, cons
     a.splits = want_splits;
     a.epi = EPI_PARTIAL;
     a.partial = c.partial;
+    a.d_rows = c.d_rows;
     launch_gemvp(a, m.stream);
     *splits = gemvp_splits(L.in, want_splits);
 }
@@ -554,6 +556,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         Reduce3Args r;
         r.partial = c.partial, r.S = S, r.bias = bias, r.xg = c.xg, r.XRB = c.rb, r.rows = nb, r.C = M;
         r.gamma = ln.g, r.beta = ln.b, r.Hh = c.hH, r.Hl = c.hL, r.RB = c.rb;
+        r.d_rows = c.d_rows;
         if (decoder_output) {  // also fp32 rows (c.hN) and the per-position capture (the reference's teacher-forced pass)
             r.hrow = c.dec_hidden, r.hrow_bs = (int64_t)(c.cap - 1) * M, r.hrow_rows = c.dec_hidden ? c.cap - 1 : 0, r.d_pos = c.d_pos;
             r.hfix = c.hN;
@@ -671,6 +674,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         v.am_part = c.am_part, v.am_tiles_cap = c.am_tiles, v.am_eos_logit = c.am_eos_logit, v.am_pos = c.d_pos;
         v.am_min_step_for_eos = c.min_seq_len, v.am_force_eos_step = c.force_eos_step;
         v.am_pad_idx = W.pad_idx, v.am_eos_idx = W.eos_idx, v.am_unk_idx = W.unk_idx, v.am_unk_penalty = c.unk_penalty;
+        v.d_rows = c.d_rows;
         launch_vocab3(v, m.stream);
         launch_argmax_finalize(c.am_part, vocab3_groups(nb), nb, c.am_eos_logit, c.d_pos, c.force_eos_step, W.pad_idx, W.eos_idx,
                                c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len, c.d_score, m.stream);
@@ -1092,6 +1096,7 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
     c.unk_penalty = o.unk_penalty;
     S.ints = Buf<int>(m.pp(), (size_t)8 + 4 * n + (size_t)n * max_len);
     c.d_pos = S.ints;
+    c.d_rows_greedy = S.ints.get() + 1;  // becomes StepCtx::d_rows of a row-group (gen-3) generation session below
     c.d_tok = S.ints.get() + 8;
     c.d_finished = c.d_tok + n;
     c.d_out_len = c.d_finished + n;
@@ -1122,6 +1127,9 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
         c.am_tiles = fused_argmax ? gemvp_argmax_tiles(cfg.text_vocab_size, c.am_ntl) : 0;
         if (gen3) {
             c.gen3 = true;
+            // greedy generation: the row-group kernels and the attention skip the row groups / rows behind *d_rows (= n until
+            // the live-row compaction of run_generate_text lowers it); the captured step reads the counter on every replay
+            if (!forced) c.d_rows = c.d_rows_greedy;
             S.xg = Buf<float>(m.pp(), (size_t)M * c.rb);
             S.qkvr = Buf<float>(m.pp(), (size_t)n * M);
             c.xg = S.xg;
@@ -1307,6 +1315,7 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     const int feed_len = forced ? forced_len : prefix_len;
     for (int b = 0; b < n; ++b)
         for (int t = 0; t < feed_len; ++t) hist[(size_t)b * max_len + t] = forced ? h_forced_tokens[(size_t)b * forced_len + t] : h_prefix[t];
+    init[1] = n;  // live rows (StepCtx::d_rows_greedy)
     for (int b = 0; b < n; ++b) {
         init[8 + b] = hist[(size_t)b * max_len];  // token fed at position 0
         init[8 + n + b] = 0;                      // finished
@@ -1381,6 +1390,22 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     const int first = prefix_len - 1;
     const bool use_graph = o.use_graph != 0;
     std::vector<int32_t> fin(n);
+    // ---- live-row compaction (row-group chain): a step costs the same with 5 rows alive as with 64, and on a ragged batch a
+    // third of the steps run with less than half of the rows alive (bench config.decoder_rows).  Whenever the host looks at
+    // the finished flags, the rows still generating are packed to the front - each one behind the new boundary moves into the
+    // slot of a finished row in front of it (row_swap_kernel: K / V rows, encoder K / V, tokens, scores; the finished row's
+    // results move the other way) - and *d_rows drops to their number: the attention and reduce kernels skip the rows behind
+    // it, the row-group products neither read nor write them and skip whole row groups, the vocabulary projection its 32-row halves.
+    // slot_utt names the utterance a slot holds; results are handed out by utterance.  SC_GREEDY_COMPACT=0 keeps the rows
+    // where they are.  A row's arithmetic does not depend on its slot (tests/test_eos_gpu.py: ids, hidden states, units and
+    // waveforms equal to the un-compacted run and to the oracle).
+    const char* gc_env = getenv("SC_GREEDY_COMPACT");
+    const bool compact = c.gen3 && c.d_rows == c.d_rows_greedy && n > 16 && cfg.dec_layers <= ROWSWAP_MAX_LAYERS && n <= 255 &&
+                         M % 4 == 0 && !(gc_env && atoi(gc_env) == 0);
+    std::vector<int> slot_utt(n);
+    for (int b = 0; b < n; ++b) slot_utt[b] = b;
+    int live_slots = n;
+    bool moved = false;
     for (int step = first; step <= max_len - 2; ++step) {
         if (use_graph) {
             if (!S->exec) {
@@ -1418,6 +1443,36 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
             bool all = true;
             for (int b = 0; b < n; ++b) all = all && fin[b];
             if (all) break;
+            if (compact) {
+                int alive = 0;
+                for (int b = 0; b < live_slots; ++b) alive += fin[b] ? 0 : 1;
+                const int want = std::max(1, alive);  // the rows still generating, packed to the front
+                if (want < live_slots) {
+                    RowSwapArgs rs;
+                    rs.layers = cfg.dec_layers;
+                    for (int li = 0; li < cfg.dec_layers; ++li) rs.k[li] = c.kcache[li], rs.v[li] = c.vcache[li], rs.cross[li] = c.cross_kv[li];
+                    rs.M = M, rs.cap = c.cap, rs.s_enc = c.s_enc, rs.filled = step + 1;
+                    rs.tok = c.d_tok, rs.finished = c.d_finished, rs.out_len = c.d_out_len, rs.enc_lens = c.d_enc_lens;
+                    rs.lprob = c.d_lprob, rs.score = c.d_score, rs.hist = c.d_hist, rs.hidden = c.dec_hidden;
+                    int free_slot = 0;
+                    for (int b = want; b < live_slots; ++b) {
+                        if (fin[b]) continue;
+                        while (!fin[free_slot]) ++free_slot;  // alive <= want: a finished slot in front exists for every such row
+                        rs.src[rs.pairs] = (unsigned char)b, rs.dst[rs.pairs] = (unsigned char)free_slot;
+                        ++rs.pairs;
+                        std::swap(slot_utt[b], slot_utt[free_slot]);
+                        fin[free_slot] = 0, fin[b] = 1;
+                        if (rs.pairs == ROWSWAP_MAX_PAIRS) {
+                            launch_row_swap(rs, m.stream);
+                            rs.pairs = 0;
+                        }
+                    }
+                    launch_row_swap(rs, m.stream);
+                    SC_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c.d_rows_greedy), want, 1, m.stream));
+                    live_slots = want;
+                    moved = true;
+                }
+            }
         }
     }
     std::vector<int32_t> lens(n);
@@ -1425,14 +1480,23 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     SC_HIP(hipMemcpyAsync(hist.data(), c.d_hist, hist.size() * 4, hipMemcpyDeviceToHost, m.stream));
     SC_HIP(hipMemcpyAsync(lens.data(), c.d_out_len, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
     SC_HIP(hipMemcpyAsync(scores.data(), c.d_score, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
-    if (want_hidden)
-        SC_HIP(hipMemcpyAsync(d_dec_hidden, c.dec_hidden, (size_t)n * (max_len - 1) * M * 4, hipMemcpyDeviceToDevice, m.stream));
+    if (want_hidden) {
+        const size_t row = (size_t)(max_len - 1) * M;
+        if (!moved) {
+            SC_HIP(hipMemcpyAsync(d_dec_hidden, c.dec_hidden, (size_t)n * row * 4, hipMemcpyDeviceToDevice, m.stream));
+        } else {  // slot s holds utterance slot_utt[s]
+            for (int s = 0; s < n; ++s)
+                SC_HIP(hipMemcpyAsync(d_dec_hidden + (size_t)slot_utt[s] * row, c.dec_hidden + (size_t)s * row, row * 4, hipMemcpyDeviceToDevice,
+                                      m.stream));
+        }
+    }
     SC_HIP(hipStreamSynchronize(m.stream));
-    for (int b = 0; b < n; ++b) {
-        const int len = lens[b];
-        for (int t = 0; t < max_len; ++t) h_out_ids[(size_t)b * max_len + t] = t < len ? hist[(size_t)b * max_len + t] : cfg.pad_idx;
+    for (int s = 0; s < n; ++s) {
+        const int b = slot_utt[s];
+        const int len = lens[s];
+        for (int t = 0; t < max_len; ++t) h_out_ids[(size_t)b * max_len + t] = t < len ? hist[(size_t)s * max_len + t] : cfg.pad_idx;
         h_out_lens[b] = len;
-        if (h_scores) h_scores[b] = scores[b];
+        if (h_scores) h_scores[b] = scores[s];
     }
 }
 

@@ -100,6 +100,54 @@ def test_s2st_chain_on_rows_of_different_lengths(spec, report_dir):
     assert max(errs) < 2e-3
 
 
+@pytest.mark.parametrize("spec", [common.EOS_MIXED, common.EOS_SPREAD])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_live_row_compaction_of_a_40_row_batch(spec, use_graph, report_dir, monkeypatch):
+    """Greedy generation above 16 rows moves the rows still generating into the slots of finished rows in front whenever they
+    fit into fewer 16-row groups (model_decoder.hip: run_generate_text, row_swap_kernel) and lowers the live-row counter the
+    step kernels read.  A row's results must not depend on its slot: ids, lengths, scores and the captured decoder outputs of
+    the compacted run equal the un-compacted run's BIT FOR BIT (SC_GREEDY_COMPACT=0) and the oracle's (ids exact, hidden 2e-4)."""
+    from oracle import unity as ou
+
+    cfg, tt, orc, hip = _env(spec)
+    ws = []
+    for rep in range(5):
+        ws += common.waves(AUDIO, start=100 * rep)
+    fb, lens = orc.collate_fbank(ws)
+    seqs, enc, enc_lens, margins = orc.s2tt(fb, lens, "fra", (1, 200), CAP)
+    want_lens = [len(s) for s in seqs]
+    assert len(seqs) == 40 and len(set(want_lens)) >= 3, want_lens
+
+    def run():
+        return hip.generate_text(enc.cuda().contiguous(), enc_lens.tolist(), tt.target_prefix("fra"), soft_max_seq_len=(1, 200),
+                                 hard_max_seq_len=CAP, use_graph=use_graph, source_len=int(lens.max()))
+
+    monkeypatch.setenv("SC_GREEDY_COMPACT", "0")
+    ids0, lens0, sc0, hid0 = run()
+    hid0 = hid0.clone()
+    monkeypatch.setenv("SC_GREEDY_COMPACT", "1")
+    ids1, lens1, sc1, hid1 = run()
+    # the prompt holds 2 tokens: generation starts at step 1, the host looks at the flags after steps 4, 8, ...; a row of n tokens
+    # writes its EOS at step n - 2
+    alive_at_polls = [sum(n - 2 > t for n in want_lens) for t in range(4, max(want_lens) - 2, 4)]
+    _log(report_dir, "eos_compaction", spec=spec, use_graph=use_graph, lens=sorted(want_lens), alive_at_polls=alive_at_polls,
+         min_margin=min(min(m) for m in margins))
+    assert any(0 < a <= 32 for a in alive_at_polls), "the fixture must reach a compaction"
+    assert lens1.tolist() == want_lens and lens0.tolist() == want_lens
+    assert [ids1[b, : lens1[b]].tolist() for b in range(40)] == seqs
+    assert np.array_equal(ids0, ids1) and np.array_equal(sc0, sc1)
+    for b in range(40):
+        assert torch.equal(hid0[b, : want_lens[b] - 1], hid1[b, : want_lens[b] - 1]), b
+    L = max(want_lens)
+    text = torch.full((40, L), cfg.pad_idx, dtype=torch.int64)
+    for i, sq in enumerate(seqs):
+        text[i, : len(sq)] = torch.tensor(sq)
+    tl = torch.tensor(want_lens) - 1
+    ref = ou.decode_text(orc.P, cfg, text[:, :-1], tl, enc, enc_lens, orc.pos_table)
+    errs = [float((hid1[b, : tl[b]].cpu() - ref[b, : tl[b]]).abs().max()) for b in range(40)]
+    assert max(errs) < 2e-4, errs
+
+
 def _translator(spec):
     from seamless_communication_amd.inference import Translator
     from seamless_communication_amd.inference.translator import DEFAULT_CARDS
