@@ -242,11 +242,12 @@ def pmc_traffic(family: str):
 def decoder_row_stats(text_lens, B, groups, stage_ms):
     """What the ragged text lengths cost the batched greedy step (SURVEY.md section 8e names it as the loss source of the
     data-parallel path): a slice runs until its longest hypothesis ends (the host looks at the finished flags every 4th
-    step), rows that finished earlier ride along.  useful row-steps = generated tokens; computed row-steps = rows of the
-    slice x steps the slice ran."""
+    step), rows that finished earlier ride along - behind the live-row boundary since round 4's compaction, where the step
+    kernels skip them.  useful row-steps = generated tokens; computed row-steps = rows the step kernels worked on, summed
+    over the steps the slice ran (without compaction: rows of the slice x steps)."""
     from seamless_communication_amd.distributed import shard_range
 
-    useful = computed = 0
+    useful = computed = live_rows = 0
     per_slice = []
     for g in range(groups):
         lo, hi = shard_range(B, g, groups)
@@ -259,8 +260,17 @@ def decoder_row_stats(text_lens, B, groups, stage_ms):
                           "rows_alive_at_quartiles": [alive[int(q * (longest - 1))] for q in (0.0, 0.25, 0.5, 0.75, 1.0)]})
         useful += sum(gen)
         computed += (hi - lo) * steps
-    out = {"useful_row_steps": int(useful), "computed_row_steps": int(computed), "row_step_efficiency": round(useful / max(1, computed), 3),
-           "slices": per_slice}
+        # live-row compaction (model_decoder.hip: run_generate_text): at every look at the flags (after generated tokens 4, 8, ...)
+        # the rows still generating are packed to the front and the step kernels stop at their number
+        live = hi - lo
+        for t in range(steps):
+            live_rows += live
+            if t % 4 == 3:
+                live = max(1, sum(1 for x in gen if x > t + 1))
+    compaction = os.environ.get("SC_GREEDY_COMPACT", "1") != "0" and B // groups > 16
+    out = {"useful_row_steps": int(useful), "computed_row_steps": int(live_rows if compaction else computed),
+           "row_step_efficiency": round(useful / max(1, live_rows if compaction else computed), 3),
+           "live_row_compaction": bool(compaction), "row_steps_without_compaction": int(computed), "slices": per_slice}
     if stage_ms.get("text_decoder"):
         out["slice0_decoder_us_per_useful_row_step"] = round(1e3 * stage_ms["text_decoder"] / max(1, sum(l - 2 for l in text_lens[: shard_range(B, 0, groups)[1]])), 2)
     return out
@@ -604,7 +614,7 @@ def main():
             "config": {
                 "workload": "S2ST 10 s 16 kHz audio -> text -> units -> 16 kHz waveform (BASELINE configs[2])",
                 "arch": args.arch, "weights": checkpoint + " (reference state-dict schema, fp16)",
-                "text_lengths": ("hypotheses stop on their own (eos_ramp weights), finished rows ride along in the batched step"
+                "text_lengths": ("hypotheses stop on their own (eos_ramp weights), finished rows ride along in the batched step behind the live-row boundary"
                                  if args.workload == "ragged" else "every hypothesis cut at hard_max_seq_len (plain random weights never emit EOS)"),
                 "batch_per_gpu": B, "global_batch": world * B, "tgt_lang": "fra",
                 "text_search": f"greedy, soft_max_seq_len=(1,200), hard_max_seq_len={args.text_len}",

@@ -1402,6 +1402,9 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     const char* gc_env = getenv("SC_GREEDY_COMPACT");
     const bool compact = c.gen3 && c.d_rows == c.d_rows_greedy && n > 16 && cfg.dec_layers <= ROWSWAP_MAX_LAYERS && n <= 255 &&
                          M % 4 == 0 && !(gc_env && atoi(gc_env) == 0);
+    // steps between two looks of the host at the finished flags (each is a stream synchronisation); SC_GREEDY_POLL for A/B runs
+    const char* poll_env = getenv("SC_GREEDY_POLL");
+    const int poll = poll_env ? std::min(64, std::max(1, atoi(poll_env))) : 4;
     std::vector<int> slot_utt(n);
     for (int b = 0; b < n; ++b) slot_utt[b] = b;
     int live_slots = n;
@@ -1437,7 +1440,7 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
         } else {
             decoder_step(m, c, true);
         }
-        if (((step - first) & 3) == 3 && step < max_len - 2) {
+        if ((step - first + 1) % poll == 0 && step < max_len - 2) {
             SC_HIP(hipMemcpyAsync(fin.data(), c.d_finished, (size_t)n * 4, hipMemcpyDeviceToHost, m.stream));
             SC_HIP(hipStreamSynchronize(m.stream));
             bool all = true;
