@@ -668,6 +668,13 @@ def main():
                 roof["profiled_pass"] = ("one whole-batch pass alone on one stream (the unit of the pipelined schedule; un-overlapped launch durations)"
                                          if whole_pass else
                                          f"the {batcher.groups} slices of the timed passes run one after the other (un-overlapped launch durations)")
+                rows_stat = (result.get("config") or {}).get("decoder_rows") or {}
+                if roof.get("kernel", "").endswith("step_graph") and rows_stat.get("live_row_compaction"):
+                    # the profiler scope of a replayed step counts the K / V rows of every slot of the batch; with the live-row
+                    # compaction the attention kernels read those of the rows still generating only
+                    share = rows_stat["computed_row_steps"] / max(1, rows_stat["row_steps_without_compaction"])
+                    roof["kv_cache_note"] = (f"kv_cache_bytes_per_launch / achieved_incl_kv_cache count all {step_bytes['rows']} slots at every step; "
+                                             f"the live rows are {share:.2f} of them on this batch (config.decoder_rows)")
             result["roofline"] = roof
             result["kernel_families_profiled_step"] = shares
             result["stage_ms_profiled_step"] = {k: round(v, 3) for k, v in stage_ms.items()}
