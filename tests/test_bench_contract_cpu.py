@@ -55,6 +55,24 @@ def test_decoder_row_statistics():
     assert d["slice0_decoder_us_per_useful_row_step"] == round(2000.0 / (8 + 4 + 1 + 10), 2)
 
 
+def test_decoder_row_statistics_with_live_row_compaction(monkeypatch):
+    """More than 16 rows per slice: the greedy decoder packs the rows still generating to the front at every look at the
+    finished flags (after generated tokens 4, 8, ...), the step kernels stop at their number - `computed_row_steps` follows
+    that; SC_GREEDY_COMPACT=0 (and slices of up to 16 rows) report rows x steps as before."""
+    lens = [6] * 10 + [10] * 6 + [14] * 4          # generated tokens 4 / 8 / 12 per row
+    monkeypatch.delenv("SC_GREEDY_COMPACT", raising=False)
+    d = bench.decoder_row_stats(lens, 20, 1, {})
+    assert d["live_row_compaction"] is True and d["row_steps_without_compaction"] == 20 * 12
+    # steps 0-3 on 20 rows, then the 10 rows that wrote their EOS at token 4 are behind the boundary: 4-7 on 10, 8-11 on 4
+    assert d["computed_row_steps"] == 4 * 20 + 4 * 10 + 4 * 4
+    assert d["useful_row_steps"] == 10 * 4 + 6 * 8 + 4 * 12
+    monkeypatch.setenv("SC_GREEDY_COMPACT", "0")
+    d0 = bench.decoder_row_stats(lens, 20, 1, {})
+    assert d0["live_row_compaction"] is False and d0["computed_row_steps"] == 20 * 12
+    monkeypatch.delenv("SC_GREEDY_COMPACT")
+    assert bench.decoder_row_stats(lens[:16], 16, 1, {})["live_row_compaction"] is False
+
+
 def test_margin_histogram_and_parity_block_without_oracle_output():
     assert bench._margin_hist([5e-6, 2e-4, 0.5, 3e-3, 1e-5]) == {"<1e-5": 1, "<1e-4": 1, "<1e-3": 1, "<1e-2": 1, ">=1e-2": 1}
     p = bench.parity_block({"error": "boom"}, None, None, None, None, None, None, None)
