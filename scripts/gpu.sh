@@ -20,6 +20,8 @@
 #   gemmhalf     scripts/gemm_bench.py at SC_PS_HALF=0 / 1 (barrier in front of the slab / mid-slab)
 #   pyprof       rocprofv3 kernel stats of `python $PYPROF` under each setting of $SWEEP
 #   cover        kernel trace of a bench pass -> device-busy share, idle gaps, timeline (scripts/trace_cover.py)
+#                (cover / sqbench are cut off after COVER_TIMEOUT / SQB_TIMEOUT seconds: a process that aborts inside
+#                rocprofv3 leaves the profiler waiting, which cost round 4 its last 16 GPU-minutes)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -108,7 +110,7 @@ for task in "$@"; do
       # matrix-pipe utilisation of EVERY kernel of a bench pass (one --pmc pass of SQ / GRBM counters on the PMC command line)
       rm -rf gpurun_out/${TAG}_sqb
       PMC_ARGS=${PMC_ARGS:---steps 1 --warmup 0 --no-cpu-baseline --no-profile-step --no-latency --no-graph --no-extra}
-      ( cd /tmp && timeout 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_sqb -o bench -- python $R/bench.py $PMC_ARGS > $R/${O}_sqb.log 2>&1; echo "exit $?" >> $R/${O}_sqb.log )
+      ( cd /tmp && timeout -k 10 ${SQB_TIMEOUT:-200} rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_sqb -o bench -- python $R/bench.py $PMC_ARGS > $R/${O}_sqb.log 2>&1; echo "exit $?" >> $R/${O}_sqb.log )
       python scripts/pmc_sq_summary.py gpurun_out/${TAG}_sqb --by-kernel > ${O}_bench_pmc_sq.txt 2>&1
       tail -2 ${O}_sqb.log | cut -c1-200; head -30 ${O}_bench_pmc_sq.txt | cut -c1-220
       find gpurun_out/${TAG}_sqb -name "*.csv" -size +2M -delete 2>/dev/null ;;
@@ -150,7 +152,7 @@ for task in "$@"; do
     cover)
       # kernel trace of two bench passes: how busy the device is over the last pass (union of kernel intervals, idle gaps, timeline)
       rm -rf gpurun_out/${TAG}_cover
-      ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_cover -o b -- python $R/bench.py --steps ${COVER_STEPS:-9} --warmup 1 --no-cpu-baseline --no-latency --no-extra --no-profile-step > $R/${O}_cover.log 2>&1; echo "exit $?" >> $R/${O}_cover.log )
+      ( cd /tmp && timeout -k 10 ${COVER_TIMEOUT:-150} rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_cover -o b -- python $R/bench.py --steps ${COVER_STEPS:-9} --warmup 1 --no-cpu-baseline --no-latency --no-extra --no-profile-step > $R/${O}_cover.log 2>&1; echo "exit $?" >> $R/${O}_cover.log )
       f=$(find gpurun_out/${TAG}_cover -name "*kernel_trace.csv" | head -1)
       ms=$(python -c "import json,sys; print(json.loads([l for l in open('${O}_cover.log') if l.startswith('{')][-1])['ms_per_step'])" 2>/dev/null || echo 260)
       [ -n "$f" ] && python scripts/trace_cover.py $f --window-ms $ms --bin-ms ${COVER_BIN:-5} --skip-tail-ms ${COVER_SKIP_TAIL:-$(python -c "print(3.5 * $ms)")} > ${O}_cover.txt 2>&1; head -90 ${O}_cover.txt | cut -c1-200
