@@ -86,6 +86,14 @@ def parse_args():
     ap.add_argument("--dec-priority", type=int, nargs="?", const=1, default=0,
                     help="greedy decoder steps on a stream of the highest (1) / lowest (-1) priority of each handle (sc_set_decoder_priority), no CU mask")
     ap.add_argument("--cu-layout", default="low", choices=["low", "xcd"], help="mask layout of --dec-cus (runtime.cu_masks)")
+    ap.add_argument("--engine-slots", type=int, default=64,
+                    help="decode engine (pipeline schedule): ONE greedy decoder-step chain shared by the passes in flight, this many rows "
+                         "per step, continuous refill (runtime.DecodeEngine); 0 = every pass runs its own chain (round 4)")
+    ap.add_argument("--no-engine", action="store_true", help="same as --engine-slots 0")
+    ap.add_argument("--engine-low-water", type=int, default=-1,
+                    help="the engine pauses below this many rows while announced rows are on their way (-1: half of the slots)")
+    ap.add_argument("--engine-poll", type=int, default=4, help="steps between two looks of the engine at the finished flags")
+    ap.add_argument("--engine-wait-ms", type=int, default=150, help="longest pause below the low-water mark")
     ap.add_argument("--arch", default="base_v2", choices=["base_v2", "tiny_v2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -221,13 +229,13 @@ def pmc_traffic(family: str):
         # one replayed decoder step = all launches between two position increments: sum the step's kernels of the PMC run
         # (which launches them eagerly, --no-graph) and divide by the number of steps (= add_i32 launches)
         step_kernels = ("gemvp_kernel<", "gemv3_kernel<", "vocab3_kernel<", "reduce3_kernel<", "reduce_ln_kernel", "dattn_kernel<",
-                        "ln3_kernel", "embed3_kernel", "argmax_finalize_kernel", "add_i32_kernel")
+                        "ln3_kernel", "embed3_kernel", "argmax_finalize_kernel", "add_i32_kernel", "engine_finalize_kernel")
         total, steps = 0.0, 0
         for row in rows:
             if any(k in row["kernel"] for k in step_kernels):
                 total += float(row["hbm_bytes_per_launch_corrected"]) * int(row["launches"])
-                if "add_i32_kernel" in row["kernel"]:
-                    steps = int(row["launches"])
+                if "add_i32_kernel" in row["kernel"] or "engine_finalize_kernel" in row["kernel"]:
+                    steps += int(row["launches"])  # the closing launch of a step (own chain / decode engine)
         if steps > 0 and total > 0:
             return total / steps, name + " (sum over the kernels of a step / steps)"
         return None, None
@@ -433,8 +441,11 @@ def main():
         args.schedule = "pipeline"
     args.pipeline_passes = args.schedule == "pipeline"
     args.free_run = args.schedule == "freerun"
+    if args.no_engine or not args.pipeline_passes:
+        args.engine_slots = 0
     if args.microbatches <= 0:
-        args.microbatches = 3 if args.pipeline_passes else 2
+        # passes in flight: with the engine a pass waits for the shared chain to get to its rows, so one more is kept in flight
+        args.microbatches = (4 if args.engine_slots > 0 else 3) if args.pipeline_passes else 2
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -484,6 +495,15 @@ def main():
 
     batcher = MicroBatcher(translator, min(args.microbatches, B), decoder_cus=args.dec_cus, cu_layout=args.cu_layout,
                            decoder_priority=args.dec_priority)
+    engine_cfg = None
+    if args.engine_slots > 0 and batcher.groups > 1:
+        max_len, s_enc = MicroBatcher.engine_geometry(translator, ns, opts)
+        low = args.engine_low_water if args.engine_low_water >= 0 else args.engine_slots // 2
+        engine_cfg = dict(slots=args.engine_slots, rows=max(4 * args.engine_slots, (batcher.groups + 1) * B), poll=args.engine_poll,
+                          low_water=min(low, args.engine_slots), max_wait_ms=args.engine_wait_ms, use_graph=not args.no_graph)
+        batcher.enable_engine(max_len, s_enc, **engine_cfg)
+        engine_cfg.update(max_len=max_len, s_enc=s_enc)
+        log(f"decode engine: {engine_cfg}")
     last = {}
     gather_s = []  # wall time of every ragged all-gather of ids (N > 1): two collectives + the host packing around them
 
@@ -552,6 +572,8 @@ def main():
     free_run = (args.free_run or args.pipeline_passes) and batcher.groups > 1
     stagger = args.stagger if args.stagger >= 0 else (warm_s / batcher.groups if args.warmup > 0 else 0.0)
     fence()
+    if batcher.engine is not None:
+        batcher.engine.stats(reset=True)
     t0 = time.perf_counter()
     step_marks = [t0]
     if free_run:
@@ -575,7 +597,8 @@ def main():
             step_marks.append(time.perf_counter())  # a pass ends with its ids / waveforms on the host: no extra sync
     fence()
     elapsed = time.perf_counter() - t0
-    log(f"timed region: {args.steps} steps in {elapsed:.3f} s; last step {stage_ms}")
+    engine_stats = batcher.engine.stats() if batcher.engine is not None else None
+    log(f"timed region: {args.steps} steps in {elapsed:.3f} s; last step {stage_ms}; engine {engine_stats}")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -633,6 +656,7 @@ def main():
                 "pass_latency_ms": (round(1e3 * float(np.mean(batcher.last_pass_seconds)), 1) if args.pipeline_passes and free_run and
                                     getattr(batcher, "last_pass_seconds", None) else round(ms_per_step, 1)),
                 "microbatch_schedule": ((f"{batcher.groups} whole-batch passes in flight (pipelined across passes), start offsets {stagger * 1e3:.0f} ms"
+                                         + ("; greedy text generation on ONE shared decoder-step chain (decode engine)" if batcher.engine is not None else "")
                                          if args.pipeline_passes else f"free-running slices, start offsets {stagger * 1e3:.0f} ms")
                                         if free_run else "lock-step (join per pass)"),
                 "decoder_stream_priority": ("default" if not args.dec_priority or args.dec_cus > 0 else ("highest" if args.dec_priority > 0 else "lowest")),
@@ -641,6 +665,28 @@ def main():
             "stage_ms_last_step_slice0": {k: round(v, 3) for k, v in stage_snapshot.items()},
             "load_seconds": round(load_s, 1),
         }
+        if engine_stats is not None:
+            # the shared chain over the timed region: what a pass costs in steps and what a useful row-step costs in engine time
+            es = engine_stats
+            rows_cfg = result["config"]["decoder_rows"]
+            eng = {**engine_cfg, "steps": int(es["steps"]), "steps_per_pass": round(es["steps"] / max(1, args.steps), 2),
+                   "mean_rows_per_step": round(es["row_steps"] / max(1, es["steps"]), 2), "max_rows_in_a_step": int(es["max_live"]),
+                   "row_steps": int(es["row_steps"]), "useful_row_steps": int(es["useful_row_steps"]),
+                   "row_step_efficiency": round(es["useful_row_steps"] / max(1, es["row_steps"]), 3),
+                   "busy_ms_per_pass": round(1e-3 * es["busy_us"] / max(1, args.steps), 2),
+                   "paused_ms_per_pass": round(1e-3 * es["wait_us"] / max(1, args.steps), 2),
+                   "decoder_us_per_useful_row_step": round(es["busy_us"] / max(1, es["useful_row_steps"]), 2),
+                   "rows_retired": int(es["rows_retired"]), "requests": int(es["requests"])}
+            result["config"]["decode_engine"] = eng
+            # under the engine a pass's "text_decoder" stage time is its WAIT for the shared chain, not chain time: the per-row-step
+            # cost of the chain is the engine's busy time over the useful row-steps it retired
+            rows_cfg["slice0_decoder_us_per_useful_row_step"] = eng["decoder_us_per_useful_row_step"]
+            rows_cfg["computed_row_steps"] = int(round(es["row_steps"] / max(1, args.steps)))
+            rows_cfg["row_step_efficiency"] = eng["row_step_efficiency"]
+            rows_cfg["live_row_compaction"] = "decode engine: finished rows leave their slots, waiting rows of any pass take them"
+            result["config"]["text_lengths"] = ("hypotheses stop on their own (eos_ramp weights); the rows of all passes in flight share ONE "
+                                                "decoder-step chain with continuous refill (decode engine)")
+        result["config"]["rows_at_length_cap"] = int(sum(1 for n in text_lens if n >= args.text_len))
 
     # ---- one extra profiled step: per-launch HIP events on the library's stream ----------
     if not args.no_profile_step:
@@ -778,15 +824,28 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
     except Exception as e:  # noqa: BLE001
         out["s2st_beam5"] = {"error": repr(e)[:300]}
     if args.pipeline_passes and batcher.groups > 1:
+        from seamless_communication_amd.distributed import MicroBatcher
+
+        class _Sub(MicroBatcher):  # k of the existing views (no new handles), no engine
+            def __init__(self, parent, k):
+                self.groups, self.views, self.pool = k, parent.views[:k], parent.pool
+                self.torch_streams, self.decoder_cus, self.engine = parent.torch_streams[:k], parent.decoder_cus, None
+
+        if batcher.engine is not None:
+            try:  # round 4's schedule on the same box, same process: three whole-batch passes in flight, every pass its own chain
+                batcher.engine.close()
+                batcher.engine = None
+                three = _Sub(batcher, min(3, batcher.groups))
+                k = 2 * three.groups
+                one = timed(lambda: three.predict_passes(wav_dev, ns, three.groups, "S2ST", "fra", text_generation_opts=opts), 1) / three.groups
+                dt = timed(lambda: three.predict_passes(wav_dev, ns, k, "S2ST", "fra", stagger_s=one, text_generation_opts=opts), 1) / k
+                out["own_chains"] = {"metric": "S2ST utterances/s, same workload, round 4's schedule: three whole-batch passes in flight, one "
+                                               "decoder chain per pass (no decode engine)",
+                                     "value": B / dt, "ms_per_step": 1e3 * dt, "rtf": dt / (B * AUDIO_SECONDS)}
+            except Exception as e:  # noqa: BLE001
+                out["own_chains"] = {"error": repr(e)[:300]}
         try:  # the lock-step schedule of rounds 1-3 on the same workload: two concurrent slices, joined after every pass
-            from seamless_communication_amd.distributed import MicroBatcher
-
-            class _Two(MicroBatcher):  # two of the existing views (no new handles)
-                def __init__(self, parent):
-                    self.groups, self.views, self.pool = 2, parent.views[:2], parent.pool
-                    self.torch_streams, self.decoder_cus = parent.torch_streams[:2], parent.decoder_cus
-
-            two = _Two(batcher)
+            two = _Sub(batcher, 2)
             dt = timed(lambda: two.predict(wav_dev, ns, "S2ST", "fra", text_generation_opts=opts), 3)
             out["lockstep"] = {"metric": "S2ST utterances/s, same workload, lock-step schedule (two 32-utterance slices joined after every pass)",
                                "value": B / dt, "ms_per_step": 1e3 * dt, "rtf": dt / (B * AUDIO_SECONDS)}

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 7
+#define SC_ABI_VERSION 8
 #define SC_MAX_UPSAMPLES 8
 #define SC_MAX_RESBLOCK_KERNELS 4
 #define SC_MAX_RESBLOCK_DILATIONS 4
@@ -225,6 +225,50 @@ int32_t sc_text_max_len(const sc_model* m, const sc_gen_opts* opts, int32_t s_en
 int sc_generate_text(sc_model* m, const float* d_enc, int32_t n, int32_t s_enc, const int32_t* h_enc_lens,
                      const sc_gen_opts* opts, const int32_t* h_prefix, int32_t prefix_len, int32_t* h_out_ids,
                      int32_t* h_out_lens, float* h_out_scores, float* d_dec_hidden);
+
+/* Decode engine (ABI 8; no reference counterpart - the reference generates one batch at a time, inference/generator.py:
+ * 227-299, and has no serving layer).  ONE greedy decoder-step chain per GPU, shared by every handle it is attached to: a
+ * greedy sc_generate_text call on such a handle hands its rows to the engine after projecting their encoder K / V, the engine
+ * puts them into free slots of its captured step, advances every slot at its row's own position, drops a row when it has
+ * emitted EOS (or reached its own length limit) and refills the slot with a waiting row of any request - the decoder's
+ * weights are streamed once per step for the rows of all passes in flight, a hypothesis costs as many steps as it has tokens,
+ * and no pass carries its finished rows.  Per row the results (ids, lengths, scores, captured decoder outputs) are those of
+ * the call without an engine, bit for bit: a row's arithmetic depends neither on its slot nor on its neighbours nor on the
+ * step at which it entered.  Calls that do not fit (beam search, step processors, longer limits than the engine was built
+ * for, other min_seq_len / unk_penalty) run on the handle's own chain as before.
+ *   slots        rows per step (1..512; 0 = 64)                 rows   row states kept: rows in slots + rows that wait (0 = 4 x slots)
+ *   max_len      longest hypothesis (prompt + tokens + EOS) a request may ask for (the K / V positions kept per row)
+ *   s_enc        longest encoder output a request may bring
+ *   poll         steps between two looks of the engine at the finished flags (0 = 4)
+ *   low_water    with fewer rows than this the engine pauses WHILE announced rows (sc_engine_expect) are still on their way,
+ *                at most max_wait_ms (0 = 100) - a step costs the same for 5 rows as for 64; 0 = never pause
+ *   use_graph    replay the step from a captured hipGraph
+ * The engine runs its own host thread and HIP stream; sc_engine_free stops it (requests still inside fail).  The model handle
+ * given to sc_engine_create (and its weights) must outlive the engine, the engine the handles it is attached to. */
+typedef struct sc_engine sc_engine;
+typedef struct sc_engine_opts {
+    int32_t slots, rows, max_len, s_enc;
+    int32_t min_seq_len;
+    float unk_penalty;
+    int32_t poll, low_water, max_wait_ms, use_graph;
+} sc_engine_opts;
+typedef struct sc_engine_stats {
+    int64_t steps;            /* step replays */
+    int64_t row_steps;        /* sum over the steps of the rows in slots */
+    int64_t useful_row_steps; /* sum over retired rows of the positions they needed (length - 1) */
+    int64_t rows_admitted, rows_retired, requests, max_live;
+    double busy_us;           /* wall time of the engine thread between starting an admit/step/look round and its end */
+    double wait_us;           /* wall time paused below low_water */
+} sc_engine_stats;
+sc_engine* sc_engine_create(sc_model* m, const sc_engine_opts* opts);
+void sc_engine_free(sc_engine* e);
+/* e != NULL: greedy sc_generate_text calls of handle m that fit go through the engine (same device, same weights); NULL detaches */
+int sc_engine_attach(sc_model* m, sc_engine* e);
+/* handle m will submit n_rows rows soon (called when a pass starts, before its encoder stage): lets the engine wait for them
+ * instead of stepping a nearly empty chain; the announcement ends with the handle's next sc_generate_text call, whatever
+ * path that takes, or with n_rows < 0 (takes back up to -n_rows rows) */
+int sc_engine_expect(sc_model* m, int32_t n_rows);
+int sc_engine_get_stats(sc_engine* e, sc_engine_stats* out, int32_t reset);
 
 /* Teacher-forced decoder pass over given tokens (UnitYModel.decode without
  * state bag, models/unity/model.py:154-180).  h_tokens [n][s_text];

@@ -11,7 +11,7 @@ from typing import Optional
 
 LIB_PATH = Path(__file__).resolve().parent / "libseamless_hip.so"
 
-SC_ABI_VERSION = 7
+SC_ABI_VERSION = 8
 SC_MAX_UPSAMPLES = 8
 SC_MAX_RESBLOCK_KERNELS = 4
 SC_MAX_RESBLOCK_DILATIONS = 4
@@ -77,6 +77,20 @@ class sc_gen_opts(C.Structure):
     ]
 
 
+class sc_engine_opts(C.Structure):
+    _fields_ = [
+        ("slots", _i), ("rows", _i), ("max_len", _i), ("s_enc", _i), ("min_seq_len", _i), ("unk_penalty", C.c_float),
+        ("poll", _i), ("low_water", _i), ("max_wait_ms", _i), ("use_graph", _i),
+    ]
+
+
+class sc_engine_stats(C.Structure):
+    _fields_ = [
+        ("steps", C.c_int64), ("row_steps", C.c_int64), ("useful_row_steps", C.c_int64), ("rows_admitted", C.c_int64),
+        ("rows_retired", C.c_int64), ("requests", C.c_int64), ("max_live", C.c_int64), ("busy_us", C.c_double), ("wait_us", C.c_double),
+    ]
+
+
 _P = C.c_void_p
 _PI = C.POINTER(C.c_int32)
 
@@ -103,6 +117,11 @@ SIGNATURES = {
     "sc_text_max_len": (_i, [_P, C.POINTER(sc_gen_opts), _i]),
     "sc_generate_text": (C.c_int, [_P, _P, _i, _i, _P, C.POINTER(sc_gen_opts), _P, _i, _P, _P, _P, _P]),
     "sc_decode_text": (C.c_int, [_P, _P, _i, _i, _P, _P, _i, _P]),
+    "sc_engine_create": (_P, [_P, C.POINTER(sc_engine_opts)]),
+    "sc_engine_free": (None, [_P]),
+    "sc_engine_attach": (C.c_int, [_P, _P]),
+    "sc_engine_expect": (C.c_int, [_P, _i]),
+    "sc_engine_get_stats": (C.c_int, [_P, C.POINTER(sc_engine_stats), _i]),
     "sc_t2u_nar": (C.c_int, [_P, _P, _i, _i, _P, _P, C.c_float, _P, _PI, _PI]),
     "sc_get_units": (C.c_int, [_P, _P]),
     "sc_get_durations": (C.c_int, [_P, _P, _P, _P]),

@@ -1,12 +1,19 @@
 // extern "C" surface of libseamless_hip.so (declared in include/seamless_hip.h).
 #include <cstring>
 
+#include "engine.h"
 #include "model.h"
 
 using namespace sc;
 
 struct sc_model {
     Model m;
+};
+
+struct sc_engine {
+    std::unique_ptr<Engine> e;
+    int device = 0;
+    const void* weights = nullptr;  // identity of the model the engine was built on (the text embedding's address)
 };
 
 #define SC_API_BEGIN try {
@@ -219,6 +226,55 @@ int sc_generate_text(sc_model* m, const float* d_enc, int32_t n, int32_t s_enc, 
     SC_HIP(hipSetDevice(m->m.device));
     run_generate_text(m->m, d_enc, n, s_enc, h_enc_lens, *opts, h_prefix, prefix_len, h_out_ids, h_out_lens, h_out_scores,
                       d_dec_hidden, nullptr, 0);
+    SC_API_END
+}
+
+sc_engine* sc_engine_create(sc_model* m, const sc_engine_opts* opts) {
+    sc_engine* h = nullptr;
+    try {
+        SC_CHECK(m && opts, "sc_engine_create: null argument");
+        SC_HIP(hipSetDevice(m->m.device));
+        h = new sc_engine();
+        h->device = m->m.device;
+        h->weights = m->m.text_embed;
+        h->e.reset(new Engine(m->m, *opts));
+        return h;
+    } catch (const sc::Error&) {
+    } catch (const std::exception& e) {
+        sc::set_error("sc_engine_create: unexpected C++ exception: %s", e.what());
+    }
+    delete h;
+    return nullptr;
+}
+
+void sc_engine_free(sc_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    delete e;
+}
+
+int sc_engine_attach(sc_model* m, sc_engine* e) {
+    SC_API_BEGIN
+    SC_CHECK(m, "sc_engine_attach: null handle");
+    if (m->m.engine) m->m.engine->expect(m->m, -m->m.engine_announced);
+    if (e) SC_CHECK(e->e && e->device == m->m.device && e->weights == m->m.text_embed,
+                    "sc_engine_attach: the engine was built on another model or device");
+    m->m.engine = e ? e->e.get() : nullptr;
+    m->m.engine_announced = 0;
+    SC_API_END
+}
+
+int sc_engine_expect(sc_model* m, int32_t n_rows) {
+    SC_API_BEGIN
+    SC_CHECK(m, "sc_engine_expect: null handle");
+    if (m->m.engine && n_rows != 0) m->m.engine->expect(m->m, n_rows);
+    SC_API_END
+}
+
+int sc_engine_get_stats(sc_engine* e, sc_engine_stats* out, int32_t reset) {
+    SC_API_BEGIN
+    SC_CHECK(e && e->e && out, "sc_engine_get_stats: null argument");
+    e->e->stats(out, reset != 0);
     SC_API_END
 }
 

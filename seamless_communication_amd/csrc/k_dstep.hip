@@ -410,7 +410,9 @@ __global__ __launch_bounds__(256) void reduce_ln_kernel(ReduceLnArgs p) {
 // clamped, masked afterwards), online soft-max across trips.  q (and the new k / v row of self-attention) arrive as
 // split-K partial sums of their projection and are added here, bias last.  The result leaves as split planes.
 // --------------------------------------------------------------------------------------------- //
-template <bool CROSS, bool ANC>
+// ROWS (decode engine): slot b of the step works on row state slot_rp[b].x at position slot_rp[b].y - the K / V cache rows,
+// the encoder K / V and kv_lens are indexed by the row state, q and the output planes by the slot.
+template <bool CROSS, bool ANC, bool ROWS>
 __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     const int lane = threadIdx.x & 63;
     const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -418,14 +420,21 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     const int b = pair / p.heads, hd = pair - b * p.heads;
     if (p.d_rows && b >= *p.d_rows) return;  // a row behind the live rows (beam search: finished utterances; greedy: compaction)
     const int c = lane & 15, g = lane >> 4;
-    const int pos = CROSS ? 0 : *p.d_pos;
-    const int kv_len = CROSS ? min(p.kv_lens[b], p.cap) : pos + 1;
+    int r = b, pos = 0;
+    if (ROWS) {
+        const int2 rp = p.slot_rp[b];
+        r = rp.x;
+        pos = CROSS ? 0 : rp.y;
+    } else if (!CROSS) {
+        pos = *p.d_pos;
+    }
+    const int kv_len = CROSS ? min(p.kv_lens[r], p.cap) : pos + 1;
     // row index clamp of the loads.  Cross-attention clamps to the capacity, not to the row's own length: every row of
     // the projected encoder K/V is initialised (finite), so the addresses do not have to wait for kv_lens[b]; keys behind
     // the length are masked below.  Self-attention rows behind `pos` are uninitialised memory and are never touched.
     const int last = CROSS ? p.cap - 1 : kv_len - 1;
     // beam search: the beams of an utterance share its encoder K / V (projected once per utterance, in utterance order)
-    const int crow = CROSS ? ((ANC && p.kv_item) ? p.kv_item[b / p.kv_row_div] : b / p.kv_row_div) : b;
+    const int crow = ROWS ? r : (CROSS ? ((ANC && p.kv_item) ? p.kv_item[b / p.kv_row_div] : b / p.kv_row_div) : b);
     const float* kc = p.kcache + (int64_t)crow * p.cache_bs + hd * 64 + 4 * c;
     const float* vc = p.vcache + (int64_t)crow * p.cache_bs + hd * 64 + 4 * c;
 
@@ -501,8 +510,8 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     }
     if (!CROSS && g == 0) {  // append the new key / value row (the loads above may have raced with it: row `pos` is
                              // taken from the registers below, never from memory)
-        *reinterpret_cast<float4*>(p.kcache + (int64_t)b * p.cache_bs + (int64_t)pos * p.cache_ld + hd * 64 + 4 * c) = kn;
-        *reinterpret_cast<float4*>(p.vcache + (int64_t)b * p.cache_bs + (int64_t)pos * p.cache_ld + hd * 64 + 4 * c) = vn;
+        *reinterpret_cast<float4*>(p.kcache + (int64_t)r * p.cache_bs + (int64_t)pos * p.cache_ld + hd * 64 + 4 * c) = kn;
+        *reinterpret_cast<float4*>(p.vcache + (int64_t)r * p.cache_bs + (int64_t)pos * p.cache_ld + hd * 64 + 4 * c) = vn;
     }
 
     float m_run = -INFINITY, l_run = 0.f;
@@ -739,13 +748,17 @@ void launch_dattn(const DAttnArgs& a, bool cross, hipStream_t s) {
     // (row, head) pairs per workgroup: a CU pulls ~45 GB/s of cold K / V whatever its workgroup looks like
     // (profiles/r3_micro_percu.txt), so the pairs are spread over at least 256 workgroups before they are stacked
     const int ppw = std::max(1, std::min(4, pairs / 256));
-    if (cross && a.kv_item) hipLaunchKernelGGL((dattn_kernel<true, true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
-    else if (cross) hipLaunchKernelGGL((dattn_kernel<true, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+    if (a.slot_rp) {  // decode engine: per-slot row state and position
+        SC_CHECK(!a.anc && !a.kv_item && a.kv_row_div == 1, "dattn: the per-slot row state excludes the beam-search tables");
+        if (cross) hipLaunchKernelGGL((dattn_kernel<true, false, true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+        else hipLaunchKernelGGL((dattn_kernel<false, false, true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+    } else if (cross && a.kv_item) hipLaunchKernelGGL((dattn_kernel<true, true, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+    else if (cross) hipLaunchKernelGGL((dattn_kernel<true, false, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
     else if (a.anc) {
         SC_CHECK((int64_t)a.nb * a.cache_bs * 4 < (1ll << 32) && a.cache_ld * 4 < (1ll << 31), "dattn: K/V cache too large for the ancestor-table addressing");
-        hipLaunchKernelGGL((dattn_kernel<false, true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+        hipLaunchKernelGGL((dattn_kernel<false, true, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
     }
-    else hipLaunchKernelGGL((dattn_kernel<false, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
+    else hipLaunchKernelGGL((dattn_kernel<false, false, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
     SC_LAUNCH_CHECK();
 }
 

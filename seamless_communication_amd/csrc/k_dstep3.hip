@@ -419,9 +419,16 @@ __global__ __launch_bounds__(256) void reduce3_kernel(Reduce3Args p) {
     }
     if (p.hfix) reinterpret_cast<float4*>(p.hfix + (int64_t)row * p.C)[tid] = make_float4(o4[0], o4[1], o4[2], o4[3]);
     if (p.hrow) {
-        const int pos = p.d_pos ? *p.d_pos : 0;
+        int hr = row, pos;
+        if (p.slot_rp) {  // decode engine: the slot's row state and its own position
+            const int2 rp = p.slot_rp[row];
+            hr = rp.x;
+            pos = rp.y;
+        } else {
+            pos = p.d_pos ? *p.d_pos : 0;
+        }
         if (pos < p.hrow_rows)
-            reinterpret_cast<float4*>(p.hrow + (int64_t)row * p.hrow_bs + (int64_t)pos * p.C)[tid] = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            reinterpret_cast<float4*>(p.hrow + (int64_t)hr * p.hrow_bs + (int64_t)pos * p.C)[tid] = make_float4(o4[0], o4[1], o4[2], o4[3]);
     }
 }
 
@@ -471,11 +478,20 @@ __global__ __launch_bounds__(256) void ln3_kernel(const float* __restrict__ xg, 
 // QKV product's own)
 __global__ __launch_bounds__(256) void embed3_kernel(const int* __restrict__ tok, const __half* __restrict__ embed, float scale,
                                                      const float* __restrict__ pos_table, const int* __restrict__ d_pos,
-                                                     float* __restrict__ xg, int XRB, int C) {
+                                                     float* __restrict__ xg, int XRB, int C, const int2* __restrict__ slot_rp,
+                                                     const int* __restrict__ d_rows) {
     const int row = blockIdx.x, tid = threadIdx.x;
     if (tid >= (C >> 2)) return;
-    const int pos = d_pos ? *d_pos : 0;
-    const int token = tok[row];
+    if (d_rows && row >= *d_rows) return;
+    int r = row, pos;
+    if (slot_rp) {  // decode engine: the slot's row state and its own position
+        const int2 rp = slot_rp[row];
+        r = rp.x;
+        pos = rp.y;
+    } else {
+        pos = d_pos ? *d_pos : 0;
+    }
+    const int token = tok[r];
     const half4_t e = *reinterpret_cast<const half4_t*>(embed + (int64_t)token * C + 4 * tid);
     const float4 pe = *reinterpret_cast<const float4*>(pos_table + (int64_t)pos * C + 4 * tid);
     float4 a;
@@ -561,12 +577,17 @@ __global__ __launch_bounds__(64 * WAVES) void vocab3_kernel(Vocab3Args p) {
             *reinterpret_cast<u32x4_t*>(act_lds + (size_t)idx * 16) = v;
         }
     }
-    const int am_step = p.am_pos ? *p.am_pos : 0;
-    const bool am_force = (p.am_force_eos_step >= 0 && am_step == p.am_force_eos_step);
+    const int m = r0 + n;
+    int am_step = p.am_pos ? *p.am_pos : 0, am_force_step = p.am_force_eos_step;
+    if (!LOGITS && p.slot_rp && m < p.M) {  // decode engine: every row at its own position, with its own length limit
+        const int2 rp = p.slot_rp[m];
+        am_step = rp.y;
+        am_force_step = p.limit_row[rp.x] - 2;
+    }
+    const bool am_force = (am_force_step >= 0 && am_step == am_force_step);
     const bool am_no_eos = am_step < p.am_min_step_for_eos;
     float best = -INFINITY, mm = -INFINITY, ss = 0.f;
     int bidx = 0x7fffffff;
-    const int m = r0 + n;
     __syncthreads();
 
     while (t < t_hi) {
@@ -765,10 +786,10 @@ void launch_reduce3(const Reduce3Args& p, hipStream_t s) {
 }
 
 void launch_embed3(const int* tok, const __half* embed, float scale, const float* pos_table, const int* d_pos, float* xg, int XRB,
-                   int rows, int C, hipStream_t s) {
+                   int rows, int C, hipStream_t s, const int2* slot_rp, const int* d_rows) {
     SC_CHECK(C % 8 == 0 && C <= 1024, "embed3: C=%d unsupported", C);
     if (rows <= 0) return;
-    hipLaunchKernelGGL(embed3_kernel, dim3(rows), dim3(256), 0, s, tok, embed, scale, pos_table, d_pos, xg, XRB, C);
+    hipLaunchKernelGGL(embed3_kernel, dim3(rows), dim3(256), 0, s, tok, embed, scale, pos_table, d_pos, xg, XRB, C, slot_rp, d_rows);
     SC_LAUNCH_CHECK();
 }
 
@@ -808,7 +829,8 @@ void launch_vocab3(const Vocab3Args& a0, hipStream_t s) {
     a.w_bytes = (uint32_t)(packed_weight_halfs(a.N, a.K) * 2);
     const int groups = vocab3_groups(a.M);
     a.halves = cdiv(a.M, 32);  // 32-row groups per tile group (the arg-max epilogue is used up to 64 rows, the logits mode beyond)
-    SC_CHECK(a.logits || a.M <= 64, "vocab3: the fused arg-max epilogue takes at most 64 rows (M=%d)", a.M);
+    SC_CHECK(a.logits || a.M <= 64 || a.slot_rp, "vocab3: the fused arg-max epilogue takes at most 64 rows outside the decode engine (M=%d)", a.M);
+    SC_CHECK(!a.slot_rp || (a.limit_row && !a.logits), "vocab3: the per-slot step rules need limit_row and the fused epilogue");
     a.tpg = cdiv(a.NT_total, groups);
     SC_CHECK(a.logits || a.am_tiles_cap >= groups, "vocab3: arg-max partial buffer holds %d groups, need %d", a.am_tiles_cap, groups);
     SC_CHECK(!a.logits || a.ldl >= a.N, "vocab3: logits row stride %lld < N=%d", (long long)a.ldl, a.N);

@@ -252,6 +252,9 @@ struct DAttnArgs {
     const int* anc = nullptr;
     const int* kv_item = nullptr;  // cross (beam search): row b reads the encoder K / V of item kv_item[b / kv_row_div] (null: b / kv_row_div)
     const int* d_rows = nullptr;   // see Gemv3Args::d_rows: (row, head) pairs of rows behind *d_rows return at once
+    // decode engine (engine.hip): slot b works on row state slot_rp[b].x at position slot_rp[b].y (d_pos unused): the K / V
+    // cache rows, the encoder K / V rows and kv_lens are indexed by the row state, q and the output planes by the slot
+    const int2* slot_rp = nullptr;
     __half* Oh = nullptr;          // output planes [heads*8][ORB][8]
     __half* Ol = nullptr;
     int ORB = 32;
@@ -337,10 +340,12 @@ struct Reduce3Args {
     float* hfix = nullptr;
     int rows = 0, C = 0;
     const int* d_rows = nullptr;  // see Gemv3Args::d_rows
+    const int2* slot_rp = nullptr;  // decode engine: the captured row of slot s goes to hrow[slot_rp[s].x] at position slot_rp[s].y
 };
 void launch_reduce3(const Reduce3Args& a, hipStream_t s);
+// slot_rp != null (decode engine): slot s embeds tok[slot_rp[s].x] at position slot_rp[s].y; slots behind *d_rows are skipped
 void launch_embed3(const int* tok, const __half* embed, float scale, const float* pos_table, const int* d_pos, float* xg, int XRB,
-                   int rows, int C, hipStream_t s);
+                   int rows, int C, hipStream_t s, const int2* slot_rp = nullptr, const int* d_rows = nullptr);
 void launch_ln3(const float* xg, int XRB, const float* gamma, const float* beta, __half* Hh, __half* Hl, int RB, int rows, int C,
                 hipStream_t s);
 void launch_rows_to_kgm(const float* x, int64_t ldx, int rows, int C, int XRB, float* xg, hipStream_t s);
@@ -363,6 +368,10 @@ struct Vocab3Args {
     int am_pad_idx = -1, am_eos_idx = -1, am_unk_idx = -1;
     float am_unk_penalty = 0.f;
     const int* d_rows = nullptr;  // see Gemv3Args::d_rows
+    // decode engine: the step rules of slot m are those of row state slot_rp[m].x at position slot_rp[m].y (am_pos unused),
+    // forced EOS at position limit_row[row state] - 2 (am_force_eos_step unused)
+    const int2* slot_rp = nullptr;
+    const int* limit_row = nullptr;
     // filled by the launcher
     int KS = 0, NT_total = 0, tpg = 0, halves = 1;
     uint32_t w_bytes = 0;
@@ -581,5 +590,53 @@ struct RowSwapArgs {
     float* hidden = nullptr;  // [rows][cap - 1][M] or null
 };
 void launch_row_swap(const RowSwapArgs& a, hipStream_t s);
+
+// ---- decode engine (k_engine.hip, engine.hip) ---------------------------------------------------------------------
+// One greedy step chain per GPU shared by every pass in flight.  A ROW STATE r (0 .. rows-1) owns everything that lives as
+// long as a hypothesis: K / V cache rows, encoder K / V, token history, captured decoder outputs, position, flags.  A SLOT s
+// (0 .. slots-1) is a row of the step's activations; slot_rp[s] = {row state, its position}.  The live slots are packed to
+// the front (*d_rows of them); admitting a row or dropping a finished one only rewrites slot_rp - no cache row moves.
+struct EngineRows {
+    int* tok = nullptr;         // [rows] token fed at the next step
+    int* pos = nullptr;         // [rows] position fed at the next step
+    int* finished = nullptr;    // [rows]
+    int* out_len = nullptr;     // [rows] length of the hypothesis incl. prompt and EOS
+    int* limit = nullptr;       // [rows] longest hypothesis of the row's request (forced EOS at position limit - 2)
+    int* prefix_len = nullptr;  // [rows] prompt tokens (positions 0 .. prefix_len-2 are fed from hist, nothing is chosen there)
+    int* enc_lens = nullptr;    // [rows]
+    float* score = nullptr;     // [rows]
+    int* hist = nullptr;        // [rows][cap]
+    float* hidden = nullptr;    // [rows][cap - 1][M] captured decoder outputs
+    int cap = 0, M = 0;
+};
+// closing launch of an engine step: combines the vocabulary projection's per-group records of every live slot (same
+// expressions as argmax_finalize_kernel), applies the row's own forced-EOS / prompt rules, appends the token, and advances the
+// row's position (a finished row keeps its position and is fed padding until the host drops it from the live slots)
+struct EngineFinalizeArgs {
+    const float4* part = nullptr;  // [tiles][slots]
+    int tiles = 0, slots = 0;
+    const float* eos_logit = nullptr;  // [slots]
+    int2* slot_rp = nullptr;
+    const int* d_rows = nullptr;
+    int pad_idx = 0, eos_idx = 0;
+    EngineRows rows;
+};
+void launch_engine_finalize(const EngineFinalizeArgs& a, hipStream_t s);
+// new rows: one record each (uploaded by the host), state initialised on the device
+constexpr int ENGINE_MAX_PREFIX = 12;
+struct EngineAdmitRec {
+    int rid, limit, prefix_len, enc_len;
+    int prefix[ENGINE_MAX_PREFIX];
+};
+void launch_engine_admit(const EngineAdmitRec* d_recs, int n, const EngineRows& rows, int pad_idx, hipStream_t s);
+// slot_rp[s] = {rids[s], pos[rids[s]]} for s < n_live, {0, 0} behind; *d_rows = n_live
+void launch_engine_set_slots(const int* d_rids, int n_live, int slots, int2* slot_rp, const int* pos, int* d_rows, hipStream_t s);
+// finished rows leave: decoder outputs 0 .. out_len-2 of row state rid -> dst[t][M] (zeros up to dst_rows), and
+// {out_len, score bits, hist[0 .. cap)} -> stage[i][2 + cap]
+struct EngineRetireRec {
+    int rid, dst_rows;
+    float* dst;  // nullable
+};
+void launch_engine_retire(const EngineRetireRec* d_recs, int n, const EngineRows& rows, int* stage, hipStream_t s);
 
 }  // namespace sc

@@ -232,6 +232,7 @@ struct ModelData {
 
 struct DecodeSession;
 void delete_decode_session(DecodeSession* s);
+class Engine;
 
 // State bag of the streaming decoder between sc_mma_begin and the sc_mma_step calls of one policy round.
 // Kept ACROSS policy rounds while the geometry fits (max_len unchanged, encoder length within cap_enc): the buffers then
@@ -298,6 +299,11 @@ struct Model : ModelData {
 
     // buffers + captured step graph of the greedy text generation, kept across calls (model_decoder.hip)
     std::unique_ptr<DecodeSession, void (*)(DecodeSession*)> dec_session{nullptr, delete_decode_session};
+
+    // decode engine attached to this handle (sc_engine_attach; not owned): greedy sc_generate_text calls that fit it hand
+    // their rows to the engine's shared step chain; engine_announced = rows announced with sc_engine_expect, not yet submitted
+    Engine* engine = nullptr;
+    int engine_announced = 0;
 
     Model() = default;
     Model(const Model&) = delete;

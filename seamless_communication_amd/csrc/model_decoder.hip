@@ -10,11 +10,13 @@
 #include <cstdlib>
 #include <mutex>
 
-#include "model.h"
+#include "dstep.h"
+#include "engine.h"
 
 namespace sc {
 
 static std::mutex g_capture_mutex;
+std::mutex& capture_mutex() { return g_capture_mutex; }
 
 int text_max_len(const Model& m, const sc_gen_opts& o, int s_enc) {
     int max_len;
@@ -30,59 +32,9 @@ void run_generate_text_beam(Model& m, const float* d_enc, int n, int s_enc, cons
 
 namespace {
 
-struct StepCtx {
-    int nb = 0, cap = 0, s_enc = 0;
-    int* d_pos = nullptr;
-    int* d_tok = nullptr;
-    int* d_hist = nullptr;
-    int* d_finished = nullptr;
-    int* d_out_len = nullptr;
-    int* d_enc_lens = nullptr;
-    float* d_lprob = nullptr;
-    float* d_score = nullptr;
-    float *x = nullptr, *h = nullptr, *wide = nullptr, *att = nullptr, *hN = nullptr, *logits = nullptr;
-    std::vector<float*> kcache, vcache;  // per layer [nb][cap][M]
-    std::vector<float*> cross_kv;        // per layer [nb*s_enc][2M]
-    float* dec_hidden = nullptr;         // [nb][cap-1][M] or null
-    float* partial = nullptr;            // split-K partial sums [splits][nb][<=3M]
-    float4* am_part = nullptr;           // fused arg-max records [tiles][nb]
-    int am_tiles = 0;
-    float* am_eos_logit = nullptr;       // [nb]
-    int min_seq_len = 1, force_eos_step = -1;
-    float unk_penalty = 0.f;
-    // which decoder stack runs (null = the UnitY text decoder) and the monotonic p_choose hook
-    const DecStack* stack = nullptr;
-    bool pchoose = false;           // compute p_choose[layer][head] of this step's (single) row
-    const float* d_kenergy = nullptr;  // [layers][M]: k_energy_proj of the last pooled encoder position
-    float* d_pchoose = nullptr;        // [layers][heads]
-    float* qe0 = nullptr;              // [layers][M] scratch x2 for the query energy MLPs
-    float* qe1 = nullptr;
-    float* d_hq = nullptr;             // [layers][M]: every layer's normed cross-attention input of the p_choose step
-    // second-generation step (k_dstep.hip): activations between the launches as split fp16 planes [K/8][rb][8]
-    int rb = 0;  // row slots of the planes (32 or 64); 0 = first-generation step
-    int am_ntl = 4;  // 32-feature tiles per workgroup of the fused vocabulary projection
-    __half *hH = nullptr, *hL = nullptr;      // LayerNorm output       [M/8][rb][8]
-    __half *attH = nullptr, *attL = nullptr;  // attention output       [M/8][rb][8]
-    __half *wideH = nullptr, *wideL = nullptr;  // FFN inner activation [ffn/8][rb][8]
-    Buf<__half> planes;                       // backing store of the six planes
-    int touch_ahead = 0;  // > 0: the weight toucher runs this many layers ahead on Model::touch_stream (SC_DSTEP_TOUCH)
-    // third-generation step (k_dstep3.hip): fp32 residual stream in k-group-major order, complete q / k / v rows
-    bool gen3 = false;
-    float* xg = nullptr;    // [M/8][rb][8]
-    float* qkvr = nullptr;  // [nb][M]: the cross-attention query rows
-    int rg_small = 16, rg_ffn = 32;  // rows per row group of the N = M products / FFN-in (tuning knobs, SC_D3_*)
-    int ffn_in_mode = 1;   // 0: partials + reduce/LN launch + packed product; 1 / 2: LayerNorm inside the product (2 tiles / 1 tile)
-    int ffn_out_mode = 1;  // 0: gemvp, 8 K ranges; 1: gemv3 2 tiles x 512-wide K slices; 2: gemv3 1 tile x 1024-wide
-    int cross_row_div = 1;  // beam search: live row r reads the encoder K / V of cache row r / cross_row_div (one per utterance)
-    const int* anc = nullptr;  // beam search on the packed step kernels: K/V ancestor table [nb][cap] (DAttnArgs::anc)
-    // beam search, row-group chain: live rows packed to the front, *d_rows of them; slot u holds utterance kv_item[u]
-    const int* d_rows = nullptr;
-    int* d_rows_greedy = nullptr;  // greedy generation: the same counter, written by the live-row compaction (run_generate_text)
-    const int* kv_item = nullptr;
-    float* qkv3 = nullptr;  // [nb][3M] complete q | k | v rows: the wide step (> 64 live rows) projects them on gemv3
-};
-
 DecStack mma_stack(const Model& m);  // defined with the streaming decoder below
+
+}  // namespace
 
 DecStack unity_stack(const Model& m) {
     DecStack w;
@@ -100,6 +52,8 @@ DecStack unity_stack(const Model& m) {
     w.max_seq_len = m.cfg.text_max_seq_len;
     return w;
 }
+
+namespace {
 
 // the v1 autoregressive T2U decoder (unit vocabulary: bos 0, pad 1, eos 2, unk 3; t2u_builder.py:143-147)
 DecStack t2u_ar_stack(const Model& m) {
@@ -265,6 +219,8 @@ bool proj_partials(Model& m, StepCtx& c, const float* in, int64_t ld_in, const L
     return true;
 }
 
+}  // namespace
+
 // ---- second-generation step (k_dstep.hip) --------------------------------------------------------------------
 bool step2_eligible(const Model& m, const DecStack& W, int nb) {
     const int M = m.cfg.model_dim;
@@ -288,6 +244,9 @@ void alloc_step2(Model& m, StepCtx& c, int ffn_dim) {
     c.wideH = c.attL + pm;
     c.wideL = c.wideH + pf;
 }
+
+namespace {
+
 
 // the same plane layout over an existing allocation (streaming state: the planes outlive the call)
 void alloc_step2_views(Model& m, StepCtx& c, int ffn_dim, __half* base) {
@@ -508,6 +467,8 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
     launch_add_i32(c.d_pos, 1, m.stream);
 }
 
+}  // namespace
+
 // ---- third-generation step (k_dstep3.hip) ---------------------------------------------------------------------
 // 9 launches per layer: QKV (packed product, K-range partials) | self-attention | out-proj (+bias +residual inside) |
 // q (LayerNorm inside) | cross-attention | out-proj (+bias +residual inside) | FFN-in (LayerNorm inside, ReLU, planes) |
@@ -531,6 +492,9 @@ bool step3_wide_eligible(const Model& m, const DecStack& W, int nb) {
            gemv3_supported(nb, M, M, IN3_LN) && gemv3_supported(nb, W.ffn_dim, M, IN3_LN);  // the LayerNorm-fused q / FFN-in launches
 }
 
+namespace {
+
+
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -541,7 +505,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
     const int M = cfg.model_dim, nb = c.nb, H = cfg.num_heads;
     const std::vector<DecoderLayer>& layers = *W.layers;
     const int n_layers = (int)layers.size();
-    launch_embed3(c.d_tok, W.embed, sqrtf((float)M), W.pos, c.d_pos, c.xg, c.rb, nb, M, m.stream);
+    launch_embed3(c.d_tok, W.embed, sqrtf((float)M), W.pos, c.d_pos, c.xg, c.rb, nb, M, m.stream, c.slot_rp, c.slot_rp ? c.d_rows : nullptr);
     launch_ln3(c.xg, c.rb, layers[0].self_ln.g, layers[0].self_ln.b, c.hH, c.hL, c.rb, nb, M, m.stream);
     auto out_resid = [&](const Linear& L) {  // x += att . W^T + b, finished inside the product
         Gemv3Args a;
@@ -560,6 +524,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         if (decoder_output) {  // also fp32 rows (c.hN) and the per-position capture (the reference's teacher-forced pass)
             r.hrow = c.dec_hidden, r.hrow_bs = (int64_t)(c.cap - 1) * M, r.hrow_rows = c.dec_hidden ? c.cap - 1 : 0, r.d_pos = c.d_pos;
             r.hfix = c.hN;
+            r.slot_rp = c.slot_rp;
         }
         launch_reduce3(r, m.stream);
     };
@@ -603,6 +568,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         a.heads = H;
         a.anc = c.anc;
         a.d_rows = c.d_rows;
+        a.slot_rp = c.slot_rp;
         launch_dattn(a, /*cross=*/false, m.stream);
         out_resid(l.self_out);
         // encoder-decoder attention: the query projection applies its LayerNorm itself
@@ -634,6 +600,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         x.ORB = c.rb;
         x.nb = nb;
         x.heads = H;
+        x.slot_rp = c.slot_rp;
         launch_dattn(x, /*cross=*/true, m.stream);
         // feed-forward network: the inner activation stays in split planes
         if (c.ffn_in_mode == 0 && nb <= 64) {  // K-range partials + reduce / LayerNorm launch, then the packed product on planes
@@ -675,10 +642,22 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         v.am_min_step_for_eos = c.min_seq_len, v.am_force_eos_step = c.force_eos_step;
         v.am_pad_idx = W.pad_idx, v.am_eos_idx = W.eos_idx, v.am_unk_idx = W.unk_idx, v.am_unk_penalty = c.unk_penalty;
         v.d_rows = c.d_rows;
+        v.slot_rp = c.slot_rp, v.limit_row = c.limit_row;
         launch_vocab3(v, m.stream);
+        if (c.slot_rp) {  // decode engine: per-row rules and positions (the closing launch advances them)
+            EngineFinalizeArgs f;
+            f.part = c.am_part, f.tiles = vocab3_groups(nb), f.slots = nb, f.eos_logit = c.am_eos_logit;
+            f.slot_rp = c.slot_rp, f.d_rows = c.d_rows, f.pad_idx = W.pad_idx, f.eos_idx = W.eos_idx;
+            f.rows.tok = c.d_tok, f.rows.pos = c.pos_row, f.rows.finished = c.d_finished, f.rows.out_len = c.d_out_len;
+            f.rows.limit = c.limit_row, f.rows.prefix_len = c.prefix_row, f.rows.enc_lens = c.d_enc_lens, f.rows.score = c.d_score;
+            f.rows.hist = c.d_hist, f.rows.hidden = c.dec_hidden, f.rows.cap = c.cap, f.rows.M = M;
+            launch_engine_finalize(f, m.stream);
+            return;
+        }
         launch_argmax_finalize(c.am_part, vocab3_groups(nb), nb, c.am_eos_logit, c.d_pos, c.force_eos_step, W.pad_idx, W.eos_idx,
                                c.d_tok, c.d_hist, c.cap, c.d_finished, c.d_out_len, c.d_score, m.stream);
     }
+    SC_CHECK(!c.slot_rp, "decoder step: the decode engine's step always projects");
     launch_add_i32(c.d_pos, 1, m.stream);
 }
 
@@ -711,8 +690,6 @@ int decoder_step_family(const Model& m, int rows, int caller) {
     if (rows > 64) return 4;
     return step3_eligible(m, W, rows) ? 3 : 2;
 }
-
-namespace {
 
 // One decoder step for all batch rows: feeds d_tok at position *d_pos.
 void decoder_step(Model& m, StepCtx& c, bool project) {
@@ -815,8 +792,6 @@ void decoder_step(Model& m, StepCtx& c, bool project) {
     }
     launch_add_i32(c.d_pos, 1, m.stream);
 }
-
-}  // namespace
 
 // --------------------------------------------------------------------------------------------- //
 // Streaming monotonic decoder (cfg 5).  One row; the state lives in the handle between calls.
@@ -1268,6 +1243,7 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
         SC_CHECK(o.beam_size >= 1, "sc_generate_text: beam_size=%d", o.beam_size);
         SC_CHECK(o.no_repeat_ngram_size >= 0, "sc_generate_text: no_repeat_ngram_size=%d", o.no_repeat_ngram_size);
         if (o.beam_size > 1 || o.no_repeat_ngram_size > 0) {  // step processors run in the host-driven step loop
+            if (m.engine) m.engine->expect(m, -n);
             run_generate_text_beam(m, d_enc, n, s_enc, h_enc_lens, o, h_prefix, prefix_len, h_out_ids, h_out_lens, h_scores,
                                    d_dec_hidden);
             return;
@@ -1281,6 +1257,15 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     SC_CHECK(s_enc <= 4096, "sc_generate_text: encoder length %d > 4096", s_enc);
     for (int i = 0; i < n; ++i)
         SC_CHECK(h_enc_lens[i] > 0 && h_enc_lens[i] <= s_enc, "sc_generate_text: enc_lens[%d]=%d out of range", i, h_enc_lens[i]);
+
+    // ---- decode engine (sc_engine_attach): the rows join the GPU's shared step chain (engine.hip) -------------------------
+    if (!forced && m.engine) {
+        if (m.engine->fits(n, s_enc, max_len, prefix_len, o)) {
+            m.engine->generate(m, d_enc, n, s_enc, h_enc_lens, h_prefix, prefix_len, max_len, h_out_ids, h_out_lens, h_scores, d_dec_hidden);
+            return;
+        }
+        m.engine->expect(m, -n);  // announced rows that run on the handle's own chain after all
+    }
 
     // ---- the run's buffers: a fresh set for teacher forcing, the handle's cached session for generation -------------
     const bool want_hidden = d_dec_hidden != nullptr;

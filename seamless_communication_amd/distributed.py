@@ -10,7 +10,7 @@ bound; lengths are gathered first, then ids padded to the global maximum.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -118,10 +118,12 @@ class MicroBatcher:
     most in the decoder phase (a chain of ~220 short dependent kernels per token that leaves more than half of
     the chip idle on its own; DESIGN.md section 3, profiles/r3_bench_cover_timeline.txt)."""
 
-    def __init__(self, translator, groups: int, decoder_cus: int = 0, cu_layout: str = "low", decoder_priority: int = 0) -> None:
+    def __init__(self, translator, groups: int, decoder_cus: int = 0, cu_layout: str = "low", decoder_priority: int = 0,
+                 engine: Optional[dict] = None) -> None:
         from concurrent.futures import ThreadPoolExecutor
 
         self.groups = max(1, int(groups))
+        self.engine = None
         self.views = [translator] + [translator.fork() for _ in range(self.groups - 1)]
         self.pool = ThreadPoolExecutor(max_workers=self.groups) if self.groups > 1 else None
         # every slice does its torch-side device work (slices, .contiguous(), output tensors) on its own torch stream: the
@@ -134,15 +136,67 @@ class MicroBatcher:
         elif decoder_priority:
             for v in self.views:
                 v.model.set_decoder_priority(int(decoder_priority))
+        if engine:
+            self.enable_engine(**engine)
 
-    def _one(self, view, wav_dev: torch.Tensor, num_samples, task_str, tgt_lang, kwargs):
+    # ---- decode engine: one greedy step chain per GPU shared by every pass in flight (runtime.DecodeEngine) ------------ #
+    def enable_engine(self, max_len: int, s_enc: int, **opts) -> None:
+        """Greedy text generation of every view goes through ONE shared decoder-step chain with continuous refill (per row
+        the results do not change).  ``max_len`` / ``s_enc``: the longest hypothesis / encoder output a pass may bring
+        (``engine_geometry``); passes that do not fit run on their own chain as before."""
+        from .runtime import DecodeEngine
+
+        if self.engine is not None:
+            self.engine.close()
+        self.engine = DecodeEngine(self.views[0].model, max_len, s_enc, **opts)
+        for v in self.views:
+            self.engine.attach(v.model)
+
+    @staticmethod
+    def engine_geometry(translator, num_samples: Sequence[int], text_generation_opts) -> Tuple[int, int]:
+        """(max_len, s_enc) of a speech-input pass over waveforms of ``num_samples`` samples: what ``Translator.predict``
+        will ask ``sc_generate_text`` for (fbank frames padded to a multiple of 2, the adaptor's output length, the length
+        rule applied to the frame count)."""
+        import ctypes as C
+
+        m = translator.model
+        frames = max(0 if n < 400 else 1 + (int(n) - 400) // 160 for n in num_samples)
+        frames += frames % 2
+        s_enc = int(m.lib.sc_encoder_out_len(m.handle, frames))
+        o = m._gen_opts(1, text_generation_opts.soft_max_seq_len, text_generation_opts.hard_max_seq_len, 1,
+                        text_generation_opts.unk_penalty, True, source_len=frames)
+        return int(m.lib.sc_text_max_len(m.handle, C.byref(o), s_enc)), s_enc
+
+    def _one(self, view, wav_dev: torch.Tensor, num_samples, task_str, tgt_lang, kwargs, ready=None, consumer=None):
+        """``ready``: event recorded by the submitting thread on the stream that produced ``wav_dev`` (the worker's own torch
+        stream is ordered behind it); ``consumer``: the stream the caller will use the returned device tensors on."""
         ts = self.torch_streams[self.views.index(view)] if self.torch_streams else None
-        if ts is None:
-            return self._one_on_current_stream(view, wav_dev, num_samples, task_str, tgt_lang, kwargs)
-        with torch.cuda.stream(ts):
-            out = self._one_on_current_stream(view, wav_dev, num_samples, task_str, tgt_lang, kwargs)
-        ts.synchronize()  # the outputs are used by the caller's thread / stream next
-        return out
+        if self.engine is not None:
+            view.model.engine_expect(int(wav_dev.shape[0]))  # ends with the pass's sc_generate_text call, whatever path it takes
+        try:
+            if ts is None:
+                return self._one_on_current_stream(view, wav_dev, num_samples, task_str, tgt_lang, kwargs)
+            with torch.cuda.stream(ts):
+                if ready is not None:
+                    ts.wait_event(ready)
+                out = self._one_on_current_stream(view, wav_dev, num_samples, task_str, tgt_lang, kwargs)
+                if consumer is not None and out[1] is not None:
+                    # allocated on `ts`, used by the caller's stream: the caching allocator must not hand these blocks to the
+                    # next pass of this worker while the caller's kernels still read them
+                    for w in out[1].audio_wavs:
+                        w.record_stream(consumer)
+            ts.synchronize()  # the outputs are used by the caller's thread / stream next
+            return out
+        finally:
+            if self.engine is not None:
+                view.model.engine_expect(-int(wav_dev.shape[0]))  # a pass that failed before its text stage
+
+    def _submitted_from(self, wav_dev: torch.Tensor):
+        """(event on the submitting thread's current stream, that stream): what the workers order themselves behind."""
+        if self.torch_streams is None or not wav_dev.is_cuda:
+            return None, None
+        cur = torch.cuda.current_stream(wav_dev.device)
+        return cur.record_event(), cur
 
     def _one_on_current_stream(self, view, wav_dev: torch.Tensor, num_samples, task_str, tgt_lang, kwargs):
         if not wav_dev.is_contiguous():
@@ -158,11 +212,12 @@ class MicroBatcher:
         n = wav_dev.shape[0]
         g = min(self.groups, n)
         spans = [shard_range(n, i, g) for i in range(g)]
+        ready, consumer = self._submitted_from(wav_dev)
         if g == 1:
-            outs = [self._one(self.views[0], wav_dev, list(num_samples), task_str, tgt_lang, kwargs)]
+            outs = [self._one(self.views[0], wav_dev, list(num_samples), task_str, tgt_lang, kwargs, ready, consumer)]
         else:
             futs = [self.pool.submit(self._one, self.views[i], wav_dev[lo:hi], list(num_samples[lo:hi]),
-                                     task_str, tgt_lang, kwargs) for i, (lo, hi) in enumerate(spans)]
+                                     task_str, tgt_lang, kwargs, ready, consumer) for i, (lo, hi) in enumerate(spans)]
             outs = [f.result() for f in futs]
         texts: List[str] = []
         units: List[List[int]] = []
@@ -191,12 +246,14 @@ class MicroBatcher:
         if g == 1:
             return [self.predict(wav_dev, num_samples, task_str, tgt_lang, **kwargs) for _ in range(steps)]
         slices = [wav_dev[lo:hi] for lo, hi in spans]  # row ranges of a contiguous matrix: views, no copy
+        ready, consumer = self._submitted_from(wav_dev)
 
         def worker(i):
             if stagger_s > 0 and i > 0:
                 _time.sleep(i * stagger_s)
             lo, hi = spans[i]
-            return [self._one(self.views[i], slices[i], list(num_samples[lo:hi]), task_str, tgt_lang, kwargs) for _ in range(steps)]
+            return [self._one(self.views[i], slices[i], list(num_samples[lo:hi]), task_str, tgt_lang, kwargs, ready, consumer)
+                    for _ in range(steps)]
 
         futs = [self.pool.submit(worker, i) for i in range(g)]
         per_worker = [f.result() for f in futs]
@@ -227,6 +284,7 @@ class MicroBatcher:
         if g == 1:
             return [self.predict(wav_dev, num_samples, task_str, tgt_lang, **kwargs) for _ in range(steps)]
         ns = list(num_samples)
+        ready, consumer = self._submitted_from(wav_dev)
 
         seconds = {}
 
@@ -236,7 +294,7 @@ class MicroBatcher:
             outs = []
             for k in range(i, steps, g):
                 t0 = _time.perf_counter()
-                outs.append((k, self._one(self.views[i], wav_dev, ns, task_str, tgt_lang, kwargs)))
+                outs.append((k, self._one(self.views[i], wav_dev, ns, task_str, tgt_lang, kwargs, ready, consumer)))
                 seconds[k] = _time.perf_counter() - t0
             return outs
 
@@ -252,3 +310,6 @@ class MicroBatcher:
     def close(self) -> None:
         if self.pool is not None:
             self.pool.shutdown(wait=True)
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None

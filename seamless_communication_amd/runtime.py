@@ -187,6 +187,11 @@ class HipS2STModel:
         except Exception:
             pass
 
+    # ---- decode engine (sc_engine_*) --------------------------------------------------------------------- #
+    def engine_expect(self, n_rows: int) -> None:
+        """Announces ``n_rows`` rows this handle will hand to its attached decode engine soon (no-op without one)."""
+        check(self.lib.sc_engine_expect(self.handle, int(n_rows)), "sc_engine_expect")
+
     def _after_torch(self) -> None:
         """Orders the handle's (non-blocking) stream after PyTorch's current stream, where the caller's
         input tensors may still be being produced (slices, ``.contiguous()``, H2D copies)."""
@@ -435,3 +440,53 @@ class HipS2STModel:
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         check(self.lib.sc_last_padding(self.handle, C.byref(a), C.byref(b), C.byref(c)), "sc_last_padding")
         return {"t2u_rows_computed": a.value, "t2u_rows_padded": b.value, "vocoder_rows_computed": c.value}
+
+
+class DecodeEngine:
+    """One greedy decoder-step chain per GPU shared by every handle it is attached to (``sc_engine_*``, include/
+    seamless_hip.h): rows of all passes in flight share the slots of one captured step, each at its own position; finished
+    rows leave at once and waiting rows take their slots.  Per row the results are those of ``generate_text`` without an
+    engine, bit for bit.  Not part of the reference API (the reference generates one batch at a time)."""
+
+    def __init__(self, model: HipS2STModel, max_len: int, s_enc: int, slots: int = 64, rows: int = 0, min_seq_len: int = 1,
+                 unk_penalty: float = 0.0, poll: int = 4, low_water: int = 0, max_wait_ms: int = 100, use_graph: bool = True) -> None:
+        self.lib = model.lib
+        self._model = model  # the weights must outlive the engine
+        o = _lib.sc_engine_opts()
+        o.slots, o.rows, o.max_len, o.s_enc = int(slots), int(rows), int(max_len), int(s_enc)
+        o.min_seq_len, o.unk_penalty = int(min_seq_len), float(unk_penalty)
+        o.poll, o.low_water, o.max_wait_ms, o.use_graph = int(poll), int(low_water), int(max_wait_ms), int(bool(use_graph))
+        self.opts = dict(slots=int(slots) or 64, rows=int(rows) or 4 * (int(slots) or 64), max_len=int(max_len), s_enc=int(s_enc),
+                         poll=int(poll) or 4, low_water=int(low_water), max_wait_ms=int(max_wait_ms) or 100, use_graph=bool(use_graph))
+        self.handle = self.lib.sc_engine_create(model.handle, C.byref(o))
+        if not self.handle:
+            msg = self.lib.sc_last_error()
+            raise SeamlessHipError(f"sc_engine_create failed: {msg.decode() if msg else '?'}")
+        self._attached: List[HipS2STModel] = []
+
+    def attach(self, model: HipS2STModel) -> None:
+        check(self.lib.sc_engine_attach(model.handle, self.handle), "sc_engine_attach")
+        self._attached.append(model)
+
+    def detach(self, model: HipS2STModel) -> None:
+        if model.handle:
+            check(self.lib.sc_engine_attach(model.handle, None), "sc_engine_attach")
+        self._attached = [m for m in self._attached if m is not model]
+
+    def stats(self, reset: bool = False) -> Dict[str, float]:
+        st = _lib.sc_engine_stats()
+        check(self.lib.sc_engine_get_stats(self.handle, C.byref(st), int(reset)), "sc_engine_get_stats")
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            for m in list(self._attached):
+                self.detach(m)
+            self.lib.sc_engine_free(self.handle)
+            self.handle = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass

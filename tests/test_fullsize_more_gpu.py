@@ -170,6 +170,44 @@ def test_ragged_lengths_pipelined_whole_batch_passes(gold, eos, report_dir):
         mb.close()
 
 
+@pytest.mark.parametrize("slots,low_water", [(64, 32), (128, 0)])
+def test_ragged_lengths_through_the_decode_engine(gold, eos, report_dir, slots, low_water):
+    """bench.py's default schedule of round 5: four whole-batch passes in flight whose greedy text generation shares ONE
+    decoder-step chain (runtime.DecodeEngine: rows of different passes next to each other at their own positions, finished rows
+    leave, waiting rows take their slots; 128 slots = the row-group chain cut into row groups).  Every pass of every worker
+    returns the oracle's ids for all 64 utterances; char ids / durations / units of each worker's last pass too."""
+    from seamless_communication_amd.distributed import MicroBatcher
+
+    tr, vsd, lang_map, opts = eos
+    items = fg.items_by_index(gold["b64eos"])
+    wav = torch.stack(_waves(range(64), [10.0] * 64)).cuda()
+    ns = [wav.shape[1]] * 64
+    mb = MicroBatcher(tr, 4)
+    try:
+        max_len, s_enc = MicroBatcher.engine_geometry(tr, ns, opts)
+        assert max_len == gold["meta"]["eos_text_len"]
+        mb.enable_engine(max_len, s_enc, slots=slots, rows=5 * 64, low_water=low_water, max_wait_ms=100)
+        outs = mb.predict_passes(wav, ns, 8, "S2ST", "fra", stagger_s=0.05, text_generation_opts=opts)
+        st = mb.engine.stats()
+        assert len(outs) == 8
+        for k, (texts, units, wavs, text_ids, _) in enumerate(outs):
+            assert len(texts) == len(units) == len(wavs) == 64
+            reports = [fg.compare(items[i], text_ids=text_ids[i]) for i in range(64)]
+            assert all(r["text"] for r in reports), (k, [r["index"] for r in reports if not r["text"]])
+            assert all(units[i] == items[i]["speech_units"] for i in range(64)), k
+        for w, view in enumerate(mb.views):
+            _compare_batch(report_dir, f"eos_engine{slots}_worker{w}", items, list(range(64)), view.last_text_ids, view.last_t2u)
+        by_len = sorted(range(64), key=lambda i: len(items[i]["text_ids"]))
+        _check_waves(report_dir, f"eos_engine{slots}", tr, vsd, lang_map, [by_len[0], by_len[31], by_len[-1]], mb.views[3].last_t2u, outs[7][1], outs[7][2])
+        useful = 8 * sum(len(items[i]["text_ids"]) - 1 for i in range(64))
+        _log(report_dir, f"eos_engine{slots}", steps_per_pass=st["steps"] / 8, rows_per_step=st["row_steps"] / max(1, st["steps"]),
+             efficiency=st["useful_row_steps"] / max(1, st["row_steps"]), busy_ms_per_pass=1e-3 * st["busy_us"] / 8, paused_ms_per_pass=1e-3 * st["wait_us"] / 8)
+        assert st["rows_retired"] == 8 * 64 and st["useful_row_steps"] == useful
+        assert st["max_live"] <= slots and (slots == 64 or st["max_live"] > 64)
+    finally:
+        mb.close()
+
+
 def test_ragged_lengths_one_batch_and_alone(gold, eos, report_dir):
     """40 rows on one stream (the 33..64-row step instantiations) and single utterances: the shortest hypothesis of the
     fixture (it may consist of EOS alone), the longest, and one in between."""

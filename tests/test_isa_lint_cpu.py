@@ -76,8 +76,9 @@ def test_gemvp_loads_are_issued_up_front_with_counted_waits(dstep_isa, inst, loa
     assert not any(o.startswith(("v_accvgpr_read", "v_accvgpr_write", "scratch_")) for o in body)
 
 
-# template arguments: CROSS, ANC (beam search: key / value rows named by the ancestor table)
-@pytest.mark.parametrize("inst,loads", [("dattn_kernelILb0ELb0E", 12 + 32), ("dattn_kernelILb1ELb0E", 4 + 32)])  # the greedy step's two
+# template arguments: CROSS, ANC (beam search: key / value rows named by the ancestor table), ROWS (decode engine: per-slot
+# row state and position - one 8-byte load in front of everything else)
+@pytest.mark.parametrize("inst,loads", [("dattn_kernelILb0ELb0ELb0E", 12 + 32), ("dattn_kernelILb1ELb0ELb0E", 4 + 32)])  # the greedy step's two
 def test_decoder_attention_has_its_operands_in_flight_before_the_first_wait(dstep_isa, inst, loads):
     ops = _ops(_function(dstep_isa, inst))
     first_wait = next(i for i, o in enumerate(ops) if "vmcnt(" in o)
@@ -85,11 +86,24 @@ def test_decoder_attention_has_its_operands_in_flight_before_the_first_wait(dste
     assert not any(o.startswith("scratch_") for o in ops)
 
 
+@pytest.mark.parametrize("inst,early", [("dattn_kernelILb0ELb0ELb1E", 12), ("dattn_kernelILb1ELb0ELb1E", 1)])
+def test_engine_attention_waits_once_for_its_slot_then_has_the_whole_trip_in_flight(dstep_isa, inst, early):
+    """dattn_kernel<*, false, true> (decode engine): the slot's {row state, position} pair is ONE 8-byte load; the projection's
+    partial sums (indexed by the slot) travel with it, then all 32 key / value loads of the first trip are issued before the
+    next wait that drains any of them; no scratch."""
+    ops = _ops(_function(dstep_isa, inst))
+    waits = [i for i, o in enumerate(ops) if "vmcnt(" in o]
+    assert sum(o.startswith("global_load_dwordx4") for o in ops[: waits[0]]) >= early
+    assert sum(o.startswith("global_load_dwordx2") for o in ops[: waits[0]]) <= 1
+    assert sum(o.startswith("global_load_dwordx4") for o in ops[waits[0]: waits[1]]) >= 32
+    assert not any(o.startswith("scratch_") for o in ops)
+
+
 def test_beam_search_attention_fetches_the_table_entries_then_the_whole_trip(dstep_isa):
     """dattn_kernel<false, true>: the 12 projection partials and the 16 ancestor-table entries of the first trip are in
     flight before the first wait, the 32 key / value loads of the trip (addresses = kernel-argument base + a 32-bit offset
     each) before the next one that drains them; no scratch (228 VGPRs: two waves per SIMD like the plain variant)."""
-    ops = _ops(_function(dstep_isa, "dattn_kernelILb0ELb1E"))
+    ops = _ops(_function(dstep_isa, "dattn_kernelILb0ELb1ELb0E"))
     waits = [i for i, o in enumerate(ops) if "vmcnt(" in o]
     head = ops[: waits[0]]
     assert sum(o.startswith("global_load_dwordx4") for o in head) >= 12 and sum(o.startswith("global_load_dword ") or o.startswith("global_load_dword\t") or o == "global_load_dword" or o.startswith("global_load_dword v") for o in head) >= 16
