@@ -86,7 +86,7 @@ def parse_args():
     ap.add_argument("--dec-priority", type=int, nargs="?", const=1, default=0,
                     help="greedy decoder steps on a stream of the highest (1) / lowest (-1) priority of each handle (sc_set_decoder_priority), no CU mask")
     ap.add_argument("--cu-layout", default="low", choices=["low", "xcd"], help="mask layout of --dec-cus (runtime.cu_masks)")
-    ap.add_argument("--engine-slots", type=int, default=64,
+    ap.add_argument("--engine-slots", type=int, default=192,
                     help="decode engine (pipeline schedule): ONE greedy decoder-step chain shared by the passes in flight, this many rows "
                          "per step, continuous refill (runtime.DecodeEngine); 0 = every pass runs its own chain (round 4)")
     ap.add_argument("--no-engine", action="store_true", help="same as --engine-slots 0")
@@ -445,7 +445,8 @@ def main():
         args.engine_slots = 0
     if args.microbatches <= 0:
         # passes in flight: with the engine a pass waits for the shared chain to get to its rows, so one more is kept in flight
-        args.microbatches = (4 if args.engine_slots > 0 else 3) if args.pipeline_passes else 2
+        # (scripts/engine_sweep.py, profiles/r5_engine_sweep.txt: 6 passes in flight fill a 192-slot chain)
+        args.microbatches = (6 if args.engine_slots > 0 else 3) if args.pipeline_passes else 2
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -124,7 +124,13 @@ struct Engine::Impl {
 
 void Engine::Impl::setup(const Model& parent) {
     static_cast<ModelData&>(em) = static_cast<const ModelData&>(parent);
-    SC_HIP(hipStreamCreateWithFlags(&em.stream, hipStreamNonBlocking));
+    if (o.priority != 0) {  // the shared chain is what every pass waits for: its short kernels first (or last) as compute units turn over
+        int lo = 0, hi = 0;
+        SC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = numerically greatest = lowest priority
+        SC_HIP(hipStreamCreateWithPriority(&em.stream, hipStreamNonBlocking, o.priority > 0 ? hi : lo));
+    } else {
+        SC_HIP(hipStreamCreateWithFlags(&em.stream, hipStreamNonBlocking));
+    }
     em.pool.set_stream(em.stream);
     em.hook_pool(em.pool);
     const sc_config& cfg = em.cfg;
@@ -491,8 +497,7 @@ void Engine::generate(Model& m, const float* d_enc, int n, int s_enc, const int3
         if (s_enc == se)
             while (i1 < n && q.rid[i1] == q.rid[i1 - 1] + 1) ++i1;
         for (int li = 0; li < cfg.dec_layers; ++li)
-            linear(m, d_enc + (size_t)i0 * s_enc * M, M, m.dec[li].cross_kv, nullptr, 0, E.c.cross_kv[li] + (size_t)q.rid[i0] * se * 2 * M, 2 * M,
-                   (i1 - i0) * s_enc, ACT_NONE, 1.f);
+            project_cross_kv(m, d_enc + (size_t)i0 * s_enc * M, m.dec[li].cross_kv, E.c.cross_kv[li] + (size_t)q.rid[i0] * se * 2 * M, (i1 - i0) * s_enc);
         i0 = i1;
     }
     SC_HIP(hipEventCreateWithFlags(&q.ready, hipEventDisableTiming));

@@ -95,8 +95,12 @@ __global__ __launch_bounds__(256) void gemvp_kernel(GemvPArgs p) {
     const uint32_t w_voff = (uint32_t)lane * 16u;
     uint32_t a_voff[MT];
     const int live = p.d_rows ? min(*p.d_rows, p.M) : p.M;  // rows behind the live rows are neither read nor written
+    // more than 64 rows (the decode engine's step): grid.z blocks of 32 * MT rows, each the kernel of a <= 64-row launch - a
+    // row's sums do not depend on how many rows the launch covers
+    const int rb0 = blockIdx.z * (32 * MT);
+    if (rb0 >= live) return;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a_voff[i] = (32 * i + n < live) ? (uint32_t)((h * p.RB + 32 * i + n) * 16) : OOB;
+    for (int i = 0; i < MT; ++i) a_voff[i] = (rb0 + 32 * i + n < live) ? (uint32_t)((h * p.RB + rb0 + 32 * i + n) * 16) : OOB;
     const uint32_t a_kstep = (uint32_t)(2 * p.RB * 16);  // bytes per k-step in a plane
     uint32_t kill[NCH];                                  // chunks behind the K range read zeros
 #pragma unroll
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void gemvp_kernel(GemvPArgs p) {
             // out = act(sum + bias) as split planes for the next product: thread -> (row, 8 consecutive features)
             for (int u = tid; u < MT * 128; u += 256) {
                 const int i = u >> 7, row = u & 31, g = (u >> 5) & 3;
-                const int m = 32 * i + row;
+                const int m = rb0 + 32 * i + row;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void gemvp_kernel(GemvPArgs p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = rbase + 8 * q;
-                    const int m = 32 * i + row;
+                    const int m = rb0 + 32 * i + row;
                     const int o = row * 33 + f;
                     float v = (red[0][i][o] + red[1][i][o]) + (red[2][i][o] + red[3][i][o]);
                     if (m < live && feat < p.N) {
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256) void gemvp_kernel(GemvPArgs p) {
                     ss = a + b;
                     mm = nm;
                 }
-                const int m = 32 * i + rbase + 8 * q;
+                const int m = rb0 + 32 * i + rbase + 8 * q;
                 if (f == 0 && m < live) {
                     float4 rec;
                     rec.x = best;
@@ -657,7 +661,7 @@ void launch_pack_weight(const __half* w, int64_t ldw, int N, int K, __half* dst,
 }
 
 bool gemvp_supported(int M, int N, int K) {
-    return M >= 1 && M <= 64 && K % 64 == 0 && packed_weight_halfs(N, K) * 2 < (1ll << 32);
+    return M >= 1 && M <= 512 && K % 64 == 0 && packed_weight_halfs(N, K) * 2 < (1ll << 32);  // > 64 rows: blocks of 64 (grid.z)
 }
 
 // Tiling of the K range: a workgroup covers 4 * NCH chunks of 64 k (4 waves x NCH chunks), NCH in {1, 2, 4} chosen from
@@ -701,9 +705,10 @@ void launch_gemvp(const GemvPArgs& a0, hipStream_t s) {
     if (a.ntl < 1) a.ntl = 1;
     a.w_bytes = (uint32_t)(packed_weight_halfs(a.N, a.K) * 2);
     a.a_bytes = (uint32_t)((int64_t)(a.K / 8) * a.RB * 16);
-    dim3 grid(cdiv(a.NT, a.ntl), splits);
+    dim3 grid(cdiv(a.NT, a.ntl), splits, a.M > 64 ? cdiv(a.M, 64) : 1);
     SC_CHECK(a.epi != EPI_ARGMAX || a.am_tiles_cap >= (int)grid.x, "gemvp: arg-max partial buffer holds %d tiles, need %d",
              a.am_tiles_cap, (int)grid.x);
+    SC_CHECK((int64_t)(a.K / 8) * a.RB * 16 < (1ll << 31), "gemvp: activation planes too large");
     prof::Scope scope(a.M <= 32 ? "gemvp_m32" : "gemvp_m64", 2.0 * a.M * (double)a.N * a.K,
                       2.0 * a.N * (double)a.K + 4.0 * a.M * ((double)a.K + (double)a.N * splits), s);
     const bool two = a.M > 32;

@@ -374,7 +374,13 @@ std::vector<std::vector<int>> plan_length_groups(const std::vector<int>& lens, i
 
 // helpers shared by the stages
 void linear(Model& m, const float* x, int64_t ldx, const Linear& L, const float* res, int64_t ldr, float* y,
-            int64_t ldy, int rows, int act, float alpha);
+            int64_t ldy, int rows, int act, float alpha, bool row_independent = false);
+// encoder-decoder K / V of `rows` encoder rows for one decoder layer ([rows][2M]): ALWAYS the tiled product, so that an
+// utterance's K / V - and with them its hypothesis - do not depend on how many utterances share the call (alone, in a batch,
+// through the decode engine)
+inline void project_cross_kv(Model& m, const float* d_enc, const Linear& L, float* out, int rows) {
+    linear(m, d_enc, L.in, L, nullptr, 0, out, L.out, rows, ACT_NONE, 1.f, /*row_independent=*/true);
+}
 void layernorm(Model& m, const float* x, const LNorm& L, float* y, int rows, int act = ACT_NONE,
                const int* lens = nullptr, int t_per_batch = 1);
 void conv1d(Model& m, const float* x, const Conv& c, const float* res, float* y, int nb, int t_in, int stride, int pad,

@@ -533,8 +533,9 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         const bool last = li + 1 == n_layers;
         int sp = 1;
         DAttnArgs a;
-        if (nb <= 64) {
-            // self attention: q | k | v as K-range partials of the packed product (summed by the attention kernel)
+        if (nb <= 64 || c.slot_rp) {
+            // self attention: q | k | v as K-range partials of the packed product (summed by the attention kernel); the decode
+            // engine keeps this product above 64 slots too (in blocks of 64 rows): a row gets the bits it gets in a 64-slot step
             gemv2(m, c, c.hH, c.hL, l.qkv, 2, &sp);
             a.q = c.partial;
             a.sstride = (int64_t)nb * 3 * M;
@@ -1195,7 +1196,7 @@ void run_decode_text_batched(Model& m, const float* d_enc, int n, int s_enc, con
         // encoder-decoder attention
         layernorm(m, x, l.cross_ln, h, rows);
         linear(m, h, M, l.cross_q, nullptr, 0, wide, M, rows, ACT_NONE, 1.f);
-        linear(m, d_enc, M, l.cross_kv, nullptr, 0, ckv, 2 * M, erows, ACT_NONE, 1.f);
+        project_cross_kv(m, d_enc, l.cross_kv, ckv, erows);
         AttnArgs c;
         c.q = wide;
         c.k = ckv;
@@ -1292,8 +1293,7 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     StepCtx& c = S->c;
 
     // encoder-decoder K/V once per utterance (fairseq2 caches them in the state bag at step 0)
-    for (int li = 0; li < cfg.dec_layers; ++li)
-        linear(m, d_enc, M, m.dec[li].cross_kv, nullptr, 0, c.cross_kv[li], 2 * M, n * s_enc, ACT_NONE, 1.f);
+    for (int li = 0; li < cfg.dec_layers; ++li) project_cross_kv(m, d_enc, m.dec[li].cross_kv, c.cross_kv[li], n * s_enc);
 
     // ---- initial state ------------------------------------------------------------
     std::vector<int32_t> hist((size_t)n * max_len, cfg.pad_idx), init(8 + 4 * n, 0);
@@ -1672,8 +1672,7 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     for (int li = 0; li < L; ++li) {
         cross.emplace_back(m.pp(), (size_t)cross_rows * s_enc * 2 * M);
         c.cross_kv.push_back(cross.back());
-        linear(m, packed_step ? d_enc : enc_rep.get(), M, dec_layers[li].cross_kv, nullptr, 0, c.cross_kv.back(), 2 * M, cross_rows * s_enc,
-               ACT_NONE, 1.f);
+        project_cross_kv(m, packed_step ? d_enc : enc_rep.get(), dec_layers[li].cross_kv, c.cross_kv.back(), cross_rows * s_enc);
     }
     Linear proj;
     proj.w = W.embed;

@@ -723,10 +723,12 @@ void load_model(Model& m, const sc_tensor_desc* t, size_t n) {
 // --------------------------------------------------------------------------- //
 // op helpers
 // --------------------------------------------------------------------------- //
+// row_independent: the tiled product whatever the row count (every tile shape walks K in the same order: a row gets the same
+// bits in a 63-row call and in a 4032-row one); otherwise up to 64 rows take the split-K skinny kernel
 void linear(Model& m, const float* x, int64_t ldx, const Linear& L, const float* res, int64_t ldr, float* y,
-            int64_t ldy, int rows, int act, float alpha) {
+            int64_t ldy, int rows, int act, float alpha, bool row_independent) {
     if (rows <= 0) return;
-    if (rows <= 64 && L.in % 64 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    if (!row_independent && rows <= 64 && L.in % 64 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         SkinnyArgs a;
         a.A = x;
         a.lda = ldx;

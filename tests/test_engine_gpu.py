@@ -4,9 +4,10 @@ requests, each row at its own position, finished rows leaving and waiting rows e
 What has to hold (reference semantics per row: inference/generator.py:227-299 with beam_size 1; step rules ggml/examples/unity/
 fairseq2.cpp:1269-1305): whatever slot a row lands in, whatever its neighbours are and whatever step it enters at, its ids,
 length, score and the decoder outputs captured for the T2U stage are those of the row generated ALONE through
-``sc_generate_text`` without an engine - bit for bit on the <= 64-slot chain (same kernels, a row is one MFMA column), ids exact
-and outputs within the 2e-4 decoder bar on the wide chain (> 64 slots: q | k | v come from the row-group product instead of the
-packed split-K one) - and the oracle's.  Weights: the ``eos_ramp`` variants of the tiny model (rows stop on their own at
+``sc_generate_text`` without an engine, bit for bit (same kernels; a row is one MFMA column, the encoder K / V projection is
+the tiled product whatever the row count) - with one documented exception: the SCORE is a log-sum-exp over 256 102 logits whose
+partial sums are grouped by 256 tile groups up to 32 rows per step and by 128 above, so across that border it agrees to
+rounding only (ids and decoder outputs stay exact) - and the ids are the oracle's.  Weights: the ``eos_ramp`` variants of the tiny model (rows stop on their own at
 different steps), tests/common.py.
 """
 import threading
@@ -119,6 +120,33 @@ def test_rows_through_the_engine_equal_rows_generated_alone(spec, use_graph, rep
                 assert float(hid[b - lo, n - 1:].abs().max()) == 0.0, b
 
 
+def test_more_than_32_slots_keep_ids_and_outputs_of_rows_alone(report_dir):
+    """40 slots: the step runs its 33..64-row instantiations (two MFMA row tiles, 128 instead of 256 vocabulary tile groups).
+    Ids and captured decoder outputs are still those of the row alone, bit for bit; the score - a log-sum-exp over the
+    vocabulary whose partial sums are grouped differently - agrees to rounding."""
+    from seamless_communication_amd.runtime import DecodeEngine
+
+    cfg, tt, hip, seqs, enc, enc_lens, src_len = _env(common.EOS_MIXED, 8)  # 64 rows
+    prefix = tt.target_prefix("fra")
+    alone = _alone(hip, enc, enc_lens, prefix, src_len)
+    eng = DecodeEngine(hip, max_len=CAP, s_enc=enc.shape[1], slots=40, rows=64, poll=4)
+    try:
+        spans = [(0, 30), (30, 64)]
+        outs = _through_engine(hip, eng, enc, enc_lens, prefix, src_len, spans)
+        st = eng.stats()
+    finally:
+        eng.close()
+    _log(report_dir, "engine_40_slots", **st)
+    assert st["max_live"] > 32 and st["rows_retired"] == 64
+    for (lo, hi), (ids, lens, scores, hid) in zip(spans, outs):
+        for b in range(lo, hi):
+            a_ids, a_lens, a_scores, a_hid = alone[b]
+            n = int(a_lens[0])
+            assert ids[b - lo].tolist() == a_ids[0].tolist() == (seqs[b] + [cfg.pad_idx] * (CAP - n)), b
+            assert torch.equal(hid[b - lo, : n - 1], a_hid[0, : n - 1]), b
+            assert abs(float(scores[b - lo]) - float(a_scores[0])) < 1e-4
+
+
 def test_a_batched_call_without_engine_equals_rows_alone():
     """The premise the engine test stands on, checked on its own: sc_generate_text on 24 rows (live-row compaction and all)
     gives every row the bits it gets alone."""
@@ -188,9 +216,9 @@ def test_calls_that_do_not_fit_run_on_the_handles_own_chain():
 
 @pytest.mark.parametrize("slots", [96, 160])
 def test_wide_engine_more_than_64_slots(slots, report_dir):
-    """> 64 slots run the row-group chain cut into row groups (the beam search's wide step) with the fused arg-max epilogue on
-    every 32-row group: ids, lengths exact against the oracle, scores and captured outputs within the decoder bar of the
-    <= 64-slot chain (q | k | v are summed in another order there)."""
+    """> 64 slots run the same kernels as a 33..64-row step, cut into row groups / blocks of 64 rows (the packed q | k | v
+    product included: gemvp_kernel's grid.z), with the fused arg-max epilogue on every 32-row group: ids, lengths, scores and
+    captured decoder outputs equal a 40-row sc_generate_text call's BIT FOR BIT, ids the oracle's."""
     from seamless_communication_amd.runtime import DecodeEngine
 
     cfg, tt, hip, seqs, enc, enc_lens, src_len = _env(common.EOS_MIXED, 25)  # 200 rows
@@ -206,17 +234,15 @@ def test_wide_engine_more_than_64_slots(slots, report_dir):
         eng.close()
     _log(report_dir, "engine_wide", slots=slots, **st)
     assert st["max_live"] > 64 and st["rows_retired"] == n
-    worst = 0.0
     for (lo, hi), (ids, lens, scores, hid) in zip(spans, outs):
         for b in range(lo, hi):
             r_ids, r_lens, r_scores, r_hid = ref[b // 40]
             k = b % 40
             m = int(r_lens[k])
             assert ids[b - lo, : lens[b - lo]].tolist() == seqs[b], b
-            assert int(lens[b - lo]) == m
-            assert abs(float(scores[b - lo]) - float(r_scores[k])) < 1e-3
-            worst = max(worst, float((hid[b - lo, : m - 1] - r_hid[k, : m - 1]).abs().max()) if m > 1 else 0.0)
-    assert worst < 2e-4, worst
+            assert int(lens[b - lo]) == m and ids[b - lo].tolist() == r_ids[k].tolist()
+            assert scores[b - lo] == r_scores[k], (b, scores[b - lo], r_scores[k])
+            assert torch.equal(hid[b - lo, : m - 1], r_hid[k, : m - 1]), b
 
 
 def test_engine_feeds_the_speech_chain(report_dir):
