@@ -51,6 +51,13 @@ def main():
         g, slots = int(kv.get("g", 3)), int(kv.get("slots", 0))
         mb = MicroBatcher(translator, g)
         line = {"config": spec}
+        import os
+
+        for key, env in (("g4", "SC_ENGINE_G4"), ("tpw", "SC_ENGINE_G4_TPW")):  # read by the engine when it is created
+            if key in kv:
+                os.environ[env] = kv[key]
+            else:
+                os.environ.pop(env, None)
         try:
             if slots > 0:
                 max_len, s_enc = MicroBatcher.engine_geometry(translator, ns, opts)

@@ -18,6 +18,7 @@
 // into the row states it was given (on its own stream, under the other passes' work) and waits; the engine thread owns the
 // step loop: admit -> `poll` replays of the captured step -> read the finished flags -> retire.
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <condition_variable>
 #include <deque>
@@ -182,6 +183,12 @@ void Engine::Impl::setup(const Model& parent) {
     if (S > 64) {
         qkv3 = Buf<float>(em.pp(), (size_t)S * 3 * M);
         c.qkv3 = qkv3;
+        // products of the wide step on the row-group-stationary kernel (same bits); SC_ENGINE_G4 = bit mask for A/B timing
+        // (1 FFN-in, 2 FFN-out, 4 cross-attention query, 8 out-projections), SC_ENGINE_G4_TPW = tiles per wave (1 / 2)
+        const char* g4 = getenv("SC_ENGINE_G4");
+        const char* tpw = getenv("SC_ENGINE_G4_TPW");
+        c.g4 = g4 ? atoi(g4) & 15 : 0;  // off: measured slower, alone and under load (profiles/r5_gemv4_ab.txt)
+        c.g4_tpw = tpw ? std::min(2, std::max(0, atoi(tpw))) : 0;
     }
     partial = Buf<float>(em.pp(), (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * S * 3 * M);
     c.partial = partial;
