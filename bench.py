@@ -112,6 +112,8 @@ def parse_args():
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the secondary lines reported under `extra` (S2TT-only, beam 5, streaming p50)")
     ap.add_argument("--extra-timeout", type=int, default=240, help="limit of the streaming child process, seconds")
+    ap.add_argument("--host-loop", action="store_true",
+                    help="with --dry-run: run the timed region's host loop on a stub device and report the host time per pass")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch check only: every rank joins a gloo group on the CPU, rank 0 prints the rank count it saw "
                          "(tests/test_bench_launch_cpu.py); no device, no model")
@@ -409,11 +411,97 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+class _HostStubModel:
+    """Stands in for runtime.HipS2STModel in the host-loop dry run: every stage returns arrays of the shapes and sizes of the
+    benchmark workload (64 utterances, text lengths 9 .. 64, ~526 units each) at once - no device, no device time.  What is left
+    is exactly the host work a rank does per pass around the library calls: tokenizer decode, unit decoding and pad stripping,
+    waveform slicing, thread hand-over, the ragged gather."""
+
+    t2u_variant = 0
+    hop = 320
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.device = torch.device("cpu")
+        rng = np.random.RandomState(7)
+        self._text_lens = rng.randint(9, 65, size=4096)
+        self._unit_lens = rng.randint(46, 1224, size=4096)
+
+    def fork(self):
+        return self
+
+    def engine_expect(self, n):
+        pass
+
+    def fbank(self, wav, num_samples, standardize=True, pad_to_multiple=2):
+        ns = np.asarray(num_samples)
+        frames = np.where(ns < 400, 0, 1 + (ns - 400) // 160).astype(np.int32)
+        T = int(frames.max()) + int(frames.max()) % 2
+        return torch.empty(wav.shape[0], T, 80), frames
+
+    def encode_speech(self, seqs, lens):
+        n = seqs.shape[0]
+        return torch.empty(n, 63, 8), np.full(n, 63, dtype=np.int32)
+
+    def generate_text(self, enc, enc_lens, prefix, hard_max_seq_len=64, want_hidden=True, **kw):
+        n = enc.shape[0]
+        max_len = int(hard_max_seq_len)
+        lens = np.minimum(self._text_lens[:n], max_len).astype(np.int32)
+        ids = np.zeros((n, max_len), dtype=np.int32)
+        for b in range(n):
+            ids[b, : lens[b]] = 1000 + (np.arange(lens[b]) * 37 + b) % 200000
+            ids[b, : len(prefix)] = prefix
+            ids[b, lens[b] - 1] = self.cfg.eos_idx
+        return ids, lens, np.zeros(n, dtype=np.float32), (torch.empty(n, max_len - 1, 8) if want_hidden else None)
+
+    def t2u_nar(self, hidden, text_seqs, text_lens, duration_factor=1.0):
+        n = hidden.shape[0]
+        ul = self._unit_lens[:n].astype(np.int32)
+        su = int(ul.max())
+        units = np.full((n, su), self.cfg.unit_pad_idx, dtype=np.int32)
+        for b in range(n):
+            units[b, : ul[b]] = 4 + (np.arange(ul[b]) * 13 + b) % 10000
+        sc = int(max(text_lens)) * 5
+        return units, ul, np.ones((n, sc), dtype=np.int32), np.zeros((n, sc), dtype=np.int32), np.full(n, sc, dtype=np.int32)
+
+    def vocode(self, units, lang_idx, spkr_idx, unit_lens=None, dur_prediction=False):
+        u = np.asarray(units)
+        return torch.empty(u.shape[0], 1, u.shape[1] * self.hop)
+
+    def last_padding(self):
+        return {"t2u_rows_computed": 0, "t2u_rows_padded": 0, "vocoder_rows_computed": 0}
+
+
+def _host_stub_translator(arch):
+    from seamless_communication_amd import cards
+    from seamless_communication_amd.inference.translator import _ARCHS, Translator
+    from seamless_communication_amd.tokenizer import CharTokenizer, NllbTextTokenizer, UnitTokenizer
+
+    tr = object.__new__(Translator)
+    tr.cfg = _ARCHS[arch]()
+    tr.device = torch.device("cpu")
+    tr.dtype = torch.float16
+    tr.char_tokenizer = CharTokenizer(tr.cfg.char_vocab_size, None)
+    tr.text_tokenizer = NllbTextTokenizer(tr.cfg.text_vocab_size, cards.TEXT_LANGS, "eng", None)
+    tr.unit_tokenizer = UnitTokenizer(cards.NUM_UNITS, cards.UNIT_LANGS, arch)
+    tr.lang_spkr_idx_map = cards.vocoder_lang_spkr_idx_map()
+    tr.model = _HostStubModel(tr.cfg)
+    tr.has_vocoder, tr.apply_mintox, tr.use_graph = True, False, True
+    tr.last_text_ids, tr.last_stage_ms, tr.last_t2u, tr.last_wav_full = [], {}, None, None
+    return tr
+
+
 def dry_run(args):
-    """Launch check on the CPU (gloo): proves that the command line reaches N cooperating ranks."""
+    """Launch check on the CPU (gloo): proves that the command line reaches N cooperating ranks.  ``--host-loop``: every rank
+    additionally runs the REAL host loop of the timed region - `--microbatches` pass workers, Translator.predict's host code, the
+    ragged all-gather of ids after every pass - on a stub device that answers at once (_HostStubModel), pinned to its share of the
+    cores like the real run: `host_ms_per_pass` is the host time a pass costs a rank when the GPU costs nothing, to be held
+    against the GPU's ~220 ms per pass (8 ranks x 7 host threads on one node must not become the bottleneck)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     seen = 1
+    line = {"dry_run": True, "n_gpus": world, "gpus_flag": args.gpus}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
@@ -421,10 +509,47 @@ def dry_run(args):
         dist.all_reduce(t)
         seen = int(t.item())
         world = dist.get_world_size()
+    if args.host_loop:
+        from seamless_communication_amd.distributed import MicroBatcher, all_gather_ragged_lists, pin_rank_to_cores
+        from seamless_communication_amd.inference import SequenceGeneratorOptions
+
+        cores = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        tr = _host_stub_translator(args.arch if args.arch in ("base_v2",) else "base_v2")
+        B = args.batch
+        wav = torch.zeros(B, int(AUDIO_SECONDS * 16000))
+        ns = [wav.shape[1]] * B
+        opts = SequenceGeneratorOptions(beam_size=1, soft_max_seq_len=(1, 200), hard_max_seq_len=args.text_len)
+        mb = MicroBatcher(tr, min(args.microbatches, B))
+        mb.predict_passes(wav, ns, mb.groups, "S2ST", "fra", text_generation_opts=opts)  # warm: imports, tokenizer tables
+        if world > 1:
+            dist.barrier()
+        t_gather = [0.0]
+
+        def gather_pass(k, out):
+            tg = time.perf_counter()
+            all_text, all_units = all_gather_ragged_lists([out[3], out[1]], torch.device("cpu"))
+            assert len(all_text) == len(all_units) == world * B
+            t_gather[0] += time.perf_counter() - tg
+
+        t0 = time.perf_counter()
+        mb.predict_passes(wav, ns, args.steps, "S2ST", "fra", on_pass=gather_pass, text_generation_opts=opts)
+        t_loop = time.perf_counter() - t0
+        t_gather = t_gather[0]
+        mb.close()
+        mine = torch.tensor([1e3 * t_loop / args.steps, 1e3 * t_gather / args.steps], dtype=torch.float64)
+        per_rank = [mine.clone() for _ in range(world)]
+        if world > 1:
+            dist.all_gather(per_rank, mine)
+        line.update(host_loop={"passes": args.steps, "workers_per_rank": mb.groups, "cores_per_rank": len(cores), "utterances_per_pass": B,
+                               "host_ms_per_pass": round(max(float(p[0]) for p in per_rank), 2),  # the ordered gathers of the passes included
+                               "gather_ms_per_pass_gloo": round(max(float(p[1]) for p in per_rank), 2),
+                               "host_ms_per_pass_by_rank": [round(float(p[0]), 2) for p in per_rank]})
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    line["ranks_seen"] = seen
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen, "gpus_flag": args.gpus}), flush=True)
+        print(json.dumps(line), flush=True)
 
 
 def main():
@@ -465,9 +590,15 @@ def main():
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no device ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    rank_cores = []
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
+        # every rank keeps to its own share of the host's cores: its pass workers, the decode engine's thread and the torch threads
+        # that build the synthetic weights (8 ranks x all cores at once would stretch the load phase and jitter the step loop)
+        from seamless_communication_amd.distributed import pin_rank_to_cores
+
+        rank_cores = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     from seamless_communication_amd import cards, synthetic as syn
     from seamless_communication_amd.distributed import MicroBatcher, all_gather_ragged_lists
@@ -580,14 +711,19 @@ def main():
     if free_run:
         # K passes over the per-GPU batch; the micro-batch slices free-run (joined once), the all-gathers of the K
         # passes follow.  Same work as K lock-step passes, see MicroBatcher.predict_steps.
-        run = batcher.predict_passes if args.pipeline_passes else batcher.predict_steps
-        outs = run(wav_dev, ns, args.steps, "S2ST", "fra", stagger_s=stagger, text_generation_opts=opts)
-        for texts, units, wavs, text_ids, st in outs:
+        def gather_pass(k, out):  # the data-parallel path's one exchange: ids of pass k, on this thread, in pass order on every rank
             if world > 1:
                 tg = time.perf_counter()
-                all_text, all_units = all_gather_ragged_lists([text_ids, units], device)
+                all_text, all_units = all_gather_ragged_lists([out[3], out[1]], device)
                 gather_s.append(time.perf_counter() - tg)
                 assert len(all_text) == len(all_units) == world * B
+
+        if args.pipeline_passes:  # the gather of pass k runs while the later passes compute
+            outs = batcher.predict_passes(wav_dev, ns, args.steps, "S2ST", "fra", stagger_s=stagger, on_pass=gather_pass, text_generation_opts=opts)
+        else:
+            outs = batcher.predict_steps(wav_dev, ns, args.steps, "S2ST", "fra", stagger_s=stagger, text_generation_opts=opts)
+            for k, out in enumerate(outs):
+                gather_pass(k, out)
         texts, units, wavs, text_ids, st = outs[-1]
         stage_ms.clear()
         stage_ms.update(st)
@@ -600,10 +736,13 @@ def main():
     elapsed = time.perf_counter() - t0
     engine_stats = batcher.engine.stats() if batcher.engine is not None else None
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s; last step {stage_ms}; engine {engine_stats}")
+    per_rank_s = [elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        every = torch.zeros(world, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(every, mine)
+        per_rank_s = [float(x) for x in every.tolist()]
+        elapsed = max(per_rank_s)  # the job ends with its slowest rank
     stage_snapshot = dict(stage_ms)
     # per-slice T2U data of the LAST TIMED pass (later runs - profiled pass, latency, extras - overwrite the views' copies)
     # (pipelined passes: the worker that ran the last pass holds the whole batch)
@@ -649,6 +788,11 @@ def main():
                 "s_unit_max": int(max(unit_counts)), **padding_info,
                 "parallelism": f"dp{world} (utterances sharded, full replica per GPU, all-gather of ids)",
                 "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                # every rank's own rate over the timed region and how far the slowest is behind the fastest (the job runs at the
+                # slowest rank's pace); host cores each rank is pinned to
+                "per_rank_utt_per_s": [round(B * args.steps / t, 2) for t in per_rank_s],
+                "rank_imbalance": round(max(per_rank_s) / min(per_rank_s), 4),
+                "host_cores_per_rank": len(rank_cores) if rank_cores else None,
                 # the ragged all-gather of text + unit ids that ends a pass (host wall time per call on rank 0, timed passes only)
                 "gather_ms": ({"mean": round(1e3 * float(np.mean(gather_s[-args.steps:])), 3), "max": round(1e3 * float(np.max(gather_s[-args.steps:])), 3),
                                "calls": len(gather_s[-args.steps:])} if gather_s else None),

@@ -185,6 +185,10 @@ void Engine::Impl::setup(const Model& parent) {
         c.qkv3 = qkv3;
         // products of the wide step on the row-group-stationary kernel (same bits); SC_ENGINE_G4 = bit mask for A/B timing
         // (1 FFN-in, 2 FFN-out, 4 cross-attention query, 8 out-projections), SC_ENGINE_G4_TPW = tiles per wave (1 / 2)
+        // rows per row group of the N = 1024 products (out-projections, cross-attention query): 16 is tuned for <= 64 rows
+        // (latency); SC_ENGINE_RG_SMALL for A/B timing of the wide step (same bits whatever the grouping)
+        const char* rgs = getenv("SC_ENGINE_RG_SMALL");
+        if (rgs) c.rg_small = std::min(32, std::max(8, atoi(rgs)));
         const char* g4 = getenv("SC_ENGINE_G4");
         const char* tpw = getenv("SC_ENGINE_G4_TPW");
         c.g4 = g4 ? atoi(g4) & 15 : 0;  // off: measured slower, alone and under load (profiles/r5_gemv4_ab.txt)

@@ -24,6 +24,35 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def balanced_shards(lengths: Sequence[int], world: int) -> List[List[int]]:
+    """Item indices per rank so that every rank gets (almost) the same number of items AND the same total length: items
+    sorted by length, dealt out in a snake (0 1 .. w-1 w-1 .. 1 0 ...).  SURVEY.md section 8(e): ragged inputs are the loss
+    source of the data-parallel path - a contiguous split of a length-sorted corpus would hand one rank all the long
+    utterances; every rank's pass takes as long as its longest shard."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    shards: List[List[int]] = [[] for _ in range(world)]
+    for j, i in enumerate(order):
+        r = j % (2 * world)
+        shards[r if r < world else 2 * world - 1 - r].append(i)
+    return [sorted(s) for s in shards]
+
+
+def pin_rank_to_cores(local_rank: int, local_world: int) -> List[int]:
+    """Gives every rank of a node its own slice of the cores this process may run on (host threads of a rank: the pass workers,
+    the decode engine's thread, the weight builder's torch threads) - eight ranks whose threads roam over all cores take the
+    step loop's host time away from each other.  Returns the cores of this rank ([] when the platform has no affinity call)."""
+    import os
+
+    if not hasattr(os, "sched_getaffinity") or local_world <= 1:
+        return sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cores) // local_world)
+    mine = cores[local_rank * per: (local_rank + 1) * per] or cores[-per:]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(per, 16)))
+    return mine
+
+
 def _gather_rows(t: torch.Tensor, world: int) -> torch.Tensor:
     """all-gather of equally shaped (rows, cols) int32 tensors into one (world, rows, cols) tensor on the same device:
     one collective, no host round trip (RCCL on GPUs; gloo on CPU for the tests)."""
@@ -80,17 +109,21 @@ def all_gather_ragged_ids(seqs: Sequence[Sequence[int]], device: torch.device, p
     return all_gather_ragged_lists([seqs], device, pad)[0]
 
 
-def predict_batch_dp(translator, waveforms: Sequence[torch.Tensor], task_str: str, tgt_lang: str, **predict_kwargs):
+def predict_batch_dp(translator, waveforms: Sequence[torch.Tensor], task_str: str, tgt_lang: str, balance: bool = True, **predict_kwargs):
     """Shards ``waveforms`` over the ranks, runs ``translator.predict`` on the local shard (one batched call) and
     all-gathers the decoded text ids and unit ids (north star: "RCCL all-gather of decoded text/unit ids").
 
     Returns (texts_local, speech_output_local, all_text_ids, all_unit_ids): the last two hold every utterance of the
     global batch in the original order.  Waveforms stay rank-local (41 MB per 64 utterances).  A rank whose shard is
-    empty (fewer utterances than ranks) runs nothing and still takes part in the gather."""
+    empty (fewer utterances than ranks) runs nothing and still takes part in the gather.  ``balance``: utterances are dealt
+    out by length (``balanced_shards``) instead of in contiguous blocks - same results, every rank gets the same audio time."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    lo, hi = shard_range(len(waveforms), rank, world)
-    shard = waveforms[lo:hi]
+    if balance:
+        shards = balanced_shards([int(w.numel()) for w in waveforms], world)
+    else:
+        shards = [list(range(*shard_range(len(waveforms), r, world))) for r in range(world)]
+    shard = [waveforms[i] for i in shards[rank]]
     texts: List[str] = []
     speech = None
     text_ids: List[List[int]] = []
@@ -107,7 +140,13 @@ def predict_batch_dp(translator, waveforms: Sequence[torch.Tensor], task_str: st
         text_ids = [list(t) for t in translator.last_text_ids]
         units = speech.units if speech is not None else [[] for _ in shard]
     all_text, all_units = all_gather_ragged_lists([text_ids, units], translator.device)
-    return texts, speech, all_text, all_units
+    # the gather returns the items in rank order: back to the caller's order
+    order = [i for r in range(world) for i in shards[r]]
+    inv_text: List[List[int]] = [[] for _ in waveforms]
+    inv_units: List[List[int]] = [[] for _ in waveforms]
+    for pos, i in enumerate(order):
+        inv_text[i], inv_units[i] = all_text[pos], all_units[pos]
+    return texts, speech, inv_text, inv_units
 
 
 class MicroBatcher:
@@ -271,40 +310,60 @@ class MicroBatcher:
         return results
 
     def predict_passes(self, wav_dev: torch.Tensor, num_samples: Sequence[int], steps: int, task_str: str, tgt_lang: str,
-                       stagger_s: float = 0.0, **kwargs):
+                       stagger_s: float = 0.0, on_pass=None, **kwargs):
         """``steps`` passes over the same batch, pipelined ACROSS passes: worker i runs passes i, i + groups, ... each over
         the WHOLE batch (one decoder chain of all rows instead of one per slice), worker i starting ``i * stagger_s`` late,
         joined once at the end.  In flight at any time: ``groups`` passes in different phases of the path - with a CU
         partition (``decoder_cus``) the decoder chain of one pass runs on its own compute units under the GEMM-bound
         stages of its neighbours.  Same total work as ``steps`` lock-step passes; the latency of a single pass grows.
-        Returns one ``predict``-style tuple per pass, in pass order."""
+        Returns one ``predict``-style tuple per pass, in pass order.  ``on_pass(k, result)`` (optional) is called on the CALLING
+        thread for pass 0, 1, 2, ... in that order as soon as each is complete, while later passes are still running: the place for
+        the data-parallel path's all-gather of a pass's ids (a collective needs the same order on every rank; passes finish in
+        different orders on different ranks)."""
         import time as _time
+        from concurrent.futures import Future
 
         g = self.groups
         if g == 1:
-            return [self.predict(wav_dev, num_samples, task_str, tgt_lang, **kwargs) for _ in range(steps)]
+            outs = []
+            for k in range(steps):
+                outs.append(self.predict(wav_dev, num_samples, task_str, tgt_lang, **kwargs))
+                if on_pass is not None:
+                    on_pass(k, outs[-1])
+            return outs
         ns = list(num_samples)
         ready, consumer = self._submitted_from(wav_dev)
 
         seconds = {}
+        per_pass = [Future() for _ in range(steps)]
 
         def worker(i):
             if stagger_s > 0 and i > 0:
                 _time.sleep(i * stagger_s)
-            outs = []
-            for k in range(i, steps, g):
-                t0 = _time.perf_counter()
-                outs.append((k, self._one(self.views[i], wav_dev, ns, task_str, tgt_lang, kwargs, ready, consumer)))
-                seconds[k] = _time.perf_counter() - t0
-            return outs
+            k = i
+            try:
+                for k in range(i, steps, g):
+                    t0 = _time.perf_counter()
+                    out = self._one(self.views[i], wav_dev, ns, task_str, tgt_lang, kwargs, ready, consumer)
+                    seconds[k] = _time.perf_counter() - t0
+                    per_pass[k].set_result(out)
+            except BaseException as e:  # noqa: BLE001 - handed to the caller through the pass's future
+                for kk in range(k, steps, g):
+                    if not per_pass[kk].done():
+                        per_pass[kk].set_exception(e)
 
-        futs = [self.pool.submit(worker, i) for i in range(g)]
-        done = dict(kv for f in futs for kv in f.result())
-        self.last_pass_seconds = [seconds[k] for k in sorted(seconds)]  # wall time of every pass, start to finish
+        workers = [self.pool.submit(worker, i) for i in range(g)]
         results = []
-        for k in range(steps):
-            t, speech, ids, st = done[k]
-            results.append((t, speech.units if speech is not None else [], speech.audio_wavs if speech is not None else [], ids, st))
+        try:
+            for k in range(steps):
+                t, speech, ids, st = per_pass[k].result()
+                results.append((t, speech.units if speech is not None else [], speech.audio_wavs if speech is not None else [], ids, st))
+                if on_pass is not None:
+                    on_pass(k, results[-1])
+        finally:
+            for w in workers:
+                w.result()
+        self.last_pass_seconds = [seconds[k] for k in sorted(seconds)]  # wall time of every pass, start to finish
         return results
 
     def close(self) -> None:

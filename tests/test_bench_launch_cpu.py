@@ -33,3 +33,17 @@ def test_more_gpus_than_devices_fails_loudly():
     r = _run("--gpus", "2")  # no --dry-run: this container has no HIP device
     assert r.returncode != 0
     assert "HIP device" in (r.stderr + r.stdout)
+
+
+def test_host_loop_of_two_ranks_stays_far_below_the_gpu_pass_time():
+    """`--dry-run --host-loop`: the timed region's REAL host loop (six pass workers per rank, Translator.predict's host code,
+    the ordered ragged gather after every pass, every rank pinned to its share of the cores) on a stub device that answers at
+    once.  What a pass costs a rank in host time must stay far below the ~220 ms it costs the GPU - the condition for the
+    8-rank node not to be host-bound (DESIGN.md section 6 carries the 8-rank figure measured here)."""
+    r = _run("--gpus", "2", "--dry-run", "--host-loop", "--steps", "4")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    h = line["host_loop"]
+    assert line["ranks_seen"] == 2 and h["workers_per_rank"] == 6 and h["utterances_per_pass"] == 64
+    assert len(h["host_ms_per_pass_by_rank"]) == 2 and h["cores_per_rank"] >= 1
+    assert h["host_ms_per_pass"] < 150.0, h
