@@ -80,12 +80,6 @@ def parse_args():
                          "cut at --text-len (the workload of rounds 1-3)")
     ap.add_argument("--text-len", type=int, default=0,
                     help="hard_max_seq_len of the greedy text search, prompt included (default: 64 ragged, 42 fixed)")
-    ap.add_argument("--dec-cus", type=int, default=-1,
-                    help="CU partition: greedy decoder steps on this many compute units, everything else on the rest "
-                         "(sc_set_cu_partition); 0 = none; default: SC_BENCH_DEC_CUS or 0")
-    ap.add_argument("--dec-priority", type=int, nargs="?", const=1, default=0,
-                    help="greedy decoder steps on a stream of the highest (1) / lowest (-1) priority of each handle (sc_set_decoder_priority), no CU mask")
-    ap.add_argument("--cu-layout", default="low", choices=["low", "xcd"], help="mask layout of --dec-cus (runtime.cu_masks)")
     ap.add_argument("--engine-slots", type=int, default=192,
                     help="decode engine (pipeline schedule): ONE greedy decoder-step chain shared by the passes in flight, this many rows "
                          "per step, continuous refill (runtime.DecodeEngine); 0 = every pass runs its own chain (round 4)")
@@ -556,8 +550,6 @@ def main():
     args = parse_args()
     if args.text_len <= 0:
         args.text_len = 64 if args.workload == "ragged" else 42
-    if args.dec_cus < 0:
-        args.dec_cus = int(os.environ.get("SC_BENCH_DEC_CUS", "0"))
     if args.free_run:
         args.schedule = "freerun"
     if args.lock_step:
@@ -625,8 +617,7 @@ def main():
     opts = SequenceGeneratorOptions(beam_size=1, soft_max_seq_len=(1, 200), hard_max_seq_len=args.text_len)
     stage_ms = {}
 
-    batcher = MicroBatcher(translator, min(args.microbatches, B), decoder_cus=args.dec_cus, cu_layout=args.cu_layout,
-                           decoder_priority=args.dec_priority)
+    batcher = MicroBatcher(translator, min(args.microbatches, B))
     engine_cfg = None
     if args.engine_slots > 0 and batcher.groups > 1:
         max_len, s_enc = MicroBatcher.engine_geometry(translator, ns, opts)
@@ -804,8 +795,6 @@ def main():
                                          + ("; greedy text generation on ONE shared decoder-step chain (decode engine)" if batcher.engine is not None else "")
                                          if args.pipeline_passes else f"free-running slices, start offsets {stagger * 1e3:.0f} ms")
                                         if free_run else "lock-step (join per pass)"),
-                "decoder_stream_priority": ("default" if not args.dec_priority or args.dec_cus > 0 else ("highest" if args.dec_priority > 0 else "lowest")),
-                "cu_partition": ({"decoder_cus": args.dec_cus, "layout": args.cu_layout, "device_cus": model.cu_count()} if args.dec_cus > 0 else None),
             },
             "stage_ms_last_step_slice0": {k: round(v, 3) for k, v in stage_snapshot.items()},
             "load_seconds": round(load_s, 1),
@@ -974,7 +963,7 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
         class _Sub(MicroBatcher):  # k of the existing views (no new handles), no engine
             def __init__(self, parent, k):
                 self.groups, self.views, self.pool = k, parent.views[:k], parent.pool
-                self.torch_streams, self.decoder_cus, self.engine = parent.torch_streams[:k], parent.decoder_cus, None
+                self.torch_streams, self.engine = parent.torch_streams[:k], None
 
         if batcher.engine is not None:
             try:  # round 4's schedule on the same box, same process: three whole-batch passes in flight, every pass its own chain
@@ -1006,7 +995,7 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
             card = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch=args.arch, checkpoint=f"synthetic://{syn.DEFAULT_SEED}")
             tr42 = Translator(card, dict(DEFAULT_CARDS["vocoder_v2"]), device=translator.device, input_modality=Modality.SPEECH)
             tr42.use_graph = translator.use_graph
-            mb42 = MicroBatcher(tr42, 2, decoder_cus=args.dec_cus, cu_layout=args.cu_layout)
+            mb42 = MicroBatcher(tr42, 2)
             o42 = SequenceGeneratorOptions(beam_size=1, soft_max_seq_len=(1, 200), hard_max_seq_len=42)
             dt = timed(lambda: mb42.predict(wav_dev, ns, "S2ST", "fra", text_generation_opts=o42), 3)
             out["fixed42"] = {"metric": "S2ST utterances/s, workload AND schedule of rounds 1-3 (every hypothesis cut at 42 tokens, two lock-step slices)",

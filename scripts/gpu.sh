@@ -19,6 +19,9 @@
 #   pstest       GEMM op tests (bit identity of the kernel variants)       gemmab   scripts/gemm_bench.py at SC_PS_TILE=128 / 256
 #   gemmhalf     scripts/gemm_bench.py at SC_PS_HALF=0 / 1 (barrier in front of the slab / mid-slab)
 #   pyprof       rocprofv3 kernel stats of `python $PYPROF` under each setting of $SWEEP
+#   esweep       scripts/engine_sweep.py: decode-engine / schedule settings on one model load ($ESWEEP)
+#   estep        scripts/engine_step_bench.py: the engine's step alone per slot count + its kernel stats at $ESTEP_PROF_SLOTS
+#   layout       scripts/real_layout_check.py: a published-layout checkpoint through Translator(file://...)
 #   cover        kernel trace of a bench pass -> device-busy share, idle gaps, timeline (scripts/trace_cover.py)
 #                (cover / sqbench are cut off after COVER_TIMEOUT / SQB_TIMEOUT seconds: a process that aborts inside
 #                rocprofv3 leaves the profiler waiting, which cost round 4 its last 16 GPU-minutes)
@@ -157,6 +160,21 @@ for task in "$@"; do
       ms=$(python -c "import json,sys; print(json.loads([l for l in open('${O}_cover.log') if l.startswith('{')][-1])['ms_per_step'])" 2>/dev/null || echo 260)
       [ -n "$f" ] && python scripts/trace_cover.py $f --window-ms $ms --bin-ms ${COVER_BIN:-5} --skip-tail-ms ${COVER_SKIP_TAIL:-$(python -c "print(3.5 * $ms)")} > ${O}_cover.txt 2>&1; head -90 ${O}_cover.txt | cut -c1-200
       find gpurun_out/${TAG}_cover -name "*.csv" -size +2M -delete 2>/dev/null ;;
+    esweep)
+      # decode engine / schedule settings on ONE model load (scripts/engine_sweep.py): ESWEEP="g=3,slots=0;g=6,slots=192,lw=96"
+      ( timeout ${ESWEEP_TIMEOUT:-900} python scripts/engine_sweep.py --steps ${ESWEEP_STEPS:-12} ${ESWEEP:+--configs "$ESWEEP"} > ${O}_esweep.jsonl 2> ${O}_esweep.err; echo "exit $?" >> ${O}_esweep.err )
+      tail -1 ${O}_esweep.err | cut -c1-300; cut -c1-700 ${O}_esweep.jsonl ;;
+    estep)
+      # the decode engine's step ALONE on the chip per slot count, and the per-kernel times of one slot count under rocprofv3
+      ( timeout 300 python scripts/engine_step_bench.py --slots ${ESTEP_SLOTS:-32,64,128,192,256} > ${O}_estep.txt 2>&1; echo "exit $?" >> ${O}_estep.txt ); grep "^slots=" ${O}_estep.txt | cut -c1-250
+      rm -rf gpurun_out/${TAG}_estep_prof
+      ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_estep_prof -o step -- python $R/scripts/engine_step_bench.py --slots ${ESTEP_PROF_SLOTS:-192} --reps 1 > $R/${O}_estep_prof.log 2>&1; echo "exit $?" >> $R/${O}_estep_prof.log )
+      find gpurun_out/${TAG}_estep_prof -name "*kernel_trace*" -delete 2>/dev/null
+      f=$(find gpurun_out/${TAG}_estep_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f ${O}_estep_kernel_stats.csv && head -14 ${O}_estep_kernel_stats.csv | cut -c1-200 ;;
+    layout)
+      # a full-size checkpoint in the PUBLISHED wire format (fairseq keys, fp32, dummy embedding row, weight_g / weight_v) written
+      # from the synthetic weights and loaded through Translator(file://...): load time, host memory, ids vs the synthetic card
+      ( timeout 600 python scripts/real_layout_check.py > ${O}_layout.json 2> ${O}_layout.err; echo "exit $?" >> ${O}_layout.err ); tail -2 ${O}_layout.err | cut -c1-300; cut -c1-900 ${O}_layout.json ;;
     chain)
       ( timeout 200 python scripts/chain_bench.py > ${O}_chain.txt 2>&1 ); grep -v amdgpu ${O}_chain.txt | head -40 ;;
     micro)

@@ -1,9 +1,9 @@
 """Precision study: what does carrying the activation operand as hi + lo fp16 halves buy at the id level?
 Runs the S2ST path over `--n` synthetic utterances (batches of 64) and stores the text / unit ids; run it twice, once
-with SC_SPLIT_MODE=1 in the environment (Conformer products on the hi plane only, i.e. single fp16 rounding of the
+with SC_DEBUG_NUMERICS=1 SC_SPLIT_MODE=1 in the environment (Conformer products on the hi plane only, i.e. single fp16 rounding of the
 activations, 2x fewer matrix instructions), and compare with `--compare a.json b.json`.
     python scripts/split_study.py --n 512 --out gpurun_out/ids_split.json
-    SC_SPLIT_MODE=1 python scripts/split_study.py --n 512 --out gpurun_out/ids_single.json
+    SC_DEBUG_NUMERICS=1 SC_SPLIT_MODE=1 python scripts/split_study.py --n 512 --out gpurun_out/ids_single.json
     python scripts/split_study.py --compare gpurun_out/ids_split.json gpurun_out/ids_single.json"""
 import argparse
 import json

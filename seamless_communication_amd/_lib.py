@@ -103,9 +103,6 @@ SIGNATURES = {
     "sc_free": (None, [_P]),
     "sc_synchronize": (C.c_int, [_P]),
     "sc_wait_stream": (C.c_int, [_P, _P]),
-    "sc_set_cu_partition": (C.c_int, [_P, _P, _P, C.c_int]),
-    "sc_device_cu_count": (C.c_int, [_P]),
-    "sc_set_decoder_priority": (C.c_int, [_P, C.c_int]),
     "sc_decoder_step_family": (C.c_int, [_P, C.c_int, C.c_int]),
     "sc_set_nar_tables": (C.c_int, [_P, _i, _P, _P, _P, _P, _P]),
     "sc_fbank": (C.c_int, [_P, _P, _i, C.c_int64, _P, _i, _P, _i, _P]),
@@ -139,6 +136,7 @@ SIGNATURES = {
     "sc_text_to_char_seqs": (C.c_int32, [C.c_int32, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32,
                                          _P, _P, C.c_int32, _P]),
     "sc_ngram_blocked_tokens": (C.c_int32, [_PI, C.c_int32, C.c_int32, _PI, C.c_int32]),
+    "sc_op_knob": (C.c_int, [C.c_char_p, C.c_int]),
     "sc_op_force_general_gemm": (C.c_int, [C.c_int]),
     "sc_op_layernorm": (C.c_int, [_P, _P, _P, _P, _i, _i, _i]),
     "sc_op_linear": (C.c_int, [_P, _P, _P, _P, _P, _i, _i, _i, _i, C.c_float, _i, _i]),

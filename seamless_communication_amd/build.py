@@ -33,7 +33,7 @@ def _hipcc() -> str:
 def _stamp(src: Path) -> str:
     h = hashlib.sha256()
     h.update(src.read_bytes())
-    for hdr in sorted(CSRC.glob("*.h")) + [CSRC.parent.parent / "include" / "seamless_hip.h"]:
+    for hdr in sorted(CSRC.glob("*.h")) + sorted((CSRC.parent.parent / "include").glob("*.h")):
         h.update(hdr.read_bytes())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()

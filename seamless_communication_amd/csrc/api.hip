@@ -1,6 +1,7 @@
 // extern "C" surface of libseamless_hip.so (declared in include/seamless_hip.h).
 #include <cstring>
 
+#include "../../include/seamless_hip_internal.h"
 #include "engine.h"
 #include "model.h"
 
@@ -58,6 +59,7 @@ sc_model* sc_load(const sc_tensor_desc* tensors, size_t n_tensors, const sc_conf
         int ndev = 0;
         SC_HIP(hipGetDeviceCount(&ndev));
         SC_CHECK(device >= 0 && device < ndev, "sc_load: device %d not available (%d visible)", device, ndev);
+        knob::report_once();  // every SC_* switch found in the environment, and the ones ignored because they change results
         SC_HIP(hipSetDevice(device));
         h = new sc_model();
         h->m.cfg = *cfg;
@@ -108,22 +110,6 @@ int sc_synchronize(sc_model* m) {
     SC_API_END
 }
 
-int sc_set_cu_partition(sc_model* m, const uint32_t* decoder_mask, const uint32_t* other_mask, int words) {
-    SC_API_BEGIN
-    SC_CHECK(m, "null handle");
-    SC_HIP(hipSetDevice(m->m.device));
-    m->m.set_cu_partition(decoder_mask, other_mask, words);
-    SC_API_END
-}
-
-int sc_set_decoder_priority(sc_model* m, int high) {
-    SC_API_BEGIN
-    SC_CHECK(m, "null handle");
-    SC_HIP(hipSetDevice(m->m.device));
-    m->m.set_decoder_priority(high);
-    SC_API_END
-}
-
 int sc_decoder_step_family(sc_model* m, int rows, int caller) {
     if (!m || rows < 1 || caller < 0 || caller > 4) return SC_ERR_INVALID;
     try {
@@ -131,13 +117,6 @@ int sc_decoder_step_family(sc_model* m, int rows, int caller) {
     } catch (...) {
         return SC_ERR_INTERNAL;
     }
-}
-
-int sc_device_cu_count(sc_model* m) {
-    if (!m) return SC_ERR_INVALID;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, m->m.device) != hipSuccess) return SC_ERR_HIP;
-    return prop.multiProcessorCount;
 }
 
 int sc_wait_stream(sc_model* m, void* producer_stream) {
@@ -487,6 +466,8 @@ int32_t sc_ngram_blocked_tokens(const int32_t* h_seq, int32_t len, int32_t ngram
 // --------------------------------------------------------------------------- //
 // kernel-level entry points for the parity tests (default stream, synchronous)
 // --------------------------------------------------------------------------- //
+int sc_op_knob(const char* name, int dflt) { return name ? sc::knob::value(name, dflt) : dflt; }
+
 int sc_op_force_general_gemm(int on) {
     sc::g_force_general_gemm.store(on ? 1 : 0);
     return SC_OK;

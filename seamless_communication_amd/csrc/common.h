@@ -37,6 +37,19 @@ struct Error {
 
 #define SC_LAUNCH_CHECK() SC_HIP(hipGetLastError())
 
+// Every tuning / debugging switch of the library in ONE table (common.cpp: knob_table), read from the environment once per
+// process - the first time a switch is asked for; sc_load asks for all of them and reports on stderr what was set.
+//   * schedule / tile-choice switches change no result (each names kernels that are tested bit-identical);
+//   * switches that DO change results (another summation order, a dropped low half, an older kernel generation) are honoured
+//     only together with SC_DEBUG_NUMERICS=1 - a drop-in library must not change its numbers because of a stray variable;
+//   * `live` switches are re-read at every call (the parity tests flip them inside one process); they change no result.
+namespace knob {
+int value(const char* name, int dflt);  // the integer the switch is set to, `dflt` when unset (or gated off)
+bool is_set(const char* name);          // set to anything (gated like value)
+int live(const char* name, int dflt);   // re-read now
+void report_once();                     // sc_load: one stderr line per switch found in the environment
+}  // namespace knob
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t align_up(int64_t a, int64_t b) { return cdiv64(a, b) * b; }

@@ -187,12 +187,9 @@ void Engine::Impl::setup(const Model& parent) {
         // (1 FFN-in, 2 FFN-out, 4 cross-attention query, 8 out-projections), SC_ENGINE_G4_TPW = tiles per wave (1 / 2)
         // rows per row group of the N = 1024 products (out-projections, cross-attention query): 16 is tuned for <= 64 rows
         // (latency); SC_ENGINE_RG_SMALL for A/B timing of the wide step (same bits whatever the grouping)
-        const char* rgs = getenv("SC_ENGINE_RG_SMALL");
-        if (rgs) c.rg_small = std::min(32, std::max(8, atoi(rgs)));
-        const char* g4 = getenv("SC_ENGINE_G4");
-        const char* tpw = getenv("SC_ENGINE_G4_TPW");
-        c.g4 = g4 ? atoi(g4) & 15 : 0;  // off: measured slower, alone and under load (profiles/r5_gemv4_ab.txt)
-        c.g4_tpw = tpw ? std::min(2, std::max(0, atoi(tpw))) : 0;
+        c.rg_small = std::min(32, std::max(8, knob::value("SC_ENGINE_RG_SMALL", c.rg_small)));
+        c.g4 = knob::value("SC_ENGINE_G4", 0) & 15;  // off: measured slower, alone and under load (profiles/r5_gemv4_ab.txt)
+        c.g4_tpw = std::min(2, std::max(0, knob::value("SC_ENGINE_G4_TPW", 0)));
     }
     partial = Buf<float>(em.pp(), (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * S * 3 * M);
     c.partial = partial;

@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void attn_mfma16_kernel(AttnArgs p) {
 
 static bool g_attn_attr_set = false;
 static bool f32_mfma_env() {
-    static const bool v = getenv("SC_ATTN_F32") && atoi(getenv("SC_ATTN_F32")) != 0;
+    static const bool v = knob::value("SC_ATTN_F32", 0) != 0;
     return v;
 }
 
@@ -809,7 +809,7 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         g_attn_attr_set = true;
     }
-    static const bool use_valu = getenv("SC_ATTN_VALU") && atoi(getenv("SC_ATTN_VALU")) != 0;
+    static const bool use_valu = knob::value("SC_ATTN_VALU", 0) != 0;
     if (!use_valu) {
         static bool mfma_attr = false;
         if (!mfma_attr) {

@@ -283,7 +283,7 @@ void launch_gemm(const GemmArgs& a, hipStream_t s) {
     SC_CHECK(a.M > 0 && a.N > 0, "gemm: empty problem M=%d N=%d", a.M, a.N);
     SC_CHECK(a.rows_per_batch > 0 && a.cin > 0, "gemm: rows_per_batch/cin unset");
     // SC_GEMM_GENERAL=1 forces the general kernel (A/B timing of the two paths; same bits either way)
-    static const bool env_general = getenv("SC_GEMM_GENERAL") != nullptr;
+    static const bool env_general = knob::is_set("SC_GEMM_GENERAL");
     if (!env_general && !g_force_general_gemm.load(std::memory_order_relaxed) && gemm_fast_eligible(a)) {
         launch_gemm_fast(a, s);
         return;

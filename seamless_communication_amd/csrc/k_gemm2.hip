@@ -569,7 +569,7 @@ void launch_fast_cfg(const GemmArgs& a, hipStream_t s) {
     prof::Scope scope(name, flops, bytes, s);
     const dim3 grid(tiles_per_xcd * 8);
     // prefetch-distance-2 variant (raw buffer loads): both operands must be addressable with 31-bit byte offsets
-    static const int env_pf2 = getenv("SC_GEMM_PF2") ? atoi(getenv("SC_GEMM_PF2")) : GEMM_PF2_DEFAULT;
+    static const int env_pf2 = knob::value("SC_GEMM_PF2", GEMM_PF2_DEFAULT);
     const int64_t a_bytes64 = (int64_t)(a.M / a.rows_per_batch) * a.t_in * a.lda * 4;
     const int64_t w_bytes64 = (int64_t)a.N * a.ldw * 2;
     if (env_pf2 && a.K % (2 * FBK) == 0 && a.M % a.rows_per_batch == 0 && a_bytes64 < (1ll << 31) && w_bytes64 < (1ll << 31)) {
@@ -582,7 +582,7 @@ void launch_fast_cfg(const GemmArgs& a, hipStream_t s) {
                                tiles_total, tiles_per_xcd, slope, (uint32_t)a_bytes64, (uint32_t)w_bytes64);
         return;
     }
-    static const int env_gm = getenv("SC_GEMM_GROUP_M") ? atoi(getenv("SC_GEMM_GROUP_M")) : 0;
+    static const int env_gm = knob::value("SC_GEMM_GROUP_M", 0);
     const int group_m = std::max(1, std::min(env_gm > 0 ? env_gm : GEMM_GROUP_M_DEFAULT, tiles_m));
     // plain product: one tap, no stride/padding/length mask -> every row below M is valid and rows
     // >= M only feed accumulator rows that are never stored, so the validity selects are compiled out
@@ -622,7 +622,7 @@ void launch_gemm_fast(const GemmArgs& a, hipStream_t s) {
         if ((int64_t)cdiv(a.M, 128) * a.phases >= 512) launch_fast_cfg<128, 64, 2, 2>(a, s);
         else launch_fast_cfg<64, 64, 2, 2>(a, s);
     } else if (tiles128 >= 256) {
-        static const int env_tile = getenv("SC_GEMM_TILE") ? atoi(getenv("SC_GEMM_TILE")) : 0;  // experiments only
+        static const int env_tile = knob::value("SC_GEMM_TILE", 0);  // experiments only
         if (env_tile == 1) launch_fast_cfg<128, 64, 2, 2>(a, s);
         else if (env_tile == 2) launch_fast_cfg<64, 64, 2, 2>(a, s);
         else launch_fast_cfg<128, 128, 2, 2>(a, s);

@@ -170,6 +170,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
     const int bid = blockIdx.x;
     const int tile = (bid & 7) * tiles_per_xcd + (bid >> 3);
     if (tile >= tiles_total) return;
+    // static priority for the second-dispatched half of an 8-wave workgroup (MI355X_MICROARCH.md, "Two waves per SIMD", item 4:
+    // it loses every VALU arbitration to the older half); SC_PS_PRIO=1, A/B switch - timing only
+    if (NWAVE == 8 && p.prio_half && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
     const int tm = tile / tiles_n;
     const int tn = tile - tm * tiles_n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -508,10 +511,10 @@ void launch_ps_cfg(const GemmPsArgs& a, hipStream_t s) {
     snprintf(name, sizeof(name), "gemm_%dx%d_presplit", BM, BN);
     prof::Scope scope(name, 2.0 * a.M * (double)a.N * a.K,
                       4.0 * a.M * (double)a.K + 2.0 * a.N * (double)a.K + 4.0 * a.M * (double)a.N * (a.res ? 2.0 : 1.0), s);
-    static const bool ilv = !(getenv("SC_PS_ILV") && atoi(getenv("SC_PS_ILV")) == 0);  // A/B switch (development)
+    static const bool ilv = knob::value("SC_PS_ILV", 1) != 0;  // A/B switch (development)
     const dim3 grid(tiles_per_xcd * 8), block(WGM * WGN * 64);
     const uint32_t ab = (uint32_t)((int64_t)a.M * a.lda * 2), wb = (uint32_t)((int64_t)a.N * a.ldw * 2);
-    static const bool half = !(getenv("SC_PS_HALF") && atoi(getenv("SC_PS_HALF")) == 0);  // mid-slab barrier schedule (A/B switch)
+    static const bool half = knob::value("SC_PS_HALF", 1) != 0;  // mid-slab barrier schedule (A/B switch)
     if (!a.split) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (a.conv_taps > 0 && half) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (a.conv_taps > 0) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
@@ -522,7 +525,10 @@ void launch_ps_cfg(const GemmPsArgs& a, hipStream_t s) {
 
 }  // namespace
 
-void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s) {
+void launch_gemm_presplit(const GemmPsArgs& a0, hipStream_t s) {
+    GemmPsArgs a = a0;
+    static const int prio = knob::value("SC_PS_PRIO", 0);
+    a.prio_half = prio;
     SC_CHECK(a.Ah && a.Al && a.W && (a.C || a.Ch), "presplit gemm: null operand");
     SC_CHECK((a.Ch == nullptr) == (a.Cl == nullptr), "presplit gemm: Ch/Cl must be given together");
     SC_CHECK(a.M > 0 && a.N > 0 && a.K > 0 && a.K % PBK == 0, "presplit gemm: M=%d N=%d K=%d (K must be a multiple of 32)", a.M, a.N, a.K);
@@ -543,12 +549,12 @@ void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s) {
     // tile choice: 256 x 256 (8 waves) once it fills the chip about once, 128 x 128 down to one round of 256 tiles,
     // 64 x 64 below.  SC_PS_TILE=128 (development A/B) keeps the round-1 choice.  All three accumulate every output
     // element in the same order (16-wide K chunks, hi then lo): identical bits.
-    static const int max_tile = getenv("SC_PS_TILE") ? atoi(getenv("SC_PS_TILE")) : 256;
+    static const int max_tile = knob::value("SC_PS_TILE", 256);
     const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
     const int64_t tiles256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
     // (N <= 128: a 256-wide tile would idle half its columns - the 128-channel vocoder stage)
-    static const int min256 = getenv("SC_PS_MIN256") ? atoi(getenv("SC_PS_MIN256")) : 224;
-    static const int min128 = getenv("SC_PS_MIN128") ? atoi(getenv("SC_PS_MIN128")) : 256;
+    static const int min256 = knob::value("SC_PS_MIN256", 224);
+    static const int min128 = knob::value("SC_PS_MIN128", 256);
     if (max_tile >= 256 && tiles256 >= min256 && a.N > 128) launch_ps_cfg<256, 256, 4, 2>(a, s);
     else if (tiles128 >= min128) launch_ps_cfg<128, 128, 2, 2>(a, s);
     else launch_ps_cfg<64, 64, 2, 2>(a, s);

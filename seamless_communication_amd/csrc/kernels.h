@@ -91,6 +91,7 @@ struct GemmPsArgs {
     // packed (varlen) convolution: row_pos[m] = {position of row m inside its item, length of that item} (nullable);
     // replaces the uniform rows_per_item geometry: items of different lengths lie back to back, no padding rows
     const int2* row_pos = nullptr;
+    int prio_half = 0;  // filled by the launcher (SC_PS_PRIO): s_setprio 1 for waves 4-7 of the 8-wave tile
 };
 void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s);
 

@@ -269,15 +269,7 @@ struct Model : ModelData {
     };
     std::vector<std::unique_ptr<SideChain>> side;
     hipEvent_t side_fork = nullptr;
-    // CU partition (sc_set_cu_partition): `other_mask` restricts the handle's own stream and its side chains, `dec_chain`
-    // (stream on the decoder mask + own scratch pool) carries the greedy decoder-step chain.  Empty / null: no partition.
-    std::vector<uint32_t> other_mask;
-    std::unique_ptr<SideChain> dec_chain;
-    hipEvent_t dec_fork = nullptr;
-    hipStream_t make_stream(const std::vector<uint32_t>& mask);  // non-blocking when mask is empty, CU-masked otherwise
-    void set_cu_partition(const uint32_t* decoder_mask, const uint32_t* other, int words);
-    void set_decoder_priority(int level);  // decoder chain on a stream of the highest (> 0) / lowest (< 0) priority, no mask; 0: back on `stream`
-    void trim_all_pools();   // every cached block of the handle's pools (own, side chains, decoder chain) back to the driver
+    void trim_all_pools();   // every cached block of the handle's pools (own, side chains) back to the driver
     void hook_pool(DevicePool& p) { p.set_oom_hook([this] { trim_all_pools(); }); }
     DevicePool* pool_override = nullptr;
     DevicePool* pp() { return pool_override ? pool_override : &pool; }

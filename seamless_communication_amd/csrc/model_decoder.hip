@@ -224,7 +224,7 @@ bool proj_partials(Model& m, StepCtx& c, const float* in, int64_t ld_in, const L
 // ---- second-generation step (k_dstep.hip) --------------------------------------------------------------------
 bool step2_eligible(const Model& m, const DecStack& W, int nb) {
     const int M = m.cfg.model_dim;
-    static const bool off = getenv("SC_DECODER_GEN1") != nullptr;  // A/B switch: the first-generation kernels
+    static const bool off = knob::is_set("SC_DECODER_GEN1");  // A/B switch: the first-generation kernels
     if (off || nb < 1 || nb > 64 || M % 64 != 0 || M > 1024 || W.ffn_dim % 64 != 0 || M != m.cfg.num_heads * 64) return false;
     for (const DecoderLayer& l : *W.layers)
         if (!l.qkv.wp || !l.self_out.wp || !l.cross_q.wp || !l.cross_out.wp || !l.ffn_in.wp || !l.ffn_out.wp) return false;
@@ -284,7 +284,7 @@ static void gemv2(Model& m, StepCtx& c, const __half* Ah, const __half* Al, cons
 // 128 bytes), so that they sit in the memory-side cache when the chain gets there.  Results cannot change: the toucher
 // only reads.  The fork / join events are captured into the step graph like any other dependency.
 int touch_setting() {
-    static const int v = getenv("SC_DSTEP_TOUCH") ? std::max(0, atoi(getenv("SC_DSTEP_TOUCH"))) : 0;
+    static const int v = std::max(0, knob::value("SC_DSTEP_TOUCH", 0));
     return v;
 }
 
@@ -303,7 +303,7 @@ void prepare_touch(Model& m, int n_layers) {
 }
 
 static void touch_layer(Model& m, const DecoderLayer& l) {
-    static const int wgs = getenv("SC_DSTEP_TOUCH_WGS") ? std::max(1, atoi(getenv("SC_DSTEP_TOUCH_WGS"))) : 64;
+    static const int wgs = std::max(1, knob::value("SC_DSTEP_TOUCH_WGS", 64));
     TouchArgs t;
     for (const Linear* L : {&l.qkv, &l.self_out, &l.cross_q, &l.cross_out, &l.ffn_in, &l.ffn_out}) {
         if (!L->wp) continue;
@@ -474,7 +474,7 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
 // q (LayerNorm inside) | cross-attention | out-proj (+bias +residual inside) | FFN-in (LayerNorm inside, ReLU, planes) |
 // FFN-out (K-slice partials) | reduce + bias + residual + the NEXT LayerNorm as planes (after the last layer: the decoder output).
 bool step3_eligible(const Model& m, const DecStack& W, int nb) {
-    static const bool off = getenv("SC_DECODER_GEN2") != nullptr;  // A/B switch: the second-generation chain
+    static const bool off = knob::is_set("SC_DECODER_GEN2");  // A/B switch: the second-generation chain
     if (off || !step2_eligible(m, W, nb)) return false;
     const int M = m.cfg.model_dim;
     return gemv3_supported(nb, 3 * M, M, IN3_LN) && gemv3_supported(nb, M, W.ffn_dim, IN3_PLANES) && M % 8 == 0;
@@ -483,7 +483,7 @@ bool step3_eligible(const Model& m, const DecStack& W, int nb) {
 // > 64 live rows (beam search at the benchmark batch: 64 utterances x 5 beams): the same chain, every product cut into row
 // groups, q | k | v on the row-group kernel too (the packed split-K product stops at 64 rows)
 bool step3_wide_eligible(const Model& m, const DecStack& W, int nb) {
-    static const bool off = getenv("SC_DECODER_GEN2") != nullptr || getenv("SC_DECODER_GEN1") != nullptr;
+    static const bool off = knob::is_set("SC_DECODER_GEN2") || knob::is_set("SC_DECODER_GEN1");
     const int M = m.cfg.model_dim;
     if (off || nb <= 64 || nb > 512 || M % 64 != 0 || M > 1024 || W.ffn_dim % 64 != 0 || M != m.cfg.num_heads * 64) return false;
     for (const DecoderLayer& l : *W.layers)
@@ -496,8 +496,7 @@ namespace {
 
 
 static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
+    return knob::value(name, dflt);
 }
 
 void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
@@ -1007,7 +1006,7 @@ void run_mma_step(Model& m, const int32_t* h_tokens, int n_tokens, const int32_t
     // (profiles/r2_stream_latency_graph.jsonl): no gain - a one-row step is 1.3 ms of dependent GPU work + the vocabulary
     // projection whichever way it is launched (the eager launches run ahead of the GPU) - and every growth of the encoder
     // buffer costs a re-capture (8 ms); default: eager launches.
-    static const bool use_graph = getenv("SC_MMA_GRAPH") && atoi(getenv("SC_MMA_GRAPH")) != 0;
+    static const bool use_graph = knob::value("SC_MMA_GRAPH", 0) != 0;
     auto step = [&](bool with_pchoose) {
         c.pchoose = with_pchoose;
         const int gi = with_pchoose ? 1 : 0;
@@ -1261,7 +1260,7 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     SC_CHECK(n > 0 && s_enc > 0, "sc_generate_text: empty batch");
     prof::set_tag("dec");
     const bool forced = h_forced_tokens != nullptr;
-    static const bool stepwise_forced = getenv("SC_DECODE_STEPWISE") != nullptr;
+    static const bool stepwise_forced = knob::is_set("SC_DECODE_STEPWISE");
     if (forced && !stepwise_forced && d_dec_hidden) {
         run_decode_text_batched(m, d_enc, n, s_enc, h_enc_lens, h_forced_tokens, forced_len, d_dec_hidden);
         return;
@@ -1341,17 +1340,6 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     SC_HIP(hipMemsetAsync(S->fl.get(), 0, (size_t)2 * n * 4, m.stream));
     if (c.dec_hidden) SC_HIP(hipMemsetAsync(c.dec_hidden, 0, (size_t)n * (max_len - 1) * M * 4, m.stream));
 
-    // ---- CU partition (sc_set_cu_partition): from here on the run is the latency-bound step chain - it moves to the
-    // handle's decoder chain (a stream restricted to the decoder's compute units, own scratch pool), ordered behind the
-    // encoder K/V products and the initial copies above; the run ends with that stream drained, so the caller's next
-    // stage (on the handle's own stream again) finds everything complete
-    std::unique_ptr<SideScope> on_dec_chain;
-    if (!forced && m.dec_chain) {
-        SC_HIP(hipEventRecord(m.dec_fork, m.stream));
-        SC_HIP(hipStreamWaitEvent(m.dec_chain->stream, m.dec_fork, 0));
-        on_dec_chain.reset(new SideScope(m, *m.dec_chain));
-    }
-
     // ---- feed the known tokens (prompt echo / teacher forcing) ---------------------
     // positions 0 .. feed_len-2 are fed without projection; the next input is read from hist.
     // teacher forcing over more than a few positions (the re-pass behind a beam search: ~40 steps of ~220 launches): the
@@ -1413,12 +1401,10 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
     // slot_utt names the utterance a slot holds; results are handed out by utterance.  SC_GREEDY_COMPACT=0 keeps the rows
     // where they are.  A row's arithmetic does not depend on its slot (tests/test_eos_gpu.py: ids, hidden states, units and
     // waveforms equal to the un-compacted run and to the oracle).
-    const char* gc_env = getenv("SC_GREEDY_COMPACT");
     const bool compact = c.gen3 && c.d_rows == c.d_rows_greedy && n > 16 && cfg.dec_layers <= ROWSWAP_MAX_LAYERS && n <= 255 &&
-                         M % 4 == 0 && !(gc_env && atoi(gc_env) == 0);
+                         M % 4 == 0 && knob::live("SC_GREEDY_COMPACT", 1) != 0;
     // steps between two looks of the host at the finished flags (each is a stream synchronisation); SC_GREEDY_POLL for A/B runs
-    const char* poll_env = getenv("SC_GREEDY_POLL");
-    const int poll = poll_env ? std::min(64, std::max(1, atoi(poll_env))) : 4;
+    const int poll = std::min(64, std::max(1, knob::live("SC_GREEDY_POLL", 4)));
     std::vector<int> slot_utt(n);
     for (int b = 0; b < n; ++b) slot_utt[b] = b;
     int live_slots = n;
@@ -1757,7 +1743,7 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     // packed to the front every time the host looks at the counters (every 4th step); kernels skip the rows / slots behind
     // *d_rows / *d_slots.  Finished hypotheses are stored per UTTERANCE (slot_utt maps a slot to its utterance), so the
     // results below are read in utterance order whatever moved.  SC_BEAM_COMPACT=0: every slot stays where it is.
-    static const bool compact_env = !(getenv("SC_BEAM_COMPACT") && atoi(getenv("SC_BEAM_COMPACT")) == 0);
+    static const bool compact_env = knob::value("SC_BEAM_COMPACT", 1) != 0;  // process-wide, read once
     const bool compact = compact_env && use_anc && c.gen3 && n >= 2 && n <= 1024;
     Buf<int> d_slot(m.pp(), compact ? (size_t)n + 2 : 4);
     int* d_slot_utt = d_slot.get();

@@ -105,7 +105,7 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
     // inner product's epilogue, the attention kernel - and consumed by the DMA-fed product kernel (k_gemm_ps.hip);
     // the residual stream x and the tensors read by element-wise kernels stay fp32.  SC_PRESPLIT=0 selects the
     // on-the-fly split path (same bits).
-    static const bool presplit = !(getenv("SC_PRESPLIT") && atoi(getenv("SC_PRESPLIT")) == 0);
+    static const bool presplit = knob::value("SC_PRESPLIT", 1) != 0;
     const bool v1 = c.enc_variant == 1;  // w2v-BERT of the v1 models: fp32-operand path below (not the throughput path)
     const bool ps_ok = !v1 && presplit && M % 32 == 0 && c.enc_ffn_dim % 32 == 0 && (int64_t)rows * std::max(M, c.enc_ffn_dim) * 2 < (1ll << 31);
     // v1: position table [2S-1][M] once per call, its projection r_proj(table) per layer
@@ -146,14 +146,14 @@ void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, cons
         a.alpha = alpha;
         // SC_SPLIT_MODE=1 (precision study, scripts/split_study.py; never the default): the Conformer products use the
         // hi plane only, i.e. the activation operand is rounded to fp16 once instead of being carried to ~2^-22
-        static const bool single = getenv("SC_SPLIT_MODE") && atoi(getenv("SC_SPLIT_MODE")) == 1;
+        static const bool single = knob::value("SC_SPLIT_MODE", 0) == 1;
         a.split = single ? 0 : 1;
         launch_gemm_presplit(a, m.stream);
     };
 
     // fused element-wise passes (SC_ENC_FUSE=0: the separate launches, same bits): GLU + depthwise conv + LayerNorm + SiLU
     // in one kernel; a layer's closing LayerNorm together with the next layer's first one
-    static const bool fuse = !(getenv("SC_ENC_FUSE") && atoi(getenv("SC_ENC_FUSE")) == 0);
+    static const bool fuse = knob::value("SC_ENC_FUSE", 1) != 0;
     const bool fuse_conv = fuse && glu_dwconv_ln_supported(M, c.depthwise_conv_kernel_size);
     const bool fuse_ln = fuse && M <= 1024;
     bool ffn1_planes_ready = false;  // the previous layer's closing launch already wrote LN_ffn1(x) as planes

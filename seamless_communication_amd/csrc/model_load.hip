@@ -25,6 +25,7 @@ DevicePool::~DevicePool() { release_all(); }
 // become a node of the graph.
 static int debug_fill_byte() {
     static const int v = [] {
+        (void)knob::is_set("SC_DEBUG_FILL");  // in the switch table; the value is a byte, possibly hexadecimal: parsed here
         const char* e = getenv("SC_DEBUG_FILL");
         return e && *e ? (int)strtol(e, nullptr, 0) & 0xff : -1;
     }();
@@ -100,13 +101,6 @@ Model::~Model() {
     }
     side.clear();
     if (side_fork) (void)hipEventDestroy(side_fork);
-    if (dec_chain) {
-        if (dec_chain->stream) (void)hipStreamSynchronize(dec_chain->stream);
-        dec_chain->pool.release_all();
-        if (dec_chain->done) (void)hipEventDestroy(dec_chain->done);
-        if (dec_chain->stream) (void)hipStreamDestroy(dec_chain->stream);
-    }
-    if (dec_fork) (void)hipEventDestroy(dec_fork);
     pool.release_all();
     for (void* p : owned) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
@@ -115,81 +109,13 @@ Model::~Model() {
 void Model::trim_all_pools() {
     pool.trim();
     for (auto& c : side) c->pool.trim();
-    if (dec_chain) dec_chain->pool.trim();
-}
-
-hipStream_t Model::make_stream(const std::vector<uint32_t>& mask) {
-    hipStream_t st = nullptr;
-    if (mask.empty())
-        SC_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    else
-        SC_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
-    return st;
-}
-
-// see sc_set_cu_partition (include/seamless_hip.h).  The handle is idle: every stream is drained, the streams are
-// re-created on their masks, scratch that was ordered on the old streams goes back to the driver.
-void Model::set_cu_partition(const uint32_t* decoder_mask, const uint32_t* other, int words) {
-    SC_CHECK(words >= 0 && words <= 64, "sc_set_cu_partition: words=%d", words);
-    if (words > 0) {
-        SC_CHECK(decoder_mask && other, "sc_set_cu_partition: null mask");
-        bool any_d = false, any_o = false;
-        for (int i = 0; i < words; ++i) any_d = any_d || decoder_mask[i], any_o = any_o || other[i];
-        SC_CHECK(any_d && any_o, "sc_set_cu_partition: a mask selects no compute unit");
-    }
-    SC_HIP(hipStreamSynchronize(stream));
-    dec_session.reset();  // its captured graph was recorded on the old stream; buffers go back to the pool
-    for (auto& c : side) {
-        SC_HIP(hipStreamSynchronize(c->stream));
-        c->pool.release_all();
-        if (c->done) (void)hipEventDestroy(c->done);
-        (void)hipStreamDestroy(c->stream);
-    }
-    side.clear();
-    if (dec_chain) {
-        SC_HIP(hipStreamSynchronize(dec_chain->stream));
-        dec_chain->pool.release_all();
-        if (dec_chain->done) (void)hipEventDestroy(dec_chain->done);
-        (void)hipStreamDestroy(dec_chain->stream);
-        dec_chain.reset();
-    }
-    other_mask.assign(other, other + words);
-    hipStream_t fresh = make_stream(other_mask);
-    (void)hipStreamDestroy(stream);
-    stream = fresh;
-    pool.set_stream(stream);
-    if (words > 0) {
-        std::unique_ptr<SideChain> c(new SideChain());
-        c->stream = make_stream(std::vector<uint32_t>(decoder_mask, decoder_mask + words));
-        SC_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
-        c->pool.set_stream(c->stream);
-        hook_pool(c->pool);
-        dec_chain = std::move(c);
-        if (!dec_fork) SC_HIP(hipEventCreateWithFlags(&dec_fork, hipEventDisableTiming));
-    }
-}
-
-void Model::set_decoder_priority(int level) {
-    if (!other_mask.empty() || dec_chain) set_cu_partition(nullptr, nullptr, 0);  // drops a partition and an earlier chain
-    if (level == 0) return;
-    SC_HIP(hipStreamSynchronize(stream));
-    dec_session.reset();
-    int least = 0, greatest = 0;
-    SC_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    std::unique_ptr<SideChain> c(new SideChain());
-    SC_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, level > 0 ? greatest : least));
-    SC_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
-    c->pool.set_stream(c->stream);
-    hook_pool(c->pool);
-    dec_chain = std::move(c);
-    if (!dec_fork) SC_HIP(hipEventCreateWithFlags(&dec_fork, hipEventDisableTiming));
 }
 
 Model::SideChain& Model::side_chain(int k) {
     SC_CHECK(k >= 0 && k < 16, "side chain %d", k);
     while ((int)side.size() <= k) {
         std::unique_ptr<SideChain> c(new SideChain());
-        c->stream = make_stream(other_mask);
+        SC_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         SC_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
         c->pool.set_stream(c->stream);
         hook_pool(c->pool);

@@ -287,7 +287,7 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
     // 74-101: mask before each conv) and LayerNorm / the projection act on single rows, so an item's units do not
     // depend on what it is batched with.  SC_T2U_GROUPS=1 restores the single padded pass.
     std::vector<int32_t> ids((size_t)urows, c.unit_pad_idx);
-    static const int max_groups = getenv("SC_T2U_GROUPS") ? std::max(1, atoi(getenv("SC_T2U_GROUPS"))) : 8;
+    static const int max_groups = std::max(1, knob::value("SC_T2U_GROUPS", 8));
     const std::vector<std::vector<int>> groups = plan_length_groups(std::vector<int>(ulens.begin(), ulens.end()), 400, max_groups);
     int64_t rows_done = 0;
     // result slots of the handle: apply_padding_mask(pad) + UnitTokenDecoder NAR branch (unit_tokenizer.py:232-243)
@@ -317,7 +317,7 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
     // same decoder in buckets on the DMA GEMM was measured and dropped: 1.5 - 4 k rows per launch stay on 64 x 64 tiles,
     // profiles/r2_knob_experiments.txt).
     {
-        static const bool want_packed = !(getenv("SC_T2U_PACKED") && atoi(getenv("SC_T2U_PACKED")) == 0);
+        static const bool want_packed = knob::value("SC_T2U_PACKED", 1) != 0;
         const int K = c.t2u_conv_kernel, Ci = c.t2u_conv_inner_dim;
         int64_t R64 = 0;
         for (int b = 0; b < n; ++b) R64 += ulens[b];
@@ -521,7 +521,7 @@ void vocode_batch(Model& m, const int* d_units, const int* d_lang, const int* d_
         // (k_gemm_ps.hip).  Its activation operand is a pair of fp16 planes: LeakyReLU(y) is split once for the three
         // ResBlocks, every convolution's epilogue writes the LeakyReLU'd planes the next one reads (plane_neg_slope) next to
         // the fp32 residual stream.  SC_VOC_PS=0: the register-staged kernel (k_gemm2.hip) as before.
-        static const bool voc_ps = !(getenv("SC_VOC_PS") && atoi(getenv("SC_VOC_PS")) == 0);
+        static const bool voc_ps = knob::value("SC_VOC_PS", 1) != 0;
         bool wide_ps = voc_ps && g_force_general_gemm.load(std::memory_order_relaxed) == 0 && ch >= 128 && ch % 32 == 0 &&
                        (int64_t)n * t2 * ch * 2 < (1ll << 31);
         for (int j = 0; j < nk && wide_ps; ++j) {
@@ -564,7 +564,7 @@ void vocode_batch(Model& m, const int* d_units, const int* d_lang, const int* d_
         }
         // the two narrowest stages (C = 32, 16): the three ResBlocks and their average in one kernel, the residual
         // stream in registers and every intermediate in LDS (k_resblock.hip: mrf_fused_kernel).  SC_VOC_MRF=0: pair by pair.
-        static const bool voc_mrf = !(getenv("SC_VOC_MRF") && atoi(getenv("SC_VOC_MRF")) == 0);
+        static const bool voc_mrf = knob::value("SC_VOC_MRF", 1) != 0;
         if (voc_mrf && g_force_general_gemm.load(std::memory_order_relaxed) == 0) {
             MrfArgs a;
             bool ok = true;
@@ -717,7 +717,7 @@ void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h
                  c.voc_num_embeddings);
     int hop = 1;
     for (const ConvT& up : m.voc_ups) hop *= up.stride;
-    static const int max_groups = getenv("SC_VOC_GROUPS") ? std::max(1, atoi(getenv("SC_VOC_GROUPS"))) : 8;
+    static const int max_groups = std::max(1, knob::value("SC_VOC_GROUPS", 8));
     if (!h_unit_lens || max_groups == 1) {
         Buf<int> d_units(m.pp(), (size_t)n * T), d_ls(m.pp(), 2 * n);
         SC_HIP(hipMemcpyAsync(d_units.get(), h_units, (size_t)n * T * 4, hipMemcpyHostToDevice, m.stream));
@@ -736,14 +736,14 @@ void run_vocode(Model& m, const int32_t* h_units, int n, int T, const int32_t* h
     const int halo = vocoder_halo_units(m);
     std::vector<int> need(n);
     for (int i = 0; i < n; ++i) need[i] = std::min(T, h_unit_lens[i] + halo);
-    static const int group_overhead = getenv("SC_VOC_GROUP_OVERHEAD") ? std::max(0, atoi(getenv("SC_VOC_GROUP_OVERHEAD"))) : 250;
+    static const int group_overhead = std::max(0, knob::value("SC_VOC_GROUP_OVERHEAD", 250));
     const std::vector<std::vector<int>> groups = plan_length_groups(need, group_overhead, max_groups);
     SC_HIP(hipMemsetAsync(d_wav, 0, (size_t)n * T * hop * sizeof(float), m.stream));
     // The buckets are independent chains of ~150 launches each, and a bucket (a few utterances) is too small to fill the
     // chip in the wide stages (40 - 300 workgroups per product): they go round `chains` side streams, each with its own
     // scratch pool (model.h: SideChain), forked after the memset and joined before the final synchronisation.
     // SC_VOC_STREAMS=1: every bucket on the handle's own stream, as before.
-    static const int max_chains = getenv("SC_VOC_STREAMS") ? std::max(1, std::min(8, atoi(getenv("SC_VOC_STREAMS")))) : 3;
+    static const int max_chains = std::max(1, std::min(8, knob::value("SC_VOC_STREAMS", 3)));
     const int chains = std::min<int>(max_chains, (int)groups.size());
     if (chains > 1) {
         m.side_chain(chains - 1);

@@ -157,8 +157,7 @@ class MicroBatcher:
     most in the decoder phase (a chain of ~220 short dependent kernels per token that leaves more than half of
     the chip idle on its own; DESIGN.md section 3, profiles/r3_bench_cover_timeline.txt)."""
 
-    def __init__(self, translator, groups: int, decoder_cus: int = 0, cu_layout: str = "low", decoder_priority: int = 0,
-                 engine: Optional[dict] = None) -> None:
+    def __init__(self, translator, groups: int, engine: Optional[dict] = None) -> None:
         from concurrent.futures import ThreadPoolExecutor
 
         self.groups = max(1, int(groups))
@@ -166,15 +165,8 @@ class MicroBatcher:
         self.views = [translator] + [translator.fork() for _ in range(self.groups - 1)]
         self.pool = ThreadPoolExecutor(max_workers=self.groups) if self.groups > 1 else None
         # every slice does its torch-side device work (slices, .contiguous(), output tensors) on its own torch stream: the
-        # library's streams are then never ordered behind the legacy default stream, which CU-masked streams synchronise with
+        # library's streams are then never ordered behind the legacy default stream
         self.torch_streams = [torch.cuda.Stream(device=translator.device) for _ in self.views] if translator.device.type == "cuda" else None
-        self.decoder_cus = int(decoder_cus)
-        if self.decoder_cus > 0:
-            for v in self.views:
-                v.model.set_cu_partition(self.decoder_cus, cu_layout)
-        elif decoder_priority:
-            for v in self.views:
-                v.model.set_decoder_priority(int(decoder_priority))
         if engine:
             self.enable_engine(**engine)
 
@@ -313,9 +305,8 @@ class MicroBatcher:
                        stagger_s: float = 0.0, on_pass=None, **kwargs):
         """``steps`` passes over the same batch, pipelined ACROSS passes: worker i runs passes i, i + groups, ... each over
         the WHOLE batch (one decoder chain of all rows instead of one per slice), worker i starting ``i * stagger_s`` late,
-        joined once at the end.  In flight at any time: ``groups`` passes in different phases of the path - with a CU
-        partition (``decoder_cus``) the decoder chain of one pass runs on its own compute units under the GEMM-bound
-        stages of its neighbours.  Same total work as ``steps`` lock-step passes; the latency of a single pass grows.
+        joined once at the end.  In flight at any time: ``groups`` passes in different phases of the path.  Same total work
+        as ``steps`` lock-step passes; the latency of a single pass grows.
         Returns one ``predict``-style tuple per pass, in pass order.  ``on_pass(k, result)`` (optional) is called on the CALLING
         thread for pass 0, 1, 2, ... in that order as soon as each is complete, while later passes are still running: the place for
         the data-parallel path's all-gather of a pass's ids (a collective needs the same order on every rank; passes finish in

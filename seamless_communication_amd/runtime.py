@@ -135,47 +135,6 @@ class HipS2STModel:
         child._parent = self  # the parent owns the weights and must outlive the fork
         return child
 
-    # ---- CU partition (sc_set_cu_partition) ------------------------------------------------------------ #
-    def cu_count(self) -> int:
-        return int(self.lib.sc_device_cu_count(self.handle))
-
-    @staticmethod
-    def cu_masks(n_cus: int, decoder_cus: int, layout: str = "low"):
-        """(decoder_mask, other_mask) as uint32 word arrays over ``n_cus`` bits.  ``low``: the decoder gets mask bits
-        0 .. decoder_cus-1 (the driver rotates consecutive bits over the XCDs: an equal share of every XCD); ``xcd``: the
-        bits i with i % 8 < decoder_cus / (n_cus / 8) (whole XCDs under the same numbering).  The other mask is the
-        complement.  scripts/micro/cumask.hip prints which physical CUs either selects."""
-        if not 0 < decoder_cus < n_cus:
-            raise ValueError(f"decoder_cus must be in (0, {n_cus})")
-        words = (n_cus + 31) // 32
-        dec = np.zeros(words, dtype=np.uint32)
-        oth = np.zeros(words, dtype=np.uint32)
-        per_xcd = max(1, n_cus // 8)
-        for i in range(n_cus):
-            if layout == "low":
-                mine = i < decoder_cus
-            elif layout == "xcd":
-                mine = (i % 8) < max(1, decoder_cus // per_xcd)
-            else:
-                raise ValueError("layout must be 'low' or 'xcd'")
-            (dec if mine else oth)[i // 32] |= np.uint32(1 << (i % 32))
-        return dec, oth
-
-    def set_cu_partition(self, decoder_cus: int, layout: str = "low") -> None:
-        """Greedy decoder steps on ``decoder_cus`` compute units, everything else on the remaining ones (0: no partition).
-        See include/seamless_hip.h: the caller's own device work must stay off the legacy default stream while calls
-        are in flight (distributed.MicroBatcher runs every worker under its own torch stream)."""
-        if decoder_cus <= 0:
-            check(self.lib.sc_set_cu_partition(self.handle, None, None, 0), "sc_set_cu_partition")
-            return
-        dec, oth = self.cu_masks(self.cu_count(), decoder_cus, layout)
-        check(self.lib.sc_set_cu_partition(self.handle, _ptr(dec), _ptr(oth), len(dec)), "sc_set_cu_partition")
-
-    def set_decoder_priority(self, level: int = 1) -> None:
-        """Greedy decoder steps on a stream of the highest (level > 0) / lowest (level < 0) priority of the handle
-        (sc_set_decoder_priority); 0: back on its own stream."""
-        check(self.lib.sc_set_decoder_priority(self.handle, int(level)), "sc_set_decoder_priority")
-
     def close(self) -> None:
         if getattr(self, "handle", None):
             self.lib.sc_free(self.handle)

@@ -371,10 +371,12 @@ class CharTokenizer:
             self._map = {c: 4 + i for i, c in enumerate(chars)}
 
     def pieces(self) -> Optional[List[str]]:
-        """The SentencePiece pieces in model order (None for the built-in synthetic alphabet): what
-        ``_get_char_index_mapping`` (models/unity/loader.py:158-176) re-orders the char embedding by."""
+        """The pieces in model order: what ``_get_char_index_mapping`` (models/unity/loader.py:158-176) re-orders the char
+        embedding of a fairseq-keyed checkpoint by.  The built-in synthetic alphabet answers with its own (short) list - a
+        fairseq-layout rendition of the synthetic weights (scripts/real_layout_check.py) converts like a published file."""
         if self._spm is None:
-            return None
+            by_index = sorted(self._map.items(), key=lambda kv: kv[1])
+            return ["<s>", "<pad>", "</s>", "<unk>"] + [c for c, _ in by_index]
         return [self._spm.id_to_piece(i) for i in range(self._spm.get_piece_size())]
 
     def token_to_index(self, ch: str) -> int:

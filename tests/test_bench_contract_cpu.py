@@ -41,7 +41,7 @@ def test_cpu_baseline_worker_reports_the_oracle_on_one_utterance():
 def test_default_workload_is_the_ragged_one(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse_args()
-    assert a.workload == "ragged" and a.text_len == 0 and a.dec_cus == -1  # resolved in main(): 64 tokens, SC_BENCH_DEC_CUS or 0
+    assert a.workload == "ragged" and a.text_len == 0 and a.engine_slots == 192  # text length resolved in main(): 64 tokens
 
 
 def test_decoder_row_statistics():

@@ -8,13 +8,30 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
-HEADER = ROOT / "include" / "seamless_hip.h"
+HEADER = ROOT / "include" / "seamless_hip.h"                    # the drop-in boundary
+INTERNAL_HEADER = ROOT / "include" / "seamless_hip_internal.h"  # kernel-level test hooks, dispatch introspection
+
+
+def _symbols_of(path):
+    text = re.sub(r"/\*.*?\*/", "", path.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", text)))
 
 
 def declared_symbols():
-    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
-    names = re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", text)
-    return sorted(set(names))
+    return sorted(set(_symbols_of(HEADER)) | set(_symbols_of(INTERNAL_HEADER)))
+
+
+def test_public_header_holds_the_boundary_only():
+    """What a binding of the reference needs and nothing else: no kernel-level hooks, no
+    dispatch introspection, none of the experiment switches of earlier rounds."""
+    public, internal = _symbols_of(HEADER), _symbols_of(INTERNAL_HEADER)
+    assert not [s for s in public if s.startswith("sc_op_")]
+    assert not set(public) & set(internal)
+    for gone in ("sc_set_cu_partition", "sc_set_decoder_priority", "sc_device_cu_count"):
+        assert gone not in public and gone not in internal
+    assert "sc_decoder_step_family" in internal and all(s.startswith("sc_op_") or s == "sc_decoder_step_family" for s in internal)
+    text = (ROOT / "INTEGRATION.md").read_text()
+    assert not [s for s in public if s not in text], "INTEGRATION.md must name every entry of the boundary"
 
 
 @pytest.fixture(scope="module")
@@ -112,3 +129,26 @@ def test_integration_guide_names_every_entry_point():
     missing = [s for s in declared_symbols() if not s.startswith("sc_op_") and s not in text]
     assert not missing, missing
     assert "sc_op_*" in text
+
+
+def test_switches_that_change_results_need_the_debug_gate(lib_path):
+    """One table for every SC_* variable the library reads (csrc/common.cpp), read once per process.  A stray SC_SPLIT_MODE /
+    SC_DECODER_GEN1 / ... in the environment of a drop-in library must not change its numbers: those are honoured only together
+    with SC_DEBUG_NUMERICS=1; schedule switches (same bits) pass."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import ctypes; from seamless_communication_amd import _lib; l = _lib.load_library(); "
+            "print(l.sc_op_knob(b'SC_SPLIT_MODE', 0), l.sc_op_knob(b'SC_DECODER_GEN1', -1), l.sc_op_knob(b'SC_VOC_STREAMS', 3), l.sc_op_knob(b'SC_PS_TILE', 256))")
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("SC_")}
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(ROOT), env=e, timeout=120)
+        assert r.returncode == 0, r.stderr[-1000:]
+        return r.stdout.split()
+
+    assert run() == ["0", "-1", "3", "256"]
+    assert run(SC_SPLIT_MODE="1", SC_DECODER_GEN1="1", SC_VOC_STREAMS="1", SC_PS_TILE="128") == ["0", "-1", "1", "128"]
+    assert run(SC_SPLIT_MODE="1", SC_DECODER_GEN1="1", SC_DEBUG_NUMERICS="1") == ["1", "1", "3", "256"]

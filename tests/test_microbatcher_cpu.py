@@ -18,8 +18,8 @@ class _Model:
         self.log.append((self.name, "fbank", int(wav.shape[0]), threading.get_ident()))
         return wav[:, :4, None].repeat(1, 1, 2), np.asarray([4] * wav.shape[0], dtype=np.int32)
 
-    def set_cu_partition(self, k, layout="low"):
-        self.log.append((self.name, "partition", k, layout))
+    def engine_expect(self, n):
+        self.log.append((self.name, "expect", n))
 
 
 class _Translator:
@@ -79,12 +79,36 @@ def test_whole_batch_passes_pipelined_across_passes():
     mb.close()
 
 
-def test_one_group_runs_on_the_calling_thread_and_partition_reaches_every_view():
+def test_one_group_runs_on_the_calling_thread_and_passes_are_handed_over_in_order():
     log = []
     mb = MicroBatcher(_Translator(log), 1)
     outs = mb.predict_passes(_wav(2), [8, 8], 2, "S2ST", "fra")
     assert len(outs) == 2 and outs[0][0] == ["utt0", "utt1"]
-    log.clear()
-    mb2 = MicroBatcher(_Translator(log), 2, decoder_cus=32, cu_layout="low")
-    assert sorted(e[0] for e in log if e[1] == "partition") == ["t0", "t0.f1"]
-    mb2.close()
+    mb.close()
+    # on_pass: called on the calling thread for pass 0, 1, 2, ... in that order while later passes still run
+    seen = []
+    mb3 = MicroBatcher(_Translator(log), 3)
+    me = threading.get_ident()
+    outs = mb3.predict_passes(_wav(4), [8] * 4, 7, "S2ST", "fra", stagger_s=0.002,
+                              on_pass=lambda k, out: seen.append((k, threading.get_ident() == me, out[0])))
+    assert [k for k, _, _ in seen] == list(range(7)) and all(mine for _, mine, _ in seen)
+    assert all(t == outs[k][0] for k, _, t in seen)
+    mb3.close()
+
+
+def test_a_failing_pass_reaches_the_caller():
+    class _Boom(_Translator):
+        def fork(self):
+            return _Boom(self.log, self.name + ".f")
+
+        def predict(self, src, task, tgt_lang, **kw):
+            raise RuntimeError("stage failed")
+
+    mb = MicroBatcher(_Boom([]), 2)
+    try:
+        import pytest
+
+        with pytest.raises(RuntimeError, match="stage failed"):
+            mb.predict_passes(_wav(2), [8, 8], 4, "S2ST", "fra")
+    finally:
+        mb.close()

@@ -231,27 +231,3 @@ def test_named_synthetic_card_warns_and_uri_options_parse():
     assert tr.parse_synthetic_uri("synthetic://7?eos_ramp=45,1.27,0.34,2.5") == (7, {"eos_ramp": "45,1.27,0.34,2.5"})
     with pytest.raises(ValueError, match="unknown option"):
         tr.parse_synthetic_uri("synthetic://7?ramp=3")
-
-
-def test_cu_masks_partition_the_chip():
-    """runtime.cu_masks: decoder mask = the first k mask bits (k / 8 compute units of every XCD on MI355X,
-    profiles/r4_micro_cumask.txt), the other mask its complement over the device's CU count."""
-    import numpy as np
-    import pytest
-
-    from seamless_communication_amd.runtime import HipS2STModel
-
-    dec, oth = HipS2STModel.cu_masks(256, 32)
-    assert dec.dtype == np.uint32 and len(dec) == len(oth) == 8
-    assert dec.tolist() == [0xFFFFFFFF] + [0] * 7 and oth.tolist() == [0] + [0xFFFFFFFF] * 7
-    dec, oth = HipS2STModel.cu_masks(256, 64, "xcd")
-    bits = lambda m: sum(bin(int(w)).count("1") for w in m)
-    assert bits(dec) == 64 and bits(oth) == 192 and all(int(a) & int(b) == 0 for a, b in zip(dec, oth))
-    assert all((i % 8 < 2) == bool(int(dec[i // 32]) >> (i % 32) & 1) for i in range(256))
-    dec, oth = HipS2STModel.cu_masks(304, 48)   # a device whose CU count is not a multiple of 32: no bit behind the last CU
-    assert bits(dec) == 48 and bits(oth) == 256 and int(oth[-1]) >> 16 == 0
-    for bad in (0, 256, -3):
-        with pytest.raises(ValueError):
-            HipS2STModel.cu_masks(256, bad)
-    with pytest.raises(ValueError):
-        HipS2STModel.cu_masks(256, 32, "diagonal")
