@@ -51,6 +51,12 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
+# The HIP runtime maps a process's streams onto 4 hardware queues by default; the pipelined schedule has 7+ streams with work in
+# flight (six pass workers, the decode engine, the vocoder's side chains) and streams that share a queue run one behind the
+# other.  8 queues: +2.8 % with the engine, +5 % without, same box (profiles/r5_engine_sweep.txt).  Must be set before the
+# runtime starts; an explicit setting of the caller wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -788,6 +794,7 @@ def main():
                 "gather_ms": ({"mean": round(1e3 * float(np.mean(gather_s[-args.steps:])), 3), "max": round(1e3 * float(np.max(gather_s[-args.steps:])), 3),
                                "calls": len(gather_s[-args.steps:])} if gather_s else None),
                 "hip_graph_decoder_step": bool(translator.use_graph),
+                "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "microbatches_in_flight": batcher.groups,
                 "pass_latency_ms": (round(1e3 * float(np.mean(batcher.last_pass_seconds)), 1) if args.pipeline_passes and free_run and
                                     getattr(batcher, "last_pass_seconds", None) else round(ms_per_step, 1)),

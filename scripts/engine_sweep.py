@@ -9,9 +9,12 @@ measurement of bench.py without the parity / profile / extras blocks.  Prints on
 pass, engine statistics, ids of the last pass compared with the golden fixture)."""
 import argparse
 import json
+import os
 import sys
 import time
 from pathlib import Path
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # as bench.py does (the runtime's default of 4 hardware queues serialises streams)
 
 import torch
 
@@ -51,8 +54,6 @@ def main():
         g, slots = int(kv.get("g", 3)), int(kv.get("slots", 0))
         mb = MicroBatcher(translator, g)
         line = {"config": spec}
-        import os
-
         for key, env in (("g4", "SC_ENGINE_G4"), ("tpw", "SC_ENGINE_G4_TPW")):  # read by the engine when it is created
             if key in kv:
                 os.environ[env] = kv[key]

@@ -155,7 +155,7 @@ for task in "$@"; do
     cover)
       # kernel trace of two bench passes: how busy the device is over the last pass (union of kernel intervals, idle gaps, timeline)
       rm -rf gpurun_out/${TAG}_cover
-      ( cd /tmp && timeout -k 10 ${COVER_TIMEOUT:-150} rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_cover -o b -- python $R/bench.py --steps ${COVER_STEPS:-9} --warmup 1 --no-cpu-baseline --no-latency --no-extra --no-profile-step > $R/${O}_cover.log 2>&1; echo "exit $?" >> $R/${O}_cover.log )
+      ( cd /tmp && timeout -k 10 ${COVER_TIMEOUT:-150} rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_cover -o b -- python $R/bench.py --steps ${COVER_STEPS:-9} --warmup 1 --no-cpu-baseline --no-latency --no-extra --no-profile-step $COVER_ARGS > $R/${O}_cover.log 2>&1; echo "exit $?" >> $R/${O}_cover.log )
       f=$(find gpurun_out/${TAG}_cover -name "*kernel_trace.csv" | head -1)
       ms=$(python -c "import json,sys; print(json.loads([l for l in open('${O}_cover.log') if l.startswith('{')][-1])['ms_per_step'])" 2>/dev/null || echo 260)
       [ -n "$f" ] && python scripts/trace_cover.py $f --window-ms $ms --bin-ms ${COVER_BIN:-5} --skip-tail-ms ${COVER_SKIP_TAIL:-$(python -c "print(3.5 * $ms)")} > ${O}_cover.txt 2>&1; head -90 ${O}_cover.txt | cut -c1-200

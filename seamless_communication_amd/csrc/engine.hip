@@ -187,7 +187,8 @@ void Engine::Impl::setup(const Model& parent) {
         // (1 FFN-in, 2 FFN-out, 4 cross-attention query, 8 out-projections), SC_ENGINE_G4_TPW = tiles per wave (1 / 2)
         // rows per row group of the N = 1024 products (out-projections, cross-attention query): 16 is tuned for <= 64 rows
         // (latency); SC_ENGINE_RG_SMALL for A/B timing of the wide step (same bits whatever the grouping)
-        c.rg_small = std::min(32, std::max(8, knob::value("SC_ENGINE_RG_SMALL", c.rg_small)));
+        // (16 up to 128 slots, 32 above: 3.38 -> 3.22 ms per 192-slot step alone, profiles/r5_engine_sweep.txt)
+        c.rg_small = std::min(32, std::max(8, knob::value("SC_ENGINE_RG_SMALL", S > 128 ? 32 : 16)));
         c.g4 = knob::value("SC_ENGINE_G4", 0) & 15;  // off: measured slower, alone and under load (profiles/r5_gemv4_ab.txt)
         c.g4_tpw = std::min(2, std::max(0, knob::value("SC_ENGINE_G4_TPW", 0)));
     }
