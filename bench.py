@@ -910,6 +910,10 @@ def main():
         # the driver keeps `config` verbatim: the parity verdict travels there too
         result["config"]["parity"] = result["parity"]
         print(json.dumps(result), flush=True)
+    try:
+        batcher.close()  # worker pool and (if still there) the decode engine's thread
+    except Exception as e:  # noqa: BLE001 - the line is out; a shutdown hiccup must not turn the run into a failure
+        log(f"batcher.close(): {e!r}")
 
     if world > 1:
         dist.barrier()

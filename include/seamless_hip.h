@@ -217,8 +217,6 @@ int sc_generate_text(sc_model* m, const float* d_enc, int32_t n, int32_t s_enc, 
  *   low_water    with fewer rows than this the engine pauses WHILE announced rows (sc_engine_expect) are still on their way,
  *                at most max_wait_ms (0 = 100) - a step costs the same for 5 rows as for 64; 0 = never pause
  *   use_graph    replay the step from a captured hipGraph
- *   priority     stream priority of the chain (> 0 highest: its ~220 short dependent launches per step are served first as the
- *                GEMM-bound stages of the passes release compute units)
  * The engine runs its own host thread and HIP stream; sc_engine_free stops it (requests still inside fail).  The model handle
  * given to sc_engine_create (and its weights) must outlive the engine, the engine the handles it is attached to. */
 typedef struct sc_engine sc_engine;
@@ -227,7 +225,6 @@ typedef struct sc_engine_opts {
     int32_t min_seq_len;
     float unk_penalty;
     int32_t poll, low_water, max_wait_ms, use_graph;
-    int32_t priority; /* > 0: the engine's stream gets the highest stream priority, < 0 the lowest, 0 the default */
 } sc_engine_opts;
 typedef struct sc_engine_stats {
     int64_t steps;            /* step replays */

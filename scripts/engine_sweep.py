@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of bench.py's timed region under several decode-engine / schedule settings, ONE model load.
 
-    python scripts/engine_sweep.py [--steps 12] [--configs "g=3,slots=0;g=4,slots=64,lw=32;g=6,slots=128,lw=64,prio=1"]
+    python scripts/engine_sweep.py [--steps 12] [--configs "g=3,slots=0;g=4,slots=64,lw=32;g=6,slots=192,lw=96,poll=4"]
 
 Every configuration: a fresh MicroBatcher on forked handles (g passes in flight; slots = 0: every pass its own decoder
 chain, round 4's schedule), one warm round, then `steps` whole-batch passes between two device synchronisations - the
@@ -54,16 +54,11 @@ def main():
         g, slots = int(kv.get("g", 3)), int(kv.get("slots", 0))
         mb = MicroBatcher(translator, g)
         line = {"config": spec}
-        for key, env in (("g4", "SC_ENGINE_G4"), ("tpw", "SC_ENGINE_G4_TPW")):  # read by the engine when it is created
-            if key in kv:
-                os.environ[env] = kv[key]
-            else:
-                os.environ.pop(env, None)
         try:
             if slots > 0:
                 max_len, s_enc = MicroBatcher.engine_geometry(translator, ns, opts)
                 mb.enable_engine(max_len, s_enc, slots=slots, rows=max(4 * slots, (g + 1) * B), poll=int(kv.get("poll", 4)),
-                                 low_water=int(kv.get("lw", 0)), max_wait_ms=int(kv.get("wait", 150)), priority=int(kv.get("prio", 0)))
+                                 low_water=int(kv.get("lw", 0)), max_wait_ms=int(kv.get("wait", 150)))
             tw = time.perf_counter()
             mb.predict_passes(wav, ns, g, "S2ST", "fra", text_generation_opts=opts)
             torch.cuda.synchronize()

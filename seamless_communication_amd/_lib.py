@@ -80,7 +80,7 @@ class sc_gen_opts(C.Structure):
 class sc_engine_opts(C.Structure):
     _fields_ = [
         ("slots", _i), ("rows", _i), ("max_len", _i), ("s_enc", _i), ("min_seq_len", _i), ("unk_penalty", C.c_float),
-        ("poll", _i), ("low_water", _i), ("max_wait_ms", _i), ("use_graph", _i), ("priority", _i),
+        ("poll", _i), ("low_water", _i), ("max_wait_ms", _i), ("use_graph", _i),
     ]
 
 

@@ -17,7 +17,7 @@ CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = Path(__file__).resolve().parent / "libseamless_hip.so"
 OBJ_DIR = CSRC / "build"
 SOURCES = [
-    "common.cpp", "prof.hip", "k_gemm.hip", "k_gemm2.hip", "k_gemm_ps.hip", "k_resblock.hip", "k_skinny.hip", "k_dstep.hip", "k_dstep3.hip", "k_dstep4.hip", "k_norm.hip", "k_attn.hip", "k_fbank.hip", "k_misc.hip", "k_beam.hip", "k_engine.hip",
+    "common.cpp", "prof.hip", "k_gemm.hip", "k_gemm2.hip", "k_gemm_ps.hip", "k_resblock.hip", "k_skinny.hip", "k_dstep.hip", "k_dstep3.hip", "k_norm.hip", "k_attn.hip", "k_fbank.hip", "k_misc.hip", "k_beam.hip", "k_engine.hip",
     "model_load.hip", "model_encoder.hip", "model_decoder.hip", "model_t2u.hip", "engine.hip", "api.hip",
 ]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

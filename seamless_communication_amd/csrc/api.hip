@@ -727,23 +727,9 @@ int sc_op_dstep3_gemv(int32_t mode, const float* d_x, const void* d_w_f16, const
     SC_API_BEGIN
     SC_CHECK(mode >= 0 && mode <= 3 && d_x && d_w_f16 && d_y, "sc_op_dstep3_gemv: bad argument");
     const int in_mode = (mode == 0 || mode == 2) ? IN3_LN : IN3_PLANES;
-    // shape | 0x100: the row-group-stationary kernel (k_dstep4.hip) with the chunks of `shape` - must give the same bits
-    const bool g4 = (shape & 0x100) != 0;
-    shape &= 0xff;
     SC_CHECK(gemv3_supported(M, N, K, in_mode), "sc_op_dstep3_gemv: M=%d N=%d K=%d mode=%d unsupported", M, N, K, mode);
     OpScratch scratch;
     const int RB = M <= 32 ? 32 : (int)align_up(M, 32);
-    auto run = [&](Gemv3Args& a) {
-        if (!g4) {
-            launch_gemv3(a, g_op_stream);
-            return;
-        }
-        Gemv4Args b;
-        b.Wp = a.Wp, b.M = a.M, b.N = a.N, b.K = a.K, b.in_mode = a.in_mode, b.xg = a.xg, b.gamma = a.gamma, b.beta = a.beta, b.Ah = a.Ah, b.Al = a.Al;
-        b.RB = a.RB, b.ksw = a.shape == G3_T2K8 ? 8 : 4, b.epi = a.epi, b.bias = a.bias, b.out = a.out, b.ldo = a.ldo, b.xres = a.xres, b.XRB = a.XRB;
-        b.Oh = a.Oh, b.Ol = a.Ol, b.ORB = a.ORB, b.act = a.act, b.tiles_per_wave = rg > 0 && rg <= 2 ? rg : 0;
-        launch_gemv4(b, g_op_stream);
-    };
     __half* wp = scratch.get<__half>((size_t)packed_weight_halfs(N, K));
     launch_pack_weight(static_cast<const __half*>(d_w_f16), K, N, K, wp, g_op_stream);
     Gemv3Args a;
@@ -763,12 +749,12 @@ int sc_op_dstep3_gemv(int32_t mode, const float* d_x, const void* d_w_f16, const
     }
     if (mode == 0) {
         a.epi = EPI3_ROWS, a.out = d_y, a.ldo = N;
-        run(a);
+        launch_gemv3(a, g_op_stream);
     } else if (mode == 2) {
         __half* oh = scratch.get<__half>((size_t)N * RB);
         __half* ol = scratch.get<__half>((size_t)N * RB);
         a.epi = EPI3_PLANES, a.act = act, a.Oh = oh, a.Ol = ol, a.ORB = RB;
-        run(a);
+        launch_gemv3(a, g_op_stream);
         launch_planes_to_rows(oh, ol, RB, d_y, N, M, N, g_op_stream);
     } else {
         SC_CHECK(d_res, "sc_op_dstep3_gemv: modes 1 and 3 need the residual");
@@ -777,13 +763,12 @@ int sc_op_dstep3_gemv(int32_t mode, const float* d_x, const void* d_w_f16, const
         launch_rows_to_kgm(d_res, N, M, N, RB, xres, g_op_stream);
         if (mode == 1) {
             a.epi = EPI3_RESID, a.xres = xres, a.XRB = RB;
-            run(a);
+            launch_gemv3(a, g_op_stream);
         } else {
-            if (g4) SC_CHECK(shape == G3_T2K4, "sc_op_dstep3_gemv: the stationary kernel writes the K slices of shape G3_T2K4");
             const int S = gemv3_splits(K, shape);
             float* partial = scratch.get<float>((size_t)S * M * N);
             a.epi = EPI3_PARTIAL, a.out = partial, a.mt2 = 1, a.bias = nullptr;
-            run(a);
+            launch_gemv3(a, g_op_stream);
             Reduce3Args r;
             r.partial = partial, r.S = S, r.bias = d_bias, r.xg = xres, r.XRB = RB, r.rows = M, r.C = N;
             if (d_gamma) r.gamma = d_gamma, r.beta = d_beta, r.hfix = d_h, r.RB = RB;

@@ -37,7 +37,7 @@ const Knob knob_table[] = {
     {"SC_GEMM_GROUP_M", 0, "GEMM workgroup order"}, {"SC_GEMM_TILE", 0, "GEMM tile override"},
     {"SC_PS_ILV", 0, "DMA GEMM: interleaved issue"}, {"SC_PS_HALF", 0, "DMA GEMM: mid-slab barrier"},
     {"SC_PS_TILE", 0, "DMA GEMM: largest tile"}, {"SC_PS_MIN256", 0, "DMA GEMM: tiles needed for 256 x 256"},
-    {"SC_PS_MIN128", 0, "DMA GEMM: tiles needed for 128 x 128"}, {"SC_PS_PRIO", 0, "DMA GEMM: static priority for waves 4-7"},
+    {"SC_PS_MIN128", 0, "DMA GEMM: tiles needed for 128 x 128"},
     {"SC_PRESPLIT", 0, "0: Conformer operands split on the fly"}, {"SC_ENC_FUSE", 0, "0: separate Conformer element-wise launches"},
     {"SC_DSTEP_TOUCH", 0, "weight toucher: layers ahead"}, {"SC_DSTEP_TOUCH_WGS", 0, "weight toucher: workgroups"},
     {"SC_D3_RG_SMALL", 0, "decoder step: rows per row group, N = 1024 products"}, {"SC_D3_RG_FFN", 0, "decoder step: rows per row group, FFN-in"},
@@ -47,8 +47,7 @@ const Knob knob_table[] = {
     {"SC_VOC_PS", 0, "0: vocoder wide stages on the register-staged convolution"}, {"SC_VOC_MRF", 0, "0: narrow vocoder stages as nine pair launches"},
     {"SC_VOC_GROUPS", 0, "vocoder: length buckets"}, {"SC_VOC_GROUP_OVERHEAD", 0, "vocoder: bucket planning overhead rows"},
     {"SC_VOC_STREAMS", 0, "vocoder: side chains"},
-    {"SC_ENGINE_G4", 0, "decode engine: products on the row-group-stationary kernel (bit mask)"},
-    {"SC_ENGINE_G4_TPW", 0, "decode engine: tiles per wave of those"}, {"SC_ENGINE_RG_SMALL", 0, "decode engine: rows per row group, N = 1024 products"},
+    {"SC_ENGINE_RG_SMALL", 0, "decode engine: rows per row group, N = 1024 products"},
     // re-read per call
     {"SC_GREEDY_COMPACT", 2, "0: greedy generation keeps finished rows in their slots"}, {"SC_GREEDY_POLL", 2, "steps between looks at the finished flags"},
 };

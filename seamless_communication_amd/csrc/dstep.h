@@ -62,10 +62,6 @@ struct StepCtx {
     // state, every row has its own position (pos_row), length limit and prompt length, and the closing launch of the step
     // (engine_finalize_kernel) advances the positions itself.  null: slot = row, one scalar position (*d_pos).
     int2* slot_rp = nullptr;
-    // which products of a step of more than 64 rows run on the row-group-stationary kernel (k_dstep4.hip; same bits as the row-group
-    // kernel): 1 FFN-in, 2 FFN-out, 4 the cross-attention query, 8 the two out-projections
-    int g4 = 0;
-    int g4_tpw = 0;  // tiles per wave of those launches (0: the launcher's choice)
     int* pos_row = nullptr;
     int* limit_row = nullptr;
     int* prefix_row = nullptr;

@@ -75,7 +75,7 @@ struct Engine::Impl {
     int L = 0, M = 0;
     // device state
     Buf<int> ints, d_rids, d_stage;
-    Buf<float> fl, hidden, xg, qkvr, qkv3, partial, am_eos, hN;
+    Buf<float> fl, hidden, xg, qkvr, partial, am_eos, hN;
     Buf<float4> am_part;
     Buf<EngineAdmitRec> d_admit;
     Buf<EngineRetireRec> d_retire;
@@ -125,13 +125,7 @@ struct Engine::Impl {
 
 void Engine::Impl::setup(const Model& parent) {
     static_cast<ModelData&>(em) = static_cast<const ModelData&>(parent);
-    if (o.priority != 0) {  // the shared chain is what every pass waits for: its short kernels first (or last) as compute units turn over
-        int lo = 0, hi = 0;
-        SC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = numerically greatest = lowest priority
-        SC_HIP(hipStreamCreateWithPriority(&em.stream, hipStreamNonBlocking, o.priority > 0 ? hi : lo));
-    } else {
-        SC_HIP(hipStreamCreateWithFlags(&em.stream, hipStreamNonBlocking));
-    }
+    SC_HIP(hipStreamCreateWithFlags(&em.stream, hipStreamNonBlocking));
     em.pool.set_stream(em.stream);
     em.hook_pool(em.pool);
     const sc_config& cfg = em.cfg;
@@ -181,16 +175,10 @@ void Engine::Impl::setup(const Model& parent) {
     hN = Buf<float>(em.pp(), (size_t)S * M);
     c.xg = xg, c.qkvr = qkvr, c.hN = hN;
     if (S > 64) {
-        qkv3 = Buf<float>(em.pp(), (size_t)S * 3 * M);
-        c.qkv3 = qkv3;
-        // products of the wide step on the row-group-stationary kernel (same bits); SC_ENGINE_G4 = bit mask for A/B timing
-        // (1 FFN-in, 2 FFN-out, 4 cross-attention query, 8 out-projections), SC_ENGINE_G4_TPW = tiles per wave (1 / 2)
         // rows per row group of the N = 1024 products (out-projections, cross-attention query): 16 is tuned for <= 64 rows
         // (latency); SC_ENGINE_RG_SMALL for A/B timing of the wide step (same bits whatever the grouping)
         // (16 up to 128 slots, 32 above: 3.38 -> 3.22 ms per 192-slot step alone, profiles/r5_engine_sweep.txt)
         c.rg_small = std::min(32, std::max(8, knob::value("SC_ENGINE_RG_SMALL", S > 128 ? 32 : 16)));
-        c.g4 = knob::value("SC_ENGINE_G4", 0) & 15;  // off: measured slower, alone and under load (profiles/r5_gemv4_ab.txt)
-        c.g4_tpw = std::min(2, std::max(0, knob::value("SC_ENGINE_G4_TPW", 0)));
     }
     partial = Buf<float>(em.pp(), (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * S * 3 * M);
     c.partial = partial;

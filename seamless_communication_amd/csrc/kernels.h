@@ -91,7 +91,6 @@ struct GemmPsArgs {
     // packed (varlen) convolution: row_pos[m] = {position of row m inside its item, length of that item} (nullable);
     // replaces the uniform rows_per_item geometry: items of different lengths lie back to back, no padding rows
     const int2* row_pos = nullptr;
-    int prio_half = 0;  // filled by the launcher (SC_PS_PRIO): s_setprio 1 for waves 4-7 of the 8-wave tile
 };
 void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s);
 
@@ -351,40 +350,6 @@ void launch_ln3(const float* xg, int XRB, const float* gamma, const float* beta,
                 hipStream_t s);
 void launch_rows_to_kgm(const float* x, int64_t ldx, int rows, int C, int XRB, float* xg, hipStream_t s);
 void launch_kgm_to_rows(const float* xg, int XRB, float* out, int64_t ldo, int rows, int C, hipStream_t s);
-// ---- decoder step for many rows (k_dstep4.hip): the same products, row-group-stationary ----------------------------------
-// A workgroup stages ONE 32-row group in LDS (LayerNorm applied while staging for IN3_LN) and streams 8-16 weight tiles through
-// it; same arguments and the same bits as launch_gemv3 with the shape that has `ksw` k-steps per chunk (4: G3_T1 / G3_T2K4,
-// 8: G3_T2K8).  EPI3_PARTIAL writes gemv3's 512-wide K slices (gemv3_splits(K, G3_T2K4) of them).
-struct Gemv4Args {
-    const __half* Wp = nullptr;
-    int M = 0, N = 0, K = 0;
-    int in_mode = IN3_PLANES;
-    const float* xg = nullptr;
-    const float* gamma = nullptr;
-    const float* beta = nullptr;
-    const __half* Ah = nullptr;
-    const __half* Al = nullptr;
-    int RB = 32;
-    int ksw = 4;
-    int epi = EPI3_ROWS;
-    const float* bias = nullptr;
-    float* out = nullptr;
-    int64_t ldo = 0;
-    float* xres = nullptr;
-    int XRB = 32;
-    __half* Oh = nullptr;
-    __half* Ol = nullptr;
-    int ORB = 32;
-    int act = ACT_NONE;
-    const int* d_rows = nullptr;
-    int tiles_per_wave = 0;  // 0: chosen by the launcher (1 or 2)
-    // filled by the launcher
-    int KS = 0, NT_total = 0, tpg = 0, tgroups = 0, parts = 0, groups = 0;
-    uint32_t w_bytes = 0, a_bytes = 0;
-};
-bool gemv4_supported(int M, int N, int K, int in_mode, int epi);
-void launch_gemv4(const Gemv4Args& a, hipStream_t s);
-
 // vocabulary projection with the generation rules fused (record format of GemvPArgs' EPI_ARGMAX)
 struct Vocab3Args {
     const __half* Wp = nullptr;

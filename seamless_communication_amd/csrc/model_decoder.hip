@@ -506,15 +506,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
     const int n_layers = (int)layers.size();
     launch_embed3(c.d_tok, W.embed, sqrtf((float)M), W.pos, c.d_pos, c.xg, c.rb, nb, M, m.stream, c.slot_rp, c.slot_rp ? c.d_rows : nullptr);
     launch_ln3(c.xg, c.rb, layers[0].self_ln.g, layers[0].self_ln.b, c.hH, c.hL, c.rb, nb, M, m.stream);
-    const bool wide4 = nb > 64 && c.g4 != 0;  // many rows (decode engine): row-group-stationary products, same bits (k_dstep4.hip)
     auto out_resid = [&](const Linear& L) {  // x += att . W^T + b, finished inside the product
-        if (wide4 && (c.g4 & 8) && gemv4_supported(nb, L.out, L.in, IN3_PLANES, EPI3_RESID)) {
-            Gemv4Args a;
-            a.Wp = L.wp, a.M = nb, a.N = L.out, a.K = L.in, a.in_mode = IN3_PLANES, a.Ah = c.attH, a.Al = c.attL, a.RB = c.rb, a.ksw = 4;
-            a.epi = EPI3_RESID, a.bias = L.b, a.xres = c.xg, a.XRB = c.rb, a.d_rows = c.d_rows, a.tiles_per_wave = c.g4_tpw;
-            launch_gemv4(a, m.stream);
-            return;
-        }
         Gemv3Args a;
         a.Wp = L.wp, a.M = nb, a.N = L.out, a.K = L.in;
         a.in_mode = IN3_PLANES, a.Ah = c.attH, a.Al = c.attL, a.RB = c.rb, a.rg = c.rg_small;
@@ -580,13 +572,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         launch_dattn(a, /*cross=*/false, m.stream);
         out_resid(l.self_out);
         // encoder-decoder attention: the query projection applies its LayerNorm itself
-        if (wide4 && (c.g4 & 4) && gemv4_supported(nb, M, M, IN3_LN, EPI3_ROWS)) {
-            Gemv4Args q;
-            q.Wp = l.cross_q.wp, q.M = nb, q.N = M, q.K = M, q.in_mode = IN3_LN, q.xg = c.xg, q.gamma = l.cross_ln.g, q.beta = l.cross_ln.b;
-            q.RB = c.rb, q.ksw = 4, q.epi = EPI3_ROWS, q.bias = l.cross_q.b, q.out = c.qkvr, q.ldo = M, q.d_rows = c.d_rows;
-            q.tiles_per_wave = c.g4_tpw;
-            launch_gemv4(q, m.stream);
-        } else {
+        {
             Gemv3Args q;
             q.Wp = l.cross_q.wp, q.M = nb, q.N = M, q.K = M;
             q.in_mode = IN3_LN, q.xg = c.xg, q.gamma = l.cross_ln.g, q.beta = l.cross_ln.b, q.RB = c.rb, q.rg = c.rg_small;
@@ -627,14 +613,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
             launch_gemvp(f, m.stream);
         } else {  // the out-projection finishes x itself, FFN-in applies the LayerNorm itself
             out_resid(l.cross_out);
-            if (wide4 && (c.g4 & 1) && gemv4_supported(nb, W.ffn_dim, M, IN3_LN, EPI3_PLANES)) {
-                Gemv4Args f;
-                f.Wp = l.ffn_in.wp, f.M = nb, f.N = W.ffn_dim, f.K = M, f.in_mode = IN3_LN, f.xg = c.xg, f.gamma = l.ffn_ln.g, f.beta = l.ffn_ln.b;
-                f.RB = c.rb, f.ksw = c.ffn_in_mode == 1 ? 8 : 4;  // the chunks of G3_T2K8 / G3_T1
-                f.epi = EPI3_PLANES, f.bias = l.ffn_in.b, f.act = ACT_RELU, f.Oh = c.wideH, f.Ol = c.wideL, f.ORB = c.rb, f.d_rows = c.d_rows;
-                f.tiles_per_wave = c.g4_tpw;
-                launch_gemv4(f, m.stream);
-            } else {
+            {
                 Gemv3Args f;
                 f.Wp = l.ffn_in.wp, f.M = nb, f.N = W.ffn_dim, f.K = M;
                 f.in_mode = IN3_LN, f.xg = c.xg, f.gamma = l.ffn_ln.g, f.beta = l.ffn_ln.b, f.RB = c.rb, f.rg = c.rg_ffn;
@@ -646,12 +625,6 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         }
         if (c.ffn_out_mode == 0 && nb <= 64) {
             gemv2(m, c, c.wideH, c.wideL, l.ffn_out, 8, &sp);
-        } else if (wide4 && (c.g4 & 2) && c.ffn_out_mode == 1 && gemv4_supported(nb, M, W.ffn_dim, IN3_PLANES, EPI3_PARTIAL)) {
-            Gemv4Args o;  // the 512-wide K slices of G3_T2K4
-            o.Wp = l.ffn_out.wp, o.M = nb, o.N = M, o.K = W.ffn_dim, o.in_mode = IN3_PLANES, o.Ah = c.wideH, o.Al = c.wideL, o.RB = c.rb, o.ksw = 4;
-            o.epi = EPI3_PARTIAL, o.out = c.partial, o.d_rows = c.d_rows, o.tiles_per_wave = c.g4_tpw;
-            launch_gemv4(o, m.stream);
-            sp = gemv3_splits(W.ffn_dim, G3_T2K4);
         } else {
             Gemv3Args o;
             o.Wp = l.ffn_out.wp, o.M = nb, o.N = M, o.K = W.ffn_dim;
@@ -1644,7 +1617,9 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
             }
             // tuning knobs, read once per session and clamped to what the launches accept (an out-of-range value would
             // otherwise only surface as a failed check inside a captured step)
-            c.rg_small = std::min(32, std::max(1, env_int("SC_D3_RG_SMALL", 16)));
+            // (N = 1024 products: 16-row groups are tuned for <= 64 rows; above 128 live rows 32-row groups halve the workgroups that
+            //  re-read a weight tile - same bits whatever the grouping, tests/test_dstep3_gpu.py)
+            c.rg_small = std::min(32, std::max(1, env_int("SC_D3_RG_SMALL", nb > 128 ? 32 : 16)));
             c.rg_ffn = std::min(32, std::max(1, env_int("SC_D3_RG_FFN", 32)));
             c.ffn_in_mode = std::min(2, std::max(0, env_int("SC_D3_FFN_IN", 1)));
             c.ffn_out_mode = std::min(2, std::max(0, env_int("SC_D3_FFN_OUT", 1)));

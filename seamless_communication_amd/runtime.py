@@ -408,18 +408,15 @@ class DecodeEngine:
     engine, bit for bit.  Not part of the reference API (the reference generates one batch at a time)."""
 
     def __init__(self, model: HipS2STModel, max_len: int, s_enc: int, slots: int = 64, rows: int = 0, min_seq_len: int = 1,
-                 unk_penalty: float = 0.0, poll: int = 4, low_water: int = 0, max_wait_ms: int = 100, use_graph: bool = True,
-                 priority: int = 0) -> None:
+                 unk_penalty: float = 0.0, poll: int = 4, low_water: int = 0, max_wait_ms: int = 100, use_graph: bool = True) -> None:
         self.lib = model.lib
         self._model = model  # the weights must outlive the engine
         o = _lib.sc_engine_opts()
         o.slots, o.rows, o.max_len, o.s_enc = int(slots), int(rows), int(max_len), int(s_enc)
         o.min_seq_len, o.unk_penalty = int(min_seq_len), float(unk_penalty)
         o.poll, o.low_water, o.max_wait_ms, o.use_graph = int(poll), int(low_water), int(max_wait_ms), int(bool(use_graph))
-        o.priority = int(priority)
         self.opts = dict(slots=int(slots) or 64, rows=int(rows) or 4 * (int(slots) or 64), max_len=int(max_len), s_enc=int(s_enc),
-                         poll=int(poll) or 4, low_water=int(low_water), max_wait_ms=int(max_wait_ms) or 100, use_graph=bool(use_graph),
-                         priority=int(priority))
+                         poll=int(poll) or 4, low_water=int(low_water), max_wait_ms=int(max_wait_ms) or 100, use_graph=bool(use_graph))
         self.handle = self.lib.sc_engine_create(model.handle, C.byref(o))
         if not self.handle:
             msg = self.lib.sc_last_error()

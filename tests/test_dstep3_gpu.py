@@ -140,38 +140,3 @@ def test_vocab3_fused_argmax(lib, report_dir, M, N, K, mode):
     _log(report_dir, "vocab3_argmax", M=M, N=N, K=K, mode=mode, err=err)
     assert err < 1e-4
 
-
-# the row-group-stationary kernels of the decode engine's wide step (csrc/k_dstep4.hip) against the row-group kernels: same
-# chunks of k-steps added in the same order, same LayerNorm statistics -> the SAME BITS (shape | 0x100 selects them; `rg` then
-# carries the tiles per wave)
-@pytest.mark.parametrize("tpw", [1, 2])
-@pytest.mark.parametrize("mode,M,N,K,act,shape", [
-    (0, 192, 1024, 1024, 0, 0), (0, 70, 384, 128, 0, 0), (0, 33, 104, 64, 0, 0),            # LayerNorm -> rows (cross-attention query)
-    (1, 192, 1024, 1024, 0, 0), (1, 100, 128, 128, 0, 0),                                    # out-projection + residual
-    (2, 192, 8192, 1024, 1, 1), (2, 130, 256, 128, 1, 1), (2, 96, 8192, 1024, 0, 0), (2, 65, 224, 128, 1, 0),  # FFN-in (both chunkings)
-    (3, 192, 1024, 8192, 0, 2), (3, 70, 128, 256, 0, 2), (3, 40, 96, 512, 0, 2),             # FFN-out K slices + reduce
-])
-def test_gemv4_equals_gemv3_bit_for_bit(lib, report_dir, mode, M, N, K, act, shape, tpw):
-    x, w, b, gam, bet = _case(M, N, K, 11 * M + N + K + mode)
-    g = torch.Generator().manual_seed(M + 2)
-    res = torch.randn(M, N, generator=g) * 2
-    gam_n = torch.rand(N, generator=g) + 0.5
-    bet_n = torch.randn(N, generator=g) * 0.1
-    outs = []
-    for flag, rg in ((0, 32 if mode != 3 else 0), (0x100, tpw)):
-        y = torch.full((M, N), float("nan"), device="cuda")
-        h = torch.full((M, N), float("nan"), device="cuda")
-        if mode in (0, 2):
-            args = (P(dev(gam)), P(dev(bet)), P(None), P(y), P(None))
-        elif mode == 1:
-            args = (P(None), P(None), P(dev(res)), P(y), P(None))
-        else:
-            args = (P(dev(gam_n)), P(dev(bet_n)), P(dev(res)), P(y), P(h))
-        check(lib, lib.sc_op_dstep3_gemv(mode, P(dev(x)), P(dev(w)), P(dev(b)), *args, M, N, K, act, rg, shape | flag))
-        outs.append((y.cpu(), h.cpu() if mode == 3 else None))
-    _log(report_dir, "gemv4_vs_gemv3", mode=mode, M=M, N=N, K=K, shape=shape, tpw=tpw, equal=bool(torch.equal(outs[0][0], outs[1][0])),
-         max_diff=float((outs[0][0] - outs[1][0]).abs().max()))
-    assert not torch.isnan(outs[1][0]).any()
-    assert torch.equal(outs[0][0], outs[1][0])
-    if mode == 3:
-        assert torch.equal(outs[0][1], outs[1][1])
