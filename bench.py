@@ -865,6 +865,59 @@ def main():
             result["roofline"] = roof
             result["kernel_families_profiled_step"] = shares
             result["stage_ms_profiled_step"] = {k: round(v, 3) for k, v in stage_ms.items()}
+        if batcher.engine is not None:
+            # The profiled pass above ran ALONE: its 64 rows were the engine's only rows.  In the timed region the shared chain
+            # carries the rows of several passes: measure the step at THAT operating point - three passes' rows handed to the
+            # engine together, nothing else on the chip, every replay timed with HIP events on the engine's own stream.
+            import threading
+
+            fb, frames = model.fbank(wav_dev, ns, standardize=True, pad_to_multiple=2)
+            enc, enc_lens = model.encode_speech(fb, frames.tolist())
+            prefix = translator.text_tokenizer.target_prefix("fra")
+            torch.cuda.synchronize()
+            batcher.engine.stats(reset=True)
+            lib.sc_prof_reset()
+            lib.sc_prof_enable(1)
+
+            def text_only(view):
+                torch.cuda.set_device(device)
+                view.model.engine_expect(B)
+                view.model.generate_text(enc, enc_lens.tolist(), prefix, beam_size=1, soft_max_seq_len=opts.soft_max_seq_len,
+                                         hard_max_seq_len=opts.hard_max_seq_len, use_graph=translator.use_graph, source_len=int(fb.shape[1]))
+
+            th = [threading.Thread(target=text_only, args=(v,)) for v in batcher.views[: min(3, batcher.groups)]]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize()
+            lib.sc_prof_enable(0)
+            sg = prof_report(lib).get("dec:step_graph")
+            est = batcher.engine.stats()
+            if rank == 0 and sg and sg["launches"] > 0 and result.get("roofline"):
+                single = result["roofline"]
+                sec = sg["ms"] * 1e-3 / sg["launches"]
+                rows_avg = sg["flops"] / max(1.0, step_bytes["streamed_weight_bytes"] * sg["launches"])
+                ach = step_bytes["survey_weight_bytes"] / sec / 1e9
+                all_b = sg["bytes"] / sg["launches"] / sec / 1e9
+                traffic, traffic_from = pmc_traffic("dec:step_graph")
+                op = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                      "algorithmic_bytes_per_launch": step_bytes["survey_weight_bytes"],
+                      "kv_cache_bytes_per_launch": sg["bytes"] / sg["launches"] - step_bytes["streamed_weight_bytes"],
+                      "weight_bytes_streamed_per_launch": step_bytes["streamed_weight_bytes"],
+                      "achieved_incl_kv_cache": all_b, "frac_incl_kv_cache": all_b / HBM_PEAK_GBS,
+                      "rows_per_launch": round(rows_avg, 1), "us_per_row_step": round(1e6 * sec / max(1.0, rows_avg), 2),
+                      # SURVEY section 8(d) prices the same step in flops too (1.733 N GFLOP; MFMA-bound from ~256 rows on): both views
+                      "mfma_view": {"algorithmic_flops_per_launch": step_bytes["survey_weight_bytes"] * rows_avg,
+                                    "achieved_tflops": step_bytes["survey_weight_bytes"] * rows_avg / sec / 1e12,
+                                    "frac_of_dense_f16_peak": step_bytes["survey_weight_bytes"] * rows_avg / sec / 1e12 / MFMA_F16_PEAK_TFLOPS},
+                      "traffic": traffic, "traffic_from": traffic_from, "kernel": "dec:step_graph", "launches": sg["launches"],
+                      "avg_launch_us": 1e6 * sec,
+                      "measured": (f"the decode engine ALONE on the chip with the rows of {len(th)} passes ({len(th) * B}) handed over together: the operating "
+                                   f"point of the timed schedule (mean rows per step there: {result['config']['decode_engine']['mean_rows_per_step']}); "
+                                   f"one replay = one step of the shared chain, HIP events on the engine's stream; engine steps {int(est['steps'])}"),
+                      "single_pass_alone": single}
+                result["roofline"] = op
     elif rank == 0:
         result["roofline"] = None
 
