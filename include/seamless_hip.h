@@ -209,7 +209,10 @@ int sc_generate_text(sc_model* m, const float* d_enc, int32_t n, int32_t s_enc, 
  * and no pass carries its finished rows.  Per row the results (ids, lengths, scores, captured decoder outputs) are those of
  * the call without an engine, bit for bit: a row's arithmetic depends neither on its slot nor on its neighbours nor on the
  * step at which it entered.  Calls that do not fit (beam search, step processors, longer limits than the engine was built
- * for, other min_seq_len / unk_penalty) run on the handle's own chain as before.
+ * for, other min_seq_len / unk_penalty) run on the handle's own chain as before, and so does a LONE call: when no other
+ * request is inside the engine and no rows are announced (sc_engine_expect), there is nothing to share the chain with, and
+ * the handle's own chain - whose kernels are sized for the call's rows, not for the engine's slots - is faster (batch-1
+ * latency 95 instead of 121 ms).
  *   slots        rows per step (1..512; 0 = 64)                 rows   row states kept: rows in slots + rows that wait (0 = 4 x slots)
  *   max_len      longest hypothesis (prompt + tokens + EOS) a request may ask for (the K / V positions kept per row)
  *   s_enc        longest encoder output a request may bring

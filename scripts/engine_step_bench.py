@@ -33,11 +33,13 @@ for n in [int(x) for x in args.slots.split(",")]:
     view = model.fork()
     eng.attach(view)
     kw = dict(soft_max_seq_len=(1, 200), hard_max_seq_len=args.text_len, want_hidden=True)
+    view.engine_expect(n)  # (an unannounced lone call would stay on the handle's own chain)
     ids, out_lens, _, _ = view.generate_text(enc, lens, prefix, **kw)  # warm-up: graph capture
     eng.stats(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.reps):
+        view.engine_expect(n)
         ids2, _, _, _ = view.generate_text(enc, lens, prefix, **kw)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.reps

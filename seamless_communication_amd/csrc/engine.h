@@ -17,6 +17,9 @@ class Engine {
     const sc_engine_opts& opts() const;
     // can a greedy sc_generate_text call of this shape go through the engine?
     bool fits(int n, int s_enc, int max_len, int prefix_len, const sc_gen_opts& o) const;
+    // is there anything to share the chain with - rows of other requests inside, or rows announced (this handle's included)?  A lone
+    // call on an idle engine is faster on the handle's own chain (kernels sized for its rows, not for the engine's slots)
+    bool has_company() const;
     // n > 0: handle m announces n rows it will submit; n < 0: up to -n announced rows of m arrived or will not come
     void expect(Model& m, int n);
     void stats(sc_engine_stats* out, bool reset);

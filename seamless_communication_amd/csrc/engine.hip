@@ -433,6 +433,12 @@ bool Engine::fits(int n, int s_enc, int max_len, int prefix_len, const sc_gen_op
            o.min_seq_len == e.min_seq_len && o.unk_penalty == e.unk_penalty;
 }
 
+bool Engine::has_company() const {
+    Impl& E = *p_;
+    std::lock_guard<std::mutex> lk(E.mu);
+    return E.expected > 0 || !E.outstanding.empty();
+}
+
 void Engine::expect(Model& m, int n) {
     Impl& E = *p_;
     std::lock_guard<std::mutex> lk(E.mu);

@@ -1262,7 +1262,7 @@ void run_generate_text(Model& m, const float* d_enc, int n, int s_enc, const int
 
     // ---- decode engine (sc_engine_attach): the rows join the GPU's shared step chain (engine.hip) -------------------------
     if (!forced && m.engine) {
-        if (m.engine->fits(n, s_enc, max_len, prefix_len, o)) {
+        if (m.engine->fits(n, s_enc, max_len, prefix_len, o) && m.engine->has_company()) {
             m.engine->generate(m, d_enc, n, s_enc, h_enc_lens, h_prefix, prefix_len, max_len, h_out_ids, h_out_lens, h_scores, d_dec_hidden);
             return;
         }

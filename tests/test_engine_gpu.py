@@ -186,8 +186,9 @@ def test_requests_with_their_own_length_limits_share_the_chain(report_dir):
 
 
 def test_calls_that_do_not_fit_run_on_the_handles_own_chain():
-    """beam search, a longer limit than the engine was built for, another min_seq_len: same results as without an engine, and
-    the announcement they carried does not keep the engine waiting."""
+    """beam search, a longer limit than the engine was built for: same results as without an engine, and the announcement they
+    carried does not keep the engine waiting.  A lone call - nothing inside the engine, nothing announced - stays on the
+    handle's own chain too (it is faster there); announced, the same call goes through the engine: same bits."""
     from seamless_communication_amd.runtime import DecodeEngine
 
     cfg, tt, hip, seqs, enc, enc_lens, src_len = _env(common.EOS_SPREAD, 1)
@@ -202,7 +203,10 @@ def test_calls_that_do_not_fit_run_on_the_handles_own_chain():
         got_beam = _gen(view, enc, enc_lens, prefix, src_len, beam_size=3)
         view.engine_expect(8)
         got_long = _gen(view, enc, enc_lens, prefix, src_len, cap=CAP + 6)
-        got_fit = _gen(view, enc, enc_lens, prefix, src_len)  # unannounced, fits: through the engine
+        got_lone = _gen(view, enc, enc_lens, prefix, src_len)  # fits, but nothing inside and nothing announced: the handle's own chain
+        st_lone = eng.stats()
+        view.engine_expect(8)
+        got_fit = _gen(view, enc, enc_lens, prefix, src_len)  # announced: through the engine
         st = eng.stats()
     finally:
         eng.detach(view)
@@ -211,7 +215,11 @@ def test_calls_that_do_not_fit_run_on_the_handles_own_chain():
     for ref, got in ((ref_beam, got_beam), (ref_long, got_long)):
         assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1])
     assert [got_fit[0][b, : got_fit[1][b]].tolist() for b in range(8)] == seqs
-    assert st["rows_retired"] == 8 and st["requests"] == 1
+    assert st_lone["rows_admitted"] == 0 and st["rows_retired"] == 8 and st["requests"] == 1
+    assert np.array_equal(got_lone[0], got_fit[0]) and np.array_equal(got_lone[2], got_fit[2])  # same bits either way (8 rows: same kernels)
+    for b in range(8):
+        n = int(got_fit[1][b])
+        assert torch.equal(got_lone[3][b, : n - 1], got_fit[3][b, : n - 1])
 
 
 @pytest.mark.parametrize("slots", [96, 160])
