@@ -96,6 +96,11 @@ int sc_op_conv_transpose1d(const float* d_x, const void* d_v_f16, const void* d_
  * fp16 planes, the format the next product consumes) may be requested.  Same bits as sc_op_linear(split=1). */
 int sc_op_linear_presplit(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y,
                           void* d_yh_f16, void* d_yl_f16, int32_t M, int32_t N, int32_t K, int32_t act, float alpha);
+/* d_idx[m] = arg-max over n of (x.W^T + b)[m][n] with the arg-max FUSED into the pre-split product's epilogue (no logits in
+ * memory; the unit projection of the NAR T2U, reference models/unity/model.py:438-441 + inference/generator.py:346): equal to
+ * the arg-max of sc_op_linear_presplit's d_y, lowest index among equal values. */
+int sc_op_linear_presplit_argmax(const float* d_x, const void* d_w_f16, const float* d_bias, int32_t* d_idx, int32_t M, int32_t N,
+                                 int32_t K);
 /* Conv1d (stride 1) through the pre-split product kernel's implicit-convolution mode: x [nb][t][cin] is split into two
  * fp16 planes, output row (i, t) reads rows t + tap*dil - pad of item i (zeros outside the item), weights packed by
  * sc_op_pack_conv_weight.  d_row_valid (nullable, [nb*t] bytes on the device): rows with 0 are written as exact zeros.

@@ -75,6 +75,14 @@ if QUICK:
     LINEAR = [(15968, 4096, 1024), (15968, 1024, 4096), (15968, 3072, 1024), (15968, 2048, 1024), (15968, 1024, 1024),
               (31936, 4096, 1024), (31936, 1024, 4096), (31936, 1024, 1024)]
     CONV = [(16, 520, 1024, 1024, 7, 1, 3, 1, 0), (16, 2600, 256, 256, 11, 1, 25, 5, 1)]
+if "--decoder-shapes" in sys.argv:
+    # the decoder step's products at the row counts of the decode engine / of beam search, as the DMA GEMM sees them (what a
+    # tiled product could reach there; K = 8192 runs as ONE sequential K loop here, no split-K)
+    PS_ONLY = True
+    LINEAR = [(M, N, K) for M in (128, 192, 256, 320) for N, K in ((8192, 1024), (1024, 8192), (1024, 1024), (3072, 1024), (2048, 1024))]
+    CONV = []
+
+
 def timed_presplit(fn, reps=6):
     fn()
     lib.sc_prof_reset()

@@ -18,6 +18,7 @@
 #   argsweep     benchfast with each extra argument list of $ARGSWEEP (e.g. "--microbatches 1;--free-run")
 #   pstest       GEMM op tests (bit identity of the kernel variants)       gemmab   scripts/gemm_bench.py at SC_PS_TILE=128 / 256
 #   gemmhalf     scripts/gemm_bench.py at SC_PS_HALF=0 / 1 (barrier in front of the slab / mid-slab)
+#   dgemm        scripts/gemm_bench.py --decoder-shapes: the decoder step's products at 128 - 320 rows on the DMA GEMM
 #   pyprof       rocprofv3 kernel stats of `python $PYPROF` under each setting of $SWEEP
 #   esweep       scripts/engine_sweep.py: decode-engine / schedule settings on one model load ($ESWEEP)
 #   estep        scripts/engine_step_bench.py: the engine's step alone per slot count + its kernel stats at $ESTEP_PROF_SLOTS
@@ -185,6 +186,10 @@ for task in "$@"; do
     pstest)
       ( timeout 400 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "presplit or gemm" > ${O}_pytest_ps.log 2>&1; echo "pytest exit $?" >> ${O}_pytest_ps.log )
       grep -E "^FAILED|^ERROR|passed|failed|^E  |exit" ${O}_pytest_ps.log | head -20 ;;
+    dgemm)
+      # the decoder step's products (128 - 320 rows) on the DMA GEMM: default tile choice (64 x 64) and the 128 x 128 tile
+      ( timeout 200 python scripts/gemm_bench.py --decoder-shapes > ${O}_dgemm_tile64.txt 2>&1 ); grep presplit ${O}_dgemm_tile64.txt | cut -c1-170
+      ( SC_PS_MIN128=1 timeout 200 python scripts/gemm_bench.py --decoder-shapes > ${O}_dgemm_tile128.txt 2>&1 ); grep presplit ${O}_dgemm_tile128.txt | cut -c1-170 ;;
     gemmab)
       # pre-split GEMM: round-1 tile choice (128 x 128) against the 8-wave 256 x 256 tile, encoder shapes
       for t in 128 256; do ( SC_PS_TILE=$t timeout 200 python scripts/gemm_bench.py --quick --presplit-only > ${O}_gemm_tile$t.txt 2>&1 ); grep presplit ${O}_gemm_tile$t.txt | cut -c1-170; done ;;

@@ -157,6 +157,7 @@ SIGNATURES = {
     "sc_op_pack_conv_weight": (C.c_int, [_P, _P, _i, _i, _i]),
     "sc_op_conv_transpose1d": (C.c_int, [_P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i, _i, _i]),
     "sc_op_linear_presplit": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, C.c_float]),
+    "sc_op_linear_presplit_argmax": (C.c_int, [_P, _P, _P, _P, _i, _i, _i]),
     "sc_op_conv1d_presplit": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _i, _i, _i, _P, _i]),
     "sc_op_mrf_fused": (C.c_int, [_P, _P, _P, _P, _P, _P, _i, _i, _i, _P, _P, C.c_float]),
     "sc_op_resblock_pair": (C.c_int, [_P, _P, _P, _P, _P, _P, _i, _i, _i, _i, _i, C.c_float, _P, _P]),

@@ -1046,6 +1046,46 @@ int sc_op_linear_presplit(const float* d_x, const void* d_w_f16, const float* d_
     SC_API_END
 }
 
+int sc_op_linear_presplit_argmax(const float* d_x, const void* d_w_f16, const float* d_bias, int32_t* d_idx, int32_t M, int32_t N,
+                                 int32_t K) {
+    SC_API_BEGIN
+    SC_CHECK(d_x && d_w_f16 && d_idx, "sc_op_linear_presplit_argmax: null argument");
+    __half *hi = nullptr, *lo = nullptr;
+    float2* part = nullptr;
+    const int nch = gemm_presplit_amax_chunks(M, N);
+    SC_HIP(hipMalloc(&hi, (size_t)M * K * 2));
+    SC_HIP(hipMalloc(&lo, (size_t)M * K * 2));
+    SC_HIP(hipMalloc(&part, (size_t)M * nch * sizeof(float2)));
+    try {
+        SC_HIP(hipMemsetAsync(part, 0xff, (size_t)M * nch * sizeof(float2), g_op_stream));  // NaN / -1: every entry must be written
+        launch_split_f32(d_x, hi, lo, (int64_t)M * K, g_op_stream);
+        GemmPsArgs a;
+        a.Ah = hi;
+        a.Al = lo;
+        a.lda = K;
+        a.W = static_cast<const __half*>(d_w_f16);
+        a.ldw = K;
+        a.bias = d_bias;
+        a.M = M;
+        a.N = N;
+        a.K = K;
+        a.amax = part;
+        a.amax_ld = nch;
+        launch_gemm_presplit(a, g_op_stream);
+        launch_amax_finish(part, nch, M, d_idx, g_op_stream);
+        SC_HIP(hipStreamSynchronize(g_op_stream));
+    } catch (...) {
+        (void)hipFree(hi);
+        (void)hipFree(lo);
+        (void)hipFree(part);
+        throw;
+    }
+    (void)hipFree(hi);
+    (void)hipFree(lo);
+    (void)hipFree(part);
+    SC_API_END
+}
+
 int sc_op_conv1d_presplit(const float* d_x, const void* d_w_f16_packed, const float* d_bias, const float* d_res, float* d_y,
                           void* d_yh_f16, void* d_yl_f16, int32_t nb, int32_t t, int32_t cin, int32_t cout, int32_t k, int32_t pad,
                           int32_t dil, const unsigned char* d_row_valid, int32_t act) {

@@ -42,13 +42,15 @@ const Knob knob_table[] = {
     {"SC_DSTEP_TOUCH", 0, "weight toucher: layers ahead"}, {"SC_DSTEP_TOUCH_WGS", 0, "weight toucher: workgroups"},
     {"SC_D3_RG_SMALL", 0, "decoder step: rows per row group, N = 1024 products"}, {"SC_D3_RG_FFN", 0, "decoder step: rows per row group, FFN-in"},
     {"SC_D3_FFN_IN", 0, "decoder step: FFN-in workgroup shape"}, {"SC_D3_FFN_OUT", 0, "decoder step: FFN-out workgroup shape"},
-    {"SC_MMA_GRAPH", 0, "streaming decoder step from a captured graph"}, {"SC_BEAM_COMPACT", 0, "0: beam search keeps finished utterances' slots"},
+    {"SC_MMA_GRAPH", 0, "streaming decoder step from a captured graph"}, 
     {"SC_T2U_GROUPS", 0, "NAR T2U: length buckets"}, {"SC_T2U_PACKED", 0, "0: NAR decoder on padded buckets"},
+    {"SC_T2U_FUSED_ARGMAX", 0, "0: unit logits written out, arg-max as its own launch"},
     {"SC_VOC_PS", 0, "0: vocoder wide stages on the register-staged convolution"}, {"SC_VOC_MRF", 0, "0: narrow vocoder stages as nine pair launches"},
     {"SC_VOC_GROUPS", 0, "vocoder: length buckets"}, {"SC_VOC_GROUP_OVERHEAD", 0, "vocoder: bucket planning overhead rows"},
     {"SC_VOC_STREAMS", 0, "vocoder: side chains"},
     {"SC_ENGINE_RG_SMALL", 0, "decode engine: rows per row group, N = 1024 products"},
     // re-read per call
+    {"SC_BEAM_COMPACT", 2, "0: beam search keeps finished utterances' slots"},
     {"SC_GREEDY_COMPACT", 2, "0: greedy generation keeps finished rows in their slots"}, {"SC_GREEDY_POLL", 2, "steps between looks at the finished flags"},
 };
 constexpr int N_KNOBS = sizeof(knob_table) / sizeof(knob_table[0]);

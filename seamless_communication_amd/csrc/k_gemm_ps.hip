@@ -139,7 +139,9 @@ __device__ __forceinline__ void ps_epilogue(const GemmPsArgs& p, const float* ep
 // After the barrier every wave has matrix work in registers at once.  The barrier of step s also says that every wave is
 // done reading slab s (both chunks: lgkmcnt(0) in front of it), so slab s+3 may land in the same stage from there on.
 // Same instructions and the same accumulation order as the other schedules: bit-identical results.
-template <int BM, int BN, int WGM, int WGN, bool ILV, bool SPLIT, bool CONV = false, bool HALF = false>
+// AMAX: the epilogue keeps, per row, the largest value of the wave's columns and its (lowest) column instead of writing the
+// tile (GemmPsArgs::amax); a separate instantiation, so that the other kernels' code does not change by a single instruction.
+template <int BM, int BN, int WGM, int WGN, bool ILV, bool SPLIT, bool CONV = false, bool HALF = false, bool AMAX = false>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, int tiles_n, int tiles_total, int tiles_per_xcd,
                                                                  uint32_t a_bytes, uint32_t w_bytes) {
     constexpr int NWAVE = WGM * WGN;
@@ -479,6 +481,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
     const int m0w = m0 + wm * WM;
     // the wave's tile leaves in passes of EPN columns through its private LDS region (the LDS queue of a wave is in
     // order: a pass's writes follow the previous pass's reads)
+    float am_best = -INFINITY;  // AMAX: lane r < WM scans row r of the wave's tile, columns ascending over the passes
+    int am_idx = 0x7fffffff;
     auto pass = [&](auto hc) {  // compile-time pass number: the accumulator registers are indexed by constants
         constexpr int h = decltype(hc)::value;
 #pragma unroll
@@ -489,6 +493,28 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
                 for (int r = 0; r < 16; ++r)
                     ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] = acc[i][h * (EPN / 32) + j][r];
         const int n0w = n0 + wn * WN + h * EPN;
+        if constexpr (AMAX) {
+            typedef float f4_t __attribute__((ext_vector_type(4)));
+            if (lane < WM) {
+                const float* row = ep + lane * EP_LD;
+#pragma unroll
+                for (int c4 = 0; c4 < EPN / 4; ++c4) {
+                    const f4_t a = *reinterpret_cast<const f4_t*>(row + 4 * c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = n0w + 4 * c4 + e;
+                        if (col < p.N) {
+                            const float v = (a[e] + (p.bias ? p.bias[col] : 0.f)) * p.alpha;  // = ps_epilogue's value with ACT_NONE
+                            if (v > am_best) {  // strictly: the lowest column among equal values stays
+                                am_best = v;
+                                am_idx = col;
+                            }
+                        }
+                    }
+                }
+            }
+            return;
+        }
         if (p.act == ACT_NONE) ps_epilogue<WM, EPN, EP_LD, ACT_NONE>(p, ep, m0w, n0w, lane);
         else if (p.act == ACT_RELU) ps_epilogue<WM, EPN, EP_LD, ACT_RELU>(p, ep, m0w, n0w, lane);
         else if (p.act == ACT_SILU) ps_epilogue<WM, EPN, EP_LD, ACT_SILU>(p, ep, m0w, n0w, lane);
@@ -497,6 +523,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
     static_assert(WN / EPN == 1 || WN / EPN == 2, "one or two epilogue passes");
     pass(std::integral_constant<int, 0>{});
     if constexpr (WN / EPN == 2) pass(std::integral_constant<int, 1>{});
+    if constexpr (AMAX) {
+        const int64_t m = m0w + lane;
+        if (lane < WM && m < p.M) p.amax[m * p.amax_ld + tn * WGN + wn] = make_float2(am_best, __int_as_float(am_idx));
+    }
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -507,12 +537,13 @@ void launch_ps_cfg(const GemmPsArgs& a, hipStream_t s) {
     char name[64];
     snprintf(name, sizeof(name), "gemm_%dx%d_presplit", BM, BN);
     prof::Scope scope(name, 2.0 * a.M * (double)a.N * a.K,
-                      4.0 * a.M * (double)a.K + 2.0 * a.N * (double)a.K + 4.0 * a.M * (double)a.N * (a.res ? 2.0 : 1.0), s);
+                      4.0 * a.M * (double)a.K + 2.0 * a.N * (double)a.K + (a.amax ? 8.0 * a.M * (double)a.amax_ld : 4.0 * a.M * (double)a.N * (a.res ? 2.0 : 1.0)), s);
     static const bool ilv = knob::value("SC_PS_ILV", 1) != 0;  // A/B switch (development)
     const dim3 grid(tiles_per_xcd * 8), block(WGM * WGN * 64);
     const uint32_t ab = (uint32_t)((int64_t)a.M * a.lda * 2), wb = (uint32_t)((int64_t)a.N * a.ldw * 2);
     static const bool half = knob::value("SC_PS_HALF", 1) != 0;  // mid-slab barrier schedule (A/B switch)
-    if (!a.split) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
+    if (a.amax) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, false, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
+    else if (!a.split) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (a.conv_taps > 0 && half) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (a.conv_taps > 0) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (ilv && half) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, false, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
@@ -520,10 +551,24 @@ void launch_ps_cfg(const GemmPsArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, false, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
 }
 
+// tile choice: 256 x 256 (8 waves) once it fills the chip about once, 128 x 128 down to one round of 256 tiles,
+// 64 x 64 below.  SC_PS_TILE=128 (development A/B) keeps the round-1 choice.  All three accumulate every output
+// element in the same order (16-wide K chunks, hi then lo): identical bits.
+int ps_tile(int M, int N) {
+    static const int max_tile = knob::value("SC_PS_TILE", 256);
+    const int64_t tiles128 = (int64_t)cdiv(M, 128) * cdiv(N, 128);
+    const int64_t tiles256 = (int64_t)cdiv(M, 256) * cdiv(N, 256);
+    // (N <= 128: a 256-wide tile would idle half its columns - the 128-channel vocoder stage)
+    static const int min256 = knob::value("SC_PS_MIN256", 224);
+    static const int min128 = knob::value("SC_PS_MIN128", 256);
+    if (max_tile >= 256 && tiles256 >= min256 && N > 128) return 256;
+    return tiles128 >= min128 ? 128 : 64;
+}
+
 }  // namespace
 
 void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s) {
-    SC_CHECK(a.Ah && a.Al && a.W && (a.C || a.Ch), "presplit gemm: null operand");
+    SC_CHECK(a.Ah && a.Al && a.W && (a.C || a.Ch || a.amax), "presplit gemm: null operand");
     SC_CHECK((a.Ch == nullptr) == (a.Cl == nullptr), "presplit gemm: Ch/Cl must be given together");
     SC_CHECK(a.M > 0 && a.N > 0 && a.K > 0 && a.K % PBK == 0, "presplit gemm: M=%d N=%d K=%d (K must be a multiple of 32)", a.M, a.N, a.K);
     SC_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldw >= a.K, "presplit gemm: lda=%lld ldw=%lld", (long long)a.lda,
@@ -540,18 +585,55 @@ void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s) {
     } else {
         SC_CHECK(a.lda >= a.K, "presplit gemm: lda=%lld < K=%d", (long long)a.lda, a.K);
     }
-    // tile choice: 256 x 256 (8 waves) once it fills the chip about once, 128 x 128 down to one round of 256 tiles,
-    // 64 x 64 below.  SC_PS_TILE=128 (development A/B) keeps the round-1 choice.  All three accumulate every output
-    // element in the same order (16-wide K chunks, hi then lo): identical bits.
-    static const int max_tile = knob::value("SC_PS_TILE", 256);
-    const int64_t tiles128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
-    const int64_t tiles256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
-    // (N <= 128: a 256-wide tile would idle half its columns - the 128-channel vocoder stage)
-    static const int min256 = knob::value("SC_PS_MIN256", 224);
-    static const int min128 = knob::value("SC_PS_MIN128", 256);
-    if (max_tile >= 256 && tiles256 >= min256 && a.N > 128) launch_ps_cfg<256, 256, 4, 2>(a, s);
-    else if (tiles128 >= min128) launch_ps_cfg<128, 128, 2, 2>(a, s);
+    if (a.amax) {
+        SC_CHECK(a.split && a.conv_taps == 0 && !a.C && !a.Ch && !a.res && !a.row_valid && a.act == ACT_NONE,
+                 "presplit gemm: the fused arg-max takes a plain product (no C / planes / residual / activation)");
+        SC_CHECK(a.amax_ld == gemm_presplit_amax_chunks(a.M, a.N), "presplit gemm: amax_ld=%d, this shape produces %d partial results per row",
+                 a.amax_ld, gemm_presplit_amax_chunks(a.M, a.N));
+    }
+    const int tile = ps_tile(a.M, a.N);
+    if (tile == 256) launch_ps_cfg<256, 256, 4, 2>(a, s);
+    else if (tile == 128) launch_ps_cfg<128, 128, 2, 2>(a, s);
     else launch_ps_cfg<64, 64, 2, 2>(a, s);
+    SC_LAUNCH_CHECK();
+}
+
+// every tile shape has two waves side by side (WGN = 2): two partial results per tile column
+int gemm_presplit_amax_chunks(int M, int N) { return 2 * cdiv(N, ps_tile(M, N)); }
+
+namespace {
+// one wave per row: the partial results in column order, the largest value wins, the lowest column among equal values
+__global__ __launch_bounds__(256) void amax_finish_kernel(const float2* __restrict__ part, int ld, int rows, int* __restrict__ out_idx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float2* pr = part + (int64_t)row * ld;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int i = lane; i < ld; i += 64) {
+        const float2 v = pr[i];
+        const int vi = __float_as_int(v.y);
+        if (v.x > best || (v.x == best && vi < bidx)) {
+            best = v.x;
+            bidx = vi;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bidx, o);
+        if (ob > best || (ob == best && oi < bidx)) {
+            best = ob;
+            bidx = oi;
+        }
+    }
+    if (lane == 0) out_idx[row] = bidx;
+}
+}  // namespace
+
+void launch_amax_finish(const float2* part, int ld, int rows, int* out_idx, hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(amax_finish_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, part, ld, rows, out_idx);
     SC_LAUNCH_CHECK();
 }
 

@@ -91,8 +91,16 @@ struct GemmPsArgs {
     // packed (varlen) convolution: row_pos[m] = {position of row m inside its item, length of that item} (nullable);
     // replaces the uniform rows_per_item geometry: items of different lengths lie back to back, no padding rows
     const int2* row_pos = nullptr;
+    // fused arg-max over the columns (the unit projection + arg-max of the NAR T2U, models/unity/model.py:438-441 +
+    // inference/generator.py:346): nothing is written to C / Ch; every wave writes {largest value, its lowest column} of its
+    // columns of row m to amax[m * amax_ld + chunk] (amax_ld = gemm_presplit_amax_chunks(M, N)); launch_amax_finish picks the
+    // row's arg-max (lowest column among equal values, as launch_argmax_rows does on the stored logits).  act / res unused.
+    float2* amax = nullptr;
+    int amax_ld = 0;
 };
 void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s);
+int gemm_presplit_amax_chunks(int M, int N);  // partial results per row the tile choice for this shape produces
+void launch_amax_finish(const float2* part, int ld, int rows, int* out_idx, hipStream_t s);
 
 // k_resblock.hip: out = x + conv2_{k,1}(lrelu(conv1_{k,dil}(lrelu(x)) + b1)) + b2 for C in {16, 32, 64}, the
 // intermediate kept in LDS; optionally out = ((avg_a + avg_b) + that) / 3.  Weights packed [C][ldw], tap-major.

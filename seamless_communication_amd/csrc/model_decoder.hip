@@ -492,6 +492,28 @@ bool step3_wide_eligible(const Model& m, const DecStack& W, int nb) {
            gemv3_supported(nb, M, M, IN3_LN) && gemv3_supported(nb, W.ffn_dim, M, IN3_LN);  // the LayerNorm-fused q / FFN-in launches
 }
 
+// THE dispatch decision (setup_session, run_generate_beam, the streaming step and decoder_step_family's report all call this
+// and nothing else composes the predicates): which kernel family a step of `rows` rows over stack W runs on for caller
+// 0 greedy generation, 1 / 3 beam search (text / v1 unit decoder), 2 the streaming monotonic step, 4 the teacher-forced
+// stepwise pass.  SC_STEP_GENERAL 1, SC_STEP_PACKED 2, SC_STEP_ROWGROUP 3, SC_STEP_ROWGROUP_WIDE 4 (model.h).
+int choose_family(const Model& m, const DecStack& W, int rows, int caller) {
+    const int M = m.cfg.model_dim;
+    if (caller == 2) return step2_eligible(m, W, 1) ? 2 : 1;
+    if (caller == 0 || caller == 4) {
+        const bool forced = caller == 4;
+        // the packed step projects through the packed embedding (a failed pack leaves it null: first-generation step then)
+        const bool gen2 = step2_eligible(m, W, rows) && (forced || W.embed_p != nullptr);
+        const bool fused_argmax = !forced && rows <= 64 && M % 64 == 0;
+        const bool gen3 = gen2 && step3_eligible(m, W, rows) && (forced || (fused_argmax && W.embed_p && vocab3_supported(rows, W.vocab, M)));
+        return gen3 ? 3 : (gen2 ? 2 : 1);
+    }
+    // beam search: packed-weight step kernels up to 64 live rows, the wide row-group chain above
+    const bool packed = step2_eligible(m, W, rows) || step3_wide_eligible(m, W, rows);
+    if (!packed) return 1;
+    if (rows > 64) return 4;
+    return step3_eligible(m, W, rows) ? 3 : 2;
+}
+
 namespace {
 
 
@@ -672,25 +694,12 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
 // SC_STEP_PACKED (2: packed-fragment products, k_dstep.hip), SC_STEP_ROWGROUP (3: row-group products with fused LayerNorm /
 // residual, k_dstep3.hip) or SC_STEP_ROWGROUP_WIDE (4: the same chain cut into row groups, > 64 rows).
 int decoder_step_family(const Model& m, int rows, int caller) {
-    const int M = m.cfg.model_dim;
     if (caller == 2) {
         if (m.mma_dec.empty()) return SC_ERR_INVALID;
-        return step2_eligible(m, mma_stack(m), 1) ? 2 : 1;
+        return choose_family(m, mma_stack(m), 1, 2);
     }
     if (caller == 3 && m.t2u_ar_dec.empty()) return SC_ERR_INVALID;
-    const DecStack W = caller == 3 ? t2u_ar_stack(m) : unity_stack(m);
-    if (caller == 0 || caller == 4) {
-        const bool forced = caller == 4;
-        const bool gen2 = step2_eligible(m, W, rows) && (forced || W.embed_p != nullptr);
-        const bool fused_argmax = !forced && rows <= 64 && M % 64 == 0;
-        const bool gen3 = gen2 && step3_eligible(m, W, rows) && (forced || (fused_argmax && W.embed_p && vocab3_supported(rows, W.vocab, M)));
-        return gen3 ? 3 : (gen2 ? 2 : 1);
-    }
-    // beam search (run_generate_beam)
-    const bool packed = step2_eligible(m, W, rows) || step3_wide_eligible(m, W, rows);
-    if (!packed) return 1;
-    if (rows > 64) return 4;
-    return step3_eligible(m, W, rows) ? 3 : 2;
+    return choose_family(m, caller == 3 ? t2u_ar_stack(m) : unity_stack(m), rows, caller);
 }
 
 // One decoder step for all batch rows: feeds d_tok at position *d_pos.
@@ -961,7 +970,7 @@ void run_mma_step(Model& m, const int32_t* h_tokens, int n_tokens, const int32_t
     c.stack = &W;
     c.d_kenergy = st.kenergy.get();
     c.d_pchoose = st.pchoose.get();
-    const bool gen2 = step2_eligible(m, W, 1);
+    const bool gen2 = choose_family(m, W, 1, 2) == 2;
     if (gen2) {  // second-generation step kernels, p_choose hook batched; planes live in the state (stable addresses)
         if (!st.planes.get()) {
             alloc_step2(m, c, cfg.mma_ffn_dim);
@@ -1083,8 +1092,8 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
     c.d_lprob = S.fl;
     c.d_score = S.fl.get() + n;
     const DecStack W = unity_stack(m);
-    // the packed step projects through the packed embedding (a failed pack leaves it null: first-generation step then)
-    const bool gen2 = step2_eligible(m, W, n) && (forced || W.embed_p != nullptr);
+    const int family = choose_family(m, W, n, forced ? 4 : 0);
+    const bool gen2 = family >= 2;
     const int wideN = std::max(3 * M, cfg.dec_ffn_dim);
     const bool fused_argmax = !forced && n <= 64 && M % 64 == 0;
     S.fused_argmax = fused_argmax;
@@ -1097,7 +1106,7 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
     // worst case: K/256 ranges of an [n][M] out-projection, or M/256 ranges of the [n][3M] q/k/v projection
     S.partial = Buf<float>(m.pp(), (size_t)std::max(1, std::max(M, cfg.dec_ffn_dim) / 256) * n * 3 * M);
     c.partial = S.partial;
-    const bool gen3 = gen2 && step3_eligible(m, W, n) && (forced || (fused_argmax && W.embed_p && vocab3_supported(n, W.vocab, M)));
+    const bool gen3 = family == 3;
     if (gen2) {
         alloc_step2(m, c, cfg.dec_ffn_dim);
         c.am_ntl = 4;
@@ -1561,7 +1570,8 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
 
     // the packed-weight step kernels read the encoder K / V of live row r from cache row r / beams: one projection per
     // utterance instead of one per beam (5 x fewer bytes to project, to keep and to stream per step)
-    const bool packed_step = step2_eligible(m, W, nb) || step3_wide_eligible(m, W, nb);
+    const int family = choose_family(m, W, nb, 1);  // (the v1 unit decoder's search decides the same way: callers 1 and 3)
+    const bool packed_step = family != 1;
     // ---- fan the encoder output out to the beams (fairseq2.cpp `_fan_out_encoder_output`) ----------
     Buf<float> enc_rep(m.pp(), packed_step ? 4 : (size_t)nb * s_enc * M);
     if (!packed_step) {
@@ -1605,7 +1615,7 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     Buf<float> xg3(m.pp(), 4), qkvr3(m.pp(), 4), qkv3w(m.pp(), 4);
     if (packed_step) {  // packed-weight step kernels (<= 64 live rows; the wide third-generation chain up to 512)
         alloc_step2(m, c, cfg.dec_ffn_dim);
-        if (step3_eligible(m, W, nb) || nb > 64) {  // third-generation chain (the step runs without its projection here)
+        if (family >= 3) {  // third-generation chain (the step runs without its projection here)
             c.gen3 = true;
             xg3 = Buf<float>(m.pp(), (size_t)M * c.rb);
             qkvr3 = Buf<float>(m.pp(), (size_t)nb * M);
@@ -1718,7 +1728,7 @@ void run_generate_beam(Model& m, const DecStack& W, const float* d_enc, int n, i
     // packed to the front every time the host looks at the counters (every 4th step); kernels skip the rows / slots behind
     // *d_rows / *d_slots.  Finished hypotheses are stored per UTTERANCE (slot_utt maps a slot to its utterance), so the
     // results below are read in utterance order whatever moved.  SC_BEAM_COMPACT=0: every slot stays where it is.
-    static const bool compact_env = knob::value("SC_BEAM_COMPACT", 1) != 0;  // process-wide, read once
+    const bool compact_env = knob::live("SC_BEAM_COMPACT", 1) != 0;  // read per call, like SC_GREEDY_COMPACT (in-process A/B)
     const bool compact = compact_env && use_anc && c.gen3 && n >= 2 && n <= 1024;
     Buf<int> d_slot(m.pp(), compact ? (size_t)n + 2 : 4);
     int* d_slot_utt = d_slot.get();

@@ -404,15 +404,37 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
                 launch_layernorm_both(u, M, l.conv_ln.g, l.conv_ln.b, u, M, up_h, up_l, M, R, M, ACT_NONE, nullptr, 1, m.stream);
             }
             launch_layernorm_split(u, M, m.t2u_dec_ln.g, m.t2u_dec_ln.b, up_h, up_l, M, R, M, ACT_NONE, nullptr, 1, m.stream);
-            Buf<float> logits(m.pp(), (size_t)R * c.unit_vocab_size);
+            // project + arg-max (model.py:438-441, generator.py:346).  The arg-max rides in the product's epilogue: the
+            // [R][10 082] fp32 logits (1.36 GB per 64-utterance pass, written and read back once) never exist; what leaves the
+            // kernel is {max, column} per row and 128-column chunk.  SC_T2U_FUSED_ARGMAX=0: logits + arg-max launch (same ids).
             Linear proj;
             proj.w = m.unit_embed;
             proj.ldw = M;
             proj.kpad = M;
             proj.in = M;
             proj.out = c.unit_vocab_size;
-            ps(up_h, up_l, proj, nullptr, logits);
-            launch_argmax_rows(logits, c.unit_vocab_size, R, c.unit_vocab_size, nullptr, -1, -1, -1, -1, -1, 0.f, d_ids, nullptr, m.stream);
+            static const bool fused_argmax = knob::value("SC_T2U_FUSED_ARGMAX", 1) != 0;
+            if (fused_argmax) {
+                const int nch = gemm_presplit_amax_chunks(R, c.unit_vocab_size);
+                Buf<float2> part(m.pp(), (size_t)R * nch);
+                GemmPsArgs a;
+                a.Ah = up_h;
+                a.Al = up_l;
+                a.lda = M;
+                a.W = proj.w;
+                a.ldw = proj.ldw;
+                a.M = R;
+                a.N = c.unit_vocab_size;
+                a.K = M;
+                a.amax = part;
+                a.amax_ld = nch;
+                launch_gemm_presplit(a, m.stream);
+                launch_amax_finish(part, nch, R, d_ids, m.stream);
+            } else {
+                Buf<float> logits(m.pp(), (size_t)R * c.unit_vocab_size);
+                ps(up_h, up_l, proj, nullptr, logits);
+                launch_argmax_rows(logits, c.unit_vocab_size, R, c.unit_vocab_size, nullptr, -1, -1, -1, -1, -1, 0.f, d_ids, nullptr, m.stream);
+            }
             std::vector<int32_t> pids((size_t)R);
             SC_HIP(hipMemcpyAsync(pids.data(), d_ids.get(), (size_t)R * 4, hipMemcpyDeviceToHost, m.stream));
             SC_HIP(hipStreamSynchronize(m.stream));

@@ -257,6 +257,34 @@ def test_beam_search_with_utterances_that_finish_at_different_steps(n_utt, beam,
         assert float((hidden[b, : len(s) - 1] - forced[b, : len(s) - 1]).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("n_utt,beam", [(17, 5), (30, 3)])
+def test_beam_search_slot_compaction_does_not_change_a_bit(n_utt, beam, report_dir, monkeypatch):
+    """Beam search packs the slots of utterances that still search to the front and lets the step kernels skip the rest
+    (model_decoder.hip: run_generate_beam, "live-slot bookkeeping").  An utterance's results must not depend on the slots its
+    beams sit in: ids, lengths, scores and the decoder outputs of the compacted run equal the un-compacted run's
+    (SC_BEAM_COMPACT=0, read per call) bit for bit."""
+    cfg, tt, orc, hip = _env(common.EOS_MIXED)
+    secs = [0.6 + 0.13 * ((7 * i) % 15) for i in range(n_utt)]
+    fb, lens = orc.collate_fbank(common.waves(secs))
+    enc, enc_lens = hip.encode_speech(fb.cuda(), lens.tolist())
+
+    def run():
+        ids, out_lens, scores, hidden = hip.generate_text(enc, enc_lens.tolist(), tt.target_prefix("fra"), beam_size=beam,
+                                                          hard_max_seq_len=CAP, source_len=int(lens.max()))
+        return np.array(ids), np.array(out_lens), np.array(scores), hidden.clone()
+
+    monkeypatch.setenv("SC_BEAM_COMPACT", "0")
+    ids0, lens0, sc0, hid0 = run()
+    monkeypatch.setenv("SC_BEAM_COMPACT", "1")
+    ids1, lens1, sc1, hid1 = run()
+    _log(report_dir, "eos_beam_compaction", n_utt=n_utt, beam=beam, lens=sorted(lens1.tolist()))
+    assert len(set(lens1.tolist())) >= 3, lens1.tolist()  # utterances leave the search at different steps
+    assert np.array_equal(lens0, lens1) and np.array_equal(ids0, ids1)
+    assert np.array_equal(sc0, sc1)
+    for b in range(n_utt):
+        assert torch.equal(hid0[b, : lens1[b] - 1], hid1[b, : lens1[b] - 1])
+
+
 def test_hypotheses_that_consist_of_eos_alone_give_no_units(report_dir):
     """A hypothesis [</s>, lang, </s>] has no text: after the two prompt tokens are dropped nothing is left for the T2U model
     (nar_decoder_frontend.py:227-259), the row gets zero units and an empty waveform while its neighbours are synthesised.

@@ -123,11 +123,14 @@ def gemm_ps_isa(tmp_path_factory):
 
 
 # template arguments: tile, waves, ILV, SPLIT, CONV, HALF (mid-slab barrier; the shipped schedule) - both schedules are kept
-@pytest.mark.parametrize("inst,mfmas_per_slab", [("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb1E", 32),
-                                                 ("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb1ELb1E", 32),
-                                                 ("gemm_ps_kernelILi128ELi128ELi2ELi2ELb1ELb1ELb0ELb1E", 16),
-                                                 ("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb0E", 32),
-                                                 ("gemm_ps_kernelILi128ELi128ELi2ELi2ELb1ELb1ELb0ELb0E", 16)])
+@pytest.mark.parametrize("inst,mfmas_per_slab", [("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb1ELb0E", 32),
+                                                 ("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb1ELb1ELb0E", 32),
+                                                 ("gemm_ps_kernelILi128ELi128ELi2ELi2ELb1ELb1ELb0ELb1ELb0E", 16),
+                                                 ("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb0ELb0E", 32),
+                                                 ("gemm_ps_kernelILi128ELi128ELi2ELi2ELb1ELb1ELb0ELb0ELb0E", 16),
+                                                 # the arg-max epilogue (unit projection): same slab loop
+                                                 ("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb1ELb1E", 32),
+                                                 ("gemm_ps_kernelILi128ELi128ELi2ELi2ELb1ELb1ELb0ELb1ELb1E", 16)])
 def test_dma_gemm_slab_loop_keeps_its_pipeline(gemm_ps_isa, inst, mfmas_per_slab):
     """The K loop of the pre-split GEMM (plain and implicit-conv variant): no scratch, DMAs issued as
     `buffer_load_dwordx4 ... lds` between the matrix instructions, one s_barrier per slab, and the only full drain

@@ -353,6 +353,46 @@ def test_presplit_gemm_bit_identical_to_split_gemm(lib, report_dir, M, N, K, act
     assert torch.equal(gh2.cpu(), hi)
 
 
+@pytest.mark.parametrize("M,N,K", [(3001, 10082, 1024), (4100, 1000, 128), (499, 1030, 64), (70, 10082, 1024), (1, 64, 32)])
+@pytest.mark.parametrize("ties", ["none", "adjacent", "far"])
+def test_presplit_gemm_fused_argmax(lib, report_dir, M, N, K, ties):
+    """The arg-max riding in the epilogue of the DMA GEMM (the unit projection of the NAR T2U; reference
+    models/unity/model.py:438-441 + inference/generator.py:346) against the arg-max of the logits the same kernel writes out:
+    equal, lowest index among equal values - `adjacent`: every odd column repeats the even one before it (ties inside a
+    wave's chunk), `far`: the second half of the columns repeats the first (ties across chunks and tiles).  Shapes: 256 x 256,
+    128 x 128 and 64 x 64 tiles, N not a multiple of the tile or of 4."""
+    g = torch.Generator().manual_seed(3 * M + 5 * N + 11 * K)
+    x = torch.randn(M, K, generator=g) * 2.0
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half()
+    b = torch.randn(N, generator=g) * 0.1
+    if ties == "adjacent":
+        n2 = N // 2
+        w[1 : 2 * n2 : 2] = w[0 : 2 * n2 : 2]
+        b[1 : 2 * n2 : 2] = b[0 : 2 * n2 : 2]
+    elif ties == "far":
+        h = N // 2
+        w[N - h :] = w[:h]
+        b[N - h :] = b[:h]
+    x, w, b = dev(x), dev(w), dev(b)
+    logits = torch.full((M, N), float("nan"), device="cuda")
+    check(lib, lib.sc_op_linear_presplit(P(x), P(w), P(b), None, P(logits), None, None, M, N, K, 0, 1.0))
+    want = np.argmax(logits.cpu().numpy(), axis=1)  # first occurrence of the maximum
+    got = torch.full((M,), -7, device="cuda", dtype=torch.int32)
+    check(lib, lib.sc_op_linear_presplit_argmax(P(x), P(w), P(b), P(got), M, N, K))
+    got = got.cpu().numpy()
+    _log(report_dir, "presplit_gemm_fused_argmax", M=M, N=N, K=K, ties=ties, equal=int((got == want).sum()), rows=M)
+    assert np.array_equal(got, want)
+    if ties == "adjacent":
+        assert (got % 2 == 0).all() or N % 2 == 1
+    if ties == "far" and N % 2 == 0:
+        assert (got < N // 2).all()
+    # without a bias
+    check(lib, lib.sc_op_linear_presplit(P(x), P(w), None, None, P(logits), None, None, M, N, K, 0, 1.0))
+    got2 = torch.full((M,), -7, device="cuda", dtype=torch.int32)
+    check(lib, lib.sc_op_linear_presplit_argmax(P(x), P(w), None, P(got2), M, N, K))
+    assert np.array_equal(got2.cpu().numpy(), np.argmax(logits.cpu().numpy(), axis=1))
+
+
 CONV_PS_CASES = [
     # nb, T, cin, cout, k, dil, act, with_res, masked
     (3, 700, 1024, 1024, 7, 1, 1, False, True),   # the T2U FFT-decoder convolution (64 x 64 / 128 x 128 tiles), masked tail rows
