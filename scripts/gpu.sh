@@ -21,6 +21,7 @@
 #   dgemm        scripts/gemm_bench.py --decoder-shapes: the decoder step's products at 128 - 320 rows on the DMA GEMM
 #   pyprof       rocprofv3 kernel stats of `python $PYPROF` under each setting of $SWEEP
 #   esweep       scripts/engine_sweep.py: decode-engine / schedule settings on one model load ($ESWEEP)
+#   esweepenv    the same, one configuration ($ESWEEP), once per environment setting of $SWEEP (library switches are read once per process)
 #   estep        scripts/engine_step_bench.py: the engine's step alone per slot count + its kernel stats at $ESTEP_PROF_SLOTS
 #   layout       scripts/real_layout_check.py: a published-layout checkpoint through Translator(file://...)
 #   cover        kernel trace of a bench pass -> device-busy share, idle gaps, timeline (scripts/trace_cover.py)
@@ -165,6 +166,16 @@ for task in "$@"; do
       # decode engine / schedule settings on ONE model load (scripts/engine_sweep.py): ESWEEP="g=3,slots=0;g=6,slots=192,lw=96"
       ( timeout ${ESWEEP_TIMEOUT:-900} python scripts/engine_sweep.py --steps ${ESWEEP_STEPS:-12} ${ESWEEP:+--configs "$ESWEEP"} > ${O}_esweep.jsonl 2> ${O}_esweep.err; echo "exit $?" >> ${O}_esweep.err )
       tail -1 ${O}_esweep.err | cut -c1-300; cut -c1-700 ${O}_esweep.jsonl ;;
+    esweepenv)
+      # scripts/engine_sweep.py (one configuration, $ESWEEP) once per environment setting of $SWEEP (';'-separated), e.g.
+      # SWEEP="SC_VOC_GROUPS=8;SC_VOC_GROUPS=12 SC_VOC_GROUP_OVERHEAD=120;GPU_MAX_HW_QUEUES=16"
+      IFS=';' read -ra SW <<< "$SWEEP"
+      i=0
+      for e in "${SW[@]}"; do
+        i=$((i+1))
+        ( env $e timeout ${ESWEEP_TIMEOUT:-240} python scripts/engine_sweep.py --steps ${ESWEEP_STEPS:-12} --configs "${ESWEEP:-g=6,slots=192,lw=96}" > ${O}_esweepenv_$i.jsonl 2> ${O}_esweepenv_$i.err; echo "exit $?" >> ${O}_esweepenv_$i.err )
+        echo "--- $e"; tail -1 ${O}_esweepenv_$i.err | cut -c1-200; cut -c1-420 ${O}_esweepenv_$i.jsonl
+      done ;;
     estep)
       # the decode engine's step ALONE on the chip per slot count, and the per-kernel times of one slot count under rocprofv3
       ( timeout 300 python scripts/engine_step_bench.py --slots ${ESTEP_SLOTS:-32,64,128,192,256} > ${O}_estep.txt 2>&1; echo "exit $?" >> ${O}_estep.txt ); grep "^slots=" ${O}_estep.txt | cut -c1-250

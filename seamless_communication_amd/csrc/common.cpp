@@ -35,7 +35,7 @@ const Knob knob_table[] = {
     // same bits, another schedule / kernel variant
     {"SC_GEMM_GENERAL", 0, "general GEMM kernel instead of the fast path"}, {"SC_GEMM_PF2", 0, "GEMM prefetch depth"},
     {"SC_GEMM_GROUP_M", 0, "GEMM workgroup order"}, {"SC_GEMM_TILE", 0, "GEMM tile override"},
-    {"SC_PS_ILV", 0, "DMA GEMM: interleaved issue"}, {"SC_PS_HALF", 0, "DMA GEMM: mid-slab barrier"},
+    {"SC_PS_ILV", 0, "DMA GEMM: interleaved issue"}, {"SC_PS_HALF", 0, "DMA GEMM: mid-slab barrier"}, {"SC_PS_PP", 0, "0: 8-wave DMA GEMM in lock step instead of alternating load / compute segments"},
     {"SC_PS_TILE", 0, "DMA GEMM: largest tile"}, {"SC_PS_MIN256", 0, "DMA GEMM: tiles needed for 256 x 256"},
     {"SC_PS_MIN128", 0, "DMA GEMM: tiles needed for 128 x 128"},
     {"SC_PRESPLIT", 0, "0: Conformer operands split on the fly"}, {"SC_ENC_FUSE", 0, "0: separate Conformer element-wise launches"},

@@ -141,7 +141,22 @@ __device__ __forceinline__ void ps_epilogue(const GemmPsArgs& p, const float* ep
 // Same instructions and the same accumulation order as the other schedules: bit-identical results.
 // AMAX: the epilogue keeps, per row, the largest value of the wave's columns and its (lowest) column instead of writing the
 // tile (GemmPsArgs::amax); a separate instantiation, so that the other kernels' code does not change by a single instruction.
-template <int BM, int BN, int WGM, int WGN, bool ILV, bool SPLIT, bool CONV = false, bool HALF = false, bool AMAX = false>
+// PP (8 waves, needs SPLIT): the two waves of a SIMD take TURNS.  With HALF both run the same program in lock step - both ask LDS
+// for fragments at the same time, both issue their DMAs at the same time, both want the matrix pipe at the same time - and
+// the pipe measured 47 - 53 % busy (profiles/r3_gemm_ps256_pmc_sq.txt).  Here every 16-wide K chunk of a slab is a LOAD
+// segment (the chunk's 8 fragment reads into registers + 3 of the wave's 6 DMAs of the slab two ahead) and a COMPUTE segment
+// (the chunk's 16 matrix instructions out of registers, nothing else, s_setprio 1), one s_barrier after each; waves 0-3 (one
+// per SIMD) load while waves 4-7 compute and the other way round:
+//     segment 4s   : waves 0-3  LOAD (s, 0)      waves 4-7  COMPUTE (s-1, 1)
+//     segment 4s+1 : waves 0-3  COMPUTE (s, 0)   waves 4-7  LOAD (s, 0)
+//     segment 4s+2 : waves 0-3  LOAD (s, 1)      waves 4-7  COMPUTE (s, 0)
+//     segment 4s+3 : waves 0-3  COMPUTE (s, 1)   waves 4-7  LOAD (s, 1);  all: wait for slab s+1
+// A wave's matrix instructions find the pipe free (its partner is in its load segment), and its loads cost no matrix time.
+// Ordering: the DMAs of slab s+1 are awaited (counted vmcnt, the 6 of slab s+2 stay in flight) in front of the barrier that
+// ends segment 4s+3 and read from segment 4s+4 on; a stage is refilled (slab s+2 -> stage of slab s-1) from segment 4s on, its
+// last reads were issued in segment 4s-1 and retired (lgkmcnt(0)) in front of that segment's barrier.  Same instructions per
+// accumulator in the same order (slab, 16-wide K chunk, hi then lo): bit-identical to every other schedule.
+template <int BM, int BN, int WGM, int WGN, bool ILV, bool SPLIT, bool CONV = false, bool HALF = false, bool AMAX = false, int PP = 0>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, int tiles_n, int tiles_total, int tiles_per_xcd,
                                                                  uint32_t a_bytes, uint32_t w_bytes) {
     constexpr int NWAVE = WGM * WGN;
@@ -371,7 +386,107 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
     } while (0)
 
     const int nslab = p.K / PBK;
-    if constexpr (HALF) {
+    if constexpr (PP > 0) {
+        static_assert(PP == 0 || (ILV && SPLIT && NWAVE == 8 && NDMA == 6), "the alternating schedule is written for the split 8-wave tile");
+        constexpr int NH = NDMA / 2;  // DMAs of a slab per 16-wide K chunk and wave
+        constexpr int NL = PP - 1;    // ... of which the LOAD segment issues NL, the COMPUTE segment (between its matrix instructions) NH - NL
+        const bool grp_b = __builtin_amdgcn_readfirstlane(wave) >= NWAVE / 2;
+        half8_t f_ah[TM], f_al[TM], f_bf[TN];  // the fragments of one 16-wide K chunk
+#define PS_LDS8(BASE, OFF) (*reinterpret_cast<const half8_t*>(reinterpret_cast<const char*>(BASE) + (OFF)))
+// LOAD segment of chunk KC of slab S (stage C*): the chunk's 8 fragment reads, then NL of the wave's DMAs of slab S+2 (stage
+// N*), then every read retired (the stage may be refilled one segment after the barrier that follows)
+#define PP_LOADSEG(S, KC, CAH, CAL, CB, NAH, NAL, NB)                                           \
+    do {                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) f_bf[j] = PS_LDS8(CB, b_off[j][KC]);     \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
+            f_ah[i] = PS_LDS8(CAH, a_off[i][KC]);                                               \
+            f_al[i] = PS_LDS8(CAL, a_off[i][KC]);                                               \
+        }                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (NL > 0 && (S) + 2 < nslab) {                                                        \
+            if ((KC) == 0) PS_NEXT_ADDR();                                                      \
+            _Pragma("unroll") for (int q = (KC) * NH; q < (KC) * NH + NL; ++q) PS_DMA_Q(q, NAH, NAL, NB, ((S) + 2) * (PBK * 2)); \
+        }                                                                                       \
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0), vmcnt untouched */                   \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    } while (0)
+// COMPUTE segment: the chunk's hi products of all eight accumulators, then the lo products (an accumulator's two instructions
+// are eight issues apart; its order hi, lo is the one of every other schedule); if DO_DMA, the DMAs Q0 .. Q0 + NH - NL - 1
+// of slab SLAB (stage N*) spread between them (an LDS-DMA issue among matrix instructions costs the wave ~60 cycles, in a
+// segment that carries fragment reads 100 - 185: MI355X_MICROARCH.md)
+#define PP_MFMA(DO_DMA, Q0, SLAB, NAH, NAL, NB)                                                                    \
+    do {                                                                                                           \
+        constexpr int NC_ = NH - NL; /* DMAs of this segment */                                                    \
+        const bool dma_ = (DO_DMA);                                                                                \
+        if (NC_ > 0 && dma_ && (Q0) == 0) PS_NEXT_ADDR();                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                             \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                           \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                         \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h_ == 0 ? f_ah[i] : f_al[i], f_bf[j], acc[i][j], 0, 0, 0); \
+                    const int n_ = h_ * TM * TN + i * TN + j + 1; /* matrix instructions issued so far */          \
+                    _Pragma("unroll") for (int d_ = 0; d_ < NC_; ++d_)                                             \
+                        if (n_ == (d_ + 1) * (2 * TM * TN) / (NC_ + 1)) {                                          \
+                            __builtin_amdgcn_sched_barrier(0);                                                     \
+                            if (dma_) PS_DMA_Q((Q0) + d_, NAH, NAL, NB, (SLAB) * (PBK * 2));                       \
+                            __builtin_amdgcn_sched_barrier(0);                                                     \
+                        }                                                                                          \
+                }                                                                                                  \
+        __builtin_amdgcn_s_setprio(0);                                                                             \
+    } while (0)
+#define PP_BARRIER()                            \
+    do {                                        \
+        __builtin_amdgcn_sched_barrier(0);      \
+        __builtin_amdgcn_s_barrier();           \
+        asm volatile("" ::: "memory");          \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
+// slab S (stage C*; O* = stage of slab S+1, N* = stage of slab S+2, the one slab S-1 sat in): four segments.  ROLE_B = false
+// (waves 0-3): load / compute / load / compute; true (waves 4-7): compute (the previous chunk) / load / compute / load.  The
+// two roles are two separate loops (no control flow joins inside the K loop: the 128 accumulator registers stay where they
+// are); both execute the same number of barriers.  At the end of the step slab S+1 must have landed: waves 0-3 have issued
+// all 6 DMAs of slab S+2 by then, waves 4-7 only NH + NL of them (their second compute segment of the slab is the first
+// segment of the next step).
+#define PP_STEP(ROLE_B, S, CAH, CAL, CB, OAH, OAL, OB, NAH, NAL, NB)                            \
+    do {                                                                                        \
+        if (!(ROLE_B)) PP_LOADSEG(S, 0, CAH, CAL, CB, NAH, NAL, NB);                            \
+        else if ((S) > 0) PP_MFMA((S) + 1 < nslab, NH + NL, (S) + 1, OAH, OAL, OB);             \
+        PP_BARRIER();                                                                           \
+        if (!(ROLE_B)) PP_MFMA((S) + 2 < nslab, NL, (S) + 2, NAH, NAL, NB);                     \
+        else PP_LOADSEG(S, 0, CAH, CAL, CB, NAH, NAL, NB);                                      \
+        PP_BARRIER();                                                                           \
+        if (!(ROLE_B)) PP_LOADSEG(S, 1, CAH, CAL, CB, NAH, NAL, NB);                            \
+        else PP_MFMA((S) + 2 < nslab, NL, (S) + 2, NAH, NAL, NB);                               \
+        PP_BARRIER();                                                                           \
+        if (!(ROLE_B)) PP_MFMA((S) + 2 < nslab, NH + NL, (S) + 2, NAH, NAL, NB);                \
+        else PP_LOADSEG(S, 1, CAH, CAL, CB, NAH, NAL, NB);                                      \
+        if ((S) + 2 < nslab) __builtin_amdgcn_s_waitcnt((ROLE_B) ? (0x0070 | (NH + NL)) : 0x0076); \
+        else __builtin_amdgcn_s_waitcnt(0x0070);                                                \
+        PP_BARRIER();                                                                           \
+    } while (0)
+#define PP_LOOP(ROLE_B)                                                                         \
+    do {                                                                                        \
+        for (int s = 0; s < nslab; s += 3) {                                                    \
+            PP_STEP(ROLE_B, s, sAh0, sAl0, sB0, sAh1, sAl1, sB1, sAh2, sAl2, sB2);              \
+            if (s + 1 < nslab) PP_STEP(ROLE_B, s + 1, sAh1, sAl1, sB1, sAh2, sAl2, sB2, sAh0, sAl0, sB0); \
+            if (s + 2 < nslab) PP_STEP(ROLE_B, s + 2, sAh2, sAl2, sB2, sAh0, sAl0, sB0, sAh1, sAl1, sB1); \
+        }                                                                                       \
+        if (ROLE_B) PP_MFMA(false, 0, 0, sAh0, sAl0, sB0); /* the last chunk of waves 4-7 */    \
+    } while (0)
+        PS_ISSUE(sAh0, sAl0, sB0, 0);
+        if (nslab > 1) PS_ISSUE(sAh1, sAl1, sB1, PBK * 2);
+        if (nslab > 1) __builtin_amdgcn_s_waitcnt(0x0076);
+        else __builtin_amdgcn_s_waitcnt(0x0070);
+        PP_BARRIER();
+        if (grp_b) PP_LOOP(true);
+        else PP_LOOP(false);
+#undef PP_LOOP
+#undef PP_STEP
+#undef PP_BARRIER
+#undef PP_LOADSEG
+#undef PP_MFMA
+#undef PS_LDS8
+    } else if constexpr (HALF) {
         static_assert(!HALF || (ILV && SPLIT), "the mid-slab barrier schedule is written for the split, interleaved kernel");
         constexpr int NH = NDMA / 2;  // DMAs of a slab issued in the second half of step s-3; the rest in the first half of step s-2
         half8_t c_ah[TM], c_al[TM], c_bf[TN];  // chunk-0 fragments of the current slab, carried from the previous step
@@ -542,6 +657,23 @@ void launch_ps_cfg(const GemmPsArgs& a, hipStream_t s) {
     const dim3 grid(tiles_per_xcd * 8), block(WGM * WGN * 64);
     const uint32_t ab = (uint32_t)((int64_t)a.M * a.lda * 2), wb = (uint32_t)((int64_t)a.N * a.ldw * 2);
     static const bool half = knob::value("SC_PS_HALF", 1) != 0;  // mid-slab barrier schedule (A/B switch)
+    // the 8-wave tile on the alternating schedule (SC_PS_PP=0: the lock-step mid-slab-barrier schedule, same bits)
+    // SC_PS_PP=0: the lock-step schedule (HALF).  Template value n = 1 .. 4: alternating, n - 1 of a chunk's 3 DMAs in the load
+    // segment, the rest between the compute segment's matrix instructions; 4 is shipped
+    static const int pp = knob::value("SC_PS_PP", 4);
+    if constexpr (BM == 256) {
+        if (pp > 0 && a.split) {
+#define PS_PP_LAUNCH(N)                                                                                                                             \
+    do {                                                                                                                                            \
+        if (a.amax) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, false, false, true, N>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb); \
+        else if (a.conv_taps > 0) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, true, false, false, N>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb); \
+        else hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, false, false, false, N>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb); \
+    } while (0)
+            PS_PP_LAUNCH(4);  // (1 .. 3 measured slower: profiles/r5_gemm_alternating_schedule.txt; instantiate them here to repeat the A/B)
+#undef PS_PP_LAUNCH
+            return;
+        }
+    }
     if (a.amax) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, false, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (!a.split) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (a.conv_taps > 0 && half) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);

@@ -122,15 +122,16 @@ def gemm_ps_isa(tmp_path_factory):
     return _isa("k_gemm_ps.hip", tmp_path_factory.mktemp("gemmps"))
 
 
-# template arguments: tile, waves, ILV, SPLIT, CONV, HALF (mid-slab barrier; the shipped schedule) - both schedules are kept
-@pytest.mark.parametrize("inst,mfmas_per_slab", [("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb1ELb0E", 32),
-                                                 ("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb1ELb1ELb0E", 32),
-                                                 ("gemm_ps_kernelILi128ELi128ELi2ELi2ELb1ELb1ELb0ELb1ELb0E", 16),
-                                                 ("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb0ELb0E", 32),
-                                                 ("gemm_ps_kernelILi128ELi128ELi2ELi2ELb1ELb1ELb0ELb0ELb0E", 16),
+# template arguments: tile, waves, ILV, SPLIT, CONV, HALF (mid-slab barrier), AMAX (arg-max epilogue), PP (alternating load /
+# compute segments: the shipped schedule of the 8-wave tile, linted separately below)
+@pytest.mark.parametrize("inst,mfmas_per_slab", [("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb1ELb0ELi0E", 32),
+                                                 ("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb1ELb1ELb0ELi0E", 32),
+                                                 ("gemm_ps_kernelILi128ELi128ELi2ELi2ELb1ELb1ELb0ELb1ELb0ELi0E", 16),
+                                                 ("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb0ELb0ELi0E", 32),
+                                                 ("gemm_ps_kernelILi128ELi128ELi2ELi2ELb1ELb1ELb0ELb0ELb0ELi0E", 16),
                                                  # the arg-max epilogue (unit projection): same slab loop
-                                                 ("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb1ELb1E", 32),
-                                                 ("gemm_ps_kernelILi128ELi128ELi2ELi2ELb1ELb1ELb0ELb1ELb1E", 16)])
+                                                 ("gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb1ELb1ELi0E", 32),
+                                                 ("gemm_ps_kernelILi128ELi128ELi2ELi2ELb1ELb1ELb0ELb1ELb1ELi0E", 16)])
 def test_dma_gemm_slab_loop_keeps_its_pipeline(gemm_ps_isa, inst, mfmas_per_slab):
     """The K loop of the pre-split GEMM (plain and implicit-conv variant): no scratch, DMAs issued as
     `buffer_load_dwordx4 ... lds` between the matrix instructions, one s_barrier per slab, and the only full drain
@@ -150,6 +151,34 @@ def test_dma_gemm_slab_loop_keeps_its_pipeline(gemm_ps_isa, inst, mfmas_per_slab
     first = next(i for i, o in enumerate(ops) if o.startswith("v_mfma"))
     last = max(i for i, o in enumerate(ops) if o.startswith("v_mfma"))
     assert any(o.startswith("buffer_load_dwordx4") for o in ops[first:last])
+
+
+@pytest.mark.parametrize("inst", ["gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb0ELb0ELi4E",   # plain
+                                  "gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb1ELb0ELb0ELi4E",   # implicit convolution
+                                  "gemm_ps_kernelILi256ELi256ELi4ELi2ELb1ELb1ELb0ELb0ELb1ELi4E"])  # arg-max epilogue
+def test_dma_gemm_alternating_schedule_keeps_its_segments(gemm_ps_isa, inst):
+    """The 8-wave tile's alternating schedule (k_gemm_ps.hip, PP): no scratch (the two roles are two loops - one loop with a
+    role branch per segment spilt 900 bytes per lane); a COMPUTE segment is `s_setprio 1`, 16 matrix instructions and nothing
+    else, `s_setprio 0`; a LOAD segment is 8 fragment reads, 3 DMAs, lgkmcnt(0); segments end in a barrier; the DMAs of the
+    slab two ahead are left in flight by a counted vmcnt(6), and only tail branches drain."""
+    fn = _function(gemm_ps_isa, inst)
+    ops = _ops(fn)
+    assert not any(o.startswith("scratch_") for o in ops)
+    prio1 = [i for i, o in enumerate(ops) if o.startswith("s_setprio 1")]
+    prio0 = [i for i, o in enumerate(ops) if o.startswith("s_setprio 0")]
+    assert len(prio1) == len(prio0) >= 12  # 2 roles x 3 stages x 2 chunks (+ the first / last chunk of waves 4-7)
+    for a, b in zip(prio1, prio0):
+        body = [o for o in ops[a + 1: b] if not o.startswith("s_nop")]
+        assert len(body) == 16 and all(o.startswith("v_mfma_f32_32x32x16") for o in body), body[:3]
+    loop = _innermost_loop_with(fn, "v_mfma_f32_32x32x16", "s_barrier", "ds_read_b128")
+    lops = _ops(loop)
+    n_bar = sum(o.startswith("s_barrier") for o in lops)
+    assert n_bar % 4 == 0 and n_bar >= 4
+    assert sum(o.startswith("v_mfma_f32_32x32x16") for o in lops) == 8 * n_bar  # 32 per slab, 4 barriers per slab
+    assert sum(o.startswith("ds_read_b128") for o in lops) == 4 * n_bar         # 16 per slab
+    assert sum(o.startswith("buffer_load_dwordx4") and o.endswith("lds") for o in lops) == 6 * n_bar // 4
+    assert any(re.search(r"vmcnt\(6\)", o) for o in lops)
+    assert sum("vmcnt(0)" in o for o in lops) <= n_bar // 4  # the tail branch of each unrolled step
 
 
 @pytest.fixture(scope="module")
