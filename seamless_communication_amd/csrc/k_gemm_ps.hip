@@ -669,7 +669,9 @@ void launch_ps_cfg(const GemmPsArgs& a, hipStream_t s) {
         else if (a.conv_taps > 0) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, true, false, false, N>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb); \
         else hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, false, false, false, N>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb); \
     } while (0)
-            PS_PP_LAUNCH(4);  // (1 .. 3 measured slower: profiles/r5_gemm_alternating_schedule.txt; instantiate them here to repeat the A/B)
+            // 1 .. 3 measured slower, and neither dropping the priorities, nor raising the load segment's, nor whole-slab segments
+            // (two barriers per slab) moved the time: profiles/r5_gemm_alternating_schedule.txt
+            PS_PP_LAUNCH(4);
 #undef PS_PP_LAUNCH
             return;
         }
