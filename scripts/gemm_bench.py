@@ -83,6 +83,13 @@ if "--decoder-shapes" in sys.argv:
     CONV = []
 
 
+if any(a.startswith("--shapes=") for a in sys.argv):
+    # --shapes=M,N,K;M,N,K: any list of products on the DMA GEMM (e.g. L2-resident operands: 2048,1024,1024 with SC_PS_MIN256=1)
+    PS_ONLY = True
+    LINEAR = [tuple(int(v) for v in t.split(",")) for a in sys.argv if a.startswith("--shapes=") for t in a[len("--shapes="):].split(";")]
+    CONV = []
+
+
 def timed_presplit(fn, reps=6):
     fn()
     lib.sc_prof_reset()
