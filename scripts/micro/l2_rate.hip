@@ -58,6 +58,35 @@ __global__ __launch_bounds__(512) void pull_dma(const void* __restrict__ src, si
     out[blockIdx.x * 512 + threadIdx.x] = reinterpret_cast<float*>(smem)[threadIdx.x];
 }
 
+// the DMA GEMM's access pattern: a wave instruction = 16 rows x 64 B (lane p: row p >> 2, 16-byte piece p & 3) at a row stride of
+// 2 KB; a workgroup's 8 waves cover 128 rows; the 64-byte column window moves on by 64 B per step and wraps at the row length
+template <int DEPTH>
+__global__ __launch_bounds__(512) void pull_dma_rows(const void* __restrict__ src, size_t bytes, int steps_total, float* __restrict__ out) {
+    extern __shared__ char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    i32x4_t r;
+    const unsigned long long b = reinterpret_cast<unsigned long long>(src);
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xffff));
+    r[2] = __builtin_amdgcn_readfirstlane((int)(unsigned)bytes);
+    r[3] = 0x00020000;
+    const unsigned rows = (unsigned)(bytes / 2048);
+    const unsigned row0 = (blockIdx.x * 128u + wave * 16u + (lane >> 2)) % rows;
+    const unsigned base = row0 * 2048u + (lane & 3) * 16u;
+    unsigned col = (blockIdx.x * 64u) % 2048u;
+    for (int it = 0; it < steps_total / DEPTH; ++it) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int ldsp = __builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)(smem + (d * 8 + wave) * 1024));
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(ldsp), "v"(base), "s"(r), "s"((int)col) : "memory");
+            col = (col + 64u) % 2048u;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);
+    }
+    __syncthreads();
+    out[blockIdx.x * 512 + threadIdx.x] = reinterpret_cast<float*>(smem)[threadIdx.x];
+}
+
 int main() {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -104,5 +133,22 @@ int main() {
             printf("\n");
             CK(hipDeviceSynchronize());
         }
+    // the same bytes per instruction (1 KB) as 16 x 64-byte row pieces: footprints that stay in the L2s
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(pull_dma_rows<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    for (size_t sz : {(size_t)1 << 20, (size_t)4 << 20, (size_t)64 << 20}) {
+        const int steps = 60000;
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(pull_dma_rows<6>, dim3(256), dim3(512), 64 * 1024, 0, d_src, sz, steps, d_out);
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        printf("footprint %5zu MB, LDS-DMA of 16 rows x 64 B per wave instruction (row stride 2 KB), 48 KB in flight: %.2f TB/s  (%.1f ns per wave instruction and CU)\n",
+               sz >> 20, 256.0 * steps * 8192.0 / (best * 1e-3) / 1e12, best * 1e6 / (steps * 8.0));
+    }
     return 0;
 }
