@@ -103,9 +103,10 @@ def timed_presplit(fn, reps=6):
     return {"presplit": (name, ms / launches, flops / launches, byts / launches)}
 
 
+ZEROS = "--zeros" in sys.argv  # all-zero operands: the same instruction stream without toggling data (power management)
 for M, N, K in LINEAR:
-    x = torch.randn(M, K, device="cuda")
-    w = (torch.randn(N, K, device="cuda") / math.sqrt(K)).half()
+    x = torch.zeros(M, K, device="cuda") if ZEROS else torch.randn(M, K, device="cuda")
+    w = torch.zeros(N, K, device="cuda", dtype=torch.float16) if ZEROS else (torch.randn(N, K, device="cuda") / math.sqrt(K)).half()
     b = torch.randn(N, device="cuda")
     y = torch.empty(M, N, device="cuda")
     torch.cuda.synchronize()
