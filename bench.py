@@ -174,6 +174,12 @@ def roofline_of(fams, step_bytes=None):
                   "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
               for k, v in sorted(fams.items(), key=lambda kv: -kv[1]["ms"])}
     shares["_profiled_total_ms"] = round(total, 3)
+    if any(k.startswith("voc:") for k in shares):
+        # the vocoder's length buckets go round three side chains (SC_VOC_STREAMS, read once per process): the HIP-event durations of
+        # the voc:* launches OVERLAP in this pass and sum to more than the stage takes; their TFLOP/s and GB/s are understated
+        shares["_note_voc"] = ("voc:* families ran on concurrent side chains (their durations overlap and sum to more than stage_ms_profiled_step.vocoder; "
+                               "TFLOP/s and GB/s of these rows are understated); un-overlapped per-family times of a one-chain pass: profiles/r4_single_chain_pass.json "
+                               "(SC_VOC_STREAMS=1 bench.py --schedule lockstep --microbatches 1)")
     return roof, shares
 
 
