@@ -677,6 +677,7 @@ void launch_ps_cfg(const GemmPsArgs& a, hipStream_t s) {
         }
     }
     if (a.amax) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, false, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
+    else if (!a.split && a.conv_taps > 0) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, false, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (!a.split) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, false>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (a.conv_taps > 0 && half) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
     else if (a.conv_taps > 0) hipLaunchKernelGGL((gemm_ps_kernel<BM, BN, WGM, WGN, true, true, true>), grid, block, 0, s, a, tiles_n, tiles_total, tiles_per_xcd, ab, wb);
@@ -713,7 +714,7 @@ void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s) {
              "presplit gemm: operands must be 16-byte aligned");
     SC_CHECK((int64_t)a.M * a.lda * 2 < (1ll << 31) && (int64_t)a.N * a.ldw * 2 < (1ll << 31), "presplit gemm: operand larger than 2 GB");
     if (a.conv_taps > 0) {
-        SC_CHECK(a.split && a.conv_cin % PBK == 0 && a.K == a.conv_taps * a.conv_cin && a.lda >= a.conv_cin &&
+        SC_CHECK(a.conv_cin % PBK == 0 && a.K == a.conv_taps * a.conv_cin && a.lda >= a.conv_cin &&
                      (a.row_pos || (a.rows_per_item > 0 && a.M % a.rows_per_item == 0)) && a.conv_dil >= 1 && a.conv_pad >= 0,
                  "presplit conv: taps=%d cin=%d K=%d rows_per_item=%d M=%d", a.conv_taps, a.conv_cin, a.K, a.rows_per_item, a.M);
     } else {

@@ -92,7 +92,7 @@ __device__ __forceinline__ void conv_from_lds(const _Float16* __restrict__ ah_pl
 template <int C, int NF>
 __device__ __forceinline__ void conv_from_lds_w(const _Float16* __restrict__ ah_plane, const _Float16* __restrict__ al_plane,
                                                 int a_row0, int tap_step, int tap0, int ntaps, const _Float16* __restrict__ sW,
-                                                int ldb, int lane, float16_t (&acc)[NF]) {
+                                                int ldb, int lane, float16_t (&acc)[NF], bool single = false) {
     constexpr int CS = C + 8;
     constexpr int CPT = C / 16;
     const int koff = (lane >> 5) * 8;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void conv_from_lds_w(const _Float16* __restrict__ ah_
             for (int nf = 0; nf < NF; ++nf) {
                 const half8_t b = wok[nf] ? *reinterpret_cast<const half8_t*>(sW + w_base[nf] + (t * CPT + cc) * 16) : zero8;
                 acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b, acc[nf], 0, 0, 0);
-                acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[nf], 0, 0, 0);
+                if (!single) acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[nf], 0, 0, 0);
             }
         }
     }
@@ -221,12 +221,12 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
             TapRegs<C> wr;
             for (int t = 0; t < k; ++t) {  // tap t from buffer t&1 while tap t+1 travels: registers, then the other buffer
                 if (t + 1 < k) tap_load<C>(p.w1, p.ldw1, (t + 1) * C, tid, wr);
-                conv_from_lds_w<C, NF>(xh, xl, 32 * wave, dil, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc);
+                conv_from_lds_w<C, NF>(xh, xl, 32 * wave, dil, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc, p.single != 0);
                 if (t + 1 < k) tap_store<C>(wr, sW + ((t + 1) & 1) * C * ldb, ldb, tid);  // read last at tap t-1: barrier since
                 __syncthreads();
             }
         } else {
-            conv_from_lds_w<C, NF>(xh, xl, 32 * wave, dil, 0, k, sW, ldb, lane, acc);
+            conv_from_lds_w<C, NF>(xh, xl, 32 * wave, dil, 0, k, sW, ldb, lane, acc, p.single != 0);
             __syncthreads();  // every wave is done reading x (and W1) before the tmp tile / W2 overwrite them
         }
         if (PER_TAP) stage_weights<C>(p.w2, p.ldw2, 0, C, sW, ldb, tid);
@@ -261,14 +261,14 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
             TapRegs<C> wr;
             for (int t = 0; t < k; ++t) {
                 if (t + 1 < k) tap_load<C>(p.w2, p.ldw2, (t + 1) * C, tid, wr);
-                conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc);
+                conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc, p.single != 0);
                 if (t + 1 < k) {
                     tap_store<C>(wr, sW + ((t + 1) & 1) * C * ldb, ldb, tid);
                     __syncthreads();
                 }
             }
         } else {
-            conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, 0, k, sW, ldb, lane, acc);
+            conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, 0, k, sW, ldb, lane, acc, p.single != 0);
         }
         // epilogue through LDS: (acc + bias) as a row-major fp32 tile over the (now dead) tmp planes, then 16 bytes per
         // lane: residual read, optional 3-way average and store are 4x fewer (and fully coalesced) memory instructions
@@ -373,7 +373,7 @@ __device__ __forceinline__ void mrf_w_dma(const __half* __restrict__ W, int64_t 
 // columns: lanes 16-31 multiply the weight rows of columns 0-15 again instead of branching around the read.
 template <int C>
 __device__ __forceinline__ void mrf_conv(const _Float16* __restrict__ ph, const _Float16* __restrict__ pl, int a_row0, int tap_step, int k,
-                                         const _Float16* __restrict__ sW, int ldb, int lane, float16_t& acc) {
+                                         const _Float16* __restrict__ sW, int ldb, int lane, float16_t& acc, bool single = false) {
     constexpr int CS = C + 8;
     constexpr int CPT = C / 16;
     const int koff = (lane >> 5) * 8;
@@ -393,7 +393,7 @@ __device__ __forceinline__ void mrf_conv(const _Float16* __restrict__ ph, const 
     for (int ch = 0; ch < nch; ++ch) {
         if (ch + 1 < nch) MRF_LD(ch + 1, h1, l1, b1);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(l0, b0, acc, 0, 0, 0);
+        if (!single) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(l0, b0, acc, 0, 0, 0);
         h0 = h1, l0 = l1, b0 = b1;
     }
 #undef MRF_LD
@@ -479,7 +479,7 @@ __device__ __forceinline__ void mrf_tile(const MrfArgs& p, _Float16* __restrict_
                 float16_t acc[1];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-                if (act) mrf_conv<C>(ph, pl, MRF_G + 32 * wave - hk * dil, dil, k, sW1, ldb, lane, acc[0]);
+                if (act) mrf_conv<C>(ph, pl, MRF_G + 32 * wave - hk * dil, dil, k, sW1, ldb, lane, acc[0], p.single != 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this pair's second weights (DMA) have landed
                 __syncthreads();  // every wave is done with the x planes and with this pair's first weights
                 if (more) mrf_w_dma<C>(p.w1[qn], p.ldw1[qn], kn, sW1, lane, wave);
@@ -501,7 +501,7 @@ __device__ __forceinline__ void mrf_tile(const MrfArgs& p, _Float16* __restrict_
                 float16_t acc[1];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-                if (act) mrf_conv<C>(ph, pl, MRF_G + 32 * wave - hk, 1, k, sW2, ldb, lane, acc[0]);
+                if (act) mrf_conv<C>(ph, pl, MRF_G + 32 * wave - hk, 1, k, sW2, ldb, lane, acc[0], p.single != 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next pair's first weights (DMA) have landed
                 __syncthreads();  // every wave is done with the intermediate and with this pair's second weights
                 if (more) mrf_w_dma<C>(p.w2[qn], p.ldw2[qn], kn, sW2, lane, wave);

@@ -351,7 +351,7 @@ void run_t2u_nar(Model& m, const float* d_dec_hidden, int n, int s_text, const i
 // row_pos != null: packed items (rows_total rows in all, row_pos[m] = {position, item length}); nb / t are then unused
 void conv1d_presplit(Model& m, const __half* xh, const __half* xl, const Conv& c, const float* res, float* C, __half* Ch, __half* Cl,
                      int nb, int t, int pad, int dil, const unsigned char* row_valid, int act, int rows_total = 0,
-                     const int2* row_pos = nullptr, float plane_neg_slope = 1.0f);
+                     const int2* row_pos = nullptr, float plane_neg_slope = 1.0f, int split = 1);
 void run_vocoder_durations(Model& m, const int32_t* h_units, int n, int s_units, int32_t* h_durations);
 void run_t2u_ar(Model& m, const float* d_dec_hidden, int n, int s_text, const int32_t* h_text_lens, const sc_gen_opts& o,
                 const int32_t* h_prefix, int prefix_len, int32_t* h_out_ids, int32_t* h_out_lens, float* h_scores);

@@ -743,7 +743,7 @@ void conv1d(Model& m, const float* x, const Conv& c, const float* res, float* y,
 
 void conv1d_presplit(Model& m, const __half* xh, const __half* xl, const Conv& c, const float* res, float* C, __half* Ch, __half* Cl,
                      int nb, int t, int pad, int dil, const unsigned char* row_valid, int act, int rows_total, const int2* row_pos,
-                     float plane_neg_slope) {
+                     float plane_neg_slope, int split) {
     SC_CHECK(c.kpad == c.cin * c.k && 2 * pad == dil * (c.k - 1), "conv1d_presplit: needs an unpadded weight row and 'same' padding");
     if (row_pos ? rows_total <= 0 : (nb <= 0 || t <= 0)) return;
     GemmPsArgs a;
@@ -772,6 +772,7 @@ void conv1d_presplit(Model& m, const __half* xh, const __half* xl, const Conv& c
     a.row_pos = row_pos;
     a.row_valid = row_valid;
     a.plane_neg_slope = plane_neg_slope;
+    a.split = split;
     launch_gemm_presplit(a, m.stream);
 }
 

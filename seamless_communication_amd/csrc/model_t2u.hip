@@ -527,6 +527,10 @@ void vocode_batch(Model& m, const int* d_units, const int* d_lang, const int* d_
     }
     const int nk = c.voc_num_resblock_kernels;
     SC_CHECK(nk == 3, "sc_vocode: %d resblock kernels (only 3 is implemented)", nk);
+    // precision study (SC_VOC_SINGLE, honoured with SC_DEBUG_NUMERICS=1 only): bit 0 - the wide stages' ResBlock convolutions, bit
+    // 2 - the narrow stages' - multiply the hi fp16 plane of their activations only (one matrix instruction per product instead
+    // of two).  scripts / tests report what that does to the waveform.
+    static const int voc_single = knob::value("SC_VOC_SINGLE", 0);
     for (int i = 0; i < c.voc_num_upsamples; ++i) {
         const ConvT& up = m.voc_ups[i];
         const int t2 = t * up.stride;
@@ -571,10 +575,11 @@ void vocode_batch(Model& m, const int* d_units, const int* d_lang, const int* d_
                     const int k = r.convs1[d].k, k2 = r.convs2[d].k;
                     const bool last = d == nd - 1;
                     float* dst = last ? rout[j].get() : ((d & 1) ? rb.get() : ra.get());
+                    const int split = (voc_single & 1) ? 0 : 1;
                     conv1d_presplit(m, ch_, cl_, r.convs1[d], nullptr, nullptr, pt_h, pt_l, n, t2, (k * r.dil[d] - r.dil[d]) / 2, r.dil[d], nullptr,
-                                    ACT_NONE, 0, nullptr, 0.1f);
+                                    ACT_NONE, 0, nullptr, 0.1f, split);
                     conv1d_presplit(m, pt_h, pt_l, r.convs2[d], cur, dst, last ? nullptr : pn_h, last ? nullptr : pn_l, n, t2, (k2 - 1) / 2, 1,
-                                    nullptr, ACT_NONE, 0, nullptr, 0.1f);
+                                    nullptr, ACT_NONE, 0, nullptr, 0.1f, split);
                     cur = dst;
                     ch_ = pn_h;
                     cl_ = pn_l;
@@ -610,6 +615,7 @@ void vocode_batch(Model& m, const int* d_units, const int* d_lang, const int* d_
                 a.T = t2;
                 a.C = ch;
                 a.slope = 0.1f;
+                a.single = (voc_single & 4) ? 1 : 0;
                 launch_mrf_fused(a, m.stream);
                 t = t2;
                 continue;
@@ -640,6 +646,7 @@ void vocode_batch(Model& m, const int* d_units, const int* d_lang, const int* d_
                     a.k = k;
                     a.dil = r.dil[d];
                     a.slope = 0.1f;
+                    a.single = (voc_single & 4) ? 1 : 0;
                     if (j == nk - 1 && d == nd - 1) {
                         a.avg_a = rout[0];
                         a.avg_b = rout[1];
