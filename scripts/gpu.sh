@@ -23,6 +23,7 @@
 #   esweep       scripts/engine_sweep.py: decode-engine / schedule settings on one model load ($ESWEEP)
 #   esweepenv    the same, one configuration ($ESWEEP), once per environment setting of $SWEEP (library switches are read once per process)
 #   estep        scripts/engine_step_bench.py: the engine's step alone per slot count + its kernel stats at $ESTEP_PROF_SLOTS
+#   estepenv     the step alone ($ESTEP_SLOTS) once per environment setting of $SWEEP
 #   layout       scripts/real_layout_check.py: a published-layout checkpoint through Translator(file://...)
 #   cover        kernel trace of a bench pass -> device-busy share, idle gaps, timeline (scripts/trace_cover.py)
 #                (cover / sqbench are cut off after COVER_TIMEOUT / SQB_TIMEOUT seconds: a process that aborts inside
@@ -183,6 +184,15 @@ for task in "$@"; do
       ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_estep_prof -o step -- python $R/scripts/engine_step_bench.py --slots ${ESTEP_PROF_SLOTS:-192} --reps 1 > $R/${O}_estep_prof.log 2>&1; echo "exit $?" >> $R/${O}_estep_prof.log )
       find gpurun_out/${TAG}_estep_prof -name "*kernel_trace*" -delete 2>/dev/null
       f=$(find gpurun_out/${TAG}_estep_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f ${O}_estep_kernel_stats.csv && head -14 ${O}_estep_kernel_stats.csv | cut -c1-200 ;;
+    estepenv)
+      # the engine's step alone ($ESTEP_SLOTS) once per environment setting of $SWEEP (';'-separated; library switches are read once per process)
+      IFS=';' read -ra SW <<< "$SWEEP"
+      i=0
+      for e in "${SW[@]}"; do
+        i=$((i+1))
+        ( env $e timeout 200 python scripts/engine_step_bench.py --slots ${ESTEP_SLOTS:-128,192,256} > ${O}_estepenv_$i.txt 2>&1; echo "exit $?" >> ${O}_estepenv_$i.txt )
+        echo "--- $e"; grep -E "^slots=|^exit|Error|error" ${O}_estepenv_$i.txt | cut -c1-250
+      done ;;
     layout)
       # a full-size checkpoint in the PUBLISHED wire format (fairseq keys, fp32, dummy embedding row, weight_g / weight_v) written
       # from the synthetic weights and loaded through Translator(file://...): load time, host memory, ids vs the synthetic card

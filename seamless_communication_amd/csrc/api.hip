@@ -733,7 +733,10 @@ int sc_op_dstep3_gemv(int32_t mode, const float* d_x, const void* d_w_f16, const
     __half* wp = scratch.get<__half>((size_t)packed_weight_halfs(N, K));
     launch_pack_weight(static_cast<const __half*>(d_w_f16), K, N, K, wp, g_op_stream);
     Gemv3Args a;
-    a.Wp = wp, a.M = M, a.N = N, a.K = K, a.in_mode = in_mode, a.RB = RB, a.rg = rg, a.bias = d_bias, a.shape = shape;
+    a.Wp = wp, a.M = M, a.N = N, a.K = K, a.in_mode = in_mode, a.RB = RB, a.rg = rg, a.bias = d_bias, a.shape = shape & 15;
+    // bits 4..7 of `shape`: 0 the launcher decides, 15 one workgroup per row group, k weights stationary with k workgroups per tile
+    a.stationary = ((shape >> 4) & 15) == 0 ? -1 : (((shape >> 4) & 15) == 15 ? 0 : ((shape >> 4) & 15));
+    shape &= 15;
     if (in_mode == IN3_LN) {
         float* xg = scratch.get<float>((size_t)K * RB);
         SC_HIP(hipMemsetAsync(xg, 0xff, (size_t)K * RB * 4, g_op_stream));  // NaN in the unused row slots: must not leak

@@ -42,6 +42,7 @@ const Knob knob_table[] = {
     {"SC_PRESPLIT", 0, "0: Conformer operands split on the fly"}, {"SC_ENC_FUSE", 0, "0: separate Conformer element-wise launches"},
     {"SC_DSTEP_TOUCH", 0, "weight toucher: layers ahead"}, {"SC_DSTEP_TOUCH_WGS", 0, "weight toucher: workgroups"},
     {"SC_D3_RG_SMALL", 0, "decoder step: rows per row group, N = 1024 products"}, {"SC_D3_RG_FFN", 0, "decoder step: rows per row group, FFN-in"},
+    {"SC_G3_STATIONARY", 0, "row-group products of wide steps: 0 one workgroup per row group, n = workgroup budget of the weight-stationary launch"},
     {"SC_D3_FFN_IN", 0, "decoder step: FFN-in workgroup shape"}, {"SC_D3_FFN_OUT", 0, "decoder step: FFN-out workgroup shape"},
     {"SC_MMA_GRAPH", 0, "streaming decoder step from a captured graph"}, 
     {"SC_T2U_GROUPS", 0, "NAR T2U: length buckets"}, {"SC_T2U_PACKED", 0, "0: NAR decoder on padded buckets"},

@@ -336,6 +336,264 @@ __global__ __launch_bounds__(64 * WAVES) void gemv3_kernel(Gemv3Args p) {
 }
 
 // --------------------------------------------------------------------------------------------- //
+// gemv3s_kernel<NT, MT, WAVES, KSW, IN, EPI>: the same product with the WEIGHTS STATIONARY (round 5, wide steps of the
+// decode engine / beam search).  gemv3_kernel at 192 rows is 768 workgroups of one row group each: three rounds over the
+// chip, every workgroup a serial load -> (LayerNorm) -> multiply -> reduce -> store chain of ~8 us with its weights
+// pulled again per row group.  Here a workgroup keeps its tiles' weight fragments in registers and WALKS the row groups
+// g = blockIdx.y, + gridDim.y, ... that hold live rows; the activation registers of a k-step are refilled with the NEXT
+// group's rows as soon as the step's matrix instructions have consumed them (rolling prefetch: no second register set),
+// so the next group's rows arrive under this group's multiply / reduce / epilogue.  One round of <= 256 workgroups.
+// A row's arithmetic is gemv3_kernel's to the instruction (same wave -> K chunk map, same matrix instruction order,
+// same LDS sum over chunks): bit-identical, tests/test_dstep3_gpu.py::test_gemv3_stationary_bit_identical.
+// Only the two shapes the wide step needs: (IN3_LN, EPI3_PLANES) FFN-in and (IN3_PLANES, EPI3_PARTIAL) FFN-out.
+// --------------------------------------------------------------------------------------------- //
+template <int NT, int MT, int WAVES, int KSW, int IN, int EPI>
+__global__ __launch_bounds__(64 * WAVES) void gemv3s_kernel(Gemv3Args p) {
+    static_assert((IN == IN3_LN && EPI == EPI3_PLANES && MT == 1) || (IN == IN3_PLANES && EPI == EPI3_PARTIAL),
+                  "gemv3s_kernel: FFN-in and FFN-out shapes only");
+    constexpr int T = 64 * WAVES;
+    constexpr int NJ = NT * MT;
+    __shared__ float red[WAVES][NJ][32 * 33];
+    __shared__ float gb[IN == IN3_LN ? 2 : 1][IN == IN3_LN ? 1024 : 1];
+    __shared__ float stat[2][WAVES][32 * MT];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31;
+    const int h = lane >> 5;
+    const int nt0 = blockIdx.x * NT;
+    const int live = p.d_rows ? min(*p.d_rows, p.M) : p.M;
+    const int groups = (live + p.rg - 1) / p.rg;  // row groups that hold live rows
+    int g = blockIdx.y;
+    if (g >= groups) return;
+    const int rot = blockIdx.x % WAVES;
+    const int chunk = (wave + rot) % WAVES;
+    const int ks_w0 = (blockIdx.z * WAVES + chunk) * KSW;
+
+    // ---- the workgroup's weights: once, before anything else --------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rw = rsrc3(p.Wp, p.w_bytes);
+    const uint32_t w_voff = (uint32_t)lane * 16u;
+    u32x4_t w[NT][KSW];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        const uint32_t tkill = (nt0 + jt < p.NT_total) ? 0u : OOB;
+        const uint32_t w_tile = (uint32_t)(nt0 + jt) * (uint32_t)p.KS * 1024u;
+#pragma unroll
+        for (int j = 0; j < KSW; ++j) {
+            const uint32_t kk = (ks_w0 + j < p.KS) ? 0u : OOB;
+            w[jt][j] = gridDim.y == 1 ? __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff | tkill | kk, w_tile + (uint32_t)(ks_w0 + j) * 1024u, 2 /*nt*/)
+                                      : __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff | tkill | kk, w_tile + (uint32_t)(ks_w0 + j) * 1024u, 0);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t ra0 = rsrc3(IN == IN3_PLANES ? (const void*)p.Ah : (const void*)p.xg, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t ra1 = rsrc3(IN == IN3_PLANES ? (const void*)p.Al : (const void*)p.xg, p.a_bytes);
+    constexpr uint32_t ESZ = IN == IN3_PLANES ? 16u : 32u;        // bytes of a row's 8 columns
+    const uint32_t a_kstep = (uint32_t)(2 * p.RB) * ESZ;          // bytes per k-step
+    u32x4_t a0[MT][KSW], a1[MT][KSW];  // IN3_PLANES: hi / lo fragments; IN3_LN: the 8 fp32 columns of (row, k half)
+    // the rows of group gg for k-step j (rows behind the live rows / the group / K: out-of-range offsets, no traffic)
+    auto fetch = [&](int gg, int j) {
+        const int r0 = gg * p.rg;
+        const uint32_t kk = (ks_w0 + j < p.KS && gg < groups) ? 0u : OOB;
+        const uint32_t so = (uint32_t)(ks_w0 + j) * a_kstep;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const bool ok = (32 * i + n < p.rg) && (r0 + 32 * i + n < live);
+            const uint32_t voff = ok ? (uint32_t)(h * p.RB + r0 + 32 * i + n) * ESZ : OOB;
+            a0[i][j] = __builtin_amdgcn_raw_buffer_load_b128(ra0, voff | kk, so, 0);
+            a1[i][j] = __builtin_amdgcn_raw_buffer_load_b128(ra1, voff | kk, so + (IN == IN3_PLANES ? 0u : 16u), 0);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) fetch(g, j);
+
+    // LayerNorm parameters of the whole row into LDS, the bias of this thread's output features: once
+    if (IN == IN3_LN) {
+#pragma unroll
+        for (int u = 0; u < 1024 / T; ++u) {
+            const int col = tid + u * T;
+            gb[0][col] = col < p.K ? p.gamma[col] : 0.f;
+            gb[1][col] = col < p.K ? p.beta[col] : 0.f;
+        }
+    }
+    constexpr int ITER = (NJ * 1024) / T;
+    constexpr int PITER = (NJ * 128 + T - 1) / T;
+    float bias8[EPI == EPI3_PLANES ? PITER : 1][8];
+    if (EPI == EPI3_PLANES) {
+#pragma unroll
+        for (int it = 0; it < PITER; ++it) {
+            const int u = tid + it * T;
+            const int jj = u >> 7, jt = jj / MT, gq = (u >> 5) & 3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int feat = (nt0 + jt) * 32 + 8 * gq + e;
+                bias8[it][e] = (p.bias && u < NJ * 128 && feat < p.N) ? p.bias[feat] : 0.f;
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (IN == IN3_LN) __syncthreads();  // gb
+
+    for (;;) {
+        const int r0 = g * p.rg;
+        const int gn = g + (int)gridDim.y;
+        // ---- LayerNorm of the row group (IN3_LN): statistics across the waves, two pass (gemv3_kernel's order) -------
+        float mean[MT], rstd[MT];
+        if (IN == IN3_LN) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < KSW; ++j) {
+                    const f32x4_t v0 = __builtin_bit_cast(f32x4_t, a0[i][j]), v1 = __builtin_bit_cast(f32x4_t, a1[i][j]);
+                    s += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+                }
+                s += __shfl_xor(s, 32);
+                if (h == 0) stat[0][chunk][32 * i + n] = s;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < WAVES; ++c) s += stat[0][c][32 * i + n];
+                mean[i] = s / (float)p.K;
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < KSW; ++j) {
+                    if (ks_w0 + j < p.KS) {
+                        const f32x4_t v0 = __builtin_bit_cast(f32x4_t, a0[i][j]), v1 = __builtin_bit_cast(f32x4_t, a1[i][j]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = v0[e] - mean[i];
+                            q = fmaf(d, d, q);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = v1[e] - mean[i];
+                            q = fmaf(d, d, q);
+                        }
+                    }
+                }
+                q += __shfl_xor(q, 32);
+                if (h == 0) stat[1][chunk][32 * i + n] = q;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                float q = 0.f;
+#pragma unroll
+                for (int c = 0; c < WAVES; ++c) q += stat[1][c][32 * i + n];
+                rstd[i] = 1.0f / sqrtf(q / (float)p.K + 1e-5f);
+            }
+        }
+
+        // ---- products; the registers of a consumed k-step take the next group's rows -------------------------------
+        float16_t acc[NT][MT];
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jt][i][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KSW; ++j) {
+            half8_t bh[MT], bl[MT];
+            if (IN == IN3_PLANES) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    bh[i] = __builtin_bit_cast(half8_t, a0[i][j]);
+                    bl[i] = __builtin_bit_cast(half8_t, a1[i][j]);
+                }
+            } else {
+                const int k0 = min((ks_w0 + j) * 16 + h * 8, 1024 - 8);
+                const float4 g0 = *reinterpret_cast<const float4*>(&gb[0][k0]), g1 = *reinterpret_cast<const float4*>(&gb[0][k0 + 4]);
+                const float4 b0 = *reinterpret_cast<const float4*>(&gb[1][k0]), b1 = *reinterpret_cast<const float4*>(&gb[1][k0 + 4]);
+                const float g8[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float b8[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const f32x4_t v0 = __builtin_bit_cast(f32x4_t, a0[i][j]), v1 = __builtin_bit_cast(f32x4_t, a1[i][j]);
+                    float y[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y[e] = (v0[e] - mean[i]) * rstd[i] * g8[e] + b8[e];
+                        y[4 + e] = (v1[e] - mean[i]) * rstd[i] * g8[4 + e] + b8[4 + e];
+                    }
+                    split8v(y, bh[i], bl[i]);
+                }
+            }
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const half8_t wf = __builtin_bit_cast(half8_t, w[jt][j]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    acc[jt][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, bh[i], acc[jt][i], 0, 0, 0);
+                    acc[jt][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, bl[i], acc[jt][i], 0, 0, 0);
+                }
+            }
+            fetch(gn, j);  // (behind the last group: out-of-range offsets)
+        }
+
+        // ---- cross-wave sum through LDS -------------------------------------------------------------------------
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    red[chunk][jt * MT + i][n * 33 + f] = acc[jt][i][r];
+                }
+        __syncthreads();
+
+        if (EPI == EPI3_PLANES) {
+#pragma unroll
+            for (int it = 0; it < PITER; ++it) {
+                const int u = tid + it * T;
+                if (u >= NJ * 128) break;
+                const int jj = u >> 7, jt = jj / MT, i = jj % MT, rn = u & 31, gq = (u >> 5) & 3;
+                const int row = r0 + 32 * i + rn;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int o = rn * 33 + 8 * gq + e;
+                    float s = 0.f;
+#pragma unroll
+                    for (int c = 0; c < WAVES; ++c) s += red[c][jj][o];
+                    s += bias8[it][e];
+                    if (p.act == ACT_RELU) s = s > 0.f ? s : 0.f;
+                    if ((nt0 + jt) * 32 + 8 * gq + e >= p.N) s = 0.f;
+                    v[e] = s;
+                }
+                if (32 * i + rn < p.rg && row < live && ((nt0 + jt) * 4 + gq) * 8 < p.N) {
+                    half8_t hi, lo;
+                    split8v(v, hi, lo);
+                    const int64_t off = ((int64_t)((nt0 + jt) * 4 + gq) * p.ORB + row) * 8;
+                    *reinterpret_cast<half8_t*>(p.Oh + off) = hi;
+                    *reinterpret_cast<half8_t*>(p.Ol + off) = lo;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int u = tid + it * T;
+                const int jj = u >> 10, jt = jj / MT, i = jj % MT, rn = (u >> 5) & 31, f = u & 31;
+                const int feat = (nt0 + jt) * 32 + f, row = r0 + 32 * i + rn;
+                const int o = rn * 33 + f;
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < WAVES; ++c) s += red[c][jj][o];
+                if (feat < p.N && 32 * i + rn < p.rg && row < live) p.out[((int64_t)blockIdx.z * p.M + row) * p.N + feat] = s;
+            }
+        }
+        if (gn >= groups) break;
+        g = gn;
+        __syncthreads();  // the next group's partial sums overwrite red
+    }
+}
+
+// --------------------------------------------------------------------------------------------- //
 // reduce3_kernel<LN>: x[row] += bias + sum_s partial[s][row] on the k-group-major residual stream; LN: additionally
 // h = LayerNorm(x[row]) as split planes / fp32 rows (the decoder output after the last layer).  One workgroup per row,
 // thread t owns columns 4t .. 4t+3; every global load is issued before the first use.
@@ -762,6 +1020,24 @@ void launch_gemv3(const Gemv3Args& a0, hipStream_t s) {
     dim3 grid(cdiv(a.NT_total, nt), groups, splits);
     prof::Scope scope(a.in_mode == IN3_LN ? "gemv3_ln" : "gemv3_planes", 2.0 * a.M * (double)a.N * a.K,
                       2.0 * a.N * (double)a.K + 4.0 * a.M * ((double)a.K + (double)a.N * splits), s);
+    // wide steps (decode engine, beam search): weights stationary, the workgroup walks the row groups (gemv3s_kernel) when
+    // one workgroup per row group would be more than one round over the chip.  SC_G3_STATIONARY: 0 never, n = the
+    // workgroup budget of a launch (default 256 = the compute units).
+    const bool ffn_in = a.shape == G3_T2K8 && a.in_mode == IN3_LN && a.epi == EPI3_PLANES && !two;
+    const bool ffn_out = a.shape == G3_T2K4 && a.in_mode == IN3_PLANES && a.epi == EPI3_PARTIAL && two;
+    if ((ffn_in || ffn_out) && a.stationary != 0 && groups > 1) {
+        static const int budget = knob::value("SC_G3_STATIONARY", 256);
+        const int per_group = (int)(grid.x * grid.z);
+        int gy = a.stationary > 0 ? a.stationary : (budget > 0 ? budget / per_group : groups);
+        gy = gy < 1 ? 1 : gy;
+        if (gy < groups) {
+            grid.y = gy;
+            if (ffn_in) hipLaunchKernelGGL((gemv3s_kernel<2, 1, 8, 8, IN3_LN, EPI3_PLANES>), grid, dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((gemv3s_kernel<2, 2, 8, 4, IN3_PLANES, EPI3_PARTIAL>), grid, dim3(512), 0, s, a);
+            SC_LAUNCH_CHECK();
+            return;
+        }
+    }
     if (a.shape == G3_T1) {
         if (two) gemv3_dispatch<1, 2, 16, 4>(a, grid, s);
         else gemv3_dispatch<1, 1, 16, 4>(a, grid, s);

@@ -308,6 +308,8 @@ struct Gemv3Args {
     int RB = 32;   // row slots of the input buffers
     int rg = 0;    // rows per row group (<= 32; <= 64 with mt2); 0 = as many as the shape allows
     int mt2 = 0;   // 33..64 rows as ONE row group (two MFMA row tiles per workgroup)
+    int stationary = -1;  // FFN-in / FFN-out shapes over several row groups: -1 the launcher decides, 0 one workgroup per row group,
+                          // k >= 1 weights stationary with k workgroups per tile walking the row groups (same bits; tests)
     int shape = 0; // G3_T1 / G3_T2K8 / G3_T2K4: tiles per workgroup x waves x k-steps per wave (k_dstep3.hip)
     int epi = EPI3_ROWS;
     const float* bias = nullptr;

@@ -104,6 +104,43 @@ def test_gemv3_partials_and_reduce(lib, report_dir, M, N, K, ln, shape):
     assert err < 2e-6 and eh < 2e-5
 
 
+# Wide steps (decode engine, beam search): the FFN products with the weights stationary - a workgroup keeps its tiles'
+# fragments in registers and walks the row groups (gemv3s_kernel).  `shape` bits 4..7 of the op entry: 15 = one workgroup
+# per row group (gemv3_kernel), k = stationary with k workgroups per tile.  Same bits whatever the walk.
+@pytest.mark.parametrize("M", [192, 150, 97, 320, 64, 65, 512])
+def test_gemv3_stationary_bit_identical(lib, report_dir, M):
+    # FFN-in: act(LayerNorm(x) . W1^T + b) as planes, 2 tiles x 8 waves x 8 k-steps
+    N, K = 8192, 1024
+    x, w, b, gam, bet = _case(M, N, K, 11 * M + N + K)
+    ref = torch.relu(F.layer_norm(x.double(), (K,), gam.double(), bet.double(), 1e-5) @ w.double().t() + b.double())
+    outs = {}
+    for walk in (15, 1, 2, 3, 0):
+        y = torch.full((M, N), float("nan"), device="cuda")
+        check(lib, lib.sc_op_dstep3_gemv(2, P(dev(x)), P(dev(w)), P(dev(b)), P(dev(gam)), P(dev(bet)), P(None), P(y), P(None), M, N, K, 1, 32,
+                                         1 | (walk << 4)))
+        outs[walk] = y.cpu()
+    err_in = float((outs[15].double() - ref).abs().max())
+    assert err_in < 2e-5, err_in
+    for walk in (1, 2, 3, 0):
+        assert torch.equal(outs[15], outs[walk]), f"FFN-in: stationary walk {walk} differs from one workgroup per row group"
+    # FFN-out: K-slice partial sums (64-row groups, 2 x 2 tiles x 8 waves x 4 k-steps) + the reduce kernel
+    N, K = 1024, 8192
+    x, w, b, _, _ = _case(M, N, K, 13 * M + N + K)
+    res = torch.randn(M, N, generator=torch.Generator().manual_seed(M + 2)) * 2
+    ref = res.double() + x.double() @ w.double().t() + b.double()
+    outs = {}
+    for walk in (15, 1, 2, 0):
+        y = torch.full((M, N), float("nan"), device="cuda")
+        check(lib, lib.sc_op_dstep3_gemv(3, P(dev(x)), P(dev(w)), P(dev(b)), P(None), P(None), P(dev(res)), P(y), P(None), M, N, K, 0, 0,
+                                         2 | (walk << 4)))
+        outs[walk] = y.cpu()
+    err_out = rel_err(outs[15], ref)
+    assert err_out < 2e-6, err_out
+    for walk in (1, 2, 0):
+        assert torch.equal(outs[15], outs[walk]), f"FFN-out: stationary walk {walk} differs from one workgroup per row group"
+    _log(report_dir, "gemv3_stationary", M=M, err_in=err_in, err_out=err_out)
+
+
 @pytest.mark.parametrize("M,N,K", [(16, 256102, 1024), (1, 256102, 1024), (64, 256102, 1024), (33, 256102, 1024), (5, 1200, 128), (40, 10082, 1024),
                                    (33, 1200, 128)])
 @pytest.mark.parametrize("mode", ["plain", "no_eos", "force_eos", "unk_pen"])
