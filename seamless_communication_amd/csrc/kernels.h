@@ -327,6 +327,7 @@ struct Gemv3Args {
     // filled by the launcher
     int KS = 0, NT_total = 0;
     uint32_t w_bytes = 0, a_bytes = 0;
+    int xcd_swizzle = 0, touch = 0;  // gemv3s_kernel: K slices dealt out per XCD; cooperative L2 touch of the activations
 };
 enum Gemv3Shape { G3_T1 = 0, G3_T2K8 = 1, G3_T2K4 = 2 };
 bool gemv3_supported(int M, int N, int K, int in_mode);
