@@ -236,7 +236,7 @@ def pmc_traffic(family: str):
     if fam == "step_graph":
         # one replayed decoder step = all launches between two position increments: sum the step's kernels of the PMC run
         # (which launches them eagerly, --no-graph) and divide by the number of steps (= add_i32 launches)
-        step_kernels = ("gemvp_kernel<", "gemv3_kernel<", "vocab3_kernel<", "reduce3_kernel<", "reduce_ln_kernel", "dattn_kernel<",
+        step_kernels = ("gemvp_kernel<", "gemv3_kernel<", "gemv3s_kernel<", "gemv3t_kernel<", "vocab3_kernel<", "reduce3_kernel<", "reduce_ln_kernel", "dattn_kernel<",
                         "ln3_kernel", "embed3_kernel", "argmax_finalize_kernel", "add_i32_kernel", "engine_finalize_kernel")
         total, steps = 0.0, 0
         for row in rows:

@@ -43,6 +43,7 @@ const Knob knob_table[] = {
     {"SC_DSTEP_TOUCH", 0, "weight toucher: layers ahead"}, {"SC_DSTEP_TOUCH_WGS", 0, "weight toucher: workgroups"},
     {"SC_D3_RG_SMALL", 0, "decoder step: rows per row group, N = 1024 products"}, {"SC_D3_RG_FFN", 0, "decoder step: rows per row group, FFN-in"},
     {"SC_G3_STATIONARY", 0, "row-group products of wide steps: 0 one workgroup per row group, n = workgroup budget of the weight-stationary launch"},
+    {"SC_G3_TILES", 0, "0: FFN-out of wide steps on the weight-stationary row-group walk instead of tile-owning waves"},
     {"SC_G3_TOUCH", 0, "weight-stationary products: bit 0 cooperative L2 touch of the activations, bit 1 K slices per XCD (FFN-out); default 3"},
     {"SC_D3_FFN_IN", 0, "decoder step: FFN-in workgroup shape"}, {"SC_D3_FFN_OUT", 0, "decoder step: FFN-out workgroup shape"},
     {"SC_MMA_GRAPH", 0, "streaming decoder step from a captured graph"}, 

@@ -630,6 +630,121 @@ __global__ __launch_bounds__(64 * WAVES) void gemv3s_kernel(Gemv3Args p) {
 }
 
 // --------------------------------------------------------------------------------------------- //
+// gemv3t_kernel<KSW, CH>: the K-slice partial products (FFN-out) of a wide step with TILE-OWNING waves (round 5).
+// In gemv3_kernel / gemv3s_kernel the waves of a workgroup are the K chunks of the same output tiles and meet in LDS: per
+// 64 rows 128 KB of partial sums written and read back between two barriers - more time than the matrix instructions.
+// Here the workgroup's weight fragments (2 feature tiles x the slice's CH * KSW k-steps: 64 KB) go to LDS once; wave
+// (ft, rt) of 16 owns the 32 x 32 output tile of feature tile ft and row tile rt and walks the WHOLE slice itself: per
+// chunk the KSW k-steps accumulate from zero (weights from LDS, activation fragments straight from L2 through a
+// rolling 8-k-step register window), then the chunk is added to the running total - the sum ((0 + c0) + c1) + ... of
+// the row-group kernels, bit for bit, with no cross-wave reduction and no barrier after the prologue.  256 rows per
+// pass; the K slices are dealt out per XCD (xcd_swizzle) so that an XCD's L2 holds its slices' planes.
+// --------------------------------------------------------------------------------------------- //
+template <int KSW, int CH>
+__global__ __launch_bounds__(1024) void gemv3t_kernel(Gemv3Args p) {
+    constexpr int KSL = KSW * CH;  // k-steps per K slice
+    constexpr int W = 8;           // k-steps of activation fragments in flight per wave
+    static_assert(KSL % W == 0 && (2 * KSL * 64) % 1024 == 0, "gemv3t_kernel: slice shape");
+    __shared__ u32x4_t wl[2][KSL][64];
+    __shared__ float tr[16][32 * 33];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31;
+    const int h = lane >> 5;
+    const int live = p.d_rows ? min(*p.d_rows, p.M) : p.M;
+    if (live <= 0) return;
+    const int lin = (int)(blockIdx.x + gridDim.x * blockIdx.z);
+    int bx = (int)blockIdx.x, bz = (int)blockIdx.z;
+    if (p.xcd_swizzle) {  // grid.z a multiple of 8: XCD (= lin & 7) <- its own K slices, all feature blocks
+        const int xcd = lin & 7, rank = lin >> 3, zs = (int)gridDim.z >> 3;
+        bz = xcd * zs + rank % zs;
+        bx = rank / zs;
+    }
+    const int nt0 = bx * 2;
+    const int ks0 = bz * KSL;
+
+    // ---- the workgroup's weight fragments -> LDS (fragment order: one wave instruction = one KiB) ----------------------
+    {
+        const __amdgpu_buffer_rsrc_t rw = rsrc3(p.Wp, p.w_bytes);
+        constexpr int U = (2 * KSL * 64) / 1024;
+        u32x4_t wr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = tid + u * 1024;
+            const int ft = idx / (KSL * 64), ks = (idx / 64) % KSL, ln = idx & 63;
+            const bool ok = (nt0 + ft < p.NT_total) && (ks0 + ks < p.KS);
+            const uint32_t off = ok ? ((uint32_t)(nt0 + ft) * (uint32_t)p.KS + (uint32_t)(ks0 + ks)) * 1024u + (uint32_t)ln * 16u : OOB;
+            wr[u] = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 2 /*nt: read once*/);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = tid + u * 1024;
+            wl[idx / (KSL * 64)][(idx / 64) % KSL][idx & 63] = wr[u];
+        }
+    }
+    __syncthreads();
+
+    const int ft = wave & 1, rt = wave >> 1;
+    const __amdgpu_buffer_rsrc_t rah = rsrc3(p.Ah, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t ral = rsrc3(p.Al, p.a_bytes);
+    const uint32_t a_kstep = (uint32_t)(2 * p.RB * 16);
+    for (int pass0 = 0; pass0 + rt * 32 < live; pass0 += 256) {
+        asm volatile("" ::: "memory");  // the weight fragments are read from LDS per pass (hoisted out of the loop they are 128 registers: spills)
+        const int row = pass0 + rt * 32 + n;
+        const uint32_t voff = row < live ? (uint32_t)(h * p.RB + row) * 16u : OOB;
+        u32x4_t bh[W], bl[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const uint32_t kk = (ks0 + j < p.KS) ? 0u : OOB;
+            bh[j] = __builtin_amdgcn_raw_buffer_load_b128(rah, voff | kk, (uint32_t)(ks0 + j) * a_kstep, 0);
+            bl[j] = __builtin_amdgcn_raw_buffer_load_b128(ral, voff | kk, (uint32_t)(ks0 + j) * a_kstep, 0);
+        }
+        float16_t tot, acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[r] = 0.f, acc[r] = 0.f;
+        u32x4_t wcur = wl[ft][0][lane], wnext = wcur;
+        __builtin_amdgcn_sched_barrier(0);
+        // one k-step per scheduling region (nothing crosses the sched_barrier): the next step's weight fragment is requested
+        // from LDS first, the two matrix instructions of this step follow, then its activation registers are refilled with
+        // k-step ks + W - the loads stay W steps ahead of their use (left alone the scheduler sinks them to 2 - 3 steps)
+#pragma unroll
+        for (int ks = 0; ks < KSL; ++ks) {
+            if (ks + 1 < KSL) wnext = wl[ft][ks + 1][lane];
+            if (ks % KSW == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
+            const half8_t wf = __builtin_bit_cast(half8_t, wcur);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(half8_t, bh[ks % W]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(half8_t, bl[ks % W]), acc, 0, 0, 0);
+            if (ks + W < KSL) {
+                const uint32_t kk = (ks0 + ks + W < p.KS) ? 0u : OOB;
+                bh[ks % W] = __builtin_amdgcn_raw_buffer_load_b128(rah, voff | kk, (uint32_t)(ks0 + ks + W) * a_kstep, 0);
+                bl[ks % W] = __builtin_amdgcn_raw_buffer_load_b128(ral, voff | kk, (uint32_t)(ks0 + ks + W) * a_kstep, 0);
+            }
+            if (ks % KSW == KSW - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[r] += acc[r];
+                asm volatile("" : "+v"(tot));  // the chunk is added HERE (left to instruction selection the adds drift to the end and the chunks spill)
+            }
+            wcur = wnext;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the wave's tile through its own LDS patch: rows become contiguous 128-byte runs
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tr[wave][n * 33 + (r & 3) + 8 * (r >> 2) + 4 * h] = tot[r];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = lane + 64 * it, rn = idx >> 5, f = idx & 31;
+            const int feat = (nt0 + ft) * 32 + f, rowo = pass0 + rt * 32 + rn;
+            if (feat < p.N && rowo < live) p.out[((int64_t)bz * p.M + rowo) * p.N + feat] = tr[wave][rn * 33 + f];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------- //
 // reduce3_kernel<LN>: x[row] += bias + sum_s partial[s][row] on the k-group-major residual stream; LN: additionally
 // h = LayerNorm(x[row]) as split planes / fp32 rows (the decoder output after the last layer).  One workgroup per row,
 // thread t owns columns 4t .. 4t+3; every global load is issued before the first use.
@@ -1061,7 +1176,18 @@ void launch_gemv3(const Gemv3Args& a0, hipStream_t s) {
     // workgroup budget of a launch (default 256 = the compute units).
     const bool ffn_in = a.shape == G3_T2K8 && a.in_mode == IN3_LN && a.epi == EPI3_PLANES && !two;
     const bool ffn_out = a.shape == G3_T2K4 && a.in_mode == IN3_PLANES && a.epi == EPI3_PARTIAL && two;
-    if ((ffn_in || ffn_out) && a.stationary != 0 && groups > 1) {
+    if (ffn_out && a.M > 64 && (a.stationary == 14 || a.stationary == -1)) {  // tile-owning waves: no cross-wave sums
+        static const int tiles = knob::value("SC_G3_TILES", 1);
+        if (tiles || a.stationary == 14) {
+            static const int touch = knob::value("SC_G3_TOUCH", 3);
+            grid.y = 1;
+            a.xcd_swizzle = grid.z % 8 == 0 && (touch & 2) ? 1 : 0;
+            hipLaunchKernelGGL((gemv3t_kernel<4, 8>), grid, dim3(1024), 0, s, a);
+            SC_LAUNCH_CHECK();
+            return;
+        }
+    }
+    if ((ffn_in || ffn_out) && a.stationary != 0 && a.stationary != 14 && groups > 1) {
         static const int budget = knob::value("SC_G3_STATIONARY", 256);
         const int per_group = (int)(grid.x * grid.z);
         int gy = a.stationary > 0 ? a.stationary : (budget > 0 ? budget / per_group : groups);
