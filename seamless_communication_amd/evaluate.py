@@ -9,8 +9,8 @@ fbank per example, ``bucket(batch_size)``, ``Collater(pad_value=0, pad_to_multip
 NaN filter :278-289, the empty-batch rule :292-314, file names and TSV headers :259-274, :324-343).
 Out of scope here: text-input tasks and the quality metrics (Whisper ASR-BLEU / sacrebleu, :352-360).
 
-Differences, all in how bytes reach the path: audio is decoded with the standard library (RIFF/WAVE PCM16,
-PCM32 or float32, mono or first channel) or loaded from ``.npy`` because libsndfile / torchaudio are not in
+Differences, all in how bytes reach the path: audio is decoded with the standard library (RIFF/WAVE: PCM 8 - 32 bit,
+float 32 / 64, A-law / mu-law, plain or extensible headers; mono or first channel) or loaded from ``.npy`` because libsndfile / torchaudio are not in
 this image; the fbank runs on the GPU through ``sc_fbank`` for the whole bucket at once.
 """
 from __future__ import annotations
@@ -78,37 +78,78 @@ def read_manifest(ctx: EvalContext) -> Iterator[Dict[str, str]]:
             raise NotImplementedError(ctx.data_file_type)
 
 
-def load_audio(path: Path) -> Tuple[np.ndarray, int]:
-    """-> (mono float32 waveform in [-1, 1), sample rate).  ``.npy`` (float waveform at 16 kHz) or RIFF/WAVE."""
+_ULAW = None
+_ALAW = None
+
+
+def _g711_tables() -> Tuple[np.ndarray, np.ndarray]:
+    """8-bit mu-law / A-law code -> linear 16-bit sample (ITU-T G.711), as libsndfile expands them."""
+    global _ULAW, _ALAW
+    if _ULAW is None:
+        u = np.arange(256, dtype=np.int32) ^ 0xFF
+        t = (((u & 0x0F) << 3) + 0x84) << ((u & 0x70) >> 4)
+        _ULAW = np.where(u & 0x80, 0x84 - t, t - 0x84).astype(np.float32)
+        a = np.arange(256, dtype=np.int32) ^ 0x55
+        seg, mant = (a & 0x70) >> 4, a & 0x0F
+        t = np.where(seg == 0, (mant << 4) + 8, ((mant << 4) + 0x108) << np.maximum(seg - 1, 0))
+        _ALAW = np.where(a & 0x80, t, -t).astype(np.float32)
+    return _ULAW, _ALAW
+
+
+def load_audio(path: Path, all_channels: bool = False) -> Tuple[np.ndarray, int]:
+    """-> (float32 waveform in [-1, 1), sample rate): mono (the first channel), or (frames, channels) with
+    ``all_channels``.  ``.npy`` (float waveform at 16 kHz) or RIFF/WAVE: PCM 8 / 16 / 24 / 32 bit, IEEE float 32 / 64,
+    A-law, mu-law, plain or WAVE_FORMAT_EXTENSIBLE headers - integer samples scaled by 2^-(bits-1) as libsndfile does
+    for float reads (the reference decodes with fairseq2's AudioDecoder = libsndfile, inference/translator.py:135,
+    270-273).  Compressed containers (FLAC, Ogg, MP3) need a decoder this image does not have: a clear error."""
     if path.suffix == ".npy":
-        return np.asarray(np.load(path), dtype=np.float32).reshape(-1), 16000
+        x = np.asarray(np.load(path), dtype=np.float32)
+        return (x.reshape(len(x), -1) if all_channels else x.reshape(-1)), 16000
     with open(path, "rb") as f:
         data = f.read()
+    if data[:4] in (b"fLaC", b"OggS", b"ID3\x03", b"ID3\x04") or data[:2] in (b"\xff\xfb", b"\xff\xf3"):
+        raise ValueError(f"{path}: compressed audio (FLAC / Ogg / MP3) cannot be decoded here - convert to RIFF/WAVE or .npy")
     if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
         raise ValueError(f"{path}: not a RIFF/WAVE file")
-    pos, fmt, pcm = 12, None, None
+    pos, fmt, pcm, fmt_body = 12, None, None, b""
     while pos + 8 <= len(data):
         cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
         body = data[pos + 8:pos + 8 + size]
         if cid == b"fmt ":
-            fmt = struct.unpack("<HHIIHH", body[:16])
+            fmt, fmt_body = struct.unpack("<HHIIHH", body[:16]), body
         elif cid == b"data":
             pcm = body
         pos += 8 + size + (size & 1)
     if fmt is None or pcm is None:
         raise ValueError(f"{path}: missing fmt/data chunk")
-    tag, channels, rate, _, _, bits = fmt
-    if tag == 1 and bits == 16:
+    tag, channels, rate, _, block_align, bits = fmt
+    if tag == 0xFFFE and len(fmt_body) >= 26:  # WAVE_FORMAT_EXTENSIBLE: the real tag leads the sub-format GUID
+        tag = struct.unpack("<H", fmt_body[24:26])[0]
+    if channels < 1:
+        raise ValueError(f"{path}: {channels} channels")
+    width = block_align // channels if block_align else (bits + 7) // 8  # container bytes per sample
+    pcm = pcm[: len(pcm) - len(pcm) % (width * channels)]
+    if tag == 1 and width == 1:
+        x = (np.frombuffer(pcm, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif tag == 1 and width == 2:
         x = np.frombuffer(pcm, dtype="<i2").astype(np.float32) / 32768.0
-    elif tag == 1 and bits == 32:
-        x = np.frombuffer(pcm, dtype="<i4").astype(np.float32) / 2147483648.0
-    elif tag == 3 and bits == 32:
+    elif tag == 1 and width == 3:
+        b = np.frombuffer(pcm, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        x = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
+    elif tag == 1 and width == 4:
+        x = (np.frombuffer(pcm, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    elif tag == 3 and width == 4:
         x = np.frombuffer(pcm, dtype="<f4").astype(np.float32)
+    elif tag == 3 and width == 8:
+        x = np.frombuffer(pcm, dtype="<f8").astype(np.float32)
+    elif tag in (6, 7) and width == 1:
+        ulaw, alaw = _g711_tables()
+        x = (alaw if tag == 6 else ulaw)[np.frombuffer(pcm, dtype=np.uint8)] / 32768.0
     else:
         raise ValueError(f"{path}: unsupported WAVE encoding (format {tag}, {bits} bit)")
-    if channels > 1:
-        x = x.reshape(-1, channels)[:, 0]
-    return np.ascontiguousarray(x), int(rate)
+    x = x.reshape(-1, channels)
+    return np.ascontiguousarray(x if all_channels else x[:, 0]), int(rate)
 
 
 def save_wav_f32(path: Path, wav: Tensor, sample_rate: int) -> None:

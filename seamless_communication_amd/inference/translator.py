@@ -273,7 +273,7 @@ class Translator:
             audio = input
             if isinstance(audio, str):
                 # translator.py:270-273 decodes the file with fairseq2's AudioDecoder (libsndfile); here RIFF/WAVE
-                # (PCM16/PCM32/float32) and .npy are read with the standard library, first channel, 16 kHz only
+                # (PCM 8 - 32 bit, float, G.711; evaluate.load_audio) and .npy are read with the standard library, first channel, 16 kHz only
                 from ..evaluate import load_audio
 
                 samples, rate = load_audio(Path(audio))
