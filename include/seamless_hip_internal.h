@@ -67,13 +67,15 @@ int sc_op_dstep_argmax(const float* d_x, const void* d_w_f16, int32_t M, int32_t
 int sc_op_dstep_attention(const float* d_proj, int32_t S, const float* d_bias, float* d_kcache, float* d_vcache, int32_t cap,
                           int32_t pos, const int32_t* d_lens, int32_t cross, int32_t nb, int32_t heads, float* d_out);
 /* Third-generation decoder-step kernels (k_dstep3.hip): row-group products that apply the preceding LayerNorm and the
- * bias / residual / ReLU themselves.  sc_op_dstep3_gemv, M <= 64 rows, rg = rows per row group (0 = default):
+ * bias / residual / ReLU themselves.  sc_op_dstep3_gemv, rg = rows per row group (0 = default):
  *   mode 0: y = LayerNorm(x; gamma, beta) . W^T + b                         (K <= 1024)
  *   mode 1: y = res + x . W^T + b                                           (K <= 1024, res [M][N])
  *   mode 2: y = act(LayerNorm(x) . W^T + b) through the split-plane epilogue (K <= 1024)
  *   mode 3: y = res + x . W^T + b as K-slice partial sums + the reduce kernel; gamma != null: d_h = LayerNorm(y)
- * shape: workgroup shape, 0 = 1 tile x 16 waves x 4 k-steps, 1 = 2 tiles x 8 waves x 8 k-steps (K <= 1024), 2 = 2 tiles x
- * 8 waves x 4 k-steps (512-wide K slices, mode 3).
+ * shape, bits 0..3: workgroup shape, 0 = 1 tile x 16 waves x 4 k-steps, 1 = 2 tiles x 8 waves x 8 k-steps (K <= 1024), 2 = 2
+ * tiles x 8 waves x 4 k-steps (512-wide K slices, mode 3).  M up to 512 rows.  Bits 4..7 pick the kernel of the FFN shapes
+ * over several row groups (same bits whichever runs): 0 the launcher decides, 15 one workgroup per row group (gemv3_kernel),
+ * 14 tile-owning waves (gemv3t_kernel, mode 3), k in 1..13 weights stationary with k workgroups per tile (gemv3s_kernel).
  * sc_op_dstep3_argmax mirrors sc_op_dstep_argmax on the LDS-staged vocabulary projection. */
 int sc_op_dstep3_gemv(int32_t mode, const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_gamma,
                       const float* d_beta, const float* d_res, float* d_y, float* d_h, int32_t M, int32_t N, int32_t K, int32_t act,
