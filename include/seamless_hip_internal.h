@@ -76,6 +76,8 @@ int sc_op_dstep_attention(const float* d_proj, int32_t S, const float* d_bias, f
  * tiles x 8 waves x 4 k-steps (512-wide K slices, mode 3).  M up to 512 rows.  Bits 4..7 pick the kernel of the FFN shapes
  * over several row groups (same bits whichever runs): 0 the launcher decides, 15 one workgroup per row group (gemv3_kernel),
  * 14 tile-owning waves (gemv3t_kernel, mode 3), k in 1..13 weights stationary with k workgroups per tile (gemv3s_kernel).
+ * rg, bits 8..: live rows (a device-side row count as the beam search / the decode engine pass it; the rows behind it are
+ * neither read nor written), 0 = all M rows.
  * sc_op_dstep3_argmax mirrors sc_op_dstep_argmax on the LDS-staged vocabulary projection. */
 int sc_op_dstep3_gemv(int32_t mode, const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_gamma,
                       const float* d_beta, const float* d_res, float* d_y, float* d_h, int32_t M, int32_t N, int32_t K, int32_t act,

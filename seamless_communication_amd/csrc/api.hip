@@ -737,6 +737,18 @@ int sc_op_dstep3_gemv(int32_t mode, const float* d_x, const void* d_w_f16, const
     // bits 4..7 of `shape`: 0 the launcher decides, 15 one workgroup per row group, k weights stationary with k workgroups per tile
     a.stationary = ((shape >> 4) & 15) == 0 ? -1 : (((shape >> 4) & 15) == 15 ? 0 : ((shape >> 4) & 15));
     shape &= 15;
+    // bits 8.. of `rg`: live rows (the device-side row count of the beam search / the decode engine; rows behind it are
+    // neither read nor written); 0 = all M rows
+    const int live = rg >> 8;
+    rg &= 255;
+    a.rg = rg;
+    int* d_live = nullptr;
+    if (live > 0) {
+        SC_CHECK(live <= M, "sc_op_dstep3_gemv: %d live rows of %d", live, M);
+        d_live = scratch.get<int>(1);
+        SC_HIP(hipMemcpyAsync(d_live, &live, sizeof(int), hipMemcpyHostToDevice, g_op_stream));
+        a.d_rows = d_live;
+    }
     if (in_mode == IN3_LN) {
         float* xg = scratch.get<float>((size_t)K * RB);
         SC_HIP(hipMemsetAsync(xg, 0xff, (size_t)K * RB * 4, g_op_stream));  // NaN in the unused row slots: must not leak
@@ -773,7 +785,7 @@ int sc_op_dstep3_gemv(int32_t mode, const float* d_x, const void* d_w_f16, const
             a.epi = EPI3_PARTIAL, a.out = partial, a.mt2 = 1, a.bias = nullptr;
             launch_gemv3(a, g_op_stream);
             Reduce3Args r;
-            r.partial = partial, r.S = S, r.bias = d_bias, r.xg = xres, r.XRB = RB, r.rows = M, r.C = N;
+            r.partial = partial, r.S = S, r.bias = d_bias, r.xg = xres, r.XRB = RB, r.rows = M, r.C = N, r.d_rows = d_live;
             if (d_gamma) r.gamma = d_gamma, r.beta = d_beta, r.hfix = d_h, r.RB = RB;
             launch_reduce3(r, g_op_stream);
         }

@@ -141,6 +141,39 @@ def test_gemv3_stationary_bit_identical(lib, report_dir, M):
     _log(report_dir, "gemv3_stationary", M=M, err_in=err_in, err_out=err_out)
 
 
+@pytest.mark.parametrize("M,live", [(192, 150), (192, 31), (320, 257), (128, 128)])
+def test_gemv3_wide_kernels_stop_at_the_live_rows(lib, report_dir, M, live):
+    """The decode engine / the beam search hand the step a device-side count of live rows (packed to the front): every
+    variant of the wide FFN products gives the live rows the bits of the full launch and leaves the rows behind alone
+    (`rg` bits 8.. of the op entry = live rows)."""
+    N, K = 8192, 1024
+    x, w, b, gam, bet = _case(M, N, K, 17 * M + live)
+    full = torch.full((M, N), float("nan"), device="cuda")
+    check(lib, lib.sc_op_dstep3_gemv(2, P(dev(x)), P(dev(w)), P(dev(b)), P(dev(gam)), P(dev(bet)), P(None), P(full), P(None), M, N, K, 1, 32,
+                                     1 | (15 << 4)))
+    full = full.cpu()
+    for walk in (15, 1, 2, 0):
+        y = torch.full((M, N), float("nan"), device="cuda")
+        check(lib, lib.sc_op_dstep3_gemv(2, P(dev(x)), P(dev(w)), P(dev(b)), P(dev(gam)), P(dev(bet)), P(None), P(y), P(None), M, N, K, 1,
+                                         32 | (live << 8), 1 | (walk << 4)))
+        assert torch.equal(y.cpu()[:live], full[:live]), f"FFN-in walk {walk}: live rows differ"
+    N, K = 1024, 8192
+    x, w, b, _, _ = _case(M, N, K, 19 * M + live)
+    res = torch.randn(M, N, generator=torch.Generator().manual_seed(M + live)) * 2
+    full = torch.full((M, N), float("nan"), device="cuda")
+    check(lib, lib.sc_op_dstep3_gemv(3, P(dev(x)), P(dev(w)), P(dev(b)), P(None), P(None), P(dev(res)), P(full), P(None), M, N, K, 0, 0,
+                                     2 | (15 << 4)))
+    full = full.cpu()
+    for walk in (15, 1, 14, 0):
+        y = torch.full((M, N), float("nan"), device="cuda")
+        check(lib, lib.sc_op_dstep3_gemv(3, P(dev(x)), P(dev(w)), P(dev(b)), P(None), P(None), P(dev(res)), P(y), P(None), M, N, K, 0,
+                                         live << 8, 2 | (walk << 4)))
+        y = y.cpu()
+        assert torch.equal(y[:live], full[:live]), f"FFN-out walk {walk}: live rows differ"
+        assert torch.equal(y[live:], res[live:]), f"FFN-out walk {walk}: a row behind the live rows was touched"
+    _log(report_dir, "gemv3_wide_live_rows", M=M, live=live)
+
+
 @pytest.mark.parametrize("M,N,K", [(16, 256102, 1024), (1, 256102, 1024), (64, 256102, 1024), (33, 256102, 1024), (5, 1200, 128), (40, 10082, 1024),
                                    (33, 1200, 128)])
 @pytest.mark.parametrize("mode", ["plain", "no_eos", "force_eos", "unk_pen"])
