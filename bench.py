@@ -69,7 +69,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (no sparsity)
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step (BASELINE configs[3]: 64 per GPU)")
     ap.add_argument("--schedule", default="pipeline", choices=["pipeline", "lockstep", "freerun"],
@@ -86,7 +86,7 @@ def parse_args():
                          "cut at --text-len (the workload of rounds 1-3)")
     ap.add_argument("--text-len", type=int, default=0,
                     help="hard_max_seq_len of the greedy text search, prompt included (default: 64 ragged, 42 fixed)")
-    ap.add_argument("--engine-slots", type=int, default=192,
+    ap.add_argument("--engine-slots", type=int, default=256,
                     help="decode engine (pipeline schedule): ONE greedy decoder-step chain shared by the passes in flight, this many rows "
                          "per step, continuous refill (runtime.DecodeEngine); 0 = every pass runs its own chain (round 4)")
     ap.add_argument("--no-engine", action="store_true", help="same as --engine-slots 0")
@@ -573,9 +573,10 @@ def main():
     if args.no_engine or not args.pipeline_passes:
         args.engine_slots = 0
     if args.microbatches <= 0:
-        # passes in flight: with the engine a pass waits for the shared chain to get to its rows, so one more is kept in flight
-        # (scripts/engine_sweep.py, profiles/r5_engine_sweep.txt: 6 passes in flight fill a 192-slot chain)
-        args.microbatches = (6 if args.engine_slots > 0 else 3) if args.pipeline_passes else 2
+        # passes in flight: with the engine a pass waits for the shared chain to get to its rows, so more are kept in flight: one
+        # per 32 slots (scripts/engine_sweep.py; profiles/r5_engine_sweep.txt: 6 passes fill a 192-slot chain; with the weight-
+        # stationary FFN products of the wide step 8 passes on 256 slots are 1.5 - 3 % ahead, profiles/r5_wide_step_products.txt)
+        args.microbatches = (max(3, args.engine_slots // 32) if args.engine_slots > 0 else 3) if args.pipeline_passes else 2
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -873,7 +874,7 @@ def main():
             result["stage_ms_profiled_step"] = {k: round(v, 3) for k, v in stage_ms.items()}
         if batcher.engine is not None:
             # The profiled pass above ran ALONE: its 64 rows were the engine's only rows.  In the timed region the shared chain
-            # carries the rows of several passes: measure the step at THAT operating point - three passes' rows handed to the
+            # carries the rows of several passes: measure the step at THAT operating point - as many passes' rows as fill the slots handed to the
             # engine together, nothing else on the chip, every replay timed with HIP events on the engine's own stream.
             import threading
 
@@ -891,7 +892,7 @@ def main():
                 view.model.generate_text(enc, enc_lens.tolist(), prefix, beam_size=1, soft_max_seq_len=opts.soft_max_seq_len,
                                          hard_max_seq_len=opts.hard_max_seq_len, use_graph=translator.use_graph, source_len=int(fb.shape[1]))
 
-            th = [threading.Thread(target=text_only, args=(v,)) for v in batcher.views[: min(3, batcher.groups)]]
+            th = [threading.Thread(target=text_only, args=(v,)) for v in batcher.views[: max(1, min(batcher.groups, args.engine_slots // max(1, B)))]]
             for t in th:
                 t.start()
             for t in th:

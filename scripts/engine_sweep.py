@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--arch", default="base_v2")
-    ap.add_argument("--configs", default="g=3,slots=0;g=4,slots=64,lw=32;g=5,slots=128,lw=64;g=6,slots=128,lw=64;g=6,slots=192,lw=96")
+    ap.add_argument("--configs", default="g=3,slots=0;g=4,slots=64,lw=32;g=6,slots=128,lw=64;g=6,slots=192,lw=96;g=8,slots=256,lw=128")
     args = ap.parse_args()
 
     from seamless_communication_amd import synthetic as syn

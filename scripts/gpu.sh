@@ -174,7 +174,7 @@ for task in "$@"; do
       i=0
       for e in "${SW[@]}"; do
         i=$((i+1))
-        ( env $e timeout ${ESWEEP_TIMEOUT:-240} python scripts/engine_sweep.py --steps ${ESWEEP_STEPS:-12} --configs "${ESWEEP:-g=6,slots=192,lw=96}" > ${O}_esweepenv_$i.jsonl 2> ${O}_esweepenv_$i.err; echo "exit $?" >> ${O}_esweepenv_$i.err )
+        ( env $e timeout ${ESWEEP_TIMEOUT:-240} python scripts/engine_sweep.py --steps ${ESWEEP_STEPS:-12} --configs "${ESWEEP:-g=8,slots=256,lw=128}" > ${O}_esweepenv_$i.jsonl 2> ${O}_esweepenv_$i.err; echo "exit $?" >> ${O}_esweepenv_$i.err )
         echo "--- $e"; tail -1 ${O}_esweepenv_$i.err | cut -c1-200; cut -c1-420 ${O}_esweepenv_$i.jsonl
       done ;;
     estep)

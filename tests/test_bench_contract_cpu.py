@@ -16,7 +16,7 @@ spec.loader.exec_module(bench)
 def test_argument_contract(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse_args()
-    assert (a.gpus, a.steps, a.warmup, a.batch, a.arch) == (1, 12, 2, 64, "base_v2")  # ~3 s of timed passes: enough to fill the pipeline
+    assert (a.gpus, a.steps, a.warmup, a.batch, a.arch) == (1, 16, 2, 64, "base_v2")  # ~3 s of timed passes: two per pass worker of the pipeline
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
     a = bench.parse_args()
     assert (a.gpus, a.steps, a.warmup) == (8, 5, 2)
@@ -41,7 +41,7 @@ def test_cpu_baseline_worker_reports_the_oracle_on_one_utterance():
 def test_default_workload_is_the_ragged_one(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse_args()
-    assert a.workload == "ragged" and a.text_len == 0 and a.engine_slots == 192  # text length resolved in main(): 64 tokens
+    assert a.workload == "ragged" and a.text_len == 0 and a.engine_slots == 256  # text length resolved in main(): 64 tokens
 
 
 def test_decoder_row_statistics():

@@ -36,7 +36,7 @@ def test_more_gpus_than_devices_fails_loudly():
 
 
 def test_host_loop_of_two_ranks_stays_far_below_the_gpu_pass_time():
-    """`--dry-run --host-loop`: the timed region's REAL host loop (six pass workers per rank, Translator.predict's host code,
+    """`--dry-run --host-loop`: the timed region's REAL host loop (eight pass workers per rank, Translator.predict's host code,
     the ordered ragged gather after every pass, every rank pinned to its share of the cores) on a stub device that answers at
     once.  What a pass costs a rank in host time must stay far below the ~220 ms it costs the GPU - the condition for the
     8-rank node not to be host-bound (DESIGN.md section 6 carries the 8-rank figure measured here)."""
@@ -44,7 +44,7 @@ def test_host_loop_of_two_ranks_stays_far_below_the_gpu_pass_time():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     h = line["host_loop"]
-    assert line["ranks_seen"] == 2 and h["workers_per_rank"] == 6 and h["utterances_per_pass"] == 64
+    assert line["ranks_seen"] == 2 and h["workers_per_rank"] == 8 and h["utterances_per_pass"] == 64
     assert len(h["host_ms_per_pass_by_rank"]) == 2 and h["cores_per_rank"] >= 1
     # the ordered gather runs over gloo / TCP loopback here (50 - 110 ms per pass on this container, load dependent); on the node
     # it is one RCCL all-gather of ids that already live on the device.  The bound is on what is left: the rank's own host work.
