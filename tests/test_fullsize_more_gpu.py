@@ -170,11 +170,12 @@ def test_ragged_lengths_pipelined_whole_batch_passes(gold, eos, report_dir):
         mb.close()
 
 
-@pytest.mark.parametrize("slots,low_water", [(64, 32), (128, 0)])
+@pytest.mark.parametrize("slots,low_water", [(64, 32), (128, 0), (256, 128)])
 def test_ragged_lengths_through_the_decode_engine(gold, eos, report_dir, slots, low_water):
     """bench.py's default schedule of round 5: four whole-batch passes in flight whose greedy text generation shares ONE
     decoder-step chain (runtime.DecodeEngine: rows of different passes next to each other at their own positions, finished rows
-    leave, waiting rows take their slots; 128 slots = the row-group chain cut into row groups).  Every pass of every worker
+    leave, waiting rows take their slots; 128 slots = the row-group chain cut into row groups; 256 slots = bench.py's width: the
+    weight-stationary / tile-owning FFN products over eight row groups).  Every pass of every worker
     returns the oracle's ids for all 64 utterances; char ids / durations / units of each worker's last pass too."""
     from seamless_communication_amd.distributed import MicroBatcher
 
