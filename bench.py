@@ -53,9 +53,10 @@ if str(ROOT) not in sys.path:
 
 # The HIP runtime maps a process's streams onto 4 hardware queues by default; the pipelined schedule has 7+ streams with work in
 # flight (six pass workers, the decode engine, the vocoder's side chains) and streams that share a queue run one behind the
-# other.  8 queues: +2.8 % with the engine, +5 % without, same box (profiles/r5_engine_sweep.txt).  Must be set before the
-# runtime starts; an explicit setting of the caller wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# other.  8 queues: +2.8 % with the engine, +5 % without, same box (profiles/r5_engine_sweep.txt); with eight pass workers 16
+# queues are another +2.5 % (299.9 / 300.2 -> 305.4 / 309.8 alternating on one box, profiles/r5_wide_step_products.txt; with
+# six workers 16 gained nothing).  Must be set before the runtime starts; an explicit setting of the caller wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 import torch

@@ -14,7 +14,7 @@ import sys
 import time
 from pathlib import Path
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # as bench.py does (the runtime's default of 4 hardware queues serialises streams)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # as bench.py does (the runtime's default of 4 hardware queues serialises streams)
 
 import torch
 
