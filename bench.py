@@ -86,7 +86,8 @@ def parse_args():
                     help="ragged: eos_ramp weights, hypotheses stop on their own (text lengths ~8..64, mean ~40); fixed: every hypothesis "
                          "cut at --text-len (the workload of rounds 1-3)")
     ap.add_argument("--text-len", type=int, default=0,
-                    help="hard_max_seq_len of the greedy text search, prompt included (default: 64 ragged, 42 fixed)")
+                    help="hard_max_seq_len of the greedy text search, prompt included (default: 1024 = the reference's default for the ragged "
+                         "workload, 42 fixed; 64 = the limit of rounds 4-5)")
     ap.add_argument("--engine-slots", type=int, default=256,
                     help="decode engine (pipeline schedule): ONE greedy decoder-step chain shared by the passes in flight, this many rows "
                          "per step, continuous refill (runtime.DecodeEngine); 0 = every pass runs its own chain (round 4)")
@@ -562,7 +563,9 @@ def dry_run(args):
 def main():
     args = parse_args()
     if args.text_len <= 0:
-        args.text_len = 64 if args.workload == "ragged" else 42
+        # ragged: the reference's own default (SequenceGeneratorOptions.hard_max_seq_len, inference/generator.py:72; the soft rule
+        # (1, 200) on ~1000 fbank frames never binds): no hypothesis of the eos_ramp workload is cut (the longest: 72 tokens)
+        args.text_len = 1024 if args.workload == "ragged" else 42
     if args.free_run:
         args.schedule = "freerun"
     if args.lock_step:
@@ -633,8 +636,8 @@ def main():
 
     batcher = MicroBatcher(translator, min(args.microbatches, B))
     engine_cfg = None
+    max_len, s_enc = MicroBatcher.engine_geometry(translator, ns, opts)  # what the length rule makes of the options for this input
     if args.engine_slots > 0 and batcher.groups > 1:
-        max_len, s_enc = MicroBatcher.engine_geometry(translator, ns, opts)
         low = args.engine_low_water if args.engine_low_water >= 0 else args.engine_slots // 2
         engine_cfg = dict(slots=args.engine_slots, rows=max(4 * args.engine_slots, (batcher.groups + 1) * B), poll=args.engine_poll,
                           low_water=min(low, args.engine_slots), max_wait_ms=args.engine_wait_ms, use_graph=not args.no_graph)
@@ -825,7 +828,11 @@ def main():
                    "busy_ms_per_pass": round(1e-3 * es["busy_us"] / max(1, args.steps), 2),
                    "paused_ms_per_pass": round(1e-3 * es["wait_us"] / max(1, args.steps), 2),
                    "decoder_us_per_useful_row_step": round(es["busy_us"] / max(1, es["useful_row_steps"]), 2),
-                   "rows_retired": int(es["rows_retired"]), "requests": int(es["requests"])}
+                   "rows_retired": int(es["rows_retired"]), "requests": int(es["requests"]),
+                   # device memory the engine holds at these limits: self-attention K / V per SLOT lane (slots x max_len positions),
+                   # encoder K / V and captured decoder outputs per row state
+                   "memory_gb": {"self_kv": round(es["self_kv_bytes"] / 1e9, 2), "cross_kv": round(es["cross_kv_bytes"] / 1e9, 2),
+                                 "captured_outputs": round(es["hidden_bytes"] / 1e9, 2)}}
             result["config"]["decode_engine"] = eng
             # under the engine a pass's "text_decoder" stage time is its WAIT for the shared chain, not chain time: the per-row-step
             # cost of the chain is the engine's busy time over the useful row-steps it retired
@@ -835,7 +842,8 @@ def main():
             rows_cfg["live_row_compaction"] = "decode engine: finished rows leave their slots, waiting rows of any pass take them"
             result["config"]["text_lengths"] = ("hypotheses stop on their own (eos_ramp weights); the rows of all passes in flight share ONE "
                                                 "decoder-step chain with continuous refill (decode engine)")
-        result["config"]["rows_at_length_cap"] = int(sum(1 for n in text_lens if n >= args.text_len))
+        result["config"]["max_len_effective"] = int(max_len)  # min(hard_max_seq_len, a * source length + b), sc_text_max_len
+        result["config"]["rows_at_length_cap"] = int(sum(1 for n in text_lens if n >= max_len))
 
     # ---- one extra profiled step: per-launch HIP events on the library's stream ----------
     if not args.no_profile_step:
@@ -989,6 +997,14 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
     from seamless_communication_amd.inference import SequenceGeneratorOptions
 
     out = {}
+    # The secondary lines run the handles' OWN decoder chains (no engine), whose K / V caches are dense [rows][max_len] per
+    # handle - 12.9 GB per 64-row chain and 64 GB for the 320-row beam search at max_len 1024.  They get a limit of 128
+    # positions: the longest hypothesis of this workload has 72 tokens, so ids and work are those of the 1024 limit; the
+    # headline above runs at the limit the line states.
+    main_opts = opts
+    x_len = min(int(args.text_len), 128)
+    opts = SequenceGeneratorOptions(beam_size=1, soft_max_seq_len=opts.soft_max_seq_len, hard_max_seq_len=x_len)
+    out["_limits"] = {"hard_max_seq_len_of_these_lines": x_len, "headline": int(main_opts.hard_max_seq_len)}
 
     def timed(fn, reps):
         fn()
@@ -1016,7 +1032,7 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
     except Exception as e:  # noqa: BLE001
         out["s2tt"] = {"error": repr(e)[:300]}
     try:  # beam_size 5 = the default of Translator.predict (translator.py:311-313): the whole batch, 64 x 5 = 320 live decoder rows
-        o5 = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(1, 200), hard_max_seq_len=args.text_len)
+        o5 = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(1, 200), hard_max_seq_len=x_len)
         fb, frames = translator.model.fbank(wav_dev, ns, standardize=True, pad_to_multiple=2)
         src = {"seqs": fb, "seq_lens": torch.from_numpy(frames.astype(np.int64)), "is_ragged": False}
         dt1 = timed(lambda: translator.predict(src, "S2ST", "fra", text_generation_opts=o5), 2)
@@ -1114,17 +1130,18 @@ def parity_from_goldens(args, groups, last, B, t2u_views, first_index=0):
             from seamless_communication_amd import synthetic as syn
 
             gold = fg.load(fg.GOLDEN_MORE)
-            if args.arch != "base_v2" or args.text_len != gold["meta"]["eos_text_len"] or gold["meta"]["eos_ramp"] != syn.EOS_RAMP_BENCH:
-                return {"n_checked": 0, "error": "the golden fixture holds arch base_v2 / text length 64 / EOS_RAMP_BENCH only"}
-            section, fixture = gold["b64eos"], "tests/golden/fullsize_more_ref.json: b64eos"
+            if args.arch != "base_v2" or gold["meta"]["eos_ramp"] != syn.EOS_RAMP_BENCH:
+                return {"n_checked": 0, "error": "the golden fixture holds arch base_v2 / EOS_RAMP_BENCH only"}
+            items, fixture = fg.ragged_items(gold, args.text_len)
+            if items is None:
+                return {"n_checked": 0, "error": fixture}
         else:
             gold = fg.load()
             if args.arch != gold["meta"]["arch"] or args.text_len != gold["meta"]["text_len"]:
                 return {"n_checked": 0, "error": "the golden fixture holds arch base_v2 / text length 42 only"}
-            section, fixture = gold["b64"], "tests/golden/fullsize_ref.json: b64"
+            items, fixture = fg.items_by_index(gold["b64"]), "tests/golden/fullsize_ref.json: b64"
     except OSError as e:
         return {"n_checked": 0, "error": f"golden fixture missing: {e}"}
-    items = fg.items_by_index(section)
     n = min(B, len(items) - first_index)  # this rank's shard holds utterances first_index .. first_index + B - 1
     if n <= 0:
         return {"n_checked": 0, "error": f"the golden fixture holds utterances 0..{len(items) - 1} only"}

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SC_ABI_VERSION 8
+#define SC_ABI_VERSION 9
 #define SC_MAX_UPSAMPLES 8
 #define SC_MAX_RESBLOCK_KERNELS 4
 #define SC_MAX_RESBLOCK_DILATIONS 4
@@ -236,6 +236,9 @@ typedef struct sc_engine_stats {
     int64_t rows_admitted, rows_retired, requests, max_live;
     double busy_us;           /* wall time of the engine thread between starting an admit/step/look round and its end */
     double wait_us;           /* wall time paused below low_water */
+    /* device memory the engine holds (fixed at creation): self-attention K / V = 2 * layers * slots * max_len * model_dim * 4
+     * (one lane per SLOT), encoder K / V and captured decoder outputs per ROW STATE */
+    int64_t self_kv_bytes, cross_kv_bytes, hidden_bytes;
 } sc_engine_stats;
 sc_engine* sc_engine_create(sc_model* m, const sc_engine_opts* opts);
 void sc_engine_free(sc_engine* e);

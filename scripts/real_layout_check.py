@@ -47,7 +47,7 @@ def main():
     t0 = time.perf_counter()
     sd = syn.make_unity_state_dict(cfg, syn.DEFAULT_SEED, eos_ramp=syn.EOS_RAMP_BENCH)
     vsd = syn.make_vocoder_state_dict(cfg, syn.DEFAULT_SEED)
-    pieces = CharTokenizer(cfg.char_vocab_size).pieces()
+    pieces = CharTokenizer(cfg.char_vocab_size).synthetic_pieces()
     fs = to_fairseq_layout(sd, pieces, text_encoder_layers=2, nllb100_dummy_row=True)
     upath, vpath = Path(args.dir) / "unity_fairseq_layout.pt", Path(args.dir) / "vocoder_fairseq_layout.pt"
     torch.save({"model": fs}, upath)
@@ -78,7 +78,7 @@ def main():
         tr.model.close()
         return load_s, ids, units
 
-    card_f = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch=args.arch, checkpoint=f"file://{upath}")
+    card_f = dict(DEFAULT_CARDS["seamlessM4T_v2_large"], model_arch=args.arch, checkpoint=f"file://{upath}", char_tokenizer="synthetic")
     vcard_f = dict(DEFAULT_CARDS["vocoder_v2"], checkpoint=f"file://{vpath}")
     load_f, ids_f, units_f = run(card_f, vcard_f)
     out.update(file_load_seconds=round(load_f, 1), peak_host_rss_gb_after_file_load=round(rss_gb(), 1))

@@ -9,9 +9,14 @@ import ctypes as C
 from pathlib import Path
 from typing import Optional
 
-LIB_PATH = Path(__file__).resolve().parent / "libseamless_hip.so"
+import os
 
-SC_ABI_VERSION = 8
+# SC_LIB_VARIANT=<name> loads libseamless_hip.<name>.so (an A/B build of `python -m seamless_communication_amd.build --variant
+# name --flags "..."`; kernel development only - the product and the driver's runs use the plain name)
+_VARIANT = os.environ.get("SC_LIB_VARIANT", "")
+LIB_PATH = Path(__file__).resolve().parent / (f"libseamless_hip.{_VARIANT}.so" if _VARIANT else "libseamless_hip.so")
+
+SC_ABI_VERSION = 9
 SC_MAX_UPSAMPLES = 8
 SC_MAX_RESBLOCK_KERNELS = 4
 SC_MAX_RESBLOCK_DILATIONS = 4
@@ -88,6 +93,7 @@ class sc_engine_stats(C.Structure):
     _fields_ = [
         ("steps", C.c_int64), ("row_steps", C.c_int64), ("useful_row_steps", C.c_int64), ("rows_admitted", C.c_int64),
         ("rows_retired", C.c_int64), ("requests", C.c_int64), ("max_live", C.c_int64), ("busy_us", C.c_double), ("wait_us", C.c_double),
+        ("self_kv_bytes", C.c_int64), ("cross_kv_bytes", C.c_int64), ("hidden_bytes", C.c_int64),
     ]
 
 

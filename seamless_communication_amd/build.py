@@ -30,23 +30,23 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def _stamp(src: Path) -> str:
+def _stamp(src: Path, flags=FLAGS) -> str:
     h = hashlib.sha256()
     h.update(src.read_bytes())
     for hdr in sorted(CSRC.glob("*.h")) + sorted((CSRC.parent.parent / "include").glob("*.h")):
         h.update(hdr.read_bytes())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(flags).encode())
     return h.hexdigest()
 
 
-def _compile(src_name: str, verbose: bool) -> Path:
+def _compile(src_name: str, verbose: bool, obj_dir: Path = OBJ_DIR, flags=FLAGS) -> Path:
     src = CSRC / src_name
-    obj = OBJ_DIR / (src_name + ".o")
-    stamp = OBJ_DIR / (src_name + ".stamp")
-    digest = _stamp(src)
+    obj = obj_dir / (src_name + ".o")
+    stamp = obj_dir / (src_name + ".stamp")
+    digest = _stamp(src, flags)
     if obj.exists() and stamp.exists() and stamp.read_text() == digest:
         return obj
-    cmd = [_hipcc(), *FLAGS, "-x", "hip", "-c", str(src), "-o", str(obj)]
+    cmd = [_hipcc(), *flags, "-x", "hip", "-c", str(src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -58,23 +58,37 @@ def _compile(src_name: str, verbose: bool) -> Path:
     return obj
 
 
-def build(verbose: bool = False, force: bool = False) -> Path:
-    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+def build(verbose: bool = False, force: bool = False, variant: str = "", extra_flags=()) -> Path:
+    """`variant` (kernel development): objects under build/<variant>/, library libseamless_hip.<variant>.so, FLAGS + extra_flags;
+    loaded with SC_LIB_VARIANT=<variant>."""
+    obj_dir = OBJ_DIR / variant if variant else OBJ_DIR
+    lib = LIB.with_name(f"libseamless_hip.{variant}.so") if variant else LIB
+    flags = [*FLAGS, *extra_flags]
+    obj_dir.mkdir(parents=True, exist_ok=True)
     if force:
-        for f in OBJ_DIR.glob("*.stamp"):
+        for f in obj_dir.glob("*.stamp"):
             f.unlink()
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, verbose), SOURCES))
+        objs = list(ex.map(lambda s: _compile(s, verbose, obj_dir, flags), SOURCES))
     newest = max(o.stat().st_mtime for o in objs)
-    if not LIB.exists() or LIB.stat().st_mtime < newest:
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB)]
+    LIB_ = lib
+    if not LIB_.exists() or LIB_.stat().st_mtime < newest:
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB_)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return LIB_
 
 
 if __name__ == "__main__":
-    print(build(verbose=True, force="--force" in sys.argv))
+    import argparse
+    import shlex
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--variant", default="")
+    ap.add_argument("--flags", default="", help="extra hipcc flags of a --variant build")
+    a = ap.parse_args()
+    print(build(verbose=True, force=a.force, variant=a.variant, extra_flags=shlex.split(a.flags)))

@@ -1,5 +1,8 @@
 // extern "C" surface of libseamless_hip.so (declared in include/seamless_hip.h).
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <set>
 
 #include "../../include/seamless_hip_internal.h"
 #include "engine.h"
@@ -15,7 +18,24 @@ struct sc_engine {
     std::unique_ptr<Engine> e;
     int device = 0;
     const void* weights = nullptr;  // identity of the model the engine was built on (the text embedding's address)
+    std::set<sc_model*> attached;   // handles routed through this engine (guarded by g_attach_mu)
 };
+
+// Engine <-> handle lifetimes are enforced HERE, not by the caller: freeing an engine detaches every handle still attached
+// to it (their next greedy call runs on the handle's own chain), freeing a handle takes its announced rows back and leaves
+// the engine's list.  One process-wide mutex: attach / free are rare.
+static std::mutex g_attach_mu;
+static std::map<Engine*, sc_engine*> g_engine_owner;
+
+static void detach_locked(sc_model* m) {
+    Engine* e = m->m.engine;
+    if (!e) return;
+    e->expect(m->m, -m->m.engine_announced);
+    auto it = g_engine_owner.find(e);
+    if (it != g_engine_owner.end()) it->second->attached.erase(m);
+    m->m.engine = nullptr;
+    m->m.engine_announced = 0;
+}
 
 #define SC_API_BEGIN try {
 #define SC_API_END                                                       \
@@ -99,6 +119,13 @@ sc_model* sc_fork(sc_model* parent) {
 void sc_free(sc_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->m.device);
+    {
+        std::lock_guard<std::mutex> lk(g_attach_mu);
+        try {
+            detach_locked(m);  // announced rows that will never come would make the engine pause below its low-water mark
+        } catch (...) {
+        }
+    }
     delete m;
 }
 
@@ -217,6 +244,10 @@ sc_engine* sc_engine_create(sc_model* m, const sc_engine_opts* opts) {
         h->device = m->m.device;
         h->weights = m->m.text_embed;
         h->e.reset(new Engine(m->m, *opts));
+        {
+            std::lock_guard<std::mutex> lk(g_attach_mu);
+            g_engine_owner[h->e.get()] = h;
+        }
         return h;
     } catch (const sc::Error&) {
     } catch (const std::exception& e) {
@@ -229,17 +260,30 @@ sc_engine* sc_engine_create(sc_model* m, const sc_engine_opts* opts) {
 void sc_engine_free(sc_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    {
+        std::lock_guard<std::mutex> lk(g_attach_mu);
+        for (sc_model* m : std::set<sc_model*>(e->attached)) {  // no handle keeps a pointer to the engine about to go
+            try {
+                detach_locked(m);
+            } catch (...) {
+            }
+        }
+        g_engine_owner.erase(e->e.get());
+    }
     delete e;
 }
 
 int sc_engine_attach(sc_model* m, sc_engine* e) {
     SC_API_BEGIN
     SC_CHECK(m, "sc_engine_attach: null handle");
-    if (m->m.engine) m->m.engine->expect(m->m, -m->m.engine_announced);
     if (e) SC_CHECK(e->e && e->device == m->m.device && e->weights == m->m.text_embed,
                     "sc_engine_attach: the engine was built on another model or device");
-    m->m.engine = e ? e->e.get() : nullptr;
-    m->m.engine_announced = 0;
+    std::lock_guard<std::mutex> lk(g_attach_mu);
+    detach_locked(m);
+    if (e) {
+        m->m.engine = e->e.get();
+        e->attached.insert(m);
+    }
     SC_API_END
 }
 

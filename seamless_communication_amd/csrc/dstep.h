@@ -58,10 +58,11 @@ struct StepCtx {
     const int* kv_item = nullptr;
     float* qkv3 = nullptr;  // [nb][3M] complete q | k | v rows: the wide step (> 64 live rows) projects them on gemv3
     // decode engine (engine.hip): slot s of the step works on ROW STATE slot_rp[s].x at position slot_rp[s].y.  d_tok / d_hist /
-    // d_finished / d_out_len / d_enc_lens / d_score, the K / V caches, the encoder K / V and dec_hidden are then indexed by row
+    // d_finished / d_out_len / d_enc_lens / d_score, the encoder K / V and dec_hidden are then indexed by row
     // state, every row has its own position (pos_row), length limit and prompt length, and the closing launch of the step
     // (engine_finalize_kernel) advances the positions itself.  null: slot = row, one scalar position (*d_pos).
     int2* slot_rp = nullptr;
+    int* slot_lane = nullptr;  // self K / V cache row of slot s (the caches are [slots][cap][M]: see DAttnArgs::slot_lane)
     int* pos_row = nullptr;
     int* limit_row = nullptr;
     int* prefix_row = nullptr;

@@ -12,9 +12,13 @@
 // A row's arithmetic depends neither on its slot nor on its neighbours nor on the step at which it entered
 // (tests/test_engine_gpu.py: ids, scores and captured decoder outputs bit-identical to the row generated alone).
 //
-// Structure: ROW STATES (K / V cache rows, encoder K / V, history, captured outputs, position, flags; `rows` of them) live as
-// long as a hypothesis; SLOTS are the rows of the step's activations; slot_rp[slot] = {row state, position} is the only thing
-// that changes when rows come and go (k_engine.hip).  The submitting thread projects the encoder K / V of its rows straight
+// Structure: ROW STATES (encoder K / V, history, captured outputs, position, flags; `rows` of them) live as long as a
+// hypothesis; SLOTS are the rows of the step's activations; slot_rp[slot] = {row state, position} is the only thing that
+// changes when rows come and go (k_engine.hip).  The self-attention K / V cache - the part that grows with the length limit,
+// 196 KB per position over the 24 layers - belongs to neither: it is cut into `slots` LANES of `max_len` positions, a row is
+// handed a lane when it enters the chain and gives it back when it retires (slot_lane[slot]; rows that wait hold none).  At
+// the reference's default limits (hard_max_seq_len 1024, inference/generator.py:72) a 256-slot engine holds 51.5 GB of
+// self K / V whatever the number of row states, where K / V per row state (round 5) needed 155 GB at 768 row states.  The submitting thread projects the encoder K / V of its rows straight
 // into the row states it was given (on its own stream, under the other passes' work) and waits; the engine thread owns the
 // step loop: admit -> `poll` replays of the captured step -> read the finished flags -> retire.
 #include <chrono>
@@ -51,7 +55,8 @@ struct Live {
     int rid;
     Request* req;
     int row;
-    int fed = 0;  // steps the row has been through (host-side estimate of its position: profiler bytes only)
+    int fed = 0;   // steps the row has been through (host-side estimate of its position: profiler bytes only)
+    int lane = 0;  // self K / V lane held while the row is in the chain
 };
 
 double now_us() {
@@ -97,8 +102,12 @@ struct Engine::Impl {
     bool stop = false, failed = false;
     std::string error;
     sc_engine_stats st{};
+    struct {
+        int64_t self_kv_bytes = 0, cross_kv_bytes = 0, hidden_bytes = 0;
+    } st_mem;  // fixed at setup
     // engine thread only
     std::vector<Live> live;
+    std::vector<int> free_lanes;  // self K / V lanes not held by a live row
     bool slots_dirty = false;
     double waited_us = 0;
     std::thread th;
@@ -146,15 +155,16 @@ void Engine::Impl::setup(const Model& parent) {
 
     c.nb = S, c.cap = cap, c.s_enc = se;
     c.min_seq_len = o.min_seq_len, c.unk_penalty = o.unk_penalty, c.force_eos_step = -1;
-    // ints: [0] unused scalar position | [1] live slots | [8 ..) slot_rp | per-row arrays | hist
-    const size_t n_ints = 8 + (size_t)2 * S + (size_t)7 * R + (size_t)R * cap;
+    // ints: [0] unused scalar position | [1] live slots | [8 ..) slot_rp | slot_lane | per-row arrays | hist
+    const size_t n_ints = 8 + (size_t)3 * S + (size_t)7 * R + (size_t)R * cap;
     ints = Buf<int>(em.pp(), n_ints);
     SC_HIP(hipMemsetAsync(ints.get(), 0, n_ints * 4, em.stream));
     c.d_pos = ints.get();
     int* d_rows = ints.get() + 1;
     c.d_rows = d_rows;
     c.slot_rp = reinterpret_cast<int2*>(ints.get() + 8);
-    int* p = ints.get() + 8 + 2 * S;
+    c.slot_lane = ints.get() + 8 + 2 * S;
+    int* p = ints.get() + 8 + 3 * S;
     c.d_tok = p, p += R;
     c.pos_row = p, p += R;
     c.d_finished = p, p += R;
@@ -189,9 +199,10 @@ void Engine::Impl::setup(const Model& parent) {
     c.dec_hidden = hidden;
     caches.reserve((size_t)3 * L);
     for (int li = 0; li < L; ++li) {
-        caches.emplace_back(em.pp(), (size_t)R * cap * M);
+        // self K / V: one lane of `cap` positions per SLOT (see the header comment)
+        caches.emplace_back(em.pp(), (size_t)S * cap * M);
         c.kcache.push_back(caches.back());
-        caches.emplace_back(em.pp(), (size_t)R * cap * M);
+        caches.emplace_back(em.pp(), (size_t)S * cap * M);
         c.vcache.push_back(caches.back());
         // encoder K / V: rows of a request shorter than s_enc leave the tail of their block unwritten; the attention clamps its
         // loads to the block and masks by length, so the tail only has to be finite
@@ -202,12 +213,16 @@ void Engine::Impl::setup(const Model& parent) {
     er.tok = c.d_tok, er.pos = c.pos_row, er.finished = c.d_finished, er.out_len = c.d_out_len, er.limit = c.limit_row;
     er.prefix_len = c.prefix_row, er.enc_lens = c.d_enc_lens, er.score = c.d_score, er.hist = c.d_hist, er.hidden = c.dec_hidden;
     er.cap = cap, er.M = M;
-    d_rids = Buf<int>(em.pp(), (size_t)S);
+    d_rids = Buf<int>(em.pp(), (size_t)2 * S);  // row states | K / V lanes of the live slots
     d_stage = Buf<int>(em.pp(), (size_t)S * (2 + cap));
     d_admit = Buf<EngineAdmitRec>(em.pp(), (size_t)S);
     d_retire = Buf<EngineRetireRec>(em.pp(), (size_t)S);
-    h_fin.alloc(R), h_rids.alloc(S), h_stage.alloc((size_t)S * (2 + cap)), h_admit.alloc(S), h_retire.alloc(S);
+    h_fin.alloc(R), h_rids.alloc((size_t)2 * S), h_stage.alloc((size_t)S * (2 + cap)), h_admit.alloc(S), h_retire.alloc(S);
     for (int r = 0; r < R; ++r) free_rids.insert(r);
+    for (int l = S - 1; l >= 0; --l) free_lanes.push_back(l);
+    st_mem.self_kv_bytes = (int64_t)2 * L * S * cap * M * 4;
+    st_mem.cross_kv_bytes = (int64_t)L * R * se * 2 * M * 4;
+    st_mem.hidden_bytes = (int64_t)R * (cap - 1) * M * 4;
     SC_HIP(hipStreamSynchronize(em.stream));
 }
 
@@ -248,9 +263,9 @@ void Engine::Impl::admit(const std::vector<Live>& rows) {
 }
 
 void Engine::Impl::set_slots() {
-    for (size_t s = 0; s < live.size(); ++s) h_rids.p[s] = live[s].rid;
-    if (!live.empty()) SC_HIP(hipMemcpyAsync(d_rids.get(), h_rids.p, live.size() * 4, hipMemcpyHostToDevice, em.stream));
-    launch_engine_set_slots(d_rids, (int)live.size(), o.slots, c.slot_rp, c.pos_row, const_cast<int*>(c.d_rows), em.stream);
+    for (size_t s = 0; s < live.size(); ++s) h_rids.p[s] = live[s].rid, h_rids.p[o.slots + s] = live[s].lane;
+    if (!live.empty()) SC_HIP(hipMemcpyAsync(d_rids.get(), h_rids.p, (size_t)2 * o.slots * 4, hipMemcpyHostToDevice, em.stream));
+    launch_engine_set_slots(d_rids, (int)live.size(), o.slots, c.slot_rp, c.slot_lane, c.pos_row, const_cast<int*>(c.d_rows), em.stream);
     slots_dirty = false;
 }
 
@@ -297,6 +312,7 @@ void Engine::Impl::look() {
     for (const Live& lv : live) (h_fin.p[lv.rid] ? gone : keep).push_back(lv);
     if (gone.empty()) return;
     live.swap(keep);
+    for (const Live& lv : gone) free_lanes.push_back(lv.lane);  // nothing of the lane is read after the row's last step
     slots_dirty = true;
     for (size_t i = 0; i < gone.size(); ++i) {
         Request* q = gone[i].req;
@@ -368,7 +384,9 @@ void Engine::Impl::loop() {
                 if (stop) break;
                 while ((int)live.size() < o.slots && !queue.empty()) {
                     Request* q = queue.front();
-                    const Live lv{q->rid[q->next_row], q, q->next_row, 0};
+                    Live lv{q->rid[q->next_row], q, q->next_row, 0, 0};
+                    lv.lane = free_lanes.back();  // live rows <= slots = lanes: never empty here
+                    free_lanes.pop_back();
                     live.push_back(lv);
                     admitted.push_back(lv);
                     --pending_rows;
@@ -454,6 +472,7 @@ void Engine::stats(sc_engine_stats* out, bool reset) {
     Impl& E = *p_;
     std::lock_guard<std::mutex> lk(E.mu);
     *out = E.st;
+    out->self_kv_bytes = E.st_mem.self_kv_bytes, out->cross_kv_bytes = E.st_mem.cross_kv_bytes, out->hidden_bytes = E.st_mem.hidden_bytes;
     if (reset) E.st = sc_engine_stats{};
 }
 
@@ -485,6 +504,9 @@ void Engine::generate(Model& m, const float* d_enc, int n, int s_enc, const int3
         ~Release() {
             if (q.ready) (void)hipEventDestroy(q.ready);
             if (!armed) return;
+            // the submitter's stream may still be projecting encoder K / V into these row states: nobody else may get them
+            // (and start writing from ANOTHER stream) before that work has drained
+            (void)hipStreamSynchronize(m.stream);
             std::lock_guard<std::mutex> lk(E.mu);
             for (int r : q.rid) E.free_rids.insert(r);
             E.cv_free.notify_all();

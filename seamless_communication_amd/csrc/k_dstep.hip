@@ -93,14 +93,16 @@ __global__ __launch_bounds__(256) void gemvp_kernel(GemvPArgs p) {
     const __amdgpu_buffer_rsrc_t rah = ds_rsrc(p.Ah, p.a_bytes);
     const __amdgpu_buffer_rsrc_t ral = ds_rsrc(p.Al, p.a_bytes);
     const uint32_t w_voff = (uint32_t)lane * 16u;
-    uint32_t a_voff[MT];
-    const int live = p.d_rows ? min(*p.d_rows, p.M) : p.M;  // rows behind the live rows are neither read nor written
+    uint32_t a_voff[MT] = {};
+    // rows behind the live rows are neither read nor written.  The scalar load of the count is requested here and first
+    // WAITED for behind the first tile's weight loads (below): with an early return in front of them the weights - cold in
+    // HBM, the launch's long pole - could only be asked for after that round trip.  Only the row blocks behind the first
+    // (grid.z, the decode engine's wide steps) return early.
+    const int live = p.d_rows ? min(*p.d_rows, p.M) : p.M;
     // more than 64 rows (the decode engine's step): grid.z blocks of 32 * MT rows, each the kernel of a <= 64-row launch - a
     // row's sums do not depend on how many rows the launch covers
     const int rb0 = blockIdx.z * (32 * MT);
-    if (rb0 >= live) return;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) a_voff[i] = (rb0 + 32 * i + n < live) ? (uint32_t)((h * p.RB + rb0 + 32 * i + n) * 16) : OOB;
+    if (blockIdx.z != 0 && rb0 >= live) return;
     const uint32_t a_kstep = (uint32_t)(2 * p.RB * 16);  // bytes per k-step in a plane
     uint32_t kill[NCH];                                  // chunks behind the K range read zeros
 #pragma unroll
@@ -158,6 +160,11 @@ __global__ __launch_bounds__(256) void gemvp_kernel(GemvPArgs p) {
 
         // issue order: W0 A0 W1 A1 W2 W3 ... (activation buffers alternate, refilled as soon as a chunk is consumed)
         DS_LOAD_W(0);
+        if (tl == 0) {
+            __builtin_amdgcn_sched_barrier(0);  // first use of `live`: behind the first weight loads
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a_voff[i] = (rb0 + 32 * i + n < live) ? (uint32_t)((h * p.RB + rb0 + 32 * i + n) * 16) : OOB;
+        }
         DS_LOAD_A(0, 0);
         if (NCH > 1) {
             DS_LOAD_W(1);
@@ -422,23 +429,27 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (pair >= p.nb * p.heads) return;
     const int b = pair / p.heads, hd = pair - b * p.heads;
-    if (p.d_rows && b >= *p.d_rows) return;  // a row behind the live rows (beam search: finished utterances; greedy: compaction)
+    // the position (own chain: one scalar, engine: the slot's {row state, position}) is requested BEFORE the live-row test so
+    // that both loads are one round trip, not two in a row
     const int c = lane & 15, g = lane >> 4;
-    int r = b, pos = 0;
+    int r = b, pos = 0, kvrow = b;
     if (ROWS) {
         const int2 rp = p.slot_rp[b];
+        if (!CROSS) kvrow = p.slot_lane[b];  // independent of rp: the two loads are one round trip
         r = rp.x;
         pos = CROSS ? 0 : rp.y;
+        if (CROSS) kvrow = r;
     } else if (!CROSS) {
         pos = *p.d_pos;
     }
+    if (p.d_rows && b >= *p.d_rows) return;  // a row behind the live rows (beam search: finished utterances; greedy: compaction)
     const int kv_len = CROSS ? min(p.kv_lens[r], p.cap) : pos + 1;
     // row index clamp of the loads.  Cross-attention clamps to the capacity, not to the row's own length: every row of
     // the projected encoder K/V is initialised (finite), so the addresses do not have to wait for kv_lens[b]; keys behind
     // the length are masked below.  Self-attention rows behind `pos` are uninitialised memory and are never touched.
     const int last = CROSS ? p.cap - 1 : kv_len - 1;
     // beam search: the beams of an utterance share its encoder K / V (projected once per utterance, in utterance order)
-    const int crow = ROWS ? r : (CROSS ? ((ANC && p.kv_item) ? p.kv_item[b / p.kv_row_div] : b / p.kv_row_div) : b);
+    const int crow = ROWS ? kvrow : (CROSS ? ((ANC && p.kv_item) ? p.kv_item[b / p.kv_row_div] : b / p.kv_row_div) : b);
     const float* kc = p.kcache + (int64_t)crow * p.cache_bs + hd * 64 + 4 * c;
     const float* vc = p.vcache + (int64_t)crow * p.cache_bs + hd * 64 + 4 * c;
 
@@ -514,8 +525,8 @@ __global__ __launch_bounds__(256) void dattn_kernel(DAttnArgs p) {
     }
     if (!CROSS && g == 0) {  // append the new key / value row (the loads above may have raced with it: row `pos` is
                              // taken from the registers below, never from memory)
-        *reinterpret_cast<float4*>(p.kcache + (int64_t)r * p.cache_bs + (int64_t)pos * p.cache_ld + hd * 64 + 4 * c) = kn;
-        *reinterpret_cast<float4*>(p.vcache + (int64_t)r * p.cache_bs + (int64_t)pos * p.cache_ld + hd * 64 + 4 * c) = vn;
+        *reinterpret_cast<float4*>(p.kcache + (int64_t)kvrow * p.cache_bs + (int64_t)pos * p.cache_ld + hd * 64 + 4 * c) = kn;
+        *reinterpret_cast<float4*>(p.vcache + (int64_t)kvrow * p.cache_bs + (int64_t)pos * p.cache_ld + hd * 64 + 4 * c) = vn;
     }
 
     float m_run = -INFINITY, l_run = 0.f;
@@ -755,6 +766,7 @@ void launch_dattn(const DAttnArgs& a, bool cross, hipStream_t s) {
     const int ppw = std::max(1, std::min(4, pairs / 256));
     if (a.slot_rp) {  // decode engine: per-slot row state and position
         SC_CHECK(!a.anc && !a.kv_item && a.kv_row_div == 1, "dattn: the per-slot row state excludes the beam-search tables");
+        SC_CHECK(cross || a.slot_lane, "dattn: the decode engine's self-attention needs the slots' K / V lanes");
         if (cross) hipLaunchKernelGGL((dattn_kernel<true, false, true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
         else hipLaunchKernelGGL((dattn_kernel<false, false, true>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
     } else if (cross && a.kv_item) hipLaunchKernelGGL((dattn_kernel<true, true, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);

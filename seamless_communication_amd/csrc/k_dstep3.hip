@@ -76,8 +76,16 @@ __global__ __launch_bounds__(64 * WAVES) void gemv3_kernel(Gemv3Args p) {
     const int r0 = blockIdx.y * p.rg;
     // rows behind the live rows (beam search: finished utterances; greedy generation: the live-row compaction) are neither
     // read nor written, a row group that starts behind them returns at once
-    const int live = p.d_rows ? min(*p.d_rows, p.M) : p.M;
-    if (r0 >= live) return;
+    // The FIRST row group (the only one of a narrow step) does not wait for *d_rows before it asks for its weights: the
+    // scalar load of the live-row count is a memory round trip of its own, and with the early return in front of them the
+    // weight loads - the launch's long pole, cold in HBM - could only be issued after it.  Later groups keep the early return
+    // (their weights would be wasted traffic when the group is dead); group 0 with no live row does nothing below (no row is
+    // valid, nothing is stored).
+    int live = p.M;
+    if (blockIdx.y != 0 && p.d_rows) {
+        live = min(*p.d_rows, p.M);
+        if (r0 >= live) return;
+    }
     const int rot = blockIdx.x % WAVES;
     const int chunk = (wave + rot) % WAVES;
     const int ks_w0 = (blockIdx.z * WAVES + chunk) * KSW;
@@ -98,6 +106,10 @@ __global__ __launch_bounds__(64 * WAVES) void gemv3_kernel(Gemv3Args p) {
             w[jt][j] = gridDim.y == 1 ? __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff | tkill | kk, w_tile + (uint32_t)(ks_w0 + j) * 1024u, 2 /*nt*/)
                                       : __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff | tkill | kk, w_tile + (uint32_t)(ks_w0 + j) * 1024u, 0);
         }
+    }
+    if (blockIdx.y == 0 && p.d_rows) {
+        __builtin_amdgcn_sched_barrier(0);  // the weight loads above stay above the wait for *d_rows
+        live = min(*p.d_rows, p.M);
     }
     bool rvalid[MT];
 #pragma unroll
@@ -753,10 +765,12 @@ template <bool LN>
 __global__ __launch_bounds__(256) void reduce3_kernel(Reduce3Args p) {
     __shared__ float red[8];
     const int row = blockIdx.x, tid = threadIdx.x;
-    if (p.d_rows && row >= *p.d_rows) return;  // a row behind the live rows (see Gemv3Args::d_rows)
+    // a row behind the live rows (see Gemv3Args::d_rows) stores nothing.  The count is only waited for in front of the first
+    // store: an early return up here would put its round trip in front of every load of the launch (a dead row's loads stay
+    // inside the buffers and are discarded).
+    const int live_rows = p.d_rows ? *p.d_rows : 0x7fffffff;
     const int nv = p.C >> 2;
-    const bool on = tid < nv;
-    const int t = on ? tid : 0;  // idle lanes read element 0 and discard it
+    const int t = tid < nv ? tid : 0;  // idle lanes read element 0 and discard it
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     float4* xp = reinterpret_cast<float4*>(p.xg + ((int64_t)(t >> 1) * p.XRB + row) * 8 + (t & 1) * 4);
     float4 a = zero;
@@ -790,6 +804,9 @@ __global__ __launch_bounds__(256) void reduce3_kernel(Reduce3Args p) {
     a.y = (a.y + bb.y) + r.y;
     a.z = (a.z + bb.z) + r.z;
     a.w = (a.w + bb.w) + r.w;
+    __builtin_amdgcn_sched_barrier(0);
+    if (row >= live_rows) return;  // block-uniform: nobody is left behind at the barriers below
+    const bool on = tid < nv;
     if (on) *xp = a;
     if (!LN) return;
     float s = on ? (a.x + a.y) + (a.z + a.w) : 0.f;

@@ -112,14 +112,18 @@ __global__ __launch_bounds__(256) void engine_admit_kernel(const EngineAdmitRec*
 }
 
 __global__ __launch_bounds__(256) void engine_set_slots_kernel(const int* __restrict__ rids, int n_live, int slots, int2* __restrict__ slot_rp,
-                                                               const int* __restrict__ pos, int* __restrict__ d_rows) {
+                                                               int* __restrict__ slot_lane, const int* __restrict__ pos,
+                                                               int* __restrict__ d_rows) {
     for (int s = threadIdx.x; s < slots; s += 256) {
         int2 v = make_int2(0, 0);
+        int lane = 0;
         if (s < n_live) {
             v.x = rids[s];
             v.y = pos[v.x];
+            lane = rids[slots + s];
         }
         slot_rp[s] = v;
+        slot_lane[s] = lane;
     }
     if (threadIdx.x == 0) *d_rows = n_live;
 }
@@ -163,9 +167,9 @@ void launch_engine_admit(const EngineAdmitRec* d_recs, int n, const EngineRows& 
     SC_LAUNCH_CHECK();
 }
 
-void launch_engine_set_slots(const int* d_rids, int n_live, int slots, int2* slot_rp, const int* pos, int* d_rows, hipStream_t s) {
-    SC_CHECK(n_live >= 0 && n_live <= slots, "engine: %d live rows for %d slots", n_live, slots);
-    hipLaunchKernelGGL(engine_set_slots_kernel, dim3(1), dim3(256), 0, s, d_rids, n_live, slots, slot_rp, pos, d_rows);
+void launch_engine_set_slots(const int* d_rids, int n_live, int slots, int2* slot_rp, int* slot_lane, const int* pos, int* d_rows, hipStream_t s) {
+    SC_CHECK(n_live >= 0 && n_live <= slots && slot_lane, "engine: %d live rows for %d slots", n_live, slots);
+    hipLaunchKernelGGL(engine_set_slots_kernel, dim3(1), dim3(256), 0, s, d_rids, n_live, slots, slot_rp, slot_lane, pos, d_rows);
     SC_LAUNCH_CHECK();
 }
 

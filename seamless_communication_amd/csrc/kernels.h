@@ -265,6 +265,10 @@ struct DAttnArgs {
     // decode engine (engine.hip): slot b works on row state slot_rp[b].x at position slot_rp[b].y (d_pos unused): the K / V
     // cache rows, the encoder K / V rows and kv_lens are indexed by the row state, q and the output planes by the slot
     const int2* slot_rp = nullptr;
+    // decode engine, self-attention: the K / V cache rows belong to the LANE slot b's row holds while it is in the chain
+    // (slot_lane[b]; handed out on admission, returned at retirement), not to the row state: the caches are [slots][cap][M]
+    // whatever the number of row states.  null: the cache row is the row state.
+    const int* slot_lane = nullptr;
     __half* Oh = nullptr;          // output planes [heads*8][ORB][8]
     __half* Ol = nullptr;
     int ORB = 32;
@@ -642,8 +646,9 @@ struct EngineAdmitRec {
     int prefix[ENGINE_MAX_PREFIX];
 };
 void launch_engine_admit(const EngineAdmitRec* d_recs, int n, const EngineRows& rows, int pad_idx, hipStream_t s);
-// slot_rp[s] = {rids[s], pos[rids[s]]} for s < n_live, {0, 0} behind; *d_rows = n_live
-void launch_engine_set_slots(const int* d_rids, int n_live, int slots, int2* slot_rp, const int* pos, int* d_rows, hipStream_t s);
+// slot_rp[s] = {rids[s], pos[rids[s]]}, slot_lane[s] = lanes[s] for s < n_live ({0, 0} / 0 behind); *d_rows = n_live.
+// d_rids holds the row states followed by the K / V lanes ([2][slots]).
+void launch_engine_set_slots(const int* d_rids, int n_live, int slots, int2* slot_rp, int* slot_lane, const int* pos, int* d_rows, hipStream_t s);
 // finished rows leave: decoder outputs 0 .. out_len-2 of row state rid -> dst[t][M] (zeros up to dst_rows), and
 // {out_len, score bits, hist[0 .. cap)} -> stage[i][2 + cap]
 struct EngineRetireRec {

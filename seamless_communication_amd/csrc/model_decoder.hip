@@ -591,6 +591,7 @@ void decoder_step3(Model& m, StepCtx& c, bool project, const DecStack& W) {
         a.anc = c.anc;
         a.d_rows = c.d_rows;
         a.slot_rp = c.slot_rp;
+        a.slot_lane = c.slot_lane;
         launch_dattn(a, /*cross=*/false, m.stream);
         out_resid(l.self_out);
         // encoder-decoder attention: the query projection applies its LayerNorm itself

@@ -180,7 +180,13 @@ class Translator:
         with_text_encoder = input_modality != Modality.SPEECH
         with_t2u = output_modality is None or output_modality == Modality.SPEECH
         self.char_tokenizer = CharTokenizer(self.cfg.char_vocab_size, card.get("char_tokenizer_path"))
-        unity_sd = _load_state_dict(card, self.cfg, "unity", with_t2u, self.char_tokenizer.pieces(), with_text_encoder)
+        # Char pieces re-order `embed_char` of a fairseq-keyed checkpoint (models/unity/loader.py:158-176).  Without a
+        # SentencePiece char model there are none and the conversion of such a checkpoint fails loudly - unless the card SAYS
+        # the file is a rendition of the synthetic weights (`char_tokenizer: synthetic`, scripts/real_layout_check.py).
+        char_pieces = self.char_tokenizer.pieces()
+        if char_pieces is None and card.get("char_tokenizer") == "synthetic":
+            char_pieces = self.char_tokenizer.synthetic_pieces()
+        unity_sd = _load_state_dict(card, self.cfg, "unity", with_t2u, char_pieces, with_text_encoder)
         langs = card.get("langs", _cards.TEXT_LANGS)
         self.text_tokenizer = text_tokenizer or NllbTextTokenizer(
             self.cfg.text_vocab_size, langs, card.get("default_lang", "eng"), card.get("tokenizer_path")

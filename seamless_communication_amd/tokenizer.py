@@ -372,12 +372,20 @@ class CharTokenizer:
 
     def pieces(self) -> Optional[List[str]]:
         """The pieces in model order: what ``_get_char_index_mapping`` (models/unity/loader.py:158-176) re-orders the char
-        embedding of a fairseq-keyed checkpoint by.  The built-in synthetic alphabet answers with its own (short) list - a
-        fairseq-layout rendition of the synthetic weights (scripts/real_layout_check.py) converts like a published file."""
+        embedding of a fairseq-keyed checkpoint by.  ``None`` without a SentencePiece model: a published fairseq-keyed
+        checkpoint loaded from a card that names no ``char_tokenizer_path`` must fail in ``convert_unity_checkpoint`` instead
+        of having the first rows of its real ``embed_char`` table permuted by the built-in alphabet."""
         if self._spm is None:
-            by_index = sorted(self._map.items(), key=lambda kv: kv[1])
-            return ["<s>", "<pad>", "</s>", "<unk>"] + [c for c, _ in by_index]
+            return None
         return [self._spm.id_to_piece(i) for i in range(self._spm.get_piece_size())]
+
+    def synthetic_pieces(self) -> List[str]:
+        """The built-in alphabet as a piece list - only for fairseq-layout renditions of the SYNTHETIC weights
+        (scripts/real_layout_check.py and ``synthetic://`` / ``file://...?synthetic_chars=1`` cards)."""
+        if self._spm is not None:
+            raise ValueError("synthetic_pieces() is the built-in alphabet's list; this tokenizer wraps a SentencePiece model")
+        by_index = sorted(self._map.items(), key=lambda kv: kv[1])
+        return ["<s>", "<pad>", "</s>", "<unk>"] + [c for c, _ in by_index]
 
     def token_to_index(self, ch: str) -> int:
         if self._spm is not None:

@@ -26,6 +26,30 @@ def items_by_index(section: Dict) -> Dict[int, Dict]:
     return {int(r["index"]): r for r in section["items"]}
 
 
+def ragged_items(gold_more: Dict, hard_max_seq_len: int):
+    """The oracle's rows of the ragged (`eos_ramp`) 64-utterance batch under a given hard_max_seq_len: ({index: row}, name of
+    the fixture) or (None, why not).  64: section b64eos as minted.  Any limit above the longest hypothesis that runs to its own
+    EOS (72 tokens) - the reference default 1024 included; the soft rule (1, 200) never binds for 10 s of audio, fairseq2
+    applies it to the ~1000 fbank frames -: b64eos with the rows it cut at 64 replaced by their b64long versions (a greedy row
+    depends on the limit only through the forced EOS at max_len - 2, so every other row is the same;
+    make_fullsize_more_goldens.py asserts that on a cross-check row)."""
+    base = items_by_index(gold_more["b64eos"])
+    cut_len = int(gold_more["meta"]["eos_text_len"])
+    if int(hard_max_seq_len) == cut_len:
+        return base, "tests/golden/fullsize_more_ref.json: b64eos"
+    long_sec = gold_more.get("b64long")
+    if long_sec is None:
+        return None, "the golden fixture has no b64long section (tests/golden/make_fullsize_more_goldens.py --sections b64long)"
+    longer = items_by_index(long_sec)
+    longest = max(len(r["text_ids"]) for r in longer.values())
+    if int(hard_max_seq_len) <= longest:
+        return None, f"the golden fixture holds hard_max_seq_len {cut_len} and > {longest} (no row cut) only"
+    assert set(long_sec["cut_at_64"]) == {i for i, r in base.items() if len(r["text_ids"]) >= cut_len}
+    merged = dict(base)
+    merged.update({i: longer[i] for i in long_sec["cut_at_64"]})
+    return merged, "tests/golden/fullsize_more_ref.json: b64eos + b64long (no row cut)"
+
+
 def _first_diff(a: Sequence[int], b: Sequence[int]) -> Optional[int]:
     for i, (x, y) in enumerate(zip(a, b)):
         if int(x) != int(y):

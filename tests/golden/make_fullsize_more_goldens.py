@@ -9,6 +9,11 @@ Sections:
   b64eos  utterances 0..63, 10 s each, greedy, hard_max_seq_len 64, weights synthetic://20240901?eos_ramp=<EOS_RAMP_BENCH>:
           every row stops ON ITS OWN at its own step (the ragged-length workload bench.py times).  Oracle chunks of 4
           equal-length utterances (no item depends on another one).  Text ids / char ids / durations / unit ids + margins.
+  b64long the rows of b64eos that were CUT at hard_max_seq_len 64 (length 64: utterances 1, 2, 20, 40, 41) and, as a cross-check,
+          utterance 0 (stops on its own at 41 tokens: must come out as in b64eos), at the reference's DEFAULT limits - hard_max_seq_len
+          1024 (inference/generator.py:72; the soft rule (1, 200) applies to the ~1000 fbank frames and never binds).  bench.py times the batch
+          at these limits since round 6 (no row is cut any more); every other row of the batch is the b64eos row (a greedy row
+          depends on the limit only through the forced EOS at max_len - 2).
   beam5eos  utterances 0..11 as one batch, beam_size 5 (the API default), hard_max_seq_len 64, the same weights: the searches of
           a batch finish at different steps (the live rows are re-packed as utterances leave).  Text ids / char ids /
           durations / units.
@@ -45,6 +50,8 @@ sys.path.insert(0, str(ROOT))
 OUT = Path(__file__).resolve().parent / "fullsize_more_ref.json"
 
 EOS_TEXT_LEN = 64
+LONG_TEXT_LEN = 1024  # SequenceGeneratorOptions.hard_max_seq_len's default
+LONG_CHECK_INDEX = 0  # a row that stops on its own below 64 tokens: the two limits must give the same row
 T2TT_SENTENCES = [
     "the quick brown fox jumps over the lazy dog near the river bank",
     "hello world",
@@ -99,7 +106,7 @@ def run_stream_traced(backend, tt, thr, wav, speech: bool):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--sections", default="b64eos,beam5eos,t2tt,t2st,medium,medium_s2st,stream")
+    ap.add_argument("--sections", default="b64eos,b64long,beam5eos,t2tt,t2st,medium,medium_s2st,stream")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--limit", type=int, default=64, help="utterances of section b64eos (debugging)")
     args = ap.parse_args()
@@ -128,11 +135,12 @@ def main():
     ct = CharTokenizer(cfg.char_vocab_size)
 
     need_b64 = "b64eos" in want and len(doc.get("b64eos", {}).get("items", [])) < args.limit
+    need_long = "b64long" in want and "b64long" not in doc
     need_t2tt = "t2tt" in want and "t2tt" not in doc
     need_beam = "beam5eos" in want and "beam5eos" not in doc
     need_t2st = "t2st" in want and "t2st" not in doc
     need_text_encoder = need_t2tt or need_t2st
-    if need_b64 or need_text_encoder or need_beam:
+    if need_b64 or need_text_encoder or need_beam or need_long:
         t0 = time.time()
         orc = OracleS2ST(cfg, syn.make_unity_state_dict(cfg, syn.DEFAULT_SEED, with_text_encoder=need_text_encoder, eos_ramp=syn.EOS_RAMP_BENCH),
                          None, tt, ct, cards.vocoder_lang_spkr_idx_map())
@@ -200,6 +208,31 @@ def main():
                 sec["items"].sort(key=lambda r: r["index"])
                 save()
                 print(f"b64eos: utterances {idx} in {time.time() - t1:.0f} s, text lengths {[len(s) for s in seqs]}", flush=True)
+        if need_long:
+            cut = [r["index"] for r in doc["b64eos"]["items"] if len(r["text_ids"]) >= EOS_TEXT_LEN]
+            todo = cut + [LONG_CHECK_INDEX]
+            items = []
+            for lo in range(0, len(todo), 4):
+                idx = todo[lo:lo + 4]
+                t1 = time.time()
+                fb, lens = orc.collate_fbank([syn.synthetic_waveform(i, 10.0).numpy() for i in idx])
+                seqs, speech_units, _, units, aux = orc.s2st(fb, lens, "fra", (1, 200), LONG_TEXT_LEN, vocode=False)
+                for j, i in enumerate(idx):
+                    nu, ncs = int(aux["unit_lens"][j]), int(aux["char_seq_lens"][j])
+                    top2 = torch.topk(aux["logits"][j, :nu], 2, dim=-1).values
+                    items.append({
+                        "index": int(i), "seconds": 10.0, "frames": int(lens[j]), "text_ids": [int(t) for t in seqs[j]],
+                        "char_ids": aux["char_seqs"][j, :ncs].tolist(), "durations": aux["durations"][j, :ncs].tolist(),
+                        "unit_len": nu, "units": units[j, :nu].tolist(), "speech_units": [int(u) for u in speech_units[j]],
+                        "unit_margins": _r(top2[:, 0] - top2[:, 1]), "text_margins": _r(aux["margins"][j])})
+                print(f"b64long: utterances {idx} in {time.time() - t1:.0f} s, text lengths {[len(s) for s in seqs]}", flush=True)
+            chk = next(r for r in items if r["index"] == LONG_CHECK_INDEX)
+            ref = next(r for r in doc["b64eos"]["items"] if r["index"] == LONG_CHECK_INDEX)
+            assert chk["text_ids"] == ref["text_ids"] and chk["units"] == ref["units"], "a row that stops on its own depends on the limit?"
+            doc["b64long"] = {"note": f"greedy, hard_max_seq_len {LONG_TEXT_LEN} (the reference default), the rows b64eos cut at "
+                                      f"{EOS_TEXT_LEN} + utterance {LONG_CHECK_INDEX} as a cross-check; eos_ramp weights; oracle chunks of 4",
+                              "cut_at_64": cut, "items": sorted(items, key=lambda r: r["index"])}
+            save()
         del orc
 
     if "medium" in want and "medium" not in doc:

@@ -67,6 +67,17 @@ def test_char_embedding_needs_the_piece_list():
         ck.convert_unity_checkpoint({"model": fs})
 
 
+def test_builtin_char_alphabet_offers_no_pieces_for_a_published_checkpoint():
+    """A card without `char_tokenizer_path` must not re-order a real `embed_char` table by the built-in alphabet: `pieces()`
+    is None there (-> the ValueError above), the synthetic list is a separate, explicit call."""
+    from seamless_communication_amd.tokenizer import CharTokenizer
+
+    tok = CharTokenizer(64)
+    assert tok.pieces() is None
+    syn = tok.synthetic_pieces()
+    assert syn[:4] == ["<s>", "<pad>", "</s>", "<unk>"] and len(syn) == len(set(syn)) and all(tok.token_to_index(c) == 4 + i for i, c in enumerate(syn[4:]))
+
+
 def test_vocoder_checkpoint_conversion_matches_the_reference_converter():
     """The reference's own convert_vocoder_checkpoint (models/vocoder/loader.py:20-36), cut out of its file and executed
     when /root/reference is present; the expectations below are its outputs either way."""

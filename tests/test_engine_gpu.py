@@ -275,3 +275,46 @@ def test_engine_feeds_the_speech_chain(report_dir):
     units, ulens, dur, cids, clens = hip.t2u_nar(hidden[:, : L - 1].contiguous(), ids[:, : L - 1].copy(), (out_lens - 1).tolist(), 1.0)
     assert cids.tolist() == aux["char_seqs"].tolist() and dur.tolist() == aux["durations"].tolist()
     assert units.tolist() == units_ref.tolist()
+
+
+def test_lanes_and_row_states_change_hands_between_requests_of_other_shapes(report_dir):
+    """An engine built for MORE than its requests ask for - 200 positions per K / V lane, encoder outputs 5 positions longer than
+    any request's - with as many row states as one request has rows, so that the second request gets the row states (and,
+    whatever order they retire in, the K / V lanes) the first one used: its shorter encoder output is projected row by row over
+    the previous occupant's (the stale tail is masked by the row's own length), its rows append their keys over the previous
+    hypotheses' in the lanes.  Three requests one after the other: full encoder width, 3 positions narrower, 1 narrower with the
+    last row's length cut.  Ids, lengths, scores and captured outputs equal the rows generated alone on the same inputs."""
+    from seamless_communication_amd.runtime import DecodeEngine
+
+    cfg, tt, hip, seqs, enc, enc_lens, src_len = _env(common.EOS_MIXED, 1)  # 8 rows
+    prefix = tt.target_prefix("fra")
+    n, S = enc.shape[0], enc.shape[1]
+    shapes = []
+    for cut, clip_last in ((0, 0), (3, 0), (1, 2)):
+        e = enc[:, : S - cut].contiguous()
+        lens = [min(x, S - cut) for x in enc_lens]
+        if clip_last:
+            lens[-1] = max(1, lens[-1] - clip_last)
+        shapes.append((e, lens))
+    eng = DecodeEngine(hip, max_len=200, s_enc=S + 5, slots=4, rows=n, poll=2)
+    try:
+        outs = []
+        for e, lens in shapes:  # one after the other: each request finds the previous one's row states and lanes
+            outs.append(_through_engine(hip, eng, e, lens, prefix, src_len, [(0, n)])[0])
+        st = eng.stats()
+    finally:
+        eng.close()
+    _log(report_dir, "engine_reuse", **st)
+    assert st["requests"] == 3 and st["rows_retired"] == 3 * n and st["max_live"] <= 4
+    assert st["self_kv_bytes"] == 2 * cfg.dec_layers * 4 * 200 * cfg.model_dim * 4  # lanes: slots x max_len, not row states
+    lens_seen = set()
+    for (e, lens), (ids, out_lens, scores, hid) in zip(shapes, outs):
+        alone = _alone(hip, e, lens, prefix, src_len)
+        for b in range(n):
+            a_ids, a_lens, a_scores, a_hid = alone[b]
+            k = int(a_lens[0])
+            lens_seen.add(k)
+            assert int(out_lens[b]) == k and ids[b].tolist() == a_ids[0].tolist(), b
+            assert scores[b] == a_scores[0], (b, scores[b], a_scores[0])
+            assert torch.equal(hid[b, : k - 1], a_hid[0, : k - 1]), b
+    assert len(lens_seen) >= 3, lens_seen

@@ -209,6 +209,45 @@ def test_ragged_lengths_through_the_decode_engine(gold, eos, report_dir, slots, 
         mb.close()
 
 
+def test_no_row_is_cut_at_the_reference_default_limits(gold, eos, report_dir):
+    """bench.py's workload since round 6: the SAME 64 utterances under the reference's default limits - hard_max_seq_len 1024
+    (inference/generator.py:72; the soft rule (1, 200) on ~1000 fbank frames never binds), no row is cut - through a 256-slot
+    engine built for 1024 positions per K / V lane (the self-attention K / V belongs to the slots' lanes: 51.5 GB at this size whatever the number
+    of row states).  The five rows the 64-token limit cut now run to their own EOS (65 ... 72 tokens, section b64long of the
+    fixture); every other row is the b64eos row.  Text ids, char ids, durations, units of every pass against the oracle's."""
+    from seamless_communication_amd.distributed import MicroBatcher
+    from seamless_communication_amd.inference import SequenceGeneratorOptions
+
+    tr, vsd, lang_map, _ = eos
+    opts = SequenceGeneratorOptions(beam_size=1, soft_max_seq_len=(1, 200))  # hard_max_seq_len: the default, 1024
+    assert opts.hard_max_seq_len == 1024
+    items, fixture = fg.ragged_items(gold, opts.hard_max_seq_len)
+    assert items is not None, fixture
+    cut = gold["b64long"]["cut_at_64"]
+    assert len(cut) >= 3 and all(64 < len(items[i]["text_ids"]) < 100 for i in cut)
+    wav = torch.stack(_waves(range(64), [10.0] * 64)).cuda()
+    ns = [wav.shape[1]] * 64
+    mb = MicroBatcher(tr, 4)
+    try:
+        max_len, s_enc = MicroBatcher.engine_geometry(tr, ns, opts)
+        assert max_len == opts.hard_max_seq_len
+        mb.enable_engine(max_len, s_enc, slots=256, rows=5 * 64, low_water=128, max_wait_ms=100)
+        outs = mb.predict_passes(wav, ns, 8, "S2ST", "fra", stagger_s=0.05, text_generation_opts=opts)
+        st = mb.engine.stats()
+        for k, (texts, units, wavs, text_ids, _) in enumerate(outs):
+            reports = [fg.compare(items[i], text_ids=text_ids[i]) for i in range(64)]
+            assert all(r["text"] for r in reports), (k, [r["index"] for r in reports if not r["text"]])
+            assert all(units[i] == items[i]["speech_units"] for i in range(64)), k
+            assert max(len(t) for t in text_ids) == max(len(items[i]["text_ids"]) for i in cut) > 64
+        for w, view in enumerate(mb.views):
+            _compare_batch(report_dir, f"eos_default_limits_worker{w}", items, list(range(64)), view.last_text_ids, view.last_t2u)
+        _log(report_dir, "eos_default_limits", fixture=fixture, self_kv_gb=st["self_kv_bytes"] / 1e9, cross_kv_gb=st["cross_kv_bytes"] / 1e9,
+             captured_gb=st["hidden_bytes"] / 1e9, steps_per_pass=st["steps"] / 8, rows_per_step=st["row_steps"] / max(1, st["steps"]))
+        assert st["self_kv_bytes"] == 2 * 24 * 256 * 1024 * 1024 * 4 and st["rows_retired"] == 8 * 64
+    finally:
+        mb.close()
+
+
 def test_ragged_lengths_one_batch_and_alone(gold, eos, report_dir):
     """40 rows on one stream (the 33..64-row step instantiations) and single utterances: the shortest hypothesis of the
     fixture (it may consist of EOS alone), the longest, and one in between."""
