@@ -82,6 +82,9 @@ def parse_args():
     ap.add_argument("--microbatches", type=int, default=0,
                     help="host threads (one forked handle + HIP stream each): passes in flight (pipeline, default 3) or slices of the "
                          "batch (lockstep / freerun, default 2)")
+    ap.add_argument("--scaling-table", action="store_true",
+                    help="with --gpus N: run N' = 1, 2, 4, ... up to N back to back (one launch each) and print every run's line plus a "
+                         "closing {\"scaling_table\": [...]} line")
     ap.add_argument("--workload", default="ragged", choices=["ragged", "fixed"],
                     help="ragged: eos_ramp weights, hypotheses stop on their own (text lengths ~8..64, mean ~40); fixed: every hypothesis "
                          "cut at --text-len (the workload of rounds 1-3)")
@@ -419,6 +422,44 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def scaling_table(args) -> int:
+    """`python bench.py --gpus N --scaling-table`: this command line once per N' in {1, 2, 4, 8} up to N, back to back on this node
+    (each a launch of its own, like the driver's SCALE runs), every run's JSON line passed through on stdout and one closing
+    line {"scaling_table": [...]} with utterances/s per N' and per GPU - absolute numbers; efficiency is for the reader (and
+    the driver) to compute.  Needs N visible devices (fails loudly otherwise, unless --dry-run)."""
+    import subprocess
+
+    if not args.dry_run:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus} --scaling-table: only {n_dev} HIP device(s) visible on this node")
+    rest, skip = [], False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+        elif a == "--gpus":
+            skip = True
+        elif not (a.startswith("--gpus=") or a == "--scaling-table"):
+            rest.append(a)
+    rows, rc = [], 0
+    for n in [k for k in (1, 2, 4, 8, 16) if k <= args.gpus]:
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), *rest]
+        log(f"scaling table: {' '.join(cmd)}")
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            rows.append({"n_gpus": n, "error": f"exit {r.returncode}"})
+            rc = rc or r.returncode or 1
+            continue
+        print(lines[-1], flush=True)
+        d = json.loads(lines[-1])
+        v = d.get("value") if "value" in d else d.get("host_ms_per_pass")
+        rows.append({"n_gpus": n, "value": v, "unit": d.get("unit"), "per_gpu": (v / n if isinstance(v, (int, float)) and "value" in d else None),
+                     "ms_per_step": d.get("ms_per_step")})
+    print(json.dumps({"scaling_table": rows, "scaling": "weak", "note": "one launch per row, same node, back to back"}), flush=True)
+    return rc
+
+
 class _HostStubModel:
     """Stands in for runtime.HipS2STModel in the host-loop dry run: every stage returns arrays of the shapes and sizes of the
     benchmark workload (64 utterances, text lengths 9 .. 64, ~526 units each) at once - no device, no device time.  What is left
@@ -583,6 +624,8 @@ def main():
         args.microbatches = (max(3, args.engine_slots // 32) if args.engine_slots > 0 else 3) if args.pipeline_passes else 2
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
+    if args.scaling_table and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(scaling_table(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     if args.dry_run:
@@ -593,21 +636,23 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` (self-launching) or "
                          f"torch.distributed.run --nproc-per-node N")
+    rank_cores = []
+    if world > 1:
+        # FIRST thing a rank does: keep to its own share of the host's cores - its pass workers, the decode engine's thread, the torch
+        # threads that build the synthetic weights and the helper threads the HIP runtime and RCCL start below inherit the mask
+        # (8 ranks x all cores at once would stretch the load phase and jitter the step loop)
+        from seamless_communication_amd.distributed import pin_rank_to_cores
+
+        rank_cores = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the HIP path has no CPU fallback")
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no device ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    rank_cores = []
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
-        # every rank keeps to its own share of the host's cores: its pass workers, the decode engine's thread and the torch threads
-        # that build the synthetic weights (8 ranks x all cores at once would stretch the load phase and jitter the step loop)
-        from seamless_communication_amd.distributed import pin_rank_to_cores
-
-        rank_cores = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     from seamless_communication_amd import cards, synthetic as syn
     from seamless_communication_amd.distributed import MicroBatcher, all_gather_ragged_lists

@@ -9,7 +9,6 @@
 #   rocprof      rocprofv3 --kernel-trace --stats of `bench.py $PROF_ARGS` (the driver's command line by default)
 #   pmc          FETCH_SIZE / WRITE_SIZE passes (separate runs) + scripts/pmc_summary.py
 #   dstep        scripts/dstep_bench.py (decoder step timing per batch size)         dtrace   kernel trace of it + gap analysis
-#   dtouch       the same with the weight toucher at several settings (SC_DSTEP_TOUCH), ids compared with the default run
 #   chain        scripts/chain_bench.py (each decoder-step kernel as a dependent chain in a replayed graph)
 #   micro        every scripts/micro/*.hip compiled with hipcc and run
 #   sqpmc        SQ / TCP counters of the encoder GEMM (three --pmc passes of scripts/gemm_bench.py) -> TAG_gemm_pmc_sq.txt
@@ -122,14 +121,6 @@ for task in "$@"; do
       find gpurun_out/${TAG}_sqb -name "*.csv" -size +2M -delete 2>/dev/null ;;
     dstep)
       ( timeout 300 python scripts/dstep_bench.py $DSTEP_ARGS > ${O}_dstep.txt 2>&1; echo "exit $?" >> ${O}_dstep.txt ); grep -v amdgpu ${O}_dstep.txt | tail -40 | cut -c1-200 ;;
-    dtouch)
-      # decoder step with the weight toucher (SC_DSTEP_TOUCH=<layers ahead>, default off) against the default, same process each;
-      # ids are compared by dstep_bench itself (it checks the generated ids against the default run's file)
-      for cfgv in "0 64" "1 64" "2 64" "1 16" "1 128"; do
-        set -- $cfgv
-        ( SC_DSTEP_TOUCH=$1 SC_DSTEP_TOUCH_WGS=$2 timeout 200 python scripts/dstep_bench.py --rows 1,32,64 --ids-file /tmp/dstep_ids.json > ${O}_dtouch_$1_$2.txt 2>&1; echo "exit $?" >> ${O}_dtouch_$1_$2.txt )
-        echo "--- SC_DSTEP_TOUCH=$1 WGS=$2"; grep -v amdgpu ${O}_dtouch_$1_$2.txt | tail -8 | cut -c1-200
-      done ;;
     dtrace)
       # kernel trace of the decoder-step bench: durations + gaps between consecutive launches (scripts/trace_gaps.py)
       rm -rf gpurun_out/${TAG}_dtrace

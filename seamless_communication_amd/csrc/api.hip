@@ -510,7 +510,8 @@ int32_t sc_ngram_blocked_tokens(const int32_t* h_seq, int32_t len, int32_t ngram
 // --------------------------------------------------------------------------- //
 // kernel-level entry points for the parity tests (default stream, synchronous)
 // --------------------------------------------------------------------------- //
-int sc_op_knob(const char* name, int dflt) { return name ? sc::knob::value(name, dflt) : dflt; }
+// test hook: an unknown name (a typo in a script) answers with the default instead of taking the process down
+int sc_op_knob(const char* name, int dflt) { return sc::knob::known(name) ? sc::knob::value(name, dflt) : dflt; }
 
 int sc_op_force_general_gemm(int on) {
     sc::g_force_general_gemm.store(on ? 1 : 0);

@@ -40,7 +40,6 @@ const Knob knob_table[] = {
     {"SC_PS_TILE", 0, "DMA GEMM: largest tile"}, {"SC_PS_MIN256", 0, "DMA GEMM: tiles needed for 256 x 256"},
     {"SC_PS_MIN128", 0, "DMA GEMM: tiles needed for 128 x 128"},
     {"SC_PRESPLIT", 0, "0: Conformer operands split on the fly"}, {"SC_ENC_FUSE", 0, "0: separate Conformer element-wise launches"},
-    {"SC_DSTEP_TOUCH", 0, "weight toucher: layers ahead"}, {"SC_DSTEP_TOUCH_WGS", 0, "weight toucher: workgroups"},
     {"SC_D3_RG_SMALL", 0, "decoder step: rows per row group, N = 1024 products"}, {"SC_D3_RG_FFN", 0, "decoder step: rows per row group, FFN-in"},
     {"SC_G3_STATIONARY", 0, "row-group products of wide steps: 0 one workgroup per row group, n = workgroup budget of the weight-stationary launch"},
     {"SC_G3_TILES", 0, "0: FFN-out of wide steps on the weight-stationary row-group walk instead of tile-owning waves"},
@@ -77,13 +76,22 @@ const State& state() {
     }();
     return st;
 }
-int find(const char* name) {
+int lookup(const char* name) {
     for (int i = 0; i < N_KNOBS; ++i)
         if (strcmp(knob_table[i].name, name) == 0) return i;
+    return -1;
+}
+// internal callers name their switch with a literal: a name missing from the table is a programming error, caught by
+// tests/test_cabi_cpu.py (every call site is checked against the table) before it can fire inside a stream capture
+int find(const char* name) {
+    const int i = lookup(name);
+    if (i >= 0) return i;
     fprintf(stderr, "libseamless_hip: switch %s is not in the knob table (common.cpp)\n", name);
     abort();
 }
 }  // namespace
+
+bool known(const char* name) { return name && lookup(name) >= 0; }
 
 int value(const char* name, int dflt) {
     const int i = find(name);

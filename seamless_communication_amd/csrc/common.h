@@ -47,6 +47,7 @@ namespace knob {
 int value(const char* name, int dflt);  // the integer the switch is set to, `dflt` when unset (or gated off)
 bool is_set(const char* name);          // set to anything (gated like value)
 int live(const char* name, int dflt);   // re-read now
+bool known(const char* name);           // the name is in the table (value / is_set / live abort on an unknown name)
 void report_once();                     // sc_load: one stderr line per switch found in the environment
 }  // namespace knob
 

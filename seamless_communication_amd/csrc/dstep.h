@@ -42,7 +42,6 @@ struct StepCtx {
     __half *attH = nullptr, *attL = nullptr;  // attention output       [M/8][rb][8]
     __half *wideH = nullptr, *wideL = nullptr;  // FFN inner activation [ffn/8][rb][8]
     Buf<__half> planes;                       // backing store of the six planes
-    int touch_ahead = 0;  // > 0: the weight toucher runs this many layers ahead on Model::touch_stream (SC_DSTEP_TOUCH)
     // third-generation step (k_dstep3.hip): fp32 residual stream in k-group-major order, complete q / k / v rows
     bool gen3 = false;
     float* xg = nullptr;    // [M/8][rb][8]

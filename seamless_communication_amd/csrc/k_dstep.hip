@@ -643,18 +643,6 @@ __global__ __launch_bounds__(256) void rows_to_planes_kernel(const float* __rest
     reinterpret_cast<_Float16*>(Hl)[off] = (_Float16)(v - (float)hh);
 }
 
-// touch_lines_kernel: see TouchArgs (kernels.h).  Every load is independent; the xor keeps them alive, the store never
-// happens in practice (and would only hit the sink word).
-__global__ __launch_bounds__(256) void touch_lines_kernel(TouchArgs a) {
-    const uint32_t t0 = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
-    unsigned acc = 0;
-    for (int r = 0; r < a.n; ++r) {
-        const unsigned* p = static_cast<const unsigned*>(a.base[r]);
-        for (uint32_t i = t0; i < a.lines[r]; i += stride) acc ^= p[(size_t)i * 32];
-    }
-    if (acc == 0x9e3779b9u && a.sink) a.sink[0] = acc;
-}
-
 }  // namespace
 
 // --------------------------------------------------------------------------------------------- //
@@ -776,12 +764,6 @@ void launch_dattn(const DAttnArgs& a, bool cross, hipStream_t s) {
         hipLaunchKernelGGL((dattn_kernel<false, true, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
     }
     else hipLaunchKernelGGL((dattn_kernel<false, false, false>), dim3(cdiv(pairs, ppw)), dim3(64 * ppw), 0, s, a);
-    SC_LAUNCH_CHECK();
-}
-
-void launch_touch(const TouchArgs& a, int workgroups, hipStream_t s) {
-    if (a.n <= 0 || workgroups <= 0) return;
-    hipLaunchKernelGGL(touch_lines_kernel, dim3(workgroups), dim3(256), 0, s, a);
     SC_LAUNCH_CHECK();
 }
 

@@ -276,17 +276,6 @@ struct DAttnArgs {
 };
 void launch_dattn(const DAttnArgs& a, bool cross, hipStream_t s);
 void launch_planes_to_rows(const __half* Hh, const __half* Hl, int RB, float* out, int64_t ldo, int rows, int C, hipStream_t s);
-// Weight toucher (SC_DSTEP_TOUCH, off by default): one 4-byte load per 128-byte line of up to 8 ranges, results discarded.
-// Run on a side stream one layer ahead of the decoder-step chain it leaves that layer's weights in the memory-side cache
-// (and partly in the L2s) so that the chain's kernels do not each pay a cold HBM round trip (scripts/micro/prefetch_chain.hip
-// measures the effect in isolation).
-struct TouchArgs {
-    const void* base[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    uint32_t lines[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 128-byte lines per range (a range ends inside its allocation)
-    int n = 0;
-    unsigned* sink = nullptr;
-};
-void launch_touch(const TouchArgs& a, int workgroups, hipStream_t s);
 void launch_rows_to_planes(const float* x, int64_t ldx, int rows, int C, int RB, __half* Hh, __half* Hl, hipStream_t s);
 
 // ---- decoder step, third generation (k_dstep3.hip) ----------------------------------------------------------------

@@ -284,10 +284,6 @@ struct Model : ModelData {
 
     std::unique_ptr<MmaState> mma;  // buffers come from `pool`: released before it (see ~Model)
 
-    // SC_DSTEP_TOUCH (off by default): side stream, per-layer fork events + the join event of the weight toucher that runs
-    // ahead of the greedy decoder step (model_decoder.hip: decoder_step2); created before the step is captured
-    hipStream_t touch_stream = nullptr;
-    std::vector<hipEvent_t> touch_events;
 
     // buffers + captured step graph of the greedy text generation, kept across calls (model_decoder.hip)
     std::unique_ptr<DecodeSession, void (*)(DecodeSession*)> dec_session{nullptr, delete_decode_session};

@@ -278,42 +278,6 @@ static void gemv2(Model& m, StepCtx& c, const __half* Ah, const __half* Al, cons
     *splits = gemvp_splits(L.in, want_splits);
 }
 
-// ---- weight toucher (SC_DSTEP_TOUCH=<layers ahead>, off by default; measured next to the default in scripts/dstep_bench.py)
-// The chain's kernels each wait for their weights to come cold from HBM; their addresses are known long before.  A side
-// stream forked off the step touches the packed weights of layer li + ahead when the chain enters layer li (one line per
-// 128 bytes), so that they sit in the memory-side cache when the chain gets there.  Results cannot change: the toucher
-// only reads.  The fork / join events are captured into the step graph like any other dependency.
-int touch_setting() {
-    static const int v = std::max(0, knob::value("SC_DSTEP_TOUCH", 0));
-    return v;
-}
-
-// streams and events cannot be created while the step is being captured: called by the owner of the session beforehand
-void prepare_touch(Model& m, int n_layers) {
-    if (!m.touch_stream) {
-        int lo = 0, hi = 0;
-        SC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        SC_HIP(hipStreamCreateWithPriority(&m.touch_stream, hipStreamNonBlocking, lo));  // lowest priority: the chain goes first
-    }
-    while ((int)m.touch_events.size() < n_layers + 1) {
-        hipEvent_t e = nullptr;
-        SC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        m.touch_events.push_back(e);
-    }
-}
-
-static void touch_layer(Model& m, const DecoderLayer& l) {
-    static const int wgs = std::max(1, knob::value("SC_DSTEP_TOUCH_WGS", 64));
-    TouchArgs t;
-    for (const Linear* L : {&l.qkv, &l.self_out, &l.cross_q, &l.cross_out, &l.ffn_in, &l.ffn_out}) {
-        if (!L->wp) continue;
-        t.base[t.n] = L->wp;
-        t.lines[t.n] = (uint32_t)(packed_weight_halfs(L->out, L->in) * 2 / 128);  // fragments are 1 KiB: whole lines
-        ++t.n;
-    }
-    launch_touch(t, wgs, m.touch_stream);
-}
-
 // One decoder step for all batch rows on the second-generation kernels: 11 launches per layer
 // (QKV | self-attention | out-proj | +res+LN | q | cross-attention | out-proj | +res+LN | FFN-in | FFN-out | +res+LN).
 void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
@@ -323,16 +287,10 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
     const int n_layers = (int)layers.size();
     launch_embed_ln(c.d_tok, W.embed, sqrtf((float)M), W.pos, c.d_pos, c.x, layers[0].self_ln.g, layers[0].self_ln.b, c.hH, c.hL,
                     c.rb, nb, M, m.stream);
-    const bool touch = c.touch_ahead > 0 && m.touch_stream && (int)m.touch_events.size() > n_layers;
     for (int li = 0; li < n_layers; ++li) {
         const DecoderLayer& l = layers[li];
         const bool last = li + 1 == n_layers;
         int sp = 1;
-        if (touch && li + c.touch_ahead < n_layers) {  // fork: the toucher of layer li + ahead starts when the chain gets here
-            SC_HIP(hipEventRecord(m.touch_events[li], m.stream));
-            SC_HIP(hipStreamWaitEvent(m.touch_stream, m.touch_events[li], 0));
-            touch_layer(m, layers[li + c.touch_ahead]);
-        }
         // self attention
         gemv2(m, c, c.hH, c.hL, l.qkv, 2, &sp);
         DAttnArgs a;
@@ -415,10 +373,6 @@ void decoder_step2(Model& m, StepCtx& c, bool project, const DecStack& W) {
         } else {
             launch_reduce_ln(c.partial, sp, l.ffn_out.b, c.x, next.g, next.b, c.hH, c.hL, c.rb, nullptr, 0, 0, nullptr, nb, M, m.stream);
         }
-    }
-    if (touch && n_layers > c.touch_ahead) {  // join (a captured graph needs every forked stream back)
-        SC_HIP(hipEventRecord(m.touch_events[n_layers], m.touch_stream));
-        SC_HIP(hipStreamWaitEvent(m.stream, m.touch_events[n_layers], 0));
     }
     if (c.pchoose) {
         SC_CHECK(nb == 1 && W.pchoose && m.mma_qe_w && M <= 1024, "p_choose hook: one row on the monotonic stack only");
@@ -1128,10 +1082,6 @@ void setup_session(Model& m, DecodeSession& S, int n, int max_len, int s_enc, bo
             c.rg_ffn = std::min(32, std::max(1, env_int("SC_D3_RG_FFN", 32)));
             c.ffn_in_mode = std::min(2, std::max(0, env_int("SC_D3_FFN_IN", 1)));
             c.ffn_out_mode = std::min(2, std::max(0, env_int("SC_D3_FFN_OUT", 1)));
-        }
-        if (touch_setting() > 0 && !forced) {  // greedy generation only: the session owns the captured step
-            prepare_touch(m, cfg.dec_layers);
-            c.touch_ahead = touch_setting();
         }
     } else {
         c.am_tiles = fused_argmax ? skinny_argmax_tiles(n, cfg.text_vocab_size) : 0;

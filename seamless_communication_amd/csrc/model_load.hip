@@ -91,8 +91,6 @@ Model::~Model() {
     mma.reset();
     dec_session.reset();
     if (order_event) (void)hipEventDestroy(order_event);
-    for (hipEvent_t e : touch_events) (void)hipEventDestroy(e);
-    if (touch_stream) (void)hipStreamDestroy(touch_stream);
     for (auto& c : side) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         c->pool.release_all();

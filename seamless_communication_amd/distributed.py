@@ -39,8 +39,12 @@ def balanced_shards(lengths: Sequence[int], world: int) -> List[List[int]]:
 
 def pin_rank_to_cores(local_rank: int, local_world: int) -> List[int]:
     """Gives every rank of a node its own slice of the cores this process may run on (host threads of a rank: the pass workers,
-    the decode engine's thread, the weight builder's torch threads) - eight ranks whose threads roam over all cores take the
-    step loop's host time away from each other.  Returns the cores of this rank ([] when the platform has no affinity call)."""
+    the decode engine's thread, the weight builder's torch threads, the HIP runtime's and RCCL's helpers) - eight ranks whose
+    threads roam over all cores take the step loop's host time away from each other.  Call it FIRST - before
+    ``init_process_group`` and before the first device call: ``sched_setaffinity(0, ...)`` moves the calling thread only and
+    threads inherit the mask of the thread that creates them.  Threads that already exist (the interpreter's, a library's
+    started at import) are moved one by one through /proc/self/task.  Returns the cores of this rank ([] when the platform has
+    no affinity call)."""
     import os
 
     if not hasattr(os, "sched_getaffinity") or local_world <= 1:
@@ -49,17 +53,30 @@ def pin_rank_to_cores(local_rank: int, local_world: int) -> List[int]:
     per = max(1, len(cores) // local_world)
     mine = cores[local_rank * per: (local_rank + 1) * per] or cores[-per:]
     os.sched_setaffinity(0, mine)
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), mine)
+            except (OSError, ValueError):  # the thread ended in between
+                pass
+    except OSError:  # no procfs: the calling thread and everything it starts from here on are pinned
+        pass
     torch.set_num_threads(max(1, min(per, 16)))
     return mine
 
 
 def _gather_rows(t: torch.Tensor, world: int) -> torch.Tensor:
     """all-gather of equally shaped (rows, cols) int32 tensors into one (world, rows, cols) tensor on the same device:
-    one collective, no host round trip (RCCL on GPUs; gloo on CPU for the tests)."""
+    one collective, no host round trip (RCCL on GPUs; gloo on CPU for the tests).  RCCL has the flat form: an error there is
+    an error of the job and is raised (retrying with another collective after a failed one would hide it once and then hang
+    with the ranks out of step).  Only backends known not to implement the flat form take the list form."""
     out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out.view(-1), t.reshape(-1))
+        return out
     try:
         dist.all_gather_into_tensor(out.view(-1), t.reshape(-1))
-    except (RuntimeError, NotImplementedError):  # a backend without the flat form
+    except (RuntimeError, NotImplementedError):  # gloo builds without the flat form
         parts = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
         out = torch.stack(parts)

@@ -50,3 +50,54 @@ def test_host_loop_of_two_ranks_stays_far_below_the_gpu_pass_time():
     # it is one RCCL all-gather of ids that already live on the device.  The bound is on what is left: the rank's own host work.
     assert h["host_ms_per_pass"] - h["gather_ms_per_pass_gloo"] < 150.0, h
     assert h["host_ms_per_pass"] < 1000.0, h
+
+
+def test_scaling_table_runs_every_rank_count_in_one_invocation():
+    """`--gpus N --scaling-table`: N' = 1, 2, 4, ... up to N back to back, each a launch of its own; every run's line on stdout and
+    a closing {"scaling_table": [...]} line (north star: throughput "reported at 1/2/4/8 GPUs")."""
+    r = _run("--gpus", "2", "--scaling-table", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert [l.get("n_gpus") for l in lines[:-1]] == [1, 2] and [l.get("ranks_seen") for l in lines[:-1]] == [1, 2]
+    assert [row["n_gpus"] for row in lines[-1]["scaling_table"]] == [1, 2]
+    r = _run("--gpus", "2", "--scaling-table")  # without devices: loud
+    assert r.returncode != 0 and "HIP device" in (r.stderr + r.stdout)
+
+
+def test_a_failed_rccl_collective_is_not_retried_with_another_one():
+    """distributed._gather_rows: on the `nccl` backend an error of the flat all-gather is the job's error (a retry with the list
+    form would hide it once and then hang with the ranks out of step); only other backends fall back."""
+    import torch
+    import torch.distributed as dist
+
+    from seamless_communication_amd import distributed as D
+
+    calls = []
+
+    class Boom(RuntimeError):
+        pass
+
+    def flat(out, t):
+        calls.append("flat")
+        raise Boom("collective failed")
+
+    def listed(parts, t):
+        calls.append("list")
+        for p in parts:
+            p.copy_(t)
+
+    saved = dist.all_gather_into_tensor, dist.all_gather, dist.get_backend
+    try:
+        dist.all_gather_into_tensor, dist.all_gather = flat, listed
+        dist.get_backend = lambda *a, **k: "nccl"
+        try:
+            D._gather_rows(torch.zeros(2, 3, dtype=torch.int32), 2)
+            raise AssertionError("the RCCL error was swallowed")
+        except Boom:
+            pass
+        assert calls == ["flat"]
+        dist.get_backend = lambda *a, **k: "gloo"
+        out = D._gather_rows(torch.ones(2, 3, dtype=torch.int32), 2)
+        assert calls == ["flat", "flat", "list"] and out.shape == (2, 2, 3) and int(out.sum()) == 12
+    finally:
+        dist.all_gather_into_tensor, dist.all_gather, dist.get_backend = saved

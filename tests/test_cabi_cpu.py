@@ -152,3 +152,25 @@ def test_switches_that_change_results_need_the_debug_gate(lib_path):
     assert run() == ["0", "-1", "3", "256"]
     assert run(SC_SPLIT_MODE="1", SC_DECODER_GEN1="1", SC_VOC_STREAMS="1", SC_PS_TILE="128") == ["0", "-1", "1", "128"]
     assert run(SC_SPLIT_MODE="1", SC_DECODER_GEN1="1", SC_DEBUG_NUMERICS="1") == ["1", "1", "3", "256"]
+
+
+def test_every_switch_the_sources_read_is_in_the_table(lib_path):
+    """knob::value / is_set / live abort on a name that is missing from the table in csrc/common.cpp (they are called with
+    literals; a miss is a programming error that would otherwise fire the first time that code path runs - possibly inside a
+    stream capture).  Every call site of the sources is checked here; the test hook `sc_op_knob` answers an unknown name with
+    the default instead of aborting."""
+    import re
+
+    csrc = ROOT / "seamless_communication_amd" / "csrc"
+    table = set(re.findall(r'\{"(SC_[A-Z0-9_]+)",\s*[012],', (csrc / "common.cpp").read_text()))
+    assert len(table) > 20
+    used = {}
+    for f in sorted(csrc.glob("*.hip")) + sorted(csrc.glob("*.cpp")) + sorted(csrc.glob("*.h")):
+        for m in re.finditer(r'(?:knob::(?:value|is_set|live)|env_int|env_set)\(\s*"(SC_[A-Z0-9_]+)"', f.read_text()):
+            used.setdefault(m.group(1), f.name)
+    missing = {k: v for k, v in used.items() if k not in table}
+    assert not missing, missing
+    from seamless_communication_amd import _lib
+
+    lib = _lib.load_library()
+    assert lib.sc_op_knob(b"SC_NO_SUCH_SWITCH", 7) == 7
