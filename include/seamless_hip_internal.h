@@ -32,6 +32,9 @@ int sc_op_knob(const char* name, int dflt);
 /* 1: route every dense product to the general MFMA kernel instead of the double-buffered fast path
  * (the two produce identical bits; used by the parity tests and for A/B timing). */
 int sc_op_force_general_gemm(int on);
+/* the ResBlock op hooks below (sc_op_resblock_pair, sc_op_resblock_pair_ps, sc_op_mrf_fused) multiply the hi fp16 plane of
+ * their activations only - the vocoder's shipped variants - while this is on (default off: the two-plane variants) */
+int sc_op_single_plane(int on);
 int sc_op_layernorm(const float* d_x, const float* d_gamma, const float* d_beta, float* d_y, int32_t rows, int32_t C,
                     int32_t act);
 int sc_op_linear(const float* d_x, const void* d_w_f16, const float* d_bias, const float* d_res, float* d_y,

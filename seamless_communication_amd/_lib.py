@@ -144,6 +144,7 @@ SIGNATURES = {
     "sc_ngram_blocked_tokens": (C.c_int32, [_PI, C.c_int32, C.c_int32, _PI, C.c_int32]),
     "sc_op_knob": (C.c_int, [C.c_char_p, C.c_int]),
     "sc_op_force_general_gemm": (C.c_int, [C.c_int]),
+    "sc_op_single_plane": (C.c_int, [C.c_int]),
     "sc_op_layernorm": (C.c_int, [_P, _P, _P, _P, _i, _i, _i]),
     "sc_op_linear": (C.c_int, [_P, _P, _P, _P, _P, _i, _i, _i, _i, C.c_float, _i, _i]),
     "sc_op_skinny_linear": (C.c_int, [_P, _P, _P, _P, _P, _i, _i, _i, _i, C.c_float]),

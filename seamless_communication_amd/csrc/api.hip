@@ -1,4 +1,5 @@
 // extern "C" surface of libseamless_hip.so (declared in include/seamless_hip.h).
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -512,6 +513,12 @@ int32_t sc_ngram_blocked_tokens(const int32_t* h_seq, int32_t len, int32_t ngram
 // --------------------------------------------------------------------------- //
 // test hook: an unknown name (a typo in a script) answers with the default instead of taking the process down
 int sc_op_knob(const char* name, int dflt) { return sc::knob::known(name) ? sc::knob::value(name, dflt) : dflt; }
+
+static std::atomic<int> g_op_single{0};
+int sc_op_single_plane(int on) {
+    g_op_single.store(on ? 1 : 0);
+    return SC_OK;
+}
 
 int sc_op_force_general_gemm(int on) {
     sc::g_force_general_gemm.store(on ? 1 : 0);
@@ -1187,17 +1194,18 @@ int sc_op_resblock_pair_ps(const float* d_x, const void* d_w1_packed, const floa
     SC_CHECK(d_x && d_w1_packed && d_w2_packed && d_out && C % 32 == 0 && (k & 1), "sc_op_resblock_pair_ps: bad argument");
     OpScratch scratch;
     const size_t n = (size_t)nb * T * C;
+    const bool one = g_op_single.load() != 0;  // hi planes only: no lo plane is produced or read
     __half* xh = scratch.get<__half>(n);
-    __half* xl = scratch.get<__half>(n);
+    __half* xl = one ? nullptr : scratch.get<__half>(n);
     __half* th = scratch.get<__half>(n);
-    __half* tl = scratch.get<__half>(n);
+    __half* tl = one ? nullptr : scratch.get<__half>(n);
     launch_lrelu_split_f32(d_x, 0.1f, xh, xl, (int64_t)n, g_op_stream);
     Model tmp;
     Conv c1, c2;
     c1.w = static_cast<const __half*>(d_w1_packed), c1.b = d_b1, c1.cin = c1.cout = C, c1.k = k, c1.kpad = C * k;
     c2.w = static_cast<const __half*>(d_w2_packed), c2.b = d_b2, c2.cin = c2.cout = C, c2.k = k, c2.kpad = C * k;
-    conv1d_presplit(tmp, xh, xl, c1, nullptr, nullptr, th, tl, nb, T, (k * dil - dil) / 2, dil, nullptr, ACT_NONE, 0, nullptr, 0.1f);
-    conv1d_presplit(tmp, th, tl, c2, d_x, d_out, nullptr, nullptr, nb, T, (k - 1) / 2, 1, nullptr, ACT_NONE, 0, nullptr, 0.1f);
+    conv1d_presplit(tmp, xh, xl, c1, nullptr, nullptr, th, tl, nb, T, (k * dil - dil) / 2, dil, nullptr, ACT_NONE, 0, nullptr, 0.1f, one ? 0 : 1);
+    conv1d_presplit(tmp, th, tl, c2, d_x, d_out, nullptr, nullptr, nb, T, (k - 1) / 2, 1, nullptr, ACT_NONE, 0, nullptr, 0.1f, one ? 0 : 1);
     SC_HIP(hipStreamSynchronize(g_op_stream));
     SC_API_END
 }
@@ -1223,6 +1231,7 @@ int sc_op_resblock_pair(const float* d_x, const void* d_w1_packed, const float* 
     a.slope = slope;
     a.avg_a = d_avg_a;
     a.avg_b = d_avg_b;
+    a.single = g_op_single.load();
     launch_resblock_pair(a, g_op_stream);
     SC_HIP(hipStreamSynchronize(g_op_stream));
     SC_API_END
@@ -1249,6 +1258,7 @@ int sc_op_mrf_fused(const float* d_x, const void* const* d_w1_packed, const floa
         a.b1[q] = d_b1[q];
         a.b2[q] = d_b2[q];
     }
+    a.single = g_op_single.load();
     launch_mrf_fused(a, g_op_stream);
     SC_HIP(hipStreamSynchronize(g_op_stream));
     SC_API_END

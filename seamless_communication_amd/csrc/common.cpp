@@ -32,7 +32,7 @@ const Knob knob_table[] = {
     {"SC_DECODER_GEN1", 1, "decoder step on the first-generation kernels"},
     {"SC_DECODER_GEN2", 1, "decoder step on the second-generation chain"},
     {"SC_DECODE_STEPWISE", 1, "teacher-forced pass step by step instead of one batched forward"},
-    {"SC_VOC_SINGLE", 1, "precision study: vocoder ResBlock products on the hi fp16 plane only (bit 0 wide stages, bit 2 narrow stages)"},
+    {"SC_VOC_SPLIT", 1, "vocoder ResBlock products on both fp16 planes of their activations again (bit 0 wide stages, bit 2 narrow stages); default: hi plane only"},
     // same bits, another schedule / kernel variant
     {"SC_GEMM_GENERAL", 0, "general GEMM kernel instead of the fast path"}, {"SC_GEMM_PF2", 0, "GEMM prefetch depth"},
     {"SC_GEMM_GROUP_M", 0, "GEMM workgroup order"}, {"SC_GEMM_TILE", 0, "GEMM tile override"},

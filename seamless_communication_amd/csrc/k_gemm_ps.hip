@@ -99,8 +99,9 @@ __device__ __forceinline__ void ps_epilogue(const GemmPsArgs& p, const float* ep
                 }
                 const h4_t hi = __builtin_convertvector(v, h4_t);
                 *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(p.Ch) + m * p.ldcs + col) = hi;
-                *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(p.Cl) + m * p.ldcs + col) =
-                    __builtin_convertvector(v - __builtin_convertvector(hi, f4_t), h4_t);
+                if (p.Cl)  // null: the consumer multiplies the hi plane only (GemmPsArgs::split == 0), no lo plane is produced
+                    *reinterpret_cast<h4_t*>(reinterpret_cast<_Float16*>(p.Cl) + m * p.ldcs + col) =
+                        __builtin_convertvector(v - __builtin_convertvector(hi, f4_t), h4_t);
             }
         } else {
 #pragma unroll
@@ -113,7 +114,7 @@ __device__ __forceinline__ void ps_epilogue(const GemmPsArgs& p, const float* ep
                     if (p.plane_neg_slope != 1.0f) x = fmaxf(x, 0.f) + p.plane_neg_slope * fminf(x, 0.f);
                     const _Float16 h = (_Float16)x;
                     reinterpret_cast<_Float16*>(p.Ch)[m * p.ldcs + col + e] = h;
-                    reinterpret_cast<_Float16*>(p.Cl)[m * p.ldcs + col + e] = (_Float16)(x - (float)h);
+                    if (p.Cl) reinterpret_cast<_Float16*>(p.Cl)[m * p.ldcs + col + e] = (_Float16)(x - (float)h);
                 }
             }
         }
@@ -703,8 +704,8 @@ int ps_tile(int M, int N) {
 }  // namespace
 
 void launch_gemm_presplit(const GemmPsArgs& a, hipStream_t s) {
-    SC_CHECK(a.Ah && a.Al && a.W && (a.C || a.Ch || a.amax), "presplit gemm: null operand");
-    SC_CHECK((a.Ch == nullptr) == (a.Cl == nullptr), "presplit gemm: Ch/Cl must be given together");
+    SC_CHECK(a.Ah && (a.Al || !a.split) && a.W && (a.C || a.Ch || a.amax), "presplit gemm: null operand");
+    SC_CHECK(a.Ch || !a.Cl, "presplit gemm: a lo output plane needs its hi plane");
     SC_CHECK(a.M > 0 && a.N > 0 && a.K > 0 && a.K % PBK == 0, "presplit gemm: M=%d N=%d K=%d (K must be a multiple of 32)", a.M, a.N, a.K);
     SC_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldw >= a.K, "presplit gemm: lda=%lld ldw=%lld", (long long)a.lda,
              (long long)a.ldw);

@@ -446,9 +446,10 @@ __global__ void lrelu_split_f32_kernel(const float* __restrict__ x, float neg_sl
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f) + neg_slope * fminf(v[e], 0.f);  // the expression of k_gemm2.hip's in_act
         const h4_t h = __builtin_convertvector(v, h4_t);
         reinterpret_cast<h4_t*>(hi)[i] = h;
-        reinterpret_cast<h4_t*>(lo)[i] = __builtin_convertvector(v - __builtin_convertvector(h, f4_t), h4_t);
+        if (lo) reinterpret_cast<h4_t*>(lo)[i] = __builtin_convertvector(v - __builtin_convertvector(h, f4_t), h4_t);
     }
 }
+// lo == null: the hi plane only (consumers that multiply one plane)
 void launch_lrelu_split_f32(const float* x, float neg_slope, __half* hi, __half* lo, int64_t n, hipStream_t s) {
     SC_CHECK(n % 4 == 0, "lrelu_split_f32: n must be a multiple of 4");
     if (n <= 0) return;

@@ -89,10 +89,11 @@ __device__ __forceinline__ void conv_from_lds(const _Float16* __restrict__ ah_pl
 // [chunk0*16, (chunk0 + nch)*16) of its packed weight row.  Per chunk and wave the global-path variant above pulls
 // NF KB through the CU's vector L1 for 2*NF MFMAs, i.e. up to 16 B/clk per wave with 12-20 waves per CU: the L1,
 // not HBM or the matrix pipe, was the limiter (profiles/r1_bench_b64.json: 0.9-1.8 TB/s, 90-190 TFLOP/s).
-template <int C, int NF>
+// SINGLE: the hi plane only - one matrix instruction per fragment, the lo plane is neither read nor (by the callers) produced
+template <int C, int NF, bool SINGLE = false>
 __device__ __forceinline__ void conv_from_lds_w(const _Float16* __restrict__ ah_plane, const _Float16* __restrict__ al_plane,
                                                 int a_row0, int tap_step, int tap0, int ntaps, const _Float16* __restrict__ sW,
-                                                int ldb, int lane, float16_t (&acc)[NF], bool single = false) {
+                                                int ldb, int lane, float16_t (&acc)[NF]) {
     constexpr int CS = C + 8;
     constexpr int CPT = C / 16;
     const int koff = (lane >> 5) * 8;
@@ -111,12 +112,13 @@ __device__ __forceinline__ void conv_from_lds_w(const _Float16* __restrict__ ah_
         for (int cc = 0; cc < CPT; ++cc) {
             const int a_off = a_base + (tap0 + t) * tap_step * CS + cc * 16;
             const half8_t ah = *reinterpret_cast<const half8_t*>(ah_plane + a_off);
-            const half8_t al = *reinterpret_cast<const half8_t*>(al_plane + a_off);
+            half8_t al = zero8;
+            if (!SINGLE) al = *reinterpret_cast<const half8_t*>(al_plane + a_off);
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) {
                 const half8_t b = wok[nf] ? *reinterpret_cast<const half8_t*>(sW + w_base[nf] + (t * CPT + cc) * 16) : zero8;
                 acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b, acc[nf], 0, 0, 0);
-                if (!single) acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[nf], 0, 0, 0);
+                if (!SINGLE) acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b, acc[nf], 0, 0, 0);
             }
         }
     }
@@ -163,7 +165,7 @@ __device__ __forceinline__ void tap_store(const TapRegs<C>& r, _Float16* sW, int
     }
 }
 
-template <int C>
+template <int C, bool SINGLE = false>
 __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int tiles) {
     constexpr int CS = C + 8;          // halfs per LDS row: 16-byte fragment reads of consecutive rows hit distinct banks
     constexpr int NF = (C + 31) / 32;  // 32-wide output column fragments (C = 16 uses half of one)
@@ -177,13 +179,15 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
     // conv2 addresses tmp rows [0, RB_M1 + k - 1) <= R0; rows >= RB_M1 only feed outputs that are not stored.
     // The tmp tile reuses the x planes (conv1 has consumed them by then), which keeps the workgroup at
     // 2 * R0 * CS halfs of LDS: 3 workgroups per CU at C = 64 instead of 1.
+    // SINGLE: no lo planes (half the activation LDS: more workgroups per CU); the epilogue tile (TT x (C + 4) floats) is the
+    // larger user of the front of the allocation then and sets where the weights start
     _Float16* xh = reinterpret_cast<_Float16*>(rb_smem);
-    _Float16* xl = xh + R0 * CS;
+    _Float16* xl = SINGLE ? xh : xh + R0 * CS;
     _Float16* th = xh;
     _Float16* tl = xl;
     // weights: the whole packed row per output channel (C <= 32: <= 22.5 KB), or one tap at a time, double buffered (C = 64)
     constexpr bool PER_TAP = C > 32;
-    _Float16* sW = xl + R0 * CS;
+    _Float16* sW = SINGLE ? xh + max(R0 * CS, RB_M1 * (C + 4) * 2) : xl + R0 * CS;
     const int ldb = (PER_TAP ? C : k * C) + 8;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -201,10 +205,12 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = lrelu(v[j], slope);
         const half4_t hi = __builtin_convertvector(v, half4_t);
-        const f32x4_t back = __builtin_convertvector(hi, f32x4_t);
-        const half4_t lo = __builtin_convertvector(v - back, half4_t);
         *reinterpret_cast<half4_t*>(xh + r * CS + c4 * 4) = hi;
-        *reinterpret_cast<half4_t*>(xl + r * CS + c4 * 4) = lo;
+        if (!SINGLE) {
+            const f32x4_t back = __builtin_convertvector(hi, f32x4_t);
+            const half4_t lo = __builtin_convertvector(v - back, half4_t);
+            *reinterpret_cast<half4_t*>(xl + r * CS + c4 * 4) = lo;
+        }
     }
     if (PER_TAP) stage_weights<C>(p.w1, p.ldw1, 0, C, sW, ldb, tid);
     else stage_weights<C>(p.w1, p.ldw1, 0, k * C, sW, ldb, tid);
@@ -221,12 +227,12 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
             TapRegs<C> wr;
             for (int t = 0; t < k; ++t) {  // tap t from buffer t&1 while tap t+1 travels: registers, then the other buffer
                 if (t + 1 < k) tap_load<C>(p.w1, p.ldw1, (t + 1) * C, tid, wr);
-                conv_from_lds_w<C, NF>(xh, xl, 32 * wave, dil, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc, p.single != 0);
+                conv_from_lds_w<C, NF, SINGLE>(xh, xl, 32 * wave, dil, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc);
                 if (t + 1 < k) tap_store<C>(wr, sW + ((t + 1) & 1) * C * ldb, ldb, tid);  // read last at tap t-1: barrier since
                 __syncthreads();
             }
         } else {
-            conv_from_lds_w<C, NF>(xh, xl, 32 * wave, dil, 0, k, sW, ldb, lane, acc, p.single != 0);
+            conv_from_lds_w<C, NF, SINGLE>(xh, xl, 32 * wave, dil, 0, k, sW, ldb, lane, acc);
             __syncthreads();  // every wave is done reading x (and W1) before the tmp tile / W2 overwrite them
         }
         if (PER_TAP) stage_weights<C>(p.w2, p.ldw2, 0, C, sW, ldb, tid);
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
                 v = lrelu(v, slope);
                 const _Float16 h = (_Float16)v;
                 th[j * CS + col] = h;
-                tl[j * CS + col] = (_Float16)(v - (float)h);
+                if (!SINGLE) tl[j * CS + col] = (_Float16)(v - (float)h);
             }
         }
     }
@@ -261,14 +267,14 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(ResPairArgs p, int t
             TapRegs<C> wr;
             for (int t = 0; t < k; ++t) {
                 if (t + 1 < k) tap_load<C>(p.w2, p.ldw2, (t + 1) * C, tid, wr);
-                conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc, p.single != 0);
+                conv_from_lds_w<C, NF, SINGLE>(th, tl, 32 * wave, 1, t, 1, sW + (t & 1) * C * ldb, ldb, lane, acc);
                 if (t + 1 < k) {
                     tap_store<C>(wr, sW + ((t + 1) & 1) * C * ldb, ldb, tid);
                     __syncthreads();
                 }
             }
         } else {
-            conv_from_lds_w<C, NF>(th, tl, 32 * wave, 1, 0, k, sW, ldb, lane, acc, p.single != 0);
+            conv_from_lds_w<C, NF, SINGLE>(th, tl, 32 * wave, 1, 0, k, sW, ldb, lane, acc);
         }
         // epilogue through LDS: (acc + bias) as a row-major fp32 tile over the (now dead) tmp planes, then 16 bytes per
         // lane: residual read, optional 3-way average and store are 4x fewer (and fully coalesced) memory instructions
@@ -371,9 +377,9 @@ __device__ __forceinline__ void mrf_w_dma(const __half* __restrict__ W, int64_t 
 // conv_from_lds_w for one 32-column fragment with the operands of chunk ch + 1 requested from LDS before the matrix
 // instructions of chunk ch are issued (same chunk order, hi then lo: same bits).  C = 16 fills only half of the 32 output
 // columns: lanes 16-31 multiply the weight rows of columns 0-15 again instead of branching around the read.
-template <int C>
+template <int C, bool SINGLE = false>
 __device__ __forceinline__ void mrf_conv(const _Float16* __restrict__ ph, const _Float16* __restrict__ pl, int a_row0, int tap_step, int k,
-                                         const _Float16* __restrict__ sW, int ldb, int lane, float16_t& acc, bool single = false) {
+                                         const _Float16* __restrict__ sW, int ldb, int lane, float16_t& acc) {
     constexpr int CS = C + 8;
     constexpr int CPT = C / 16;
     const int koff = (lane >> 5) * 8;
@@ -381,34 +387,35 @@ __device__ __forceinline__ void mrf_conv(const _Float16* __restrict__ ph, const 
     const int a_step = tap_step * CS;
     const int b_base = ((lane & 31) % C) * ldb + koff;
     const int nch = k * CPT;
-    half8_t h0, l0, b0, h1, l1, b1;
+    half8_t h0, l0 = {0, 0, 0, 0, 0, 0, 0, 0}, b0, h1, l1 = l0, b1;
 #define MRF_LD(CH, H, L, B)                                                              \
     do {                                                                                 \
         const int ao_ = a_base + ((CH) / CPT) * a_step + ((CH) % CPT) * 16;              \
         H = *reinterpret_cast<const half8_t*>(ph + ao_);                                 \
-        L = *reinterpret_cast<const half8_t*>(pl + ao_);                                 \
+        if (!SINGLE) L = *reinterpret_cast<const half8_t*>(pl + ao_);                    \
         B = *reinterpret_cast<const half8_t*>(sW + b_base + (CH) * 16);                  \
     } while (0)
     MRF_LD(0, h0, l0, b0);
     for (int ch = 0; ch < nch; ++ch) {
         if (ch + 1 < nch) MRF_LD(ch + 1, h1, l1, b1);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(h0, b0, acc, 0, 0, 0);
-        if (!single) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(l0, b0, acc, 0, 0, 0);
+        if (!SINGLE) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(l0, b0, acc, 0, 0, 0);
         h0 = h1, l0 = l1, b0 = b1;
     }
 #undef MRF_LD
 }
 
-// hi/lo planes of LeakyReLU(v) at plane row `row`
+// hi/lo planes of LeakyReLU(v) at plane row `row` (SINGLE: the hi plane only)
+template <bool SINGLE = false>
 __device__ __forceinline__ void mrf_put(_Float16* __restrict__ ph, _Float16* __restrict__ pl, int idx, float v, float slope) {
     v = fmaxf(v, slope * v);  // LeakyReLU for 0 < slope < 1, same bits as v > 0 ? v : slope * v
     const _Float16 h = (_Float16)v;
     ph[idx] = h;
-    pl[idx] = (_Float16)(v - (float)h);
+    if (!SINGLE) pl[idx] = (_Float16)(v - (float)h);
 }
 
 // EDGE: the tile reaches outside [0, T) and rows there must read / be forced to zero; interior tiles skip the tests
-template <int C, bool EDGE>
+template <int C, bool EDGE, bool SINGLE>
 __device__ __forceinline__ void mrf_tile(const MrfArgs& p, _Float16* __restrict__ ph, _Float16* __restrict__ pl, _Float16* __restrict__ sW1,
                                          _Float16* __restrict__ sW2, const float* __restrict__ sBias, int n, int t_first, int lane, int wave) {
     constexpr int CS = C + 8;
@@ -457,7 +464,7 @@ __device__ __forceinline__ void mrf_tile(const MrfArgs& p, _Float16* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 if (EDGE && !((inside >> r) & 1)) xr[r] = 0.f;
-                mrf_put(ph, pl, pbase + ((r & 3) + 8 * (r >> 2)) * CS, xr[r], slope);
+                mrf_put<SINGLE>(ph, pl, pbase + ((r & 3) + 8 * (r >> 2)) * CS, xr[r], slope);
             }
         } else {
 #pragma unroll
@@ -479,7 +486,7 @@ __device__ __forceinline__ void mrf_tile(const MrfArgs& p, _Float16* __restrict_
                 float16_t acc[1];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-                if (act) mrf_conv<C>(ph, pl, MRF_G + 32 * wave - hk * dil, dil, k, sW1, ldb, lane, acc[0], p.single != 0);
+                if (act) mrf_conv<C, SINGLE>(ph, pl, MRF_G + 32 * wave - hk * dil, dil, k, sW1, ldb, lane, acc[0]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this pair's second weights (DMA) have landed
                 __syncthreads();  // every wave is done with the x planes and with this pair's first weights
                 if (more) mrf_w_dma<C>(p.w1[qn], p.ldw1[qn], kn, sW1, lane, wave);
@@ -489,7 +496,7 @@ __device__ __forceinline__ void mrf_tile(const MrfArgs& p, _Float16* __restrict_
                     for (int r = 0; r < 16; ++r) {
                         float v = (acc[0][r] + b) * 1.0f;
                         if (EDGE && !((inside >> r) & 1)) v = 0.f;  // conv2 sees zero padding outside [0, T)
-                        mrf_put(ph, pl, pbase + ((r & 3) + 8 * (r >> 2)) * CS, v, slope);
+                        mrf_put<SINGLE>(ph, pl, pbase + ((r & 3) + 8 * (r >> 2)) * CS, v, slope);
                     }
                 }
                 __syncthreads();
@@ -501,7 +508,7 @@ __device__ __forceinline__ void mrf_tile(const MrfArgs& p, _Float16* __restrict_
                 float16_t acc[1];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-                if (act) mrf_conv<C>(ph, pl, MRF_G + 32 * wave - hk, 1, k, sW2, ldb, lane, acc[0], p.single != 0);
+                if (act) mrf_conv<C, SINGLE>(ph, pl, MRF_G + 32 * wave - hk, 1, k, sW2, ldb, lane, acc[0]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next pair's first weights (DMA) have landed
                 __syncthreads();  // every wave is done with the intermediate and with this pair's second weights
                 if (more) mrf_w_dma<C>(p.w2[qn], p.ldw2[qn], kn, sW2, lane, wave);
@@ -512,7 +519,7 @@ __device__ __forceinline__ void mrf_tile(const MrfArgs& p, _Float16* __restrict_
                         float v = (acc[0][r] + b) * 1.0f + xr[r];
                         if (EDGE && !((inside >> r) & 1)) v = 0.f;
                         xr[r] = v;
-                        if (d < 2) mrf_put(ph, pl, pbase + ((r & 3) + 8 * (r >> 2)) * CS, v, slope);
+                        if (d < 2) mrf_put<SINGLE>(ph, pl, pbase + ((r & 3) + 8 * (r >> 2)) * CS, v, slope);
                     }
                 }
                 if (d < 2) __syncthreads();  // after the last pair the next branch's x planes follow (no reader is left)
@@ -543,14 +550,15 @@ constexpr int mrf_w_halfs() {  // one weight image, rounded up to whole 1 KB DMA
     return (C * (MRF_KMAX * C / 8 + 1) + 63) / 64 * 512;
 }
 
-template <int C>
+template <int C, bool SINGLE = false>
 __global__ __launch_bounds__(MRF_THREADS) void mrf_fused_kernel(MrfArgs p, int tiles) {
     constexpr int CS = C + 8;
     constexpr int PR = MRF_R + 2 * MRF_G;  // plane rows
+    constexpr int NPL = SINGLE ? 1 : 2;    // activation planes in LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
     _Float16* const ph = reinterpret_cast<_Float16*>(rb_smem);
-    _Float16* const pl = ph + PR * CS;
-    _Float16* const sW1 = pl + PR * CS;
+    _Float16* const pl = SINGLE ? ph : ph + PR * CS;
+    _Float16* const sW1 = ph + NPL * PR * CS;
     _Float16* const sW2 = sW1 + mrf_w_halfs<C>();
     float* const sBias = reinterpret_cast<float*>(sW2 + mrf_w_halfs<C>());  // [18][C]: b1, b2 of pair 0, b1, b2 of pair 1, ...
 
@@ -575,12 +583,12 @@ __global__ __launch_bounds__(MRF_THREADS) void mrf_fused_kernel(MrfArgs p, int t
     }
     {
         const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = tid; i < 2 * PR * CS / 8; i += MRF_THREADS) reinterpret_cast<half8_t*>(ph)[i] = z;
+        for (int i = tid; i < NPL * PR * CS / 8; i += MRF_THREADS) reinterpret_cast<half8_t*>(ph)[i] = z;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t_first < 0 || t_first + MRF_R > p.T) mrf_tile<C, true>(p, ph, pl, sW1, sW2, sBias, n, t_first, lane, wave);
-    else mrf_tile<C, false>(p, ph, pl, sW1, sW2, sBias, n, t_first, lane, wave);
+    if (t_first < 0 || t_first + MRF_R > p.T) mrf_tile<C, true, SINGLE>(p, ph, pl, sW1, sW2, sBias, n, t_first, lane, wave);
+    else mrf_tile<C, false, SINGLE>(p, ph, pl, sW1, sW2, sBias, n, t_first, lane, wave);
 }
 
 }  // namespace
@@ -589,25 +597,28 @@ static size_t weights_lds_bytes(int C, int k) {
 }
 namespace {
 
-template <int C>
+template <int C, bool SINGLE>
 void launch_cfg(const ResPairArgs& a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<C>),
+        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_kernel<C, SINGLE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
         attr_set = true;
     }
     const int H2 = (a.k - 1) / 2, H1 = a.dil * (a.k - 1) / 2;
     const int TT = RB_M1 - 2 * H2;
     const int tiles = cdiv(a.T, TT);
-    const size_t lds = (size_t)2 * (RB_M1 + 2 * H1) * (C + 8) * sizeof(_Float16) + weights_lds_bytes(C, a.k);
+    // activations: two planes of R0 rows, or (SINGLE) one plane - but never less than the fp32 epilogue tile that reuses the space
+    const size_t act_halfs = SINGLE ? std::max<size_t>((size_t)(RB_M1 + 2 * H1) * (C + 8), (size_t)RB_M1 * (C + 4) * 2)
+                                    : (size_t)2 * (RB_M1 + 2 * H1) * (C + 8);
+    const size_t lds = act_halfs * sizeof(_Float16) + weights_lds_bytes(C, a.k);
     SC_CHECK(lds <= 120 * 1024, "resblock pair: %zu bytes of LDS (C=%d k=%d dil=%d)", lds, C, a.k, a.dil);
     char name[48];
     snprintf(name, sizeof(name), "resblock_pair_c%d", C);
     const double rows = (double)a.nb * a.T;
     prof::Scope scope(name, 2.0 * 2.0 * rows * C * (double)C * a.k,
                       4.0 * rows * C * (a.avg_a ? 4.0 : 2.0) + 2.0 * 2.0 * C * (double)C * a.k, s);
-    hipLaunchKernelGGL((resblock_pair_kernel<C>), dim3((unsigned)(a.nb * tiles)), dim3(256), lds, s, a, tiles);
+    hipLaunchKernelGGL((resblock_pair_kernel<C, SINGLE>), dim3((unsigned)(a.nb * tiles)), dim3(256), lds, s, a, tiles);
 }
 
 }  // namespace
@@ -626,9 +637,15 @@ void launch_resblock_pair(const ResPairArgs& a, hipStream_t s) {
              "resblock pair: packed weight rows too short");
     SC_CHECK((a.avg_a == nullptr) == (a.avg_b == nullptr), "resblock pair: avg_a/avg_b must be given together");
     SC_CHECK((int64_t)a.nb * cdiv(a.T, RB_M1 - (a.k - 1)) < (1ll << 31), "resblock pair: grid too large");
-    if (a.C == 16) launch_cfg<16>(a, s);
-    else if (a.C == 32) launch_cfg<32>(a, s);
-    else launch_cfg<64>(a, s);
+    if (a.single) {
+        if (a.C == 16) launch_cfg<16, true>(a, s);
+        else if (a.C == 32) launch_cfg<32, true>(a, s);
+        else launch_cfg<64, true>(a, s);
+    } else {
+        if (a.C == 16) launch_cfg<16, false>(a, s);
+        else if (a.C == 32) launch_cfg<32, false>(a, s);
+        else launch_cfg<64, false>(a, s);
+    }
     SC_LAUNCH_CHECK();
 }
 
@@ -654,13 +671,13 @@ bool mrf_fused_supported(int C, const int* k, const int* dil) {
 }
 
 namespace {
-template <int C>
+template <int C, bool SINGLE>
 void launch_mrf_cfg(MrfArgs a, hipStream_t s) {
-    constexpr size_t LDS = ((size_t)2 * (MRF_R + 2 * MRF_G) * (C + 8) + (size_t)2 * mrf_w_halfs<C>()) * sizeof(_Float16) + 18 * C * sizeof(float);
+    constexpr size_t LDS = ((size_t)(SINGLE ? 1 : 2) * (MRF_R + 2 * MRF_G) * (C + 8) + (size_t)2 * mrf_w_halfs<C>()) * sizeof(_Float16) + 18 * C * sizeof(float);
     static_assert(LDS <= 160 * 1024, "planes + two weight buffers must fit in the CU's LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mrf_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        SC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mrf_fused_kernel<C, SINGLE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_set = true;
     }
     a.halo = mrf_halo(a);
@@ -676,7 +693,7 @@ void launch_mrf_cfg(MrfArgs a, hipStream_t s) {
         wbytes += 3.0 * 2.0 * 2.0 * C * (double)C * a.k[j];
     }
     prof::Scope scope(name, flops, 4.0 * rows * C * 2.0 + wbytes, s);
-    hipLaunchKernelGGL((mrf_fused_kernel<C>), dim3((unsigned)(a.nb * tiles)), dim3(MRF_THREADS), LDS, s, a, tiles);
+    hipLaunchKernelGGL((mrf_fused_kernel<C, SINGLE>), dim3((unsigned)(a.nb * tiles)), dim3(MRF_THREADS), LDS, s, a, tiles);
 }
 }  // namespace
 
@@ -688,8 +705,13 @@ void launch_mrf_fused(const MrfArgs& a, hipStream_t s) {
         SC_CHECK(a.w1[q] && a.w2[q] && a.ldw1[q] % 8 == 0 && a.ldw2[q] % 8 == 0 && a.ldw1[q] >= (int64_t)k * a.C && a.ldw2[q] >= (int64_t)k * a.C,
                  "mrf: packed weight rows of pair %d missing or too short", q);
     }
-    if (a.C == 16) launch_mrf_cfg<16>(a, s);
-    else launch_mrf_cfg<32>(a, s);
+    if (a.single) {
+        if (a.C == 16) launch_mrf_cfg<16, true>(a, s);
+        else launch_mrf_cfg<32, true>(a, s);
+    } else {
+        if (a.C == 16) launch_mrf_cfg<16, false>(a, s);
+        else launch_mrf_cfg<32, false>(a, s);
+    }
     SC_LAUNCH_CHECK();
 }
 

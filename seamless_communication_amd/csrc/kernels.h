@@ -117,7 +117,7 @@ struct ResPairArgs {
     float slope = 0.1f;
     const float* avg_a = nullptr;
     const float* avg_b = nullptr;
-    int single = 0;  // precision study (SC_VOC_SINGLE): the hi fp16 plane of the activations only
+    int single = 0;  // the hi fp16 plane of the activations only: one matrix instruction per fragment, no lo plane in LDS (the vocoder's default)
 };
 bool resblock_pair_supported(int C, int k, int dil);
 void launch_resblock_pair(const ResPairArgs& a, hipStream_t s);
@@ -139,7 +139,7 @@ struct MrfArgs {
     int64_t ldw2[9] = {};
     const float* b1[9] = {};
     const float* b2[9] = {};
-    int single = 0;  // precision study (SC_VOC_SINGLE): the hi fp16 plane of the activations only
+    int single = 0;  // the hi fp16 plane of the activations only: one matrix instruction per fragment, no lo plane in LDS (the vocoder's default)
 };
 bool mrf_fused_supported(int C, const int* k, const int* dil);
 void launch_mrf_fused(const MrfArgs& a, hipStream_t s);
