@@ -104,6 +104,8 @@ def parse_args():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: every usable core)")
     ap.add_argument("--cpu-baseline-timeout", type=int, default=400)
+    ap.add_argument("--cpu-batch", type=int, default=8,
+                    help="cpu_baseline also times ONE oracle pass over a batch of this many utterances (cpu_baseline.batched; 0 / 1: off)")
     ap.add_argument("--no-profile-step", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement")
     ap.add_argument("--profile-single-stream", action="store_true",
@@ -208,6 +210,40 @@ def csrc_sha() -> str:
     return _CSRC_SHA
 
 
+_SQ_KEYS = {"gemm_256x256_presplit": "gemm_ps_kernel<256, 256", "gemm_128x128_presplit": "gemm_ps_kernel<128, 128", "gemm_64x64_presplit": "gemm_ps_kernel<64, 64",
+            "resblock_pair_c64": "resblock_pair_kernel<64", "mrf_fused_c32": "mrf_fused_kernel<32", "mrf_fused_c16": "mrf_fused_kernel<16",
+            "attention_shaw": "attn_mfma16_kernel<1>"}
+
+
+def sq_pipe_busy(family: str):
+    """(SQ_VALU_MFMA_BUSY_CYCLES share of the kernel family, source) from the newest committed per-kernel SQ counter summary
+    under profiles/ (`bash scripts/gpu.sh TAG sqbench`: one rocprofv3 --pmc pass of a bench pass, scripts/pmc_sq_summary.py).
+    Like `traffic` it is NOT measured in this run; a capture made with other kernel sources is reported as stale."""
+    import glob
+    import re
+
+    key = _SQ_KEYS.get(family.split(":")[-1])
+    files = sorted(glob.glob(str(ROOT / "profiles" / "r[0-9]*_bench_b64_pmc_sq.txt")),
+                   key=lambda f: (int(Path(f).name[1:].split("_")[0]) if Path(f).name[1:].split("_")[0].isdigit() else 0, f))
+    if not key or not files:
+        return None, None
+    newest = files[-1]
+    name = "profiles/" + Path(newest).name
+    lines = open(newest).read().splitlines()
+    stamp = lines[0].split("=", 1)[1].strip() if lines and lines[0].startswith("# csrc_sha=") else None
+    if stamp != csrc_sha():
+        return None, f"stale: {name} was captured with kernel sources {stamp or 'unknown'}, this tree is {csrc_sha()} (bash scripts/gpu.sh TAG sqbench)"
+    busy, weight = 0.0, 0.0
+    for i, l in enumerate(lines):
+        if key in l and "launches=" in l:
+            m = next((re.search(r"mfma_pipe_busy=([0-9.]+)", x) for x in lines[i + 1: i + 3] if "mfma_pipe_busy" in x), None)
+            n = re.search(r"launches=(\d+)", l)
+            if m and n:  # instantiations of one family (schedule variants): weighted by launches
+                busy += float(m.group(1)) * int(n.group(1))
+                weight += int(n.group(1))
+    return (busy / weight, name) if weight else (None, None)
+
+
 def pmc_traffic(family: str):
     """(HBM bytes per launch, source) of the kernel family from the newest committed rocprofv3 PMC summary under profiles/
     (FETCH_SIZE / WRITE_SIZE collected in separate passes of this command line by `scripts/gpu.sh TAG pmc`, FETCH_SIZE
@@ -298,7 +334,14 @@ def decoder_row_stats(text_lens, B, groups, stage_ms):
 
 
 def log(msg):
-    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+    mem = ""
+    try:  # device memory in use (whole device, every process): the caching pools of the handles never shrink - worth watching
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            free, total = torch.cuda.mem_get_info()
+            mem = f" [{(total - free) / 1e9:.0f} / {total / 1e9:.0f} GB of HBM in use]"
+    except Exception:
+        pass
+    print(f"[bench {time.strftime('%H:%M:%S')}]{mem} {msg}", file=sys.stderr, flush=True)
 
 
 def usable_cpus() -> int:
@@ -367,8 +410,35 @@ def cpu_baseline_worker(args):
         return {"seconds": t[4] - t[0], "stage_s": stage, "text_ids": seqs[0], "units": speech_units[0], "index": index,
                 "text_margins": margins[0], "unit_margins": unit_margins}
 
+    def batch(indices):
+        """the same chain on a BATCH of utterances (like for like with the GPU number, which is a batch): one pass, per-stage split"""
+        waves = [syn.synthetic_waveform(i, AUDIO_SECONDS).numpy() for i in indices]
+        t = [time.perf_counter()]
+        with torch.inference_mode():
+            fb, lens = orc.collate_fbank(waves)
+            t.append(time.perf_counter())
+            enc, enc_lens = ou.encode_speech(orc.P, cfg, fb, lens)
+            t.append(time.perf_counter())
+            seqs, margins = ou.greedy_generate(orc.P, cfg, enc, enc_lens, tt.target_prefix("fra"), (1, 200), args.text_len,
+                                               pos_table=orc.pos_table, return_margins=True)
+            t.append(time.perf_counter())
+            _, speech_units, wavs, units, aux = orc._speech_from_text(seqs, enc, enc_lens, margins, "fra", 1.0, -1, True)
+            t.append(time.perf_counter())
+        sec = t[4] - t[0]
+        return {"batch": len(indices), "value": len(indices) / sec, "unit": "utterances/s", "seconds": sec, "rtf": sec / (len(indices) * AUDIO_SECONDS),
+                "stage_ms": {"fbank": round(1e3 * (t[1] - t[0]), 1), "encoder": round(1e3 * (t[2] - t[1]), 1),
+                             "text_decoder": round(1e3 * (t[3] - t[2]), 1), "t2u_and_vocoder": round(1e3 * (t[4] - t[3]), 1)},
+                "text_tokens": [len(x) for x in seqs], "units": [len(u) for u in speech_units],
+                "sample": f"ONE pass over a batch of {len(indices)} utterances (indices {indices[0]}..{indices[-1]}), no warm-up of its own (the batch-1 passes ran before)"}
+
     warm = one(37)
     runs = [one(0) for _ in range(3)]
+    batched = None
+    if args.cpu_batch > 1:
+        try:
+            batched = batch(list(range(args.cpu_batch)))
+        except Exception as e:  # noqa: BLE001 - the batch-1 row stands on its own
+            batched = {"batch": args.cpu_batch, "value": None, "error": repr(e)[:300]}
     runs_sorted = sorted(runs, key=lambda r: r["seconds"])
     med = runs_sorted[1]
     checked = [warm, runs[0]]
@@ -378,6 +448,8 @@ def cpu_baseline_worker(args):
                   f"the fairseq2 path: 1 warm-up pass (another utterance) + 3 timed passes, median",
         "seconds": med["seconds"], "seconds_all": [r["seconds"] for r in runs], "rtf": med["seconds"] / AUDIO_SECONDS,
         "stage_ms": {k: round(1e3 * v, 1) for k, v in med["stage_s"].items()},
+        # like for like with the GPU number (a batch in flight): the oracle on a batch, same cores, same process
+        "batched": batched,
         "checked": [{"index": r["index"], "text_ids": r["text_ids"], "units": r["units"],
                      "min_text_margin": min(r["text_margins"]), "min_unit_margin": min(r["unit_margins"]),
                      "text_margin_hist": _margin_hist(r["text_margins"]), "unit_margin_hist": _margin_hist(r["unit_margins"])}
@@ -390,7 +462,7 @@ def cpu_baseline(args):
 
     threads = args.cpu_threads or usable_cpus()
     cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-worker", "--arch", args.arch, "--text-len",
-           str(args.text_len), "--cpu-threads", str(threads), "--workload", args.workload]
+           str(args.text_len), "--cpu-threads", str(threads), "--workload", args.workload, "--cpu-batch", str(args.cpu_batch)]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_baseline_timeout)
         if r.returncode != 0:
@@ -979,6 +1051,36 @@ def main():
                                    f"one replay = one step of the shared chain, HIP events on the engine's stream; engine steps {int(est['steps'])}"),
                       "single_pass_alone": single}
                 result["roofline"] = op
+        if rank == 0 and result.get("roofline"):
+            # ---- which kernel is the DOMINANT one of the timed schedule?  Per pass every family costs what the profiled pass shows,
+            # except the decoder step: under the engine a pass's share of the shared chain is steps_per_pass x the step at its
+            # operating point, not the 60+ narrow steps the profiled pass ran alone.
+            step_roof = result["roofline"]
+            per_pass = {k: v["ms"] for k, v in fams.items()}
+            eng_cfg = (result.get("config") or {}).get("decode_engine")
+            if eng_cfg and step_roof.get("kernel") == "dec:step_graph" and "dec:step_graph" in per_pass and step_roof.get("measured"):
+                per_pass["dec:step_graph"] = eng_cfg["steps_per_pass"] * step_roof["avg_launch_us"] * 1e-3
+            dom = max(per_pass, key=per_pass.get)
+            total_ms = sum(per_pass.values())
+            if dom == step_roof.get("kernel"):
+                top = dict(step_roof)
+            else:
+                top, _ = roofline_of({dom: fams[dom]}, step_bytes)
+                top["decoder_step"] = step_roof  # the weight-streaming view of the decoder step, at the engine's operating point
+            busy, busy_from = sq_pipe_busy(dom)
+            top.update({
+                "share_of_kernel_time": round(per_pass[dom] / total_ms, 4),
+                "kernel_ms_per_pass": {k: round(v, 2) for k, v in sorted(per_pass.items(), key=lambda kv: -kv[1])[:6]},
+                "mfma_pipe_busy": busy, "mfma_pipe_busy_from": busy_from,
+                "scope": {"launch_durations": "HIP events around every launch of ONE whole-batch pass alone on one stream (un-overlapped), outside the timed region",
+                          "share_of_kernel_time": "per pass of the timed schedule: profiled family times, the decoder step as the engine's steps per pass x its step time",
+                          "decoder_step": "dec:step_graph under `decoder_step`: the engine alone on the chip at the timed schedule's rows per step"},
+            })
+            if top.get("bound") == "mfma":
+                # the data-sheet peak is not reachable on real data: a kernel of nothing but v_mfma_f32_32x32x16_f16 sustains 1.69 PFLOP/s
+                # on random fp16 operands (power management; profiles/r5_micro_mfma_rate.txt) - both fractions are given
+                top["frac_of_measured_pipe_peak"] = round(top.get("mfma_issue_tflops", top["achieved"]) / 1690.0, 4)
+            result["roofline"] = top
     elif rank == 0:
         result["roofline"] = None
 
@@ -996,12 +1098,31 @@ def main():
             one()
         torch.cuda.synchronize()
         lat = (time.perf_counter() - t0) / 3
-        result["latency_batch1"] = {"seconds": lat, "rtf": lat / AUDIO_SECONDS,
-                                    "stage_ms": {k: round(v, 3) for k, v in translator.last_stage_ms.items()}}
+        stage1 = {k: round(v, 3) for k, v in translator.last_stage_ms.items()}
+        n_tok = len(translator.last_text_ids[0])
+        step_s = 1e-3 * stage1.get("text_decoder", 0.0) / max(1, n_tok - 1)
+        M_, F_, L_, V_ = cfg.model_dim, cfg.dec_ffn_dim, cfg.dec_layers, cfg.text_vocab_size
+        w_bytes = 2.0 * (L_ * (8.0 * M_ * M_ + 2.0 * M_ * F_) + float(V_) * M_)
+        result["latency_batch1"] = {
+            "metric": "S2ST wall time of ONE 10 s utterance (fbank -> waveform), greedy, one stream", "seconds": lat, "rtf": lat / AUDIO_SECONDS,
+            "stage_ms": stage1, "text_tokens": n_tok,
+            # the stage that IS the latency: one decoder step per token, 1.733 GB of weights each
+            "decoder_step": {"ms": round(1e3 * step_s, 4), "bound": "hbm", "algorithmic_bytes": w_bytes,
+                             "achieved_gbs": round(w_bytes / step_s / 1e9, 1) if step_s > 0 else None,
+                             "frac": round(w_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4) if step_s > 0 else None,
+                             "launches_per_step": 9 * L_ + 4,
+                             "note": "launch-latency bound: ~220 dependent launches of 4.4 - 10 us (DESIGN.md section 3)"}}
 
     # ---- secondary lines (not the headline): S2TT only (BASELINE cfg 2), beam 5 (the API default), streaming p50 (cfg 5) ----
     if rank == 0 and world == 1 and not args.no_extra:
         result["extra"] = extra_lines(args, batcher, translator, wav_dev, ns, B, opts)
+        st = result["extra"].get("streaming")
+        if isinstance(st, list) and st and st[0].get("p50_ms") is not None:
+            # BASELINE configs[4] as an object of its own (the driver keeps top-level keys): p50 wall time per 320 ms source segment
+            first = st[0]
+            result["streaming_p50"] = {"metric": first.get("metric"), "p50_ms": first["p50_ms"], "p90_ms": first.get("p90_ms"), "segment_ms": 320.0,
+                                       "frac_of_real_time": round(first["p50_ms"] / 320.0, 4), "rtf_whole_stream": first.get("rtf"),
+                                       "decision_method": first.get("decision_method"), "segments": first.get("segments")}
 
     if world > 1:
         dist.barrier()
@@ -1070,12 +1191,14 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
         one = timed(lambda: batcher.predict_passes(wav_dev, ns, batcher.groups, task, "fra", text_generation_opts=o), 1) / batcher.groups
         return timed(lambda: batcher.predict_passes(wav_dev, ns, k, task, "fra", stagger_s=one, text_generation_opts=o), 1) / k
 
+    log("secondary lines: S2TT ...")
     try:  # BASELINE configs[1]: S2TT (Conformer encoder + NLLB text decoder only), same batch and schedule
         dt = per_pass("S2TT", opts)
         out["s2tt"] = {"metric": "S2TT utterances/s, 10 s audio, greedy, same batch / schedule as the headline", "value": B / dt,
                        "ms_per_step": 1e3 * dt, "rtf": dt / (B * AUDIO_SECONDS)}
     except Exception as e:  # noqa: BLE001
         out["s2tt"] = {"error": repr(e)[:300]}
+    log("secondary lines: beam 5 ...")
     try:  # beam_size 5 = the default of Translator.predict (translator.py:311-313): the whole batch, 64 x 5 = 320 live decoder rows
         o5 = SequenceGeneratorOptions(beam_size=5, soft_max_seq_len=(1, 200), hard_max_seq_len=x_len)
         fb, frames = translator.model.fbank(wav_dev, ns, standardize=True, pad_to_multiple=2)
@@ -1118,6 +1241,20 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
                                "value": B / dt, "ms_per_step": 1e3 * dt, "rtf": dt / (B * AUDIO_SECONDS)}
         except Exception as e:  # noqa: BLE001
             out["lockstep"] = {"error": repr(e)[:300]}
+    # (the child loads a model of its own: it runs BEFORE the fixed-42 line, whose second model + eight handles take ~75 GB more)
+    log("secondary lines: streaming child ...")
+    try:  # BASELINE configs[4]: streaming chain, p50 wall time per 320 ms segment (child process: its own model + monotonic decoder)
+        r = subprocess.run([sys.executable, str(ROOT / "scripts" / "stream_latency.py"), "--arch", args.arch], capture_output=True,
+                           text=True, timeout=args.extra_timeout)
+        lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        if lines:
+            out["streaming"] = [{k: l.get(k) for k in ("metric", "decision_method", "segments", "p50_ms", "p90_ms", "max_ms", "rtf",
+                                                       "text_tokens_written")} for l in lines]
+        else:
+            out["streaming"] = {"error": (r.stderr or "no output")[-300:]}
+    except Exception as e:  # noqa: BLE001
+        out["streaming"] = {"error": repr(e)[:300]}
+    log("secondary lines: fixed-42 workload ...")
     if args.workload == "ragged":
         try:  # the workload of rounds 1-3 for continuity: plain random weights, every hypothesis cut at 42 tokens, same schedule
             from seamless_communication_amd import synthetic as syn
@@ -1143,20 +1280,10 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
                 out["fixed42"]["pipelined"] = {"metric": "the same workload under this run's pipelined schedule", "value": B / dtp, "ms_per_step": 1e3 * dtp}
                 mbp.close()
             mb42.close()
+            tr42.model.close()  # its weights and the scratch pools of its handles go back to the device NOW, not at some later collection
             del mb42, tr42
         except Exception as e:  # noqa: BLE001
             out["fixed42"] = {"error": repr(e)[:300]}
-    try:  # BASELINE configs[4]: streaming chain, p50 wall time per 320 ms segment (child process: its own model + monotonic decoder)
-        r = subprocess.run([sys.executable, str(ROOT / "scripts" / "stream_latency.py"), "--arch", args.arch], capture_output=True,
-                           text=True, timeout=args.extra_timeout)
-        lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-        if lines:
-            out["streaming"] = [{k: l.get(k) for k in ("metric", "decision_method", "segments", "p50_ms", "p90_ms", "max_ms", "rtf",
-                                                       "text_tokens_written")} for l in lines]
-        else:
-            out["streaming"] = {"error": (r.stderr or "no output")[-300:]}
-    except Exception as e:  # noqa: BLE001
-        out["streaming"] = {"error": repr(e)[:300]}
     return out
 
 

@@ -162,6 +162,14 @@ int sc_set_nar_tables(sc_model* m, int32_t vocab, const int32_t* h_tok_len, cons
 int sc_fbank(sc_model* m, const float* d_wav, int32_t n, int64_t wav_stride, const int32_t* h_num_samples,
              int32_t standardize, float* d_out, int32_t t_rows, int32_t* h_out_frames);
 
+/* The same at the waveform's OWN sample rate: fairseq2's converter takes {"waveform", "sample_rate"} and hands the rate to
+ * kaldi without resampling (translator.py:270-292: `sample_rate` of predict(), or the decoded file's) - window int(rate * 25 ms),
+ * shift int(rate * 10 ms), FFT size the next power of two, mel banks up to the rate's Nyquist.  16000 = sc_fbank.
+ * sc_fbank_frames: frames of num_samples samples at that rate (0 below one window). */
+int sc_fbank_rate(sc_model* m, const float* d_wav, int32_t n, int64_t wav_stride, const int32_t* h_num_samples, int32_t sample_rate,
+                  int32_t standardize, float* d_out, int32_t t_rows, int32_t* h_out_frames);
+int32_t sc_fbank_frames(int64_t num_samples, int32_t sample_rate);
+
 /* a3-a7: UnitYModel.encode_speech (models/unity/model.py:132-139).
  * d_fbank [n][t_frames][80] (t_frames even), d_enc_out [n][sc_encoder_out_len(t_frames)][model_dim]. */
 int32_t sc_encoder_out_len(const sc_model* m, int32_t t_frames);

@@ -36,17 +36,31 @@ PREEMPH = np.float32(0.97)
 FLT_EPS = np.float32(np.finfo(np.float32).eps)
 
 
-def num_frames(num_samples: int) -> int:
+def geometry(sample_rate: int = SAMPLE_RATE):
+    """(window samples, shift samples, padded FFT size) at a sample rate: feature-window.h FrameExtractionOptions -
+    WindowSize = int(rate * 0.001 * 25), WindowShift = int(rate * 0.001 * 10), PaddedWindowSize = next power of two.
+    fairseq2n's converter hands the waveform's own rate to kaldi (it does not resample): inference/translator.py:270-292."""
+    win = int(np.float32(sample_rate) * np.float32(0.001) * np.float32(25.0))
+    shift = int(np.float32(sample_rate) * np.float32(0.001) * np.float32(10.0))
+    padded = 1
+    while padded < win:
+        padded *= 2
+    return win, shift, padded
+
+
+def num_frames(num_samples: int, sample_rate: int = SAMPLE_RATE) -> int:
     # feature-window.cc NumFrames with snip_edges=true
-    if num_samples < FRAME_LENGTH:
+    win, shift, _ = geometry(sample_rate)
+    if num_samples < win:
         return 0
-    return 1 + (num_samples - FRAME_LENGTH) // FRAME_SHIFT
+    return 1 + (num_samples - win) // shift
 
 
-def povey_window() -> np.ndarray:
+def povey_window(sample_rate: int = SAMPLE_RATE) -> np.ndarray:
     # feature-window.cc:30-55 (double math, stored as float)
-    a = 2.0 * math.pi / (FRAME_LENGTH - 1)
-    i = np.arange(FRAME_LENGTH, dtype=np.float64)
+    win = geometry(sample_rate)[0]
+    a = 2.0 * math.pi / (win - 1)
+    i = np.arange(win, dtype=np.float64)
     return np.power(0.5 - 0.5 * np.cos(a * i), 0.85).astype(np.float32)
 
 
@@ -55,11 +69,12 @@ def _mel_scale(freq: np.ndarray) -> np.ndarray:
     return np.float32(1127.0) * np.log(np.float32(1.0) + freq / np.float32(700.0), dtype=np.float32)
 
 
-def mel_banks() -> np.ndarray:
-    """Dense (80, 256) matrix of the triangular filters; mel-computations.cc:107-210."""
-    num_fft_bins = PADDED // 2
-    nyquist = np.float32(0.5 * SAMPLE_RATE)
-    fft_bin_width = np.float32(SAMPLE_RATE) / np.float32(PADDED)
+def mel_banks(sample_rate: int = SAMPLE_RATE) -> np.ndarray:
+    """Dense (80, padded / 2) matrix of the triangular filters; mel-computations.cc:107-210 (high_freq 0 = Nyquist)."""
+    padded = geometry(sample_rate)[2]
+    num_fft_bins = padded // 2
+    nyquist = np.float32(0.5 * sample_rate)
+    fft_bin_width = np.float32(sample_rate) / np.float32(padded)
     mel_low = _mel_scale(np.float32(LOW_FREQ))
     mel_high = _mel_scale(nyquist)
     delta = np.float32((mel_high - mel_low) / np.float32(NUM_BINS + 1))
@@ -80,36 +95,36 @@ def mel_banks() -> np.ndarray:
     return out
 
 
-_WINDOW = None
-_BANKS = None
+_TABLES = {}
 
 
-def fbank_raw(waveform: np.ndarray, waveform_scale: float = 2.0**15) -> np.ndarray:
+def fbank_raw(waveform: np.ndarray, waveform_scale: float = 2.0**15, sample_rate: int = SAMPLE_RATE) -> np.ndarray:
     """(T,) float waveform in [-1,1) -> (frames, 80) log-mel energies."""
-    global _WINDOW, _BANKS
-    if _WINDOW is None:
-        _WINDOW, _BANKS = povey_window(), mel_banks()
+    if sample_rate not in _TABLES:
+        _TABLES[sample_rate] = (povey_window(sample_rate), mel_banks(sample_rate))
+    window, banks = _TABLES[sample_rate]
+    win, shift, padded_n = geometry(sample_rate)
     wav = (np.asarray(waveform, dtype=np.float32) * np.float32(waveform_scale)).astype(np.float32)
-    n = num_frames(wav.shape[0])
+    n = num_frames(wav.shape[0], sample_rate)
     if n == 0:
         return np.zeros((0, NUM_BINS), dtype=np.float32)
-    idx = np.arange(n)[:, None] * FRAME_SHIFT + np.arange(FRAME_LENGTH)[None, :]
-    fr = wav[idx].astype(np.float32)  # (n, 400)
+    idx = np.arange(n)[:, None] * shift + np.arange(win)[None, :]
+    fr = wav[idx].astype(np.float32)  # (n, window)
     # RemoveDcOffset: float accumulation (feature-window.cc:172-183).  The
     # reference sums sequentially in float; float64 sum rounded to float is
     # within 1 ulp of that and is what we pin against _ref with a tolerance.
-    mean = (fr.sum(axis=1, dtype=np.float64) / FRAME_LENGTH).astype(np.float32)
+    mean = (fr.sum(axis=1, dtype=np.float64) / win).astype(np.float32)
     fr = (fr - mean[:, None]).astype(np.float32)
     # Preemphasize (feature-window.cc:193-204)
     pre = np.empty_like(fr)
     pre[:, 1:] = fr[:, 1:] - PREEMPH * fr[:, :-1]
     pre[:, 0] = fr[:, 0] - PREEMPH * fr[:, 0]
-    pre = (pre * _WINDOW[None, :]).astype(np.float32)
-    padded = np.zeros((n, PADDED), dtype=np.float32)
-    padded[:, :FRAME_LENGTH] = pre
+    pre = (pre * window[None, :]).astype(np.float32)
+    padded = np.zeros((n, padded_n), dtype=np.float32)
+    padded[:, :win] = pre
     spec = np.fft.rfft(padded.astype(np.float64), axis=1)
-    power = (spec.real**2 + spec.imag**2).astype(np.float32)[:, : PADDED // 2]
-    mel = (power.astype(np.float64) @ _BANKS.T.astype(np.float64)).astype(np.float32)
+    power = (spec.real**2 + spec.imag**2).astype(np.float32)[:, : padded_n // 2]
+    mel = (power.astype(np.float64) @ banks.T.astype(np.float64)).astype(np.float32)
     return np.log(np.maximum(mel, FLT_EPS)).astype(np.float32)
 
 
@@ -122,6 +137,6 @@ def standardize(feat: np.ndarray) -> np.ndarray:
     return ((f - mean) / std).astype(np.float32)
 
 
-def waveform_to_fbank(waveform: np.ndarray, standardize_: bool = True) -> np.ndarray:
-    feat = fbank_raw(waveform)
+def waveform_to_fbank(waveform: np.ndarray, standardize_: bool = True, sample_rate: int = SAMPLE_RATE) -> np.ndarray:
+    feat = fbank_raw(waveform, sample_rate=sample_rate)
     return standardize(feat) if standardize_ else feat

@@ -29,8 +29,8 @@ class OracleS2ST:
         self.pos_table = ou.sinusoidal_table(cfg.text_max_seq_len, cfg.model_dim, 1)
 
     # translator.py:293 + Collater(pad_value=0, pad_to_multiple=2) :144-146
-    def collate_fbank(self, waveforms: Sequence[np.ndarray]) -> Tuple[Tensor, Tensor]:
-        feats = [torch.from_numpy(ofb.waveform_to_fbank(np.asarray(w))) for w in waveforms]
+    def collate_fbank(self, waveforms: Sequence[np.ndarray], sample_rate: int = 16000) -> Tuple[Tensor, Tensor]:
+        feats = [torch.from_numpy(ofb.waveform_to_fbank(np.asarray(w), sample_rate=sample_rate)) for w in waveforms]
         lens = torch.tensor([f.shape[0] for f in feats], dtype=torch.int64)
         T = int(lens.max())
         T += T % 2

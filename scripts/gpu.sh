@@ -116,7 +116,8 @@ for task in "$@"; do
       rm -rf gpurun_out/${TAG}_sqb
       PMC_ARGS=${PMC_ARGS:---steps 1 --warmup 0 --no-cpu-baseline --no-profile-step --no-latency --no-graph --no-extra}
       ( cd /tmp && timeout -k 10 ${SQB_TIMEOUT:-200} rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_sqb -o bench -- python $R/bench.py $PMC_ARGS > $R/${O}_sqb.log 2>&1; echo "exit $?" >> $R/${O}_sqb.log )
-      python scripts/pmc_sq_summary.py gpurun_out/${TAG}_sqb --by-kernel > ${O}_bench_pmc_sq.txt 2>&1
+      # first line: the digest of the kernel sources the capture was made with (bench.py reports a capture of other sources as stale)
+      ( python -c "import bench; print('# csrc_sha=' + bench.csrc_sha())"; python scripts/pmc_sq_summary.py gpurun_out/${TAG}_sqb --by-kernel ) > ${O}_bench_pmc_sq.txt 2>&1
       tail -2 ${O}_sqb.log | cut -c1-200; head -30 ${O}_bench_pmc_sq.txt | cut -c1-220
       find gpurun_out/${TAG}_sqb -name "*.csv" -size +2M -delete 2>/dev/null ;;
     dstep)

@@ -112,6 +112,8 @@ SIGNATURES = {
     "sc_decoder_step_family": (C.c_int, [_P, C.c_int, C.c_int]),
     "sc_set_nar_tables": (C.c_int, [_P, _i, _P, _P, _P, _P, _P]),
     "sc_fbank": (C.c_int, [_P, _P, _i, C.c_int64, _P, _i, _P, _i, _P]),
+    "sc_fbank_rate": (C.c_int, [_P, _P, _i, C.c_int64, _P, _i, _i, _P, _i, _P]),
+    "sc_fbank_frames": (_i, [C.c_int64, _i]),
     "sc_encoder_out_len": (_i, [_P, _i]),
     "sc_encode_speech": (C.c_int, [_P, _P, _i, _i, _P, _P, _P]),
     "sc_encode_text": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),

@@ -187,6 +187,17 @@ int sc_fbank(sc_model* m, const float* d_wav, int32_t n, int64_t wav_stride, con
 
 int32_t sc_encoder_out_len(const sc_model* m, int32_t t_frames) { return m ? encoder_out_len(m->m, t_frames) : -1; }
 
+int sc_fbank_rate(sc_model* m, const float* d_wav, int32_t n, int64_t wav_stride, const int32_t* h_num_samples, int32_t sample_rate,
+                  int32_t standardize, float* d_out, int32_t t_rows, int32_t* h_out_frames) {
+    SC_API_BEGIN
+    SC_CHECK(m && d_wav && h_num_samples && d_out, "sc_fbank_rate: null argument");
+    SC_HIP(hipSetDevice(m->m.device));
+    run_fbank(m->m, d_wav, n, wav_stride, h_num_samples, standardize, d_out, t_rows, h_out_frames, sample_rate);
+    SC_API_END
+}
+
+int32_t sc_fbank_frames(int64_t num_samples, int32_t sample_rate) { return sample_rate > 0 ? fbank_num_frames(num_samples, sample_rate) : 0; }
+
 int sc_encode_speech(sc_model* m, const float* d_fbank, int32_t n, int32_t t_frames, const int32_t* h_frame_lens,
                      float* d_enc_out, int32_t* h_out_lens) {
     SC_API_BEGIN

@@ -111,6 +111,103 @@ void launch_fbank(const float* wav, int64_t wav_stride, const int* num_samples, 
     SC_LAUNCH_CHECK();
 }
 
+// The same front-end at ANY sample rate (fairseq2n hands the waveform's own rate to kaldi and does not resample,
+// inference/translator.py:270-292): window = int(rate * 0.025) samples, shift = int(rate * 0.010), FFT size = the next power of
+// two (feature-window.h FrameExtractionOptions), mel banks up to the rate's Nyquist.  One workgroup per frame, 256 threads,
+// NFFT = 2^LOG2N in {256 .. 2048} points; consts layout: window[frame_len] | melT[NFFT/2][80] | tw_cos[NFFT/2] | tw_sin[NFFT/2].
+// The 16 kHz kernel above is this kernel at LOG2N = 9 with its loops unrolled; it stays the path of the model's own rate.
+template <int LOG2N>
+__global__ __launch_bounds__(256) void fbank_any_kernel(const float* __restrict__ wav, int64_t wav_stride, const int* __restrict__ num_samples,
+                                                        float* __restrict__ out, int t_rows, const float* __restrict__ consts, float scale,
+                                                        int frame_len, int frame_shift) {
+    constexpr int N = 1 << LOG2N, HALF = N / 2;
+    __shared__ float s_x[N];
+    __shared__ float s_re[N];
+    __shared__ float s_im[N];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x;
+    const int f = blockIdx.x;
+    const int n = blockIdx.y;
+    const int ns = num_samples[n];
+    const int nframes = ns < frame_len ? 0 : 1 + (ns - frame_len) / frame_shift;
+    float* orow = out + ((int64_t)n * t_rows + f) * NBINS;
+    if (f >= nframes) {
+        if (tid < NBINS) orow[tid] = 0.f;
+        return;
+    }
+    const float* w = wav + (int64_t)n * wav_stride + (int64_t)f * frame_shift;
+    const float* window = consts;
+    const float* melT = consts + frame_len;
+    const float* tw_cos = melT + HALF * NBINS;
+    const float* tw_sin = tw_cos + HALF;
+    float part = 0.f;
+    for (int i = tid; i < N; i += 256) {
+        const float v = i < frame_len ? w[i] * scale : 0.f;
+        s_x[i] = v;
+        part += v;
+    }
+    __syncthreads();
+    const float mean = block_sum_256(part, s_red) / (float)frame_len;
+    for (int i = tid; i < N; i += 256) {
+        float v = 0.f;
+        if (i < frame_len) {
+            const float cur = s_x[i] - mean;
+            const float prev = (i > 0 ? s_x[i - 1] : s_x[0]) - mean;
+            v = (cur - 0.97f * prev) * window[i];
+        }
+        const int rev = __brev((unsigned)i) >> (32 - LOG2N);
+        s_re[rev] = v;
+        s_im[rev] = 0.f;
+    }
+    __syncthreads();
+    for (int stage = 0; stage < LOG2N; ++stage) {
+        const int half = 1 << stage;
+        for (int b = tid; b < HALF; b += 256) {  // butterfly b of this stage
+            const int j = b & (half - 1);
+            const int i0 = ((b >> stage) << (stage + 1)) + j;
+            const int i1 = i0 + half;
+            const int tw = j << (LOG2N - 1 - stage);  // exp(-2 pi i tw / N)
+            const float c = tw_cos[tw], sn = tw_sin[tw];
+            const float xr = s_re[i1], xi = s_im[i1];
+            const float tr = xr * c - xi * sn;
+            const float ti = xr * sn + xi * c;
+            const float ur = s_re[i0], ui = s_im[i0];
+            s_re[i0] = ur + tr;
+            s_im[i0] = ui + ti;
+            s_re[i1] = ur - tr;
+            s_im[i1] = ui - ti;
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < HALF; k += 256) {
+        const float re = s_re[k], im = s_im[k];
+        s_x[k] = re * re + im * im;
+    }
+    __syncthreads();
+    if (tid < NBINS) {
+        float e = 0.f;
+        for (int k = 0; k < HALF; ++k) e = fmaf(melT[k * NBINS + tid], s_x[k], e);
+        orow[tid] = logf(e < 1.1920928955078125e-07f ? 1.1920928955078125e-07f : e);
+    }
+}
+
+void launch_fbank_any(const float* wav, int64_t wav_stride, const int* num_samples, int nb, float* out, int t_rows, const float* consts,
+                      float scale, int frame_len, int frame_shift, int nfft, hipStream_t s) {
+    if (nb <= 0 || t_rows <= 0) return;
+    SC_CHECK(frame_len >= 2 && frame_shift >= 1 && frame_len <= nfft, "fbank: window %d / shift %d / FFT %d", frame_len, frame_shift, nfft);
+    const dim3 grid(t_rows, nb), block(256);
+#define SC_FB(L) hipLaunchKernelGGL((fbank_any_kernel<L>), grid, block, 0, s, wav, wav_stride, num_samples, out, t_rows, consts, scale, frame_len, frame_shift)
+    switch (nfft) {
+        case 256: SC_FB(8); break;
+        case 512: SC_FB(9); break;
+        case 1024: SC_FB(10); break;
+        case 2048: SC_FB(11); break;
+        default: SC_CHECK(false, "fbank: FFT size %d (supported sample rates: 5.2 - 81.9 kHz, window of 129 .. 2048 samples)", nfft);
+    }
+#undef SC_FB
+    SC_LAUNCH_CHECK();
+}
+
 // Per-utterance, per-bin standardisation over the valid frames: (x - mean) / std
 // with the unbiased std and no epsilon (fairseq2n at::std_mean semantics).
 // One workgroup = one utterance x 16 bins x 64 time slices (a thread strides over the frames of its bin); the

@@ -529,6 +529,9 @@ void launch_gather_cache(const float* src, float* dst, const int* src_row, int r
 // consts = window[400] | melT[256][80] | twiddle cos[256] | twiddle sin[256]
 void launch_fbank(const float* wav, int64_t wav_stride, const int* num_samples, int nb, float* out,
                   int t_rows /*rows per item in out*/, const float* consts, float scale, hipStream_t s);
+// any sample rate (k_fbank.hip: fbank_any_kernel): consts = window[frame_len] | melT[nfft/2][80] | cos[nfft/2] | sin[nfft/2]
+void launch_fbank_any(const float* wav, int64_t wav_stride, const int* num_samples, int nb, float* out, int t_rows, const float* consts,
+                      float scale, int frame_len, int frame_shift, int nfft, hipStream_t s);
 void launch_standardize(float* feat, int nb, int t_rows, const int* num_frames, int C, hipStream_t s);
 
 // misc elementwise / gather kernels (k_misc.hip)

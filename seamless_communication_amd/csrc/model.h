@@ -284,6 +284,13 @@ struct Model : ModelData {
 
     std::unique_ptr<MmaState> mma;  // buffers come from `pool`: released before it (see ~Model)
 
+    // fbank constants of sample rates other than the model's 16 kHz, built on first use (sc_fbank_rate; owned by this handle)
+    struct FbankRate {
+        float* consts = nullptr;
+        int frame_len = 0, frame_shift = 0, nfft = 0;
+    };
+    std::map<int, FbankRate> fbank_rates;
+
 
     // buffers + captured step graph of the greedy text generation, kept across calls (model_decoder.hip)
     std::unique_ptr<DecodeSession, void (*)(DecodeSession*)> dec_session{nullptr, delete_decode_session};
@@ -318,8 +325,11 @@ struct SideScope {
 
 // stage implementations (model_*.hip)
 void load_model(Model& m, const sc_tensor_desc* t, size_t n);
+// sample_rate: the waveform's own rate (16000 = the model's; others get their own window / shift / FFT size / mel banks)
 void run_fbank(Model& m, const float* d_wav, int n, int64_t wav_stride, const int32_t* h_ns, int standardize,
-               float* d_out, int t_rows, int32_t* h_frames);
+               float* d_out, int t_rows, int32_t* h_frames, int sample_rate = 16000);
+// frames of a waveform of num_samples samples at a rate (snip_edges: 0 below one 25 ms window)
+int fbank_num_frames(int64_t num_samples, int sample_rate);
 int encoder_out_len(const Model& m, int t_frames);
 void run_encode_speech(Model& m, const float* d_fbank, int n, int t_frames, const int32_t* h_lens, float* d_out,
                        int32_t* h_out_lens);

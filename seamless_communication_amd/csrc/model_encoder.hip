@@ -9,6 +9,7 @@
 //   models/conformer_shaw/builder.py:127-156 Shaw SDPA + causal depthwise conv
 #include <cstdlib>
 
+#include <cmath>
 #include "model.h"
 
 namespace sc {
@@ -17,13 +18,66 @@ static void upload_i32(Model& m, int* d, const int32_t* h, int n) {
     SC_HIP(hipMemcpyAsync(d, h, (size_t)n * 4, hipMemcpyHostToDevice, m.stream));
 }
 
+// kaldi's FrameExtractionOptions at a sample rate (feature-window.h): float arithmetic, truncated
+static void fbank_geometry(int sample_rate, int& frame_len, int& frame_shift, int& nfft) {
+    frame_len = (int)((float)sample_rate * 0.001f * 25.0f);
+    frame_shift = (int)((float)sample_rate * 0.001f * 10.0f);
+    nfft = 1;
+    while (nfft < frame_len) nfft *= 2;
+}
+
+int fbank_num_frames(int64_t num_samples, int sample_rate) {
+    int fl, fs, nf;
+    fbank_geometry(sample_rate, fl, fs, nf);
+    return num_samples < fl ? 0 : (int)(1 + (num_samples - fl) / fs);
+}
+
+// window | melT[nfft/2][80] | cos | sin of a rate, built once per handle (the expressions of build_fbank_consts, model_load.hip:
+// feature-window.cc:30-55 povey window; mel-computations.cc:107-210 mel banks, high_freq 0 = the rate's Nyquist)
+static const Model::FbankRate& fbank_rate_consts(Model& m, int sample_rate) {
+    auto it = m.fbank_rates.find(sample_rate);
+    if (it != m.fbank_rates.end()) return it->second;
+    Model::FbankRate r;
+    fbank_geometry(sample_rate, r.frame_len, r.frame_shift, r.nfft);
+    SC_CHECK(r.frame_shift >= 1 && r.nfft >= 256 && r.nfft <= 2048,
+             "sc_fbank_rate: sample rate %d Hz gives a %d-sample window (supported: 129 .. 2048 samples, 5.2 - 81.9 kHz)", sample_rate, r.frame_len);
+    const int half = r.nfft / 2, nb = m.cfg.num_fbank_channels;
+    SC_CHECK(nb == 80, "sc_fbank_rate: %d mel bins (the kernel is built for 80)", nb);
+    std::vector<float> c((size_t)r.frame_len + (size_t)half * nb + 2 * (size_t)half, 0.f);
+    const double a = 2.0 * M_PI / (r.frame_len - 1);
+    for (int i = 0; i < r.frame_len; ++i) c[i] = (float)std::pow(0.5 - 0.5 * std::cos(a * (double)i), 0.85);
+    auto mel_scale = [](float f) { return 1127.0f * logf(1.0f + f / 700.0f); };
+    const float nyquist = 0.5f * (float)sample_rate, fft_bin_width = (float)sample_rate / (float)r.nfft;
+    const float mel_low = mel_scale(20.0f), mel_high = mel_scale(nyquist);
+    const float delta = (mel_high - mel_low) / (float)(nb + 1);
+    float* melT = c.data() + r.frame_len;
+    for (int b = 0; b < nb; ++b) {
+        const float left = mel_low + b * delta, center = mel_low + (b + 1) * delta, right = mel_low + (b + 2) * delta;
+        for (int i = 0; i < half; ++i) {
+            const float mel = mel_scale(fft_bin_width * i);
+            if (mel > left && mel < right) melT[i * nb + b] = mel <= center ? (mel - left) / (center - left) : (right - mel) / (right - center);
+        }
+    }
+    float* tw = melT + (size_t)half * nb;
+    for (int k = 0; k < half; ++k) {
+        tw[k] = (float)std::cos(-2.0 * M_PI * k / (double)r.nfft);
+        tw[half + k] = (float)std::sin(-2.0 * M_PI * k / (double)r.nfft);
+    }
+    void* d = nullptr;
+    SC_HIP(hipMalloc(&d, c.size() * 4));
+    SC_HIP(hipMemcpy(d, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+    r.consts = static_cast<float*>(d);
+    return m.fbank_rates.emplace(sample_rate, r).first->second;
+}
+
 void run_fbank(Model& m, const float* d_wav, int n, int64_t wav_stride, const int32_t* h_ns, int standardize,
-               float* d_out, int t_rows, int32_t* h_frames) {
+               float* d_out, int t_rows, int32_t* h_frames, int sample_rate) {
     SC_CHECK(n > 0 && t_rows > 0, "sc_fbank: empty batch");
+    SC_CHECK(sample_rate > 0, "sc_fbank: sample rate %d", sample_rate);
     std::vector<int32_t> frames(n);
     for (int i = 0; i < n; ++i) {
         SC_CHECK(h_ns[i] >= 0 && h_ns[i] <= wav_stride, "sc_fbank: num_samples[%d]=%d exceeds the row stride", i, h_ns[i]);
-        frames[i] = h_ns[i] < 400 ? 0 : 1 + (h_ns[i] - 400) / 160;
+        frames[i] = fbank_num_frames(h_ns[i], sample_rate);
         SC_CHECK(frames[i] <= t_rows, "sc_fbank: item %d has %d frames but the output has only %d rows", i, frames[i],
                  t_rows);
         if (h_frames) h_frames[i] = frames[i];
@@ -31,7 +85,12 @@ void run_fbank(Model& m, const float* d_wav, int n, int64_t wav_stride, const in
     Buf<int> d_ns(m.pp(), n), d_fr(m.pp(), n);
     upload_i32(m, d_ns, h_ns, n);
     upload_i32(m, d_fr, frames.data(), n);
-    launch_fbank(d_wav, wav_stride, d_ns, n, d_out, t_rows, m.fbank_consts, 32768.0f, m.stream);
+    if (sample_rate == 16000) {
+        launch_fbank(d_wav, wav_stride, d_ns, n, d_out, t_rows, m.fbank_consts, 32768.0f, m.stream);
+    } else {
+        const Model::FbankRate& r = fbank_rate_consts(m, sample_rate);
+        launch_fbank_any(d_wav, wav_stride, d_ns, n, d_out, t_rows, r.consts, 32768.0f, r.frame_len, r.frame_shift, r.nfft, m.stream);
+    }
     if (standardize) launch_standardize(d_out, n, t_rows, d_fr, m.cfg.num_fbank_channels, m.stream);
     SC_HIP(hipStreamSynchronize(m.stream));  // host-side length vectors must outlive the copies
 }

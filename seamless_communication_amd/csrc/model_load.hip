@@ -100,6 +100,8 @@ Model::~Model() {
     side.clear();
     if (side_fork) (void)hipEventDestroy(side_fork);
     pool.release_all();
+    for (auto& kv : fbank_rates)
+        if (kv.second.consts) (void)hipFree(kv.second.consts);
     for (void* p : owned) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
 }

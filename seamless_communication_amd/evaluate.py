@@ -101,16 +101,25 @@ def load_audio(path: Path, all_channels: bool = False) -> Tuple[np.ndarray, int]
     ``all_channels``.  ``.npy`` (float waveform at 16 kHz) or RIFF/WAVE: PCM 8 / 16 / 24 / 32 bit, IEEE float 32 / 64,
     A-law, mu-law, plain or WAVE_FORMAT_EXTENSIBLE headers - integer samples scaled by 2^-(bits-1) as libsndfile does
     for float reads (the reference decodes with fairseq2's AudioDecoder = libsndfile, inference/translator.py:135,
-    270-273).  Compressed containers (FLAC, Ogg, MP3) need a decoder this image does not have: a clear error."""
+    270-273).  Other containers (FLAC, Ogg, AIFF, ...) go through the `soundfile` package when it is importable; without it
+    a ValueError says so."""
     if path.suffix == ".npy":
         x = np.asarray(np.load(path), dtype=np.float32)
         return (x.reshape(len(x), -1) if all_channels else x.reshape(-1)), 16000
     with open(path, "rb") as f:
         data = f.read()
-    if data[:4] in (b"fLaC", b"OggS", b"ID3\x03", b"ID3\x04") or data[:2] in (b"\xff\xfb", b"\xff\xf3"):
-        raise ValueError(f"{path}: compressed audio (FLAC / Ogg / MP3) cannot be decoded here - convert to RIFF/WAVE or .npy")
     if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
-        raise ValueError(f"{path}: not a RIFF/WAVE file")
+        # everything else libsndfile reads (FLAC, Ogg/Vorbis, AIFF, ...): through `soundfile` when this environment has it - the
+        # reference's AudioDecoder IS libsndfile.  Without it: the reference's error type for undecodable input, naming the gap.
+        try:
+            import soundfile  # type: ignore
+        except ImportError:
+            kind = ("FLAC" if data[:4] == b"fLaC" else "Ogg" if data[:4] == b"OggS" else
+                    "MP3" if data[:3] == b"ID3" or data[:2] in (b"\xff\xfb", b"\xff\xf3") else "not RIFF/WAVE")
+            raise ValueError(f"{path}: {kind} audio needs the `soundfile` package (libsndfile), which is not installed here - "
+                             "convert to RIFF/WAVE or .npy") from None
+        x, rate = soundfile.read(str(path), dtype="float32", always_2d=True)
+        return np.ascontiguousarray(x if all_channels else x[:, 0]), int(rate)
     pos, fmt, pcm, fmt_body = 12, None, None, b""
     while pos + 8 <= len(data):
         cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
@@ -173,20 +182,20 @@ def collate_fbank(feats: Sequence[Tensor]) -> Dict[str, Any]:
     return {"seqs": seqs, "seq_lens": torch.tensor(lens, dtype=torch.int64), "is_ragged": len(set(lens)) > 1}
 
 
-FbankFn = Callable[[List[np.ndarray]], List[Tensor]]
+FbankFn = Callable[..., List[Tensor]]  # (waves) at 16 kHz, (waves, sample_rate) otherwise
 
 
 def gpu_fbank_fn(translator) -> FbankFn:
     """WaveformToFbankConverter(num_mel_bins=80, waveform_scale=2**15, standardize=True) for a bucket at once
     through sc_fbank; a waveform that contains NaN yields NaN features, like the reference's converter."""
 
-    def fn(waves: List[np.ndarray]) -> List[Tensor]:
+    def fn(waves: List[np.ndarray], sample_rate: int = 16000) -> List[Tensor]:
         n = max(len(w) for w in waves)
         buf = np.zeros((len(waves), n), dtype=np.float32)
         for i, w in enumerate(waves):
             buf[i, : len(w)] = w
         fb, frames = translator.model.fbank(torch.from_numpy(buf).to(translator.device), [len(w) for w in waves],
-                                            standardize=True, pad_to_multiple=1)
+                                            standardize=True, pad_to_multiple=1, sample_rate=sample_rate)
         return [fb[i, : int(frames[i])] for i in range(len(waves))]
 
     return fn
@@ -199,14 +208,17 @@ def iter_batches(ctx: EvalContext, fbank_fn: FbankFn) -> Iterator[Dict[str, Any]
     bucket: List[Dict[str, str]] = []
 
     def flush(items: List[Dict[str, str]]) -> Dict[str, Any]:
-        waves = []
-        for ex in items:
-            wav, rate = load_audio(Path(ctx.audio_root_dir) / ex["audio"])
-            if rate != 16000:
-                raise ValueError(f"{ex['audio']}: {rate} Hz audio (the model expects 16 kHz)")
-            waves.append(wav)
+        # every file at ITS OWN sample rate, like the reference's AudioDecoder -> WaveformToFbankConverter chain (no resampling):
+        # one front-end call per rate found in the bucket, features back in manifest order
+        loaded = [load_audio(Path(ctx.audio_root_dir) / ex["audio"]) for ex in items]
+        feats: List[Any] = [None] * len(items)
+        for rate in sorted({r for _, r in loaded}):
+            idx = [i for i, (_, r) in enumerate(loaded) if r == rate]
+            waves = [loaded[i][0] for i in idx]
+            for i, f in zip(idx, fbank_fn(waves) if rate == 16000 else fbank_fn(waves, rate)):
+                feats[i] = f
         batch: Dict[str, Any] = {k: [ex.get(k, "") for ex in items] for k in items[0]}
-        batch["audio"] = {"data": {"fbank": collate_fbank(fbank_fn(waves))}}
+        batch["audio"] = {"data": {"fbank": collate_fbank(feats)}}
         return batch
 
     for ex in read_manifest(ctx):

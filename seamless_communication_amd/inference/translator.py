@@ -241,16 +241,29 @@ class Translator:
         else:
             return Modality.TEXT, Modality.SPEECH
 
-    def _collate_audio(self, audio: Tensor) -> SequenceData:
-        """convert_to_fbank + Collater(pad_value=0, pad_to_multiple=2) (translator.py:135-146, :293)."""
+    # What a waveform with more than one channel means.  The reference hands (T, C) to fairseq2n's converter
+    # (channel_last=True, translator.py:136-143, 280-286) whose multi-channel behaviour is not restated anywhere under
+    # /root/reference; here it is a stated choice instead of an accident:
+    #   "first" (default) channel 0, with a warning - what the file path does (evaluate.load_audio) and libsndfile users expect;
+    #   "mean"  the average of the channels (a mono down-mix);
+    #   "error" refuse.
+    multi_channel: str = "first"
+
+    def _collate_audio(self, audio: Tensor, sample_rate: int = 16000) -> SequenceData:
+        """convert_to_fbank + Collater(pad_value=0, pad_to_multiple=2) (translator.py:135-146, :293): the front-end works at the
+        waveform's own ``sample_rate`` (no resampling, like fairseq2n's converter)."""
         wav = audio.to(torch.float32)
         if wav.size(1) > 1:
-            # (T, C) input (translator.py:280-286 hands it to WaveformToFbankConverter(channel_last=True)); fairseq2n's
-            # multi-channel behaviour is not restated anywhere under /root/reference (SURVEY appendix A-7), so the
-            # first channel is used, as for files (evaluate.load_audio)
-            logger.warning("Multi-channel audio (%d channels): the fbank front-end uses channel 0.", wav.size(1))
+            policy = self.multi_channel
+            if policy == "error":
+                raise ValueError(f"audio has {wav.size(1)} channels and Translator.multi_channel is 'error'")
+            if policy not in ("first", "mean"):
+                raise ValueError(f"Translator.multi_channel must be 'first', 'mean' or 'error', not {policy!r}")
+            logger.warning("Multi-channel audio (%d channels): the fbank front-end uses %s (Translator.multi_channel).", wav.size(1),
+                           "channel 0" if policy == "first" else "the mean of the channels")
+            wav = wav[:, :1] if policy == "first" else wav.mean(dim=1, keepdim=True)
         wav = wav[:, 0].contiguous().unsqueeze(0).to(self.device)
-        fb, frames = self.model.fbank(wav, [wav.shape[1]], standardize=True, pad_to_multiple=2)
+        fb, frames = self.model.fbank(wav, [wav.shape[1]], standardize=True, pad_to_multiple=2, sample_rate=int(sample_rate))
         return {"seqs": fb, "seq_lens": torch.tensor(frames.astype(np.int64)), "is_ragged": False}
 
     @torch.inference_mode()
@@ -278,13 +291,12 @@ class Translator:
         elif input_modality == Modality.SPEECH:
             audio = input
             if isinstance(audio, str):
-                # translator.py:270-273 decodes the file with fairseq2's AudioDecoder (libsndfile); here RIFF/WAVE
-                # (PCM 8 - 32 bit, float, G.711; evaluate.load_audio) and .npy are read with the standard library, first channel, 16 kHz only
+                # translator.py:270-273 decodes the file with fairseq2's AudioDecoder (libsndfile) and uses the FILE's sample rate:
+                # RIFF/WAVE (PCM 8 - 32 bit, float, G.711) and .npy are read with the standard library; FLAC / Ogg / ... through
+                # `soundfile` (libsndfile) when it is importable, a ValueError naming the missing decoder otherwise
                 from ..evaluate import load_audio
 
-                samples, rate = load_audio(Path(audio))
-                if rate != 16000:
-                    raise ValueError(f"{audio}: sample rate {rate} Hz; the fbank kernel is built for 16 kHz input")
+                samples, sample_rate = load_audio(Path(audio), all_channels=True)
                 audio = torch.from_numpy(samples)
             assert audio.dim() <= 2, "The audio tensor can't be more than 2 dimensions."
             if audio.dim() == 1:
@@ -292,7 +304,7 @@ class Translator:
             elif audio.dim() == 2 and audio.size(0) < audio.size(1):
                 logger.warning("Transposing audio tensor from (bsz, seq_len) -> (seq_len, bsz).")
                 audio = audio.transpose(0, 1)
-            src = self._collate_audio(audio)
+            src = self._collate_audio(audio, sample_rate)
         else:
             if src_lang is None:
                 raise ValueError("src_lang must be specified for T2ST, T2TT tasks.")

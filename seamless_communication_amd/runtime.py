@@ -170,11 +170,14 @@ class HipS2STModel:
         self._has_nar_tables = True
 
     def fbank(self, wav: torch.Tensor, num_samples: Sequence[int], standardize: bool = True,
-              pad_to_multiple: int = 2) -> Tuple[torch.Tensor, np.ndarray]:
-        """wav (n, max_samples) fp32 on this device -> (n, T, 80), frames (n,)."""
+              pad_to_multiple: int = 2, sample_rate: int = 16000) -> Tuple[torch.Tensor, np.ndarray]:
+        """wav (n, max_samples) fp32 on this device -> (n, T, 80), frames (n,).  ``sample_rate``: the waveform's own rate - like
+        the reference's converter the front-end works AT that rate (25 ms windows every 10 ms, mel banks up to its Nyquist)
+        and does not resample."""
         assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.is_contiguous()
         ns = _i32(num_samples)
-        frames = np.where(ns < 400, 0, 1 + (ns - 400) // 160).astype(np.int32)
+        rate = int(sample_rate)
+        frames = np.asarray([self.lib.sc_fbank_frames(int(x), rate) for x in ns], dtype=np.int32)
         T = int(frames.max())
         if pad_to_multiple > 1 and T % pad_to_multiple:
             T += pad_to_multiple - T % pad_to_multiple
@@ -183,8 +186,12 @@ class HipS2STModel:
         # a size-1 batch dimension may carry an arbitrary stride
         stride = wav.stride(0) if wav.shape[0] > 1 else wav.shape[1]
         self._after_torch()
-        check(self.lib.sc_fbank(self.handle, _ptr(wav), wav.shape[0], stride, _ptr(ns), int(standardize),
-                                _ptr(out), T, _ptr(got)), "sc_fbank")
+        if rate == 16000:
+            check(self.lib.sc_fbank(self.handle, _ptr(wav), wav.shape[0], stride, _ptr(ns), int(standardize),
+                                    _ptr(out), T, _ptr(got)), "sc_fbank")
+        else:
+            check(self.lib.sc_fbank_rate(self.handle, _ptr(wav), wav.shape[0], stride, _ptr(ns), rate, int(standardize),
+                                         _ptr(out), T, _ptr(got)), "sc_fbank_rate")
         return out, got
 
     def encode_speech(self, fbank: torch.Tensor, frame_lens: Sequence[int]) -> Tuple[torch.Tensor, np.ndarray]:

@@ -92,6 +92,28 @@ def make_fbank():
         out[k + "_fbank"] = fb
     np.savez_compressed(HERE / "fbank_knf.npz", **out)
     print("fbank_knf.npz", {k: v.shape for k, v in out.items()})
+    make_fbank_rates(lib)
+
+
+FBANK_RATES = (8000, 22050, 32000, 44100, 48000)
+
+
+def make_fbank_rates(lib):
+    """fbank_knf_rates.npz: the same compiled library at other sample rates (window 25 ms / shift 10 ms / FFT size / mel banks follow
+    the rate; fairseq2n hands the waveform's own rate to kaldi, inference/translator.py:270-292): 0.4 s of synthetic audio per rate."""
+    lib.knf_ref_fbank_rate.restype = ctypes.c_int32
+    lib.knf_ref_fbank_rate.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]
+    out = {}
+    for i, rate in enumerate(FBANK_RATES):
+        n_samp = int(0.4 * rate) + 37 * i
+        w = (syn.synthetic_waveform(20 + i, n_samp / 16000.0 + 0.01).numpy()[:n_samp]).astype(np.float32)
+        x = np.ascontiguousarray(w * np.float32(2.0**15))
+        fb = np.zeros((n_samp, 80), dtype=np.float32)  # more rows than frames
+        n = lib.knf_ref_fbank_rate(x.ctypes.data, len(x), float(rate), fb.ctypes.data)
+        out[f"r{rate}_wav"] = w
+        out[f"r{rate}_fbank"] = fb[:n].copy()
+    np.savez_compressed(HERE / "fbank_knf_rates.npz", **out)
+    print("fbank_knf_rates.npz", {k: v.shape for k, v in out.items()})
 
 
 # --------------------------------------------------------------------------- #

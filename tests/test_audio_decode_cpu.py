@@ -84,7 +84,7 @@ def test_extensible_pcm16_and_odd_sized_chunks(tmp_path):
 def test_errors_name_the_problem(tmp_path):
     p = tmp_path / "a.flac"
     p.write_bytes(b"fLaC" + b"\0" * 64)
-    with pytest.raises(ValueError, match="compressed audio"):
+    with pytest.raises(ValueError, match="FLAC audio needs the `soundfile` package"):  # not installed in this image
         load_audio(p)
     p = tmp_path / "b.wav"
     p.write_bytes(_chunks(_fmt(2, 1, 16000, 4), b"\0" * 16))  # ADPCM
@@ -92,5 +92,5 @@ def test_errors_name_the_problem(tmp_path):
         load_audio(p)
     p = tmp_path / "c.wav"
     p.write_bytes(b"not a wave file at all")
-    with pytest.raises(ValueError, match="not a RIFF/WAVE"):
+    with pytest.raises(ValueError, match="not RIFF/WAVE"):
         load_audio(p)

@@ -31,6 +31,31 @@ def test_hip_fbank_matches_reference_knf(hip, key):
     assert close_logmel(got, ref)  # 2e-3 on log-mel energies, noise-floor bins excepted (see test_oracle_fbank.py)
 
 
+@pytest.mark.parametrize("rate", [8000, 22050, 32000, 44100, 48000])
+def test_hip_fbank_at_other_sample_rates_matches_reference_knf(hip, rate):
+    """sc_fbank_rate (k_fbank.hip: fbank_any_kernel) against the reference's compiled kaldi-native-fbank AT that rate: the
+    front-end of `Translator.predict(wav, sample_rate=...)` / of a decoded file (inference/translator.py:270-292, no resampling).
+    A batch of two (the golden waveform and a shorter cut of it) also checks the per-item frame counts and the zero rows."""
+    g = np.load(G / "fbank_knf_rates.npz")
+    wav, ref = g[f"r{rate}_wav"], g[f"r{rate}_fbank"]
+    cut = len(wav) - len(wav) // 3
+    batch = np.zeros((2, len(wav)), dtype=np.float32)
+    batch[0], batch[1, :cut] = wav, wav[:cut]
+    fb, frames = hip.fbank(torch.from_numpy(batch).cuda(), [len(wav), cut], standardize=False, pad_to_multiple=2, sample_rate=rate)
+    n0, n1 = int(frames[0]), int(frames[1])
+    assert n0 == ref.shape[0] and 0 < n1 < n0 and fb.shape[1] == n0 + n0 % 2
+    got = fb.cpu().numpy()
+    assert close_logmel(got[0, :n0], ref)
+    assert close_logmel(got[1, :n1], ref[:n1])  # a frame depends on its own window only
+    assert not got[1, n1:].any() and not got[0, n0:].any()
+    # and the 16 kHz entry is untouched by the general kernel: same bits through both calls
+    g16 = np.load(G / "fbank_knf.npz")
+    w16 = torch.from_numpy(g16["synth0_1s_wav"][None]).cuda()
+    a, _ = hip.fbank(w16, [w16.shape[1]], standardize=True)
+    b, _ = hip.fbank(w16, [w16.shape[1]], standardize=True, sample_rate=16000)
+    assert torch.equal(a, b)
+
+
 def test_hip_vocoder_matches_reference_vocoder(hip):
     from oracle import vocoder as ov
     from seamless_communication_amd import cards

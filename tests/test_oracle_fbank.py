@@ -85,3 +85,36 @@ def test_standardize_is_unbiased_per_bin():
     s = ofb.standardize(f)
     assert np.allclose(s.mean(0), 0, atol=1e-5)
     assert np.allclose(s.std(0, ddof=1), 1, atol=1e-5)
+
+
+RATES_GOLDEN = ROOT / "tests" / "golden" / "fbank_knf_rates.npz"
+RATES = (8000, 22050, 32000, 44100, 48000)
+
+
+@pytest.mark.parametrize("rate", RATES)
+def test_oracle_fbank_at_other_sample_rates_matches_knf_golden(rate):
+    """fairseq2n's converter works at the waveform's own rate (no resampling; inference/translator.py:270-292): window
+    int(rate * 25 ms), shift int(rate * 10 ms), FFT size the next power of two, mel banks up to the rate's Nyquist.  Golden: the
+    reference's compiled kaldi-native-fbank at that rate (tests/golden/make_reference_goldens.py: make_fbank_rates)."""
+    g = np.load(RATES_GOLDEN)
+    wav, ref = g[f"r{rate}_wav"], g[f"r{rate}_fbank"]
+    got = ofb.fbank_raw(wav, sample_rate=rate)
+    win, shift, padded = ofb.geometry(rate)
+    assert (win, shift) == (int(rate * 0.025), int(rate * 0.010)) and padded >= win and padded < 2 * win
+    assert got.shape == ref.shape == (ofb.num_frames(len(wav), rate), 80)
+    assert close_logmel(got, ref)
+    assert ofb.geometry(16000) == (400, 160, 512)
+
+
+@pytest.mark.skipif(not REF_LIB.exists(), reason="oracle/_ref/libknf_ref.so not built (needs /root/reference)")
+def test_oracle_fbank_at_other_rates_matches_compiled_reference_live():
+    lib = ctypes.CDLL(str(REF_LIB))
+    lib.knf_ref_fbank_rate.restype = ctypes.c_int32
+    lib.knf_ref_fbank_rate.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]
+    for i, rate in enumerate((11025, 24000, 16000)):
+        wav = syn.synthetic_waveform(30 + i, 0.7).numpy()[: int(0.45 * rate)]
+        x = np.ascontiguousarray(wav.astype(np.float32) * np.float32(2.0**15))
+        out = np.zeros((len(x), 80), dtype=np.float32)
+        n = lib.knf_ref_fbank_rate(x.ctypes.data, len(x), float(rate), out.ctypes.data)
+        got = ofb.fbank_raw(wav, sample_rate=rate)
+        assert got.shape == (n, 80) and close_logmel(got, out[:n])

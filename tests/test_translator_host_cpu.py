@@ -24,8 +24,8 @@ class OracleModel:
         self.orc, self.cfg = orc, orc.cfg
         self.calls = []
 
-    def fbank(self, wav, num_samples, standardize=True, pad_to_multiple=2):
-        fb, lens = self.orc.collate_fbank([wav[i, : num_samples[i]].numpy() for i in range(wav.shape[0])])
+    def fbank(self, wav, num_samples, standardize=True, pad_to_multiple=2, sample_rate=16000):
+        fb, lens = self.orc.collate_fbank([wav[i, : num_samples[i]].numpy() for i in range(wav.shape[0])], sample_rate=sample_rate)
         return fb, lens.numpy().astype(np.int32)
 
     def encode_speech(self, seqs, frame_lens):
@@ -134,8 +134,14 @@ def test_audio_file_input(translator, tmp_path):
     want = tr.last_text_ids
     tr.predict(str(tmp_path / "a.wav"), "S2TT", "fra", text_generation_opts=OPTS)
     assert tr.last_text_ids == want
-    with pytest.raises(ValueError, match="16 kHz"):
-        tr.predict(str(tmp_path / "b.wav"), "S2TT", "fra", text_generation_opts=OPTS)
+    # a file at another rate is processed AT that rate (25 ms windows every 10 ms of 22.05 kHz samples, mel banks up to its Nyquist),
+    # like the reference's AudioDecoder -> WaveformToFbankConverter chain; so does a tensor with `sample_rate=`
+    fb, lens = orc.collate_fbank([wav.numpy()], sample_rate=22050)
+    want22 = orc.s2tt(fb, lens, "fra", (1, 200), 12)[0]
+    tr.predict(str(tmp_path / "b.wav"), "S2TT", "fra", text_generation_opts=OPTS)
+    assert tr.last_text_ids == want22
+    tr.predict(wav, "S2TT", "fra", text_generation_opts=OPTS, sample_rate=22050)
+    assert tr.last_text_ids == want22
 
 
 def test_s2st_postprocessing_matches_oracle_chain(translator):
@@ -206,6 +212,27 @@ def test_get_prediction_classmethod_and_multichannel(translator, caplog):
     with caplog.at_level(logging.WARNING):
         tr.predict(stereo, "S2TT", "fra", text_generation_opts=OPTS)
     assert tr.last_text_ids == want and any("Multi-channel" in r.message for r in caplog.records)
+    # the policy is a stated choice (Translator.multi_channel): "mean" down-mixes, "error" refuses
+    try:
+        tr.multi_channel = "mean"
+        tr.predict(torch.stack([w, w], dim=1), "S2TT", "fra", text_generation_opts=OPTS)  # the mean of two equal channels
+        assert tr.last_text_ids == want
+        tr.multi_channel = "error"
+        with pytest.raises(ValueError, match="2 channels"):
+            tr.predict(stereo, "S2TT", "fra", text_generation_opts=OPTS)
+    finally:
+        tr.multi_channel = "first"
+    # a stereo FILE goes the same way (all channels are read, the policy decides)
+    import struct
+
+    pcm = (stereo.numpy() * 32767.0).round().astype("<i2").tobytes()
+    fmt = struct.pack("<HHIIHH", 1, 2, 16000, 16000 * 4, 4, 16)
+    (tmp_stereo := __import__("pathlib").Path(__import__("tempfile").mkdtemp()) / "st.wav").write_bytes(
+        b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", len(pcm)) + pcm)
+    tr.predict(w.mul(32767.0).round().div(32768.0), "S2TT", "fra", text_generation_opts=OPTS)
+    want_q = tr.last_text_ids
+    tr.predict(str(tmp_stereo), "S2TT", "fra", text_generation_opts=OPTS)
+    assert tr.last_text_ids == want_q
     # spkr: None and -1 pick the language's default speaker, 0 is speaker 0 (models/vocoder/vocoder.py:33-42)
     _, s_def = tr.predict(w, "S2ST", "fra", text_generation_opts=OPTS, spkr=None)
     _, s_m1 = tr.predict(w, "S2ST", "fra", text_generation_opts=OPTS, spkr=-1)
