@@ -1254,6 +1254,12 @@ def extra_lines(args, batcher, translator, wav_dev, ns, B, opts):
             out["streaming"] = {"error": (r.stderr or "no output")[-300:]}
     except Exception as e:  # noqa: BLE001
         out["streaming"] = {"error": repr(e)[:300]}
+    # the headline's forked handles are not needed any more: their scratch pools (~100 GB for eight workers) go back to the device
+    # before a second model and its handles are built
+    try:
+        batcher.close(release_forks=True)
+    except Exception as e:  # noqa: BLE001
+        log(f"batcher.close(release_forks=True): {e!r}")
     log("secondary lines: fixed-42 workload ...")
     if args.workload == "ragged":
         try:  # the workload of rounds 1-3 for continuity: plain random weights, every hypothesis cut at 42 tokens, same schedule

@@ -89,7 +89,8 @@ def test_translator_t2tt_and_t2st(report_dir):
 
 
 def test_predict_reads_wave_files(tmp_path):
-    """Translator.predict(path, ...) (translator.py:270-273): a 16 kHz WAVE file gives the same result as its samples."""
+    """Translator.predict(path, ...) (translator.py:270-273): a 16 kHz WAVE file gives the same result as its samples; a file at another rate goes
+    through the front-end at ITS rate."""
     from seamless_communication_amd import evaluate as ev
     from seamless_communication_amd.inference import SequenceGeneratorOptions, Translator
     from seamless_communication_amd.inference.translator import DEFAULT_CARDS, Modality
@@ -104,5 +105,14 @@ def test_predict_reads_wave_files(tmp_path):
     want = tr.last_text_ids
     tr.predict(str(tmp_path / "a.wav"), "S2TT", "fra", text_generation_opts=opts)
     assert tr.last_text_ids == want
-    with pytest.raises(ValueError):
-        tr.predict(str(tmp_path / "b.wav"), "S2TT", "fra", text_generation_opts=opts)
+    # a file at another rate is processed AT that rate, like the reference's AudioDecoder -> WaveformToFbankConverter chain
+    # (translator.py:270-292, no resampling): the same result as the tensor with `sample_rate=`, another one than at 16 kHz
+    tr.predict(str(tmp_path / "b.wav"), "S2TT", "fra", text_generation_opts=opts)
+    got8 = tr.last_text_ids
+    tr.predict(wav, "S2TT", "fra", text_generation_opts=opts, sample_rate=8000)
+    assert tr.last_text_ids == got8
+    from oracle import fbank as ofb
+
+    fb = tr.model.fbank(wav[None].cuda(), [len(wav)], standardize=False, pad_to_multiple=1, sample_rate=8000)[0][0].cpu().numpy()
+    ref = ofb.fbank_raw(wav.numpy(), sample_rate=8000)
+    assert fb.shape == ref.shape == (ofb.num_frames(len(wav), 8000), 80) and float(abs(fb - ref).max()) < 2e-3
