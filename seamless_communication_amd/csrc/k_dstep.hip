@@ -93,16 +93,14 @@ __global__ __launch_bounds__(256) void gemvp_kernel(GemvPArgs p) {
     const __amdgpu_buffer_rsrc_t rah = ds_rsrc(p.Ah, p.a_bytes);
     const __amdgpu_buffer_rsrc_t ral = ds_rsrc(p.Al, p.a_bytes);
     const uint32_t w_voff = (uint32_t)lane * 16u;
-    uint32_t a_voff[MT] = {};
-    // rows behind the live rows are neither read nor written.  The scalar load of the count is requested here and first
-    // WAITED for behind the first tile's weight loads (below): with an early return in front of them the weights - cold in
-    // HBM, the launch's long pole - could only be asked for after that round trip.  Only the row blocks behind the first
-    // (grid.z, the decode engine's wide steps) return early.
-    const int live = p.d_rows ? min(*p.d_rows, p.M) : p.M;
+    uint32_t a_voff[MT];
+    const int live = p.d_rows ? min(*p.d_rows, p.M) : p.M;  // rows behind the live rows are neither read nor written
     // more than 64 rows (the decode engine's step): grid.z blocks of 32 * MT rows, each the kernel of a <= 64-row launch - a
     // row's sums do not depend on how many rows the launch covers
     const int rb0 = blockIdx.z * (32 * MT);
-    if (blockIdx.z != 0 && rb0 >= live) return;
+    if (rb0 >= live) return;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_voff[i] = (rb0 + 32 * i + n < live) ? (uint32_t)((h * p.RB + rb0 + 32 * i + n) * 16) : OOB;
     const uint32_t a_kstep = (uint32_t)(2 * p.RB * 16);  // bytes per k-step in a plane
     uint32_t kill[NCH];                                  // chunks behind the K range read zeros
 #pragma unroll
@@ -160,11 +158,6 @@ __global__ __launch_bounds__(256) void gemvp_kernel(GemvPArgs p) {
 
         // issue order: W0 A0 W1 A1 W2 W3 ... (activation buffers alternate, refilled as soon as a chunk is consumed)
         DS_LOAD_W(0);
-        if (tl == 0) {
-            __builtin_amdgcn_sched_barrier(0);  // first use of `live`: behind the first weight loads
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a_voff[i] = (rb0 + 32 * i + n < live) ? (uint32_t)((h * p.RB + rb0 + 32 * i + n) * 16) : OOB;
-        }
         DS_LOAD_A(0, 0);
         if (NCH > 1) {
             DS_LOAD_W(1);

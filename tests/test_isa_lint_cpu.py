@@ -86,11 +86,12 @@ def test_decoder_attention_has_its_operands_in_flight_before_the_first_wait(dste
     assert not any(o.startswith("scratch_") for o in ops)
 
 
-@pytest.mark.parametrize("inst,early", [("dattn_kernelILb0ELb0ELb1E", 12), ("dattn_kernelILb1ELb0ELb1E", 1)])
+@pytest.mark.parametrize("inst,early", [("dattn_kernelILb0ELb0ELb1E", 12), ("dattn_kernelILb1ELb0ELb1E", 0)])
 def test_engine_attention_waits_once_for_its_slot_then_has_the_whole_trip_in_flight(dstep_isa, inst, early):
-    """dattn_kernel<*, false, true> (decode engine): the slot's {row state, position} pair is ONE 8-byte load; the projection's
-    partial sums (indexed by the slot) travel with it, then all 32 key / value loads of the first trip are issued before the
-    next wait that drains any of them; no scratch."""
+    """dattn_kernel<*, false, true> (decode engine): the slot's {row state, position} pair is ONE load of at most 8 bytes, requested
+    BEFORE the live-row test (round 6: the pair and the live-row count are one round trip, not two in a row); self-attention's
+    projection partials (indexed by the slot) travel with it, cross-attention's follow the test; then all 32 key / value loads of
+    the first trip are issued before the next wait that drains any of them; no scratch."""
     ops = _ops(_function(dstep_isa, inst))
     waits = [i for i, o in enumerate(ops) if "vmcnt(" in o]
     assert sum(o.startswith("global_load_dwordx4") for o in ops[: waits[0]]) >= early
