@@ -229,3 +229,64 @@ def test_text_decoder_respects_max_consecutive_writes_and_no_early_stop(backend)
     # no_early_stop: before the source ends an EOS / low-probability step only stops the round, it never finishes the stream
     outs = common.run_stream(SeamlessStreamingS2TAgent(backend, tt, _args(no_early_stop=True, decision_threshold=0.35)), wav)
     assert outs[-1].finished and not any(o.finished for o in outs[:-1])
+
+
+def test_sample_ring_against_a_plain_list_model():
+    """streaming.agents.SampleRing (hop / window framing of an endless sample stream) against the obvious list model - the
+    reference's bookkeeping, online_feature_extractor.py:102-148 - over random feed sizes that make the ring wrap, grow
+    (a feed larger than its capacity) and sit below one window for several feeds."""
+    rng = np.random.RandomState(7)
+    for hop, win in ((160, 400), (80, 200), (220, 551)):
+        ring = A.SampleRing(hop, float(win - hop), float(hop), capacity=1 << 10)  # small: wraps and grows early
+        carry = []
+        emitted = 0
+        for step in range(200):
+            n = int(rng.choice([1, 7, 159, 160, 161, 399, 400, 1000, 5120, 3 * (1 << 10)]))
+            x = rng.randint(-1000, 1000, size=n).astype(np.float64)
+            ring.feed(x)
+            carry = carry + x.tolist()
+            assert len(ring) == len(carry)
+            if len(carry) < win:
+                assert ring.whole_windows() == 0 and ring.take_windows() is None
+                continue
+            frames = (len(carry) - (win - hop)) // hop
+            want = carry[: frames * hop + (win - hop)]
+            carry = carry[frames * hop:]
+            got = ring.take_windows()
+            assert got is not None and got.tolist() == want
+            assert len(ring) == len(carry) and ring._peek(len(ring)).tolist() == carry
+            emitted += frames
+        assert emitted > 100
+    ring.clear()
+    assert len(ring) == 0 and ring.take_windows() is None
+
+
+def test_round_rules_table_orders_the_outcomes():
+    """The text decoder's decision table (streaming.agents.ROUND_RULES): the first rule that fires names the outcome.  The cases
+    where the ORDER matters, stated as data: a hold shadows everything while audio arrives; the repeat guard is consulted
+    before the finish test; an unsure EOS finishes rather than listens once the veto is off; a confident token at the limit
+    pauses, one beyond it finishes."""
+    base = dict(is_eos=False, unsure=False, certain=False, listening=True, total=3, in_round=1, limit=10, quota=5, veto_early_stop=False,
+                repeated_run=lambda: 0)
+
+    def outcome(**kw):
+        c = A._Candidate(**{**base, **kw})
+        return next(o for o, fires in A.ROUND_RULES if fires(c))
+
+    O = A.Outcome
+    assert outcome() is O.EXTEND
+    assert outcome(unsure=True) is O.LISTEN and outcome(unsure=True, listening=False) is O.EXTEND
+    assert outcome(is_eos=True) is O.FINISH and outcome(is_eos=True, unsure=True) is O.FINISH
+    assert outcome(veto_early_stop=True, is_eos=True) is O.HOLD and outcome(veto_early_stop=True, unsure=True) is O.HOLD
+    assert outcome(veto_early_stop=True, is_eos=True, listening=False) is O.FINISH  # the veto ends with the source
+    assert outcome(repeated_run=lambda: 2) is O.REPEAT and outcome(repeated_run=lambda: 3, is_eos=True) is O.REPEAT
+    assert outcome(veto_early_stop=True, unsure=True, repeated_run=lambda: 3) is O.HOLD
+    assert outcome(total=10) is O.PAUSE and outcome(total=11) is O.FINISH and outcome(in_round=5) is O.PAUSE
+    assert [o for o, _ in A.ROUND_RULES] == [O.HOLD, O.REPEAT, O.FINISH, O.LISTEN, O.PAUSE, O.EXTEND]
+    # the guard: runs of 2 - 4 tokens that start at one of the last three run starts of the earlier text
+    g = A.RepeatGuard([1, 2, 3, 4, 5])
+    assert g.seen == {(2, 3), (2, 3, 4), (2, 3, 4, 5), (3, 4), (3, 4, 5), (4, 5)}
+    assert g.trips_on([9, 3, 4], 0) == 2 and g.trips_on([2, 3, 4], 0) == 3
+    assert g.trips_on([7, 8, 9], 0) == 0 and (7, 8, 9) in g.seen and (8, 9) in g.seen   # learnt while passing
+    assert g.trips_on([7, 8, 9], 5) == 0                                                # more than MAX_TRIPS trips: the guard rests
+    assert A.RepeatGuard([1]).seen == set() and A.RepeatGuard([1, 2]).seen == {(1, 2)}
