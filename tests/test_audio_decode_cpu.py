@@ -94,3 +94,26 @@ def test_errors_name_the_problem(tmp_path):
     p.write_bytes(b"not a wave file at all")
     with pytest.raises(ValueError, match="not RIFF/WAVE"):
         load_audio(p)
+
+
+def test_other_containers_go_through_soundfile_when_it_is_importable(tmp_path, monkeypatch):
+    """FLAC / Ogg / AIFF ...: the reference's AudioDecoder is libsndfile; `load_audio` hands such files to the `soundfile` package when
+    the environment has it (here: a stand-in module, the real one is not installed in this image) and keeps the file's own rate."""
+    import sys
+    import types
+
+    import numpy as np
+
+    calls = []
+
+    def fake_read(path, dtype="float64", always_2d=False):
+        calls.append((path, dtype, always_2d))
+        return np.stack([np.linspace(-0.5, 0.5, 100, dtype=np.float32), np.zeros(100, dtype=np.float32)], axis=1), 22050
+
+    monkeypatch.setitem(sys.modules, "soundfile", types.SimpleNamespace(read=fake_read))
+    p = tmp_path / "a.flac"
+    p.write_bytes(b"fLaC" + b"\0" * 64)
+    mono, rate = load_audio(p)
+    assert rate == 22050 and mono.shape == (100,) and mono.dtype == np.float32 and mono[0] == -0.5
+    both, _ = load_audio(p, all_channels=True)
+    assert both.shape == (100, 2) and calls[-1] == (str(p), "float32", True)
