@@ -168,22 +168,25 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
     constexpr uint32_t OOB = 0x80000000u;
     constexpr int A_TILE = BM * 32, B_TILE = BN * 32;  // halfs per stage
 
-    // three stages of [A_hi | A_lo | W] tiles; after the K loop the same memory holds one fp32 tile per wave for the
-    // transposed (row-major, 16 bytes per lane) epilogue
-    constexpr int STAGE_BYTES = (2 * A_TILE + B_TILE) * 2;
-    constexpr int EPN = WN < 64 ? WN : 64;  // columns of a wave's tile that go through LDS per epilogue pass
+    // three stages of [A_hi | A_lo | W] tiles (without SPLIT: [A_hi | W] - no LDS is set aside for a plane nobody stages: the
+    // 128 x 128 tile then takes 48 KB instead of 72 and a CU holds three workgroups instead of two); after the K loop the same
+    // memory holds one fp32 tile per wave for the transposed (row-major, 16 bytes per lane) epilogue
+    constexpr int A_PL = SPLIT ? 2 : 1;
+    constexpr int STAGE_BYTES = (A_PL * A_TILE + B_TILE) * 2;
+    // columns of a wave's tile that go through LDS per epilogue pass: 64 where the stage memory holds such tiles, else 32
+    constexpr int EPN = WN < 64 ? WN : (NWAVE * WM * (64 + 4) * 4 <= 3 * STAGE_BYTES ? 64 : 32);
     constexpr int EP_LD = EPN + 4;          // floats per row of a wave's epilogue tile
     static_assert(NWAVE * WM * EP_LD * 4 <= 3 * STAGE_BYTES, "epilogue tiles must fit in the stage memory");
     __shared__ __attribute__((aligned(16))) char smem[3 * STAGE_BYTES];
     _Float16* const sAh0 = reinterpret_cast<_Float16*>(smem);
-    _Float16* const sAl0 = sAh0 + A_TILE;
-    _Float16* const sB0 = sAl0 + A_TILE;
+    _Float16* const sAl0 = sAh0 + (A_PL - 1) * A_TILE;  // = sAh0 without SPLIT (never used then)
+    _Float16* const sB0 = sAh0 + A_PL * A_TILE;
     _Float16* const sAh1 = reinterpret_cast<_Float16*>(smem + STAGE_BYTES);
-    _Float16* const sAl1 = sAh1 + A_TILE;
-    _Float16* const sB1 = sAl1 + A_TILE;
+    _Float16* const sAl1 = sAh1 + (A_PL - 1) * A_TILE;
+    _Float16* const sB1 = sAh1 + A_PL * A_TILE;
     _Float16* const sAh2 = reinterpret_cast<_Float16*>(smem + 2 * STAGE_BYTES);
-    _Float16* const sAl2 = sAh2 + A_TILE;
-    _Float16* const sB2 = sAl2 + A_TILE;
+    _Float16* const sAl2 = sAh2 + (A_PL - 1) * A_TILE;
+    _Float16* const sB2 = sAh2 + A_PL * A_TILE;
 
     const int bid = blockIdx.x;
     const int tile = (bid & 7) * tiles_per_xcd + (bid >> 3);
@@ -636,9 +639,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_ps_kernel(GemmPsArgs p, in
         else if (p.act == ACT_SILU) ps_epilogue<WM, EPN, EP_LD, ACT_SILU>(p, ep, m0w, n0w, lane);
         else ps_epilogue<WM, EPN, EP_LD, ACT_TANH>(p, ep, m0w, n0w, lane);
     };
-    static_assert(WN / EPN == 1 || WN / EPN == 2, "one or two epilogue passes");
+    static_assert(WN % EPN == 0 && WN / EPN >= 1 && WN / EPN <= 4, "one to four epilogue passes");
     pass(std::integral_constant<int, 0>{});
-    if constexpr (WN / EPN == 2) pass(std::integral_constant<int, 1>{});
+    if constexpr (WN / EPN > 1) pass(std::integral_constant<int, 1>{});
+    if constexpr (WN / EPN > 2) pass(std::integral_constant<int, 2>{});
+    if constexpr (WN / EPN > 3) pass(std::integral_constant<int, 3>{});
     if constexpr (AMAX) {
         const int64_t m = m0w + lane;
         if (lane < WM && m < p.M) p.amax[m * p.amax_ld + tn * WGN + wn] = make_float2(am_best, __int_as_float(am_idx));
