@@ -844,7 +844,8 @@ def main():
                 assert len(all_text) == len(all_units) == world * B
 
         if args.pipeline_passes:  # the gather of pass k runs while the later passes compute
-            outs = batcher.predict_passes(wav_dev, ns, args.steps, "S2ST", "fra", stagger_s=stagger, on_pass=gather_pass, text_generation_opts=opts)
+            outs = batcher.predict_passes(wav_dev, ns, args.steps, "S2ST", "fra", stagger_s=stagger, on_pass=gather_pass, keep_last=1,
+                                          text_generation_opts=opts)  # keep_last: a long run must not grow by a pass's waveforms per pass
         else:
             outs = batcher.predict_steps(wav_dev, ns, args.steps, "S2ST", "fra", stagger_s=stagger, text_generation_opts=opts)
             for k, out in enumerate(outs):

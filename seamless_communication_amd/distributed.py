@@ -319,7 +319,7 @@ class MicroBatcher:
         return results
 
     def predict_passes(self, wav_dev: torch.Tensor, num_samples: Sequence[int], steps: int, task_str: str, tgt_lang: str,
-                       stagger_s: float = 0.0, on_pass=None, **kwargs):
+                       stagger_s: float = 0.0, on_pass=None, keep_last: Optional[int] = None, **kwargs):
         """``steps`` passes over the same batch, pipelined ACROSS passes: worker i runs passes i, i + groups, ... each over
         the WHOLE batch (one decoder chain of all rows instead of one per slice), worker i starting ``i * stagger_s`` late,
         joined once at the end.  In flight at any time: ``groups`` passes in different phases of the path.  Same total work
@@ -327,7 +327,12 @@ class MicroBatcher:
         Returns one ``predict``-style tuple per pass, in pass order.  ``on_pass(k, result)`` (optional) is called on the CALLING
         thread for pass 0, 1, 2, ... in that order as soon as each is complete, while later passes are still running: the place for
         the data-parallel path's all-gather of a pass's ids (a collective needs the same order on every rank; passes finish in
-        different orders on different ranks)."""
+        different orders on different ranks).
+        ``keep_last`` = n: only the last n passes' tuples are returned and EARLIER ONES ARE DROPPED as soon as ``on_pass`` has seen
+        them - a pass's waveforms are views of its padded vocoder output (about 130 MB at the benchmark batch), so a long run that
+        keeps every pass grows by that much per pass; with ``keep_last`` device memory stays flat however long the run is."""
+        if keep_last is not None and keep_last < 1:
+            raise ValueError("keep_last must be >= 1 (or None: keep every pass)")
         import time as _time
         from concurrent.futures import Future
 
@@ -338,6 +343,8 @@ class MicroBatcher:
                 outs.append(self.predict(wav_dev, num_samples, task_str, tgt_lang, **kwargs))
                 if on_pass is not None:
                     on_pass(k, outs[-1])
+                if keep_last is not None:
+                    del outs[:-keep_last]
             return outs
         ns = list(num_samples)
         ready, consumer = self._submitted_from(wav_dev)
@@ -357,17 +364,22 @@ class MicroBatcher:
                     per_pass[k].set_result(out)
             except BaseException as e:  # noqa: BLE001 - handed to the caller through the pass's future
                 for kk in range(k, steps, g):
-                    if not per_pass[kk].done():
-                        per_pass[kk].set_exception(e)
+                    f = per_pass[kk]
+                    if f is not None and not f.done():
+                        f.set_exception(e)
 
         workers = [self.pool.submit(worker, i) for i in range(g)]
         results = []
         try:
             for k in range(steps):
                 t, speech, ids, st = per_pass[k].result()
+                per_pass[k] = None  # the future holds the pass's tensors too
                 results.append((t, speech.units if speech is not None else [], speech.audio_wavs if speech is not None else [], ids, st))
+                del speech
                 if on_pass is not None:
                     on_pass(k, results[-1])
+                if keep_last is not None:
+                    del results[:-keep_last]
         finally:
             for w in workers:
                 w.result()

@@ -5,6 +5,7 @@ import time
 from types import SimpleNamespace
 
 import numpy as np
+import pytest
 import torch
 
 from seamless_communication_amd.distributed import MicroBatcher
@@ -94,6 +95,30 @@ def test_one_group_runs_on_the_calling_thread_and_passes_are_handed_over_in_orde
     assert [k for k, _, _ in seen] == list(range(7)) and all(mine for _, mine, _ in seen)
     assert all(t == outs[k][0] for k, _, t in seen)
     mb3.close()
+
+
+def test_keep_last_drops_earlier_passes_once_on_pass_has_seen_them():
+    """A long run must not hold every pass's waveforms: with keep_last = n only the last n tuples come back, every pass still
+    reaches on_pass in order, and an earlier pass's tensors are gone (no reference left) while later passes still run."""
+    import gc
+    import weakref
+
+    for groups in (1, 3):
+        log, seen, alive = [], [], []
+        mb = MicroBatcher(_Translator(log), groups)
+
+        def on_pass(k, out):
+            seen.append(k)
+            alive.append(weakref.ref(out[2][0]))  # the pass's first waveform tensor
+
+        outs = mb.predict_passes(_wav(4), [8] * 4, 9, "S2ST", "fra", stagger_s=0.001, on_pass=on_pass, keep_last=2)
+        assert seen == list(range(9)) and len(outs) == 2
+        assert outs[-1][0] == [f"utt{k}" for k in range(4)]
+        gc.collect()
+        assert [r() is not None for r in alive] == [False] * 7 + [True] * 2
+        with pytest.raises(ValueError):
+            mb.predict_passes(_wav(4), [8] * 4, 2, "S2ST", "fra", keep_last=0)
+        mb.close()
 
 
 def test_a_failing_pass_reaches_the_caller():
