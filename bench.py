@@ -862,6 +862,8 @@ def main():
     elapsed = time.perf_counter() - t0
     engine_stats = batcher.engine.stats() if batcher.engine is not None else None
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s; last step {stage_ms}; engine {engine_stats}")
+    hbm_free, hbm_total = torch.cuda.mem_get_info()  # whole device: model, engine, the pass workers' pools (they never shrink)
+    hbm_after_timed_gb = round((hbm_total - hbm_free) / 1e9, 1)
     per_rank_s = [elapsed]
     if world > 1:
         mine = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -935,6 +937,7 @@ def main():
             "stage_ms_last_step_slice0": {k: round(v, 3) for k, v in stage_snapshot.items()},
             "load_seconds": round(load_s, 1),
         }
+        result["config"]["hbm_in_use_gb_after_timed_region"] = hbm_after_timed_gb
         if engine_stats is not None:
             # the shared chain over the timed region: what a pass costs in steps and what a useful row-step costs in engine time
             es = engine_stats
