@@ -57,6 +57,9 @@ if str(ROOT) not in sys.path:
 # queues are another +2.5 % (299.9 / 300.2 -> 305.4 / 309.8 alternating on one box, profiles/r5_wide_step_products.txt; with
 # six workers 16 gained nothing).  Must be set before the runtime starts; an explicit setting of the caller wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# dmabuf IPC: RCCL across processes needs it on this driver (exported on the GPU boxes; a rank started by torch.distributed.run from a
+# bare environment gets it here, before the runtime starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
